@@ -1,0 +1,280 @@
+"""CPU fp32 restatement of the reference's fairness step (TEST ORACLE).
+
+Every function cites the reference lines it follows; all citations are into
+/root/reference/exp-1-debias-gender/1-main-debias.py unless another file is named.
+Pure functions here are PINNED by tests/golden/reference_pure_functions.json
+(produced by executing the reference's own source, tests/golden/make_golden.py).
+The rollout/backward uses plain torch autograd exactly the way the reference does
+(detach at the U-Net input, per-step grad hooks), so it is the ground truth for
+the product's scalar-chain recompute-backward.
+"""
+import itertools
+import math
+
+import numpy as np
+import scipy.stats
+import torch
+import torch.nn.functional as F
+
+
+# --------------------------------------------------------------------------- helpers
+def make_grad_hook(coef):  # :219-220
+    return lambda x: coef * x
+
+
+def expand_bbox(bbox, expand_coef, target_ratio):  # :238-265
+    bw, bh = bbox[2] - bbox[0], bbox[3] - bbox[1]
+    cur = bh / bw
+    if cur > target_ratio:
+        more_h = bh * expand_coef
+        more_w = (bh + more_h) / target_ratio - bw
+    else:
+        more_w = bw * expand_coef
+        more_h = (bw + more_w) * target_ratio - bh
+    return [int(round(bbox[0] - more_w * 0.5)), int(round(bbox[1] - more_h * 0.5)),
+            int(round(bbox[2] + more_w * 0.5)), int(round(bbox[3] + more_h * 0.5))]
+
+
+def crop_face(img, bbox, target_size, fill_value):  # :267-290
+    """img [3,H,W]; torchvision Pad(constant)+Resize(bilinear, no antialias on tensors)."""
+    H, W = img.shape[-2:]
+    l, r = max(bbox[0], 0), min(bbox[2], W)
+    b, t = max(bbox[1], 0), min(bbox[3], H)
+    pl, pr = max(-bbox[0], 0), max(-(W - bbox[2]), 0)
+    pt, pb = max(-bbox[1], 0), max(-(H - bbox[3]), 0)
+    face = img[:, b:t, l:r]
+    if pl > 0 or pt > 0 or pr > 0 or pb > 0:
+        face = F.pad(face, [pl, pr, pt, pb], value=fill_value)
+    return F.interpolate(face[None], size=list(target_size), mode="bilinear", align_corners=False, antialias=False)[0]
+
+
+class SyntheticFaceProvider:
+    """Stand-in for the insightface/dlib detector seam (:1192-1353):
+    every image has one face whose raw detector box is the centred half-size square;
+    the reference's own expand_bbox(0.5, 1) + crop_face then apply."""
+
+    def __init__(self, size_face=224):
+        self.size_face = size_face
+
+    def raw_box(self, H, W):
+        return [0.25 * W, 0.25 * H, 0.75 * W, 0.75 * H]
+
+    def __call__(self, images, fill_value=-1):
+        N, _, H, W = images.shape
+        bbox = expand_bbox(self.raw_box(H, W), 0.5, 1)
+        ind = torch.ones(N, dtype=torch.bool)
+        boxes = torch.tensor([bbox] * N, dtype=torch.long)
+        chips = torch.stack([crop_face(images[i], bbox, [self.size_face, self.size_face], fill_value) for i in range(N)])
+        return ind, boxes, chips
+
+
+def get_face_gender(classifier, face_chips, selector=None, fill_value=-1, slice_fn=None):  # :1355-1401
+    x = face_chips[selector] if selector is not None else face_chips
+    if x.shape[0] == 0:
+        logits_g = torch.empty([0, 2], dtype=face_chips.dtype)
+        probs = torch.empty([0, 2], dtype=face_chips.dtype)
+        preds = torch.empty([0], dtype=torch.int64)
+    else:
+        logits = classifier(x)
+        logits_g = logits.view([logits.shape[0], -1, 2])[:, 20, :] if slice_fn is None else slice_fn(logits)
+        probs = torch.softmax(logits_g, dim=-1)
+        preds = probs.max(dim=-1).indices
+    if selector is None:
+        return preds, probs, logits_g
+    def scatter(v):
+        new = torch.ones([selector.shape[0]] + list(v.shape[1:]), dtype=v.dtype) * fill_value
+        new[selector] = v
+        return new
+    return scatter(preds), scatter(probs), scatter(logits_g)
+
+
+@torch.no_grad()
+def generate_dynamic_targets(probs, target_ratio=0.5, w_uncertainty=False):  # :1403-1447
+    idxs = (probs != -1).all(dim=-1)
+    p = probs[idxs]
+    rank = torch.argsort(torch.argsort(p[:, 1]))
+    targets = (rank >= (rank.shape[0] * target_ratio)).long()
+    targets_all = torch.ones([probs.shape[0]], dtype=torch.long) * (-1)
+    targets_all[idxs] = targets
+    if not w_uncertainty:
+        return targets_all
+    unc = torch.ones([p.shape[0]], dtype=probs.dtype) * (-1)
+    unc[targets == 1] = torch.tensor(1 - scipy.stats.binom.cdf(rank[targets == 1].numpy(), p.shape[0], 1 - target_ratio)).to(probs.dtype)
+    unc[targets == 0] = torch.tensor(scipy.stats.binom.cdf(rank[targets == 0].numpy(), p.shape[0], target_ratio)).to(probs.dtype)
+    unc_all = torch.ones([probs.shape[0]], dtype=probs.dtype) * (-1)
+    unc_all[idxs] = unc
+    return targets_all, unc_all
+
+
+def apply_grad_hook_face(images, face_bboxs, face_bboxs_ori, targets, preds_ori, factor=0.1):  # :1584-1617
+    out = []
+    for image, bb, bbo, target, pred_ori in itertools.zip_longest(images, face_bboxs, face_bboxs_ori, targets, preds_ori):
+        if (bb == -1).all():
+            out.append(image[None])
+            continue
+        img_w, img_h = image.shape[1:]  # (H, W) swapped in the reference, harmless for squares (:1592)
+        l, r = max(bb[0], bbo[0], 0), min(bb[2], bbo[2], img_w)
+        b, t = max(bb[1], bbo[1], 0), min(bb[3], bbo[3], img_h)
+        face = image[:, b:t, l:r].clone()
+        coef = 1 if (target != -1 and target == pred_ori) else factor
+        face.register_hook(make_grad_hook(coef))
+        add = torch.zeros_like(image)
+        add[:, b:t, l:r] = face
+        mask = torch.zeros_like(image)
+        mask[:, b:t, l:r] = 1
+        out.append((mask * add + (1 - mask) * image)[None])
+    return torch.cat(out)
+
+
+def gen_dynamic_weights(face_indicators, targets, preds_ori, factor=0.2):  # :1619-1633
+    w = []
+    for ind, target, pred_ori in itertools.zip_longest(face_indicators, targets, preds_ori):
+        if not bool(ind):
+            w.append(1)
+        elif target == -1:
+            w.append(factor)
+        elif target == pred_ori:
+            w.append(1)
+        else:
+            w.append(factor)
+    return torch.tensor(w, dtype=torch.float32)
+
+
+def grad_coefs(scheduler):  # :1105-1109
+    c = []
+    for t in scheduler.timesteps:
+        acp = scheduler.alphas_cumprod[t]
+        c.append(acp.sqrt().item() * (1 - acp).sqrt().item() / (1 - scheduler.alphas[t].item()))
+    c = np.array(c)
+    return c / (math.prod(c) ** (1 / len(c)))
+
+
+# --------------------------------------------------------------------------- rollouts
+def encode_prompts(text_encoder, prompt_ids, prompt_mask, uncond_ids, uncond_mask, N):
+    """:1007-1036 / :1074-1102 with tokenisation replaced by explicit ids (no vocab here):
+    prompt ids/mask [L], uncond ids/mask [L] -> [2N, L, D] (negative first)."""
+    pe = text_encoder(prompt_ids[None].repeat(N, 1), prompt_mask[None].repeat(N, 1))[0]
+    ne = text_encoder(uncond_ids[None].repeat(N, 1), uncond_mask[None].repeat(N, 1))[0]
+    return torch.cat([ne, pe])
+
+
+@torch.no_grad()
+def generate_image_no_gradient(tokens, noises, S, text_encoder, unet, vae, scheduler, guidance_scale=7.5, dtype=torch.float32,
+                               trace=None):  # :998-1061
+    N = noises.shape[0]
+    emb = encode_prompts(text_encoder, *tokens, N).to(dtype)
+    scheduler.set_timesteps(S)
+    latents = noises
+    for i, t in enumerate(scheduler.timesteps):
+        x = scheduler.scale_model_input(torch.cat([latents.to(dtype)] * 2), t)
+        eps = unet(x, t, encoder_hidden_states=emb).sample.to(torch.float32)
+        eu, ec = eps.chunk(2)
+        eps = eu + guidance_scale * (ec - eu)
+        latents = scheduler.step(eps, t, latents).prev_sample
+        if trace is not None:
+            trace.append(latents.clone())
+    latents = 1 / vae.config.scaling_factor * latents
+    return vae.decode(latents.to(vae.dtype)).sample.clamp(-1, 1)
+
+
+def generate_image_w_gradient(tokens, noises, S, text_encoder, unet, vae, scheduler, guidance_scale=7.5, dtype=torch.float32,
+                              trace=None):  # :1063-1136
+    N = noises.shape[0]
+    emb = encode_prompts(text_encoder, *tokens, N).to(dtype)
+    scheduler.set_timesteps(S)
+    coefs = grad_coefs(scheduler)
+    latents = noises
+    for i, t in enumerate(scheduler.timesteps):
+        x = scheduler.scale_model_input(torch.cat([latents.detach().to(dtype)] * 2), t)
+        eps = unet(x, t, encoder_hidden_states=emb).sample.to(torch.float32)
+        eu, ec = eps.chunk(2)
+        eps = eu + guidance_scale * (ec - eu)
+        if eps.requires_grad:
+            eps.register_hook(make_grad_hook(coefs[i]))
+        latents = scheduler.step(eps, t, latents).prev_sample
+        if trace is not None:
+            trace.append(latents.detach().clone())
+    latents = 1 / vae.config.scaling_factor * latents
+    return vae.decode(latents.to(vae.dtype)).sample.clamp(-1, 1)
+
+
+# --------------------------------------------------------------------------- EMA / step
+class EMAModel:
+    """diffusers==0.19.3 ``training_utils.EMAModel`` (defaults: no warm-up schedule,
+    decay floor ``(1+n)/(10+n)``); reference :823/:874, stepped at :2025-2029."""
+
+    def __init__(self, parameters, decay=0.9999):
+        self.shadow_params = [p.clone().detach() for p in parameters]
+        self.decay = decay
+        self.optimization_step = 0
+
+    def get_decay(self, optimization_step):
+        step = max(0, optimization_step - 1)
+        if step <= 0:
+            return 0.0
+        return max(min((1 + step) / (10 + step), self.decay), 0.0)
+
+    @torch.no_grad()
+    def step(self, parameters):
+        self.optimization_step += 1
+        omd = 1 - self.get_decay(self.optimization_step)
+        for s, p in zip(self.shadow_params, parameters):
+            s.sub_(omd * (s - p))
+
+
+def fairness_step(models, tokens, noises, S, cfg, world=None):
+    """One training step (:1746-2029) on one rank, synthetic face provider,
+    loss = loss_fair only (CLIP/DINO/face terms are SURVEY 8f "next" rows).
+
+    models: dict(text_encoder, unet, vae, classifier, scheduler, eval_text_encoder, eval_unet)
+    cfg: dict(train_GPU_batch_size, val_GPU_batch_size, uncertainty_threshold, factor2, guidance_scale, size_face, slice_fn)
+    world: optional (rank, world_size, probs_all) -- when given, the dynamic targets use the
+           gathered ``probs_all`` of every rank (:1805-1837).
+    Returns dict with images, probs, targets, uncertainty, loss_fair (per image, -1 sentinel),
+    latents trace of R1, and N_backward; LoRA grads are left in the params' ``.grad``.
+    """
+    te, unet, vae, clf, sch = (models[k] for k in ("text_encoder", "unet", "vae", "classifier", "scheduler"))
+    faces = SyntheticFaceProvider(cfg.get("size_face", 224))
+    gs, B = cfg.get("guidance_scale", 7.5), noises.shape[0]
+    slice_fn = cfg.get("slice_fn")
+    out = {}
+    with torch.no_grad():
+        trace = []
+        vb = cfg["val_GPU_batch_size"]
+        images = torch.cat([generate_image_no_gradient(tokens, noises[j:j + vb], S, te, unet, vae, sch, gs,
+                                                       trace=trace if j == 0 else None) for j in range(0, B, vb)])
+        ind, boxes, chips = faces(images)
+        preds, probs, _ = get_face_gender(clf, chips, selector=ind, slice_fn=slice_fn)
+        probs_all = probs if world is None else world[2]
+        targets_all, unc_all = generate_dynamic_targets(probs_all, w_uncertainty=True)
+        targets_all[unc_all > cfg["uncertainty_threshold"]] = -1
+        r = 0 if world is None else world[0]
+        targets, unc = targets_all[B * r:B * (r + 1)], unc_all[B * r:B * (r + 1)]
+        images_ori = torch.cat([generate_image_no_gradient(tokens, noises[j:j + vb], S, models["eval_text_encoder"],
+                                                           models["eval_unet"], vae, sch, gs) for j in range(0, B, vb)])
+        ind_o, boxes_o, chips_o = faces(images_ori)
+        preds_o, probs_o, _ = get_face_gender(clf, chips_o, selector=ind_o, slice_fn=slice_fn)
+    out.update(images=images, images_ori=images_ori, probs=probs, preds=preds, targets=targets, uncertainty=unc,
+               preds_ori=preds_o, probs_ori=probs_o, latents_trace=trace)
+    tb = cfg["train_GPU_batch_size"]
+    N_backward = math.ceil(B / tb)
+    loss_fair = torch.ones(B) * (-1)
+    images_g = []
+    for j in range(N_backward):
+        idx = list(range(B))[j * tb:(j + 1) * tb]
+        img = generate_image_w_gradient(tokens, noises[idx], S, te, unet, vae, sch, gs)
+        ind_j, boxes_j, chips_j = faces(img)
+        preds_j, probs_j, logits_j = get_face_gender(clf, chips_j, selector=ind_j, slice_fn=slice_fn)
+        img = apply_grad_hook_face(img, boxes_j, boxes_o[idx], targets[idx], preds_o[idx], factor=cfg["factor2"])
+        # NB (:1904-1915): the hooked images feed only the CLIP/DINO terms in the reference; the
+        # fairness loss uses logits computed from the un-hooked chips, so the hook does not touch it.
+        lf = torch.ones(len(idx)) * (-1)
+        w = ((ind_j == True) * (targets[idx] != -1)).nonzero().view([-1])  # noqa: E712
+        lf[w] = F.cross_entropy(logits_j[w], targets[idx][w], reduction="none")
+        loss_ij = lf  # + weight_loss_img*dyn*(CLIP+DINO) + weight_loss_face*face  (next rows)
+        if loss_ij.requires_grad:
+            loss_ij.mean().backward()
+        loss_fair[idx] = lf.detach()
+        images_g.append(img.detach())
+    out.update(loss_fair=loss_fair, N_backward=N_backward, images_grad=torch.cat(images_g))
+    return out

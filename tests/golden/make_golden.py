@@ -1,0 +1,131 @@
+"""Generate golden vectors by EXECUTING the reference's own pure functions.
+
+Run in the build container only (needs /root/reference); the outputs
+(tests/golden/reference_pure_functions.json, reference_cli.json) are committed and
+are what travels to the GPU box.  Functions nested inside ``main`` are lifted by AST
+(source segment -> exec) exactly as SURVEY.md section 8c describes; module-level
+functions are lifted the same way so no third-party import of the reference runs.
+No reference source text is stored: only inputs and outputs.
+"""
+import argparse
+import ast
+import itertools
+import json
+import math
+import os
+import sys
+
+import numpy as np
+import scipy
+import scipy.stats
+import torch
+import yaml
+
+REF = "/root/reference/exp-1-debias-gender/1-main-debias.py"
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def lift(names):
+    src = open(REF).read()
+    tree = ast.parse(src)
+    found = {}
+    for node in ast.walk(tree):
+        if isinstance(node, ast.FunctionDef) and node.name in names:
+            node.decorator_list = []
+            found[node.name] = ast.get_source_segment(src, node)
+    ns = dict(torch=torch, np=np, scipy=scipy, itertools=itertools, math=math, argparse=argparse, yaml=yaml, os=os)
+    for n in ["make_grad_hook"] + [x for x in names if x != "make_grad_hook"]:
+        seg = found[n]
+        seg = "\n".join(l for l in seg.splitlines() if not l.strip().startswith("@"))
+        import textwrap
+        exec(textwrap.dedent(seg), ns)
+    return ns
+
+
+def main():
+    ns = lift(["make_grad_hook", "expand_bbox", "generate_dynamic_targets", "gen_dynamic_weights",
+               "apply_grad_hook_face", "get_face_gender", "parse_args"])
+    out = {}
+    # expand_bbox -------------------------------------------------------------
+    rng = np.random.RandomState(0)
+    cases = [[100.2, 120.7, 300.9, 380.1], [128.0, 128.0, 384.0, 384.0], [-10.5, 3.2, 200.1, 150.9], [32.0, 32.0, 96.0, 96.0]]
+    for _ in range(12):
+        x0, y0 = rng.uniform(-20, 300, 2)
+        cases.append([float(x0), float(y0), float(x0 + rng.uniform(20, 250)), float(y0 + rng.uniform(20, 250))])
+    eb = []
+    for c in cases:
+        for coef, ratio in [(0.5, 1), (1.1, 1), (0.3, 1.25)]:
+            eb.append(dict(bbox=c, expand_coef=coef, target_ratio=ratio, out=ns["expand_bbox"](np.array(c), coef, ratio)))
+    out["expand_bbox"] = eb
+    # generate_dynamic_targets --------------------------------------------------
+    gdt = []
+    for seed, n, nmiss in [(0, 8, 1), (1, 8, 0), (2, 16, 3), (3, 24, 2), (4, 5, 0), (5, 64, 5), (6, 1, 0), (7, 12, 12)]:
+        g = torch.Generator().manual_seed(seed)
+        p1 = torch.rand(n, generator=g)
+        probs = torch.stack([1 - p1, p1], dim=-1)
+        miss = torch.randperm(n, generator=g)[:nmiss]
+        probs[miss] = -1
+        t, u = ns["generate_dynamic_targets"](probs, target_ratio=0.5, w_uncertainty=True)
+        t2 = ns["generate_dynamic_targets"](probs, target_ratio=0.5, w_uncertainty=False)
+        assert torch.equal(t, t2)
+        gdt.append(dict(probs=probs.tolist(), targets=t.tolist(), uncertainty=u.tolist()))
+    out["generate_dynamic_targets"] = gdt
+    # gen_dynamic_weights -------------------------------------------------------
+    gdw = []
+    for seed in range(4):
+        g = torch.Generator().manual_seed(100 + seed)
+        n = 8
+        ind = torch.rand(n, generator=g) > 0.2
+        targets = torch.randint(-1, 2, (n,), generator=g)
+        preds = torch.randint(0, 2, (n,), generator=g)
+        probs = torch.rand(n, 2, generator=g)
+        w = ns["gen_dynamic_weights"](ind, targets, preds, probs, factor=0.2)
+        gdw.append(dict(face_indicators=ind.tolist(), targets=targets.tolist(), preds_ori=preds.tolist(), weights=w.tolist()))
+    out["gen_dynamic_weights"] = gdw
+    # apply_grad_hook_face: forward identity + gradient mask -----------------------
+    agh = []
+    for seed in range(3):
+        g = torch.Generator().manual_seed(200 + seed)
+        n, H = 4, 32
+        images = torch.randn(n, 3, H, H, generator=g, requires_grad=True)
+        bb = torch.tensor([[4, 6, 20, 24], [-1, -1, -1, -1], [0, 0, 40, 40], [10, 3, 30, 17]])
+        bbo = torch.tensor([[8, 2, 28, 22], [3, 3, 9, 9], [5, 5, 25, 25], [-3, -2, 12, 40]])
+        targets = torch.tensor([1, 0, -1, 0])
+        preds = torch.tensor([1, 0, 1, 1])
+        probs = torch.rand(n, 2, generator=g)
+        y = ns["apply_grad_hook_face"](images, bb, bbo, targets, preds, probs, factor=0.2)
+        gw = torch.randn(y.shape, generator=g)
+        (y * gw).sum().backward()
+        ratio = (images.grad / gw)
+        agh.append(dict(seed=200 + seed, bbox=bb.tolist(), bbox_ori=bbo.tolist(), targets=targets.tolist(), preds_ori=preds.tolist(),
+                        max_abs_fwd_diff=float((y - images).abs().max()),
+                        grad_ratio_ch0=ratio[:, 0].round(decimals=4).tolist()))
+    out["apply_grad_hook_face"] = agh
+    # get_face_gender scatter with a linear stand-in classifier --------------------
+    gfg = []
+    for seed in range(3):
+        g = torch.Generator().manual_seed(300 + seed)
+        n = 6
+        W = torch.randn(80, 12, generator=g)
+        ns["gender_classifier"] = lambda x, W=W: x.flatten(1) @ W.t()
+        chips = torch.randn(n, 3, 2, 2, generator=g)
+        sel = torch.tensor([True, False, True, True, False, True]) if seed else torch.zeros(n, dtype=torch.bool)
+        preds, probs, logits = ns["get_face_gender"](chips, selector=sel, fill_value=-1)
+        gfg.append(dict(W=W.tolist(), chips=chips.tolist(), selector=sel.tolist(), preds=preds.tolist(), probs=probs.tolist(), logits=logits.tolist()))
+    out["get_face_gender"] = gfg
+    json.dump(out, open(os.path.join(HERE, "reference_pure_functions.json"), "w"))
+
+    # CLI: defaults + YAML overlays of every exp-1 config ---------------------------
+    cli = {}
+    os.environ.pop("LOCAL_RANK", None)
+    cli["defaults"] = vars(ns["parse_args"]([]))
+    cfg_dir = "/root/reference/exp-1-debias-gender/configs"
+    for f in ["debias-unet.yaml", "debias-text-encoder.yaml", "debias-text-encoder-and-unet.yaml"]:
+        cli[f] = dict(yaml=yaml.safe_load(open(os.path.join(cfg_dir, f))), args=vars(ns["parse_args"](["--config", os.path.join(cfg_dir, f)])))
+        cli[f]["args"]["config"] = f
+    json.dump(cli, open(os.path.join(HERE, "reference_cli.json"), "w"), indent=1, sort_keys=True)
+    print("wrote golden vectors:", {k: len(v) for k, v in out.items()}, len(cli["defaults"]), "flags")
+
+
+if __name__ == "__main__":
+    main()
