@@ -1,0 +1,480 @@
+// Fused (flash-style) attention for gfx950: forward, dQ and dK/dV kernels.
+//
+// All three kernels use v_mfma_f32_32x32x16_f16 in the "transposed score" arrangement:
+//   S^T[key][q] = K . Q^T   (A = K rows from LDS, B = Q rows held in VGPRs)
+// so a lane owns ONE query column (q = lane & 31) and 16 keys per 32-key sub-tile
+// (key = (r&3) + 8*(r>>2) + 4*(lane>>5)); the softmax row reduction is in-lane plus one
+// cross-half shuffle, and P (fp16) is directly the B operand of the next MFMA
+//   O^T[dv][q] += V^T[dv][key] . P^T[key][q]
+// with the k index of that MFMA permuted consistently on both operands (element j of a lane's
+// 8-wide operand <-> key 4*(lane>>5) + (j&3) + 8*(j>>2) of the 16-key step), which the A side
+// realises as two 8-byte LDS reads from a key-contiguous (transposed) tile.  Head dims that are
+// not MFMA multiples (40, 80) are zero-padded in LDS: D -> DK (x16) for contractions over d and
+// D -> DV (x32) where d is an output dimension.
+#include "common.h"
+
+#define LOG2E 1.4426950408889634f
+
+__device__ __forceinline__ f32x16 mfma32(f16x8 a, f16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x16 zero16() {
+    f32x16 z;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) z[i] = 0.f;
+    return z;
+}
+// row index inside a 32x32 C/D tile for accumulator register r of lane-half g
+__device__ __forceinline__ int crow(int r, int g) { return (r & 3) + 8 * (r >> 2) + 4 * g; }
+
+// stage a row-major [rows x D] fp16 tile (global row stride ld) into LDS [rows][DKP], zero padded
+template <int ROWS, int D, int DKP>
+__device__ __forceinline__ void stage_rows(f16* dst, const f16* src, int64_t ld, int row0, int nrows_valid) {
+    constexpr int CH = DKP / 8;  // chunks per LDS row (incl. pad columns beyond D up to DK)
+    for (int c = threadIdx.x; c < ROWS * CH; c += 256) {
+        const int r = c / CH, cc = (c - r * CH) * 8;
+        f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (row0 + r < nrows_valid && cc < D) v = *(const f16x8*)(src + (int64_t)(row0 + r) * ld + cc);
+        *(f16x8*)(dst + r * DKP + cc) = v;
+    }
+}
+// stage a transposed tile: global [D rows (channels) x T] (row stride ldt) -> LDS [DV][72], cols col0..col0+63
+template <int D, int DV>
+__device__ __forceinline__ void stage_cols(f16* dst, const f16* src, int64_t ldt, int col0, int ncols_valid) {
+    for (int c = threadIdx.x; c < DV * 8; c += 256) {
+        const int r = c >> 3, cc = (c & 7) * 8;
+        f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (r < D && col0 + cc < ncols_valid) v = *(const f16x8*)(src + (int64_t)r * ldt + col0 + cc);
+        *(f16x8*)(dst + r * 72 + cc) = v;
+    }
+}
+// the permuted-k A operand from a key-contiguous LDS tile [.][72]: keys base + 4g + {0..3} and base + 8 + 4g + {0..3}
+__device__ __forceinline__ f16x8 read_perm(const f16* tile, int row, int base, int g) {
+    const f16x4 lo = *(const f16x4*)(tile + row * 72 + base + 4 * g);
+    const f16x4 hi = *(const f16x4*)(tile + row * 72 + base + 8 + 4 * g);
+    return (f16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+
+// ================================================================================== forward
+template <int D>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const f16* __restrict__ Q, const f16* __restrict__ K, const f16* __restrict__ Vt,
+                                                       f16* __restrict__ O, float* __restrict__ LSE, int H, int Tq, int Tk, int Tkp,
+                                                       int kv_div, float scale) {
+    constexpr int DK = (D + 15) / 16 * 16, DV = (D + 31) / 32 * 32, DKP = DK + 8;
+    constexpr int NKS = DK / 16, NDV = DV / 32;
+    extern __shared__ __attribute__((aligned(16))) f16 smem[];
+    f16* Ks = smem;               // [64][DKP]
+    f16* Vts = smem + 64 * DKP;   // [DV][72]
+
+    const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 128;
+    const int bk = b / kv_div;
+    const int C = H * D;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ql = lane & 31, g = lane >> 5;
+    const int t = q0 + wave * 32 + ql;
+    const bool tvalid = t < Tq;
+
+    f16x8 qf[NKS];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+        const int col = ks * 16 + g * 8;
+        qf[ks] = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
+        if (tvalid && col < D) qf[ks] = *(const f16x8*)(Q + ((int64_t)b * Tq + t) * C + h * D + col);
+    }
+    f32x16 oacc[NDV];
+#pragma unroll
+    for (int i = 0; i < NDV; ++i) oacc[i] = zero16();
+    float m_run = -INFINITY, l_run = 0.f;
+    const float sl2 = scale * LOG2E;
+
+    const f16* Kb = K + (int64_t)bk * Tk * C + h * D;
+    const f16* Vtb = Vt + ((int64_t)bk * C + h * D) * Tkp;
+
+    for (int k0 = 0; k0 < Tk; k0 += 64) {
+        __syncthreads();
+        stage_rows<64, D, DKP>(Ks, Kb, C, k0, Tk);
+        stage_cols<D, DV>(Vts, Vtb, Tkp, k0, Tkp);
+        __syncthreads();
+
+        f32x16 s[2];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            s[kt] = zero16();
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                const f16x8 kf = *(const f16x8*)(Ks + (kt * 32 + ql) * DKP + ks * 16 + g * 8);
+                s[kt] = mfma32(kf, qf[ks], s[kt]);
+            }
+        }
+        // scale, mask, online softmax
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = k0 + kt * 32 + crow(r, g);
+                float v = s[kt][r] * sl2;
+                if (key >= Tk) v = -INFINITY;
+                s[kt][r] = v;
+                mx = fmaxf(mx, v);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = exp2f(m_run - m_new);
+        float rs = 0.f;
+        f16x8 pf[4];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = exp2f(s[kt][r] - m_new);
+                rs += p;
+                pf[kt * 2 + (r >> 3)][r & 7] = (f16)p;
+            }
+        rs += __shfl_xor(rs, 32, 64);
+        l_run = l_run * alpha + rs;
+        m_run = m_new;
+#pragma unroll
+        for (int i = 0; i < NDV; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
+#pragma unroll
+        for (int st = 0; st < 4; ++st)
+#pragma unroll
+            for (int i = 0; i < NDV; ++i) {
+                const f16x8 vf = read_perm(Vts, i * 32 + ql, st * 16, g);
+                oacc[i] = mfma32(vf, pf[st], oacc[i]);
+            }
+    }
+    if (tvalid) {
+        const float inv = 1.f / l_run;
+        f16* Op = O + ((int64_t)b * Tq + t) * C + h * D;
+#pragma unroll
+        for (int i = 0; i < NDV; ++i)
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                const int dv = i * 32 + 8 * rq + 4 * g;
+                if (dv < D) {
+                    f16x4 o;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] = (f16)(oacc[i][rq * 4 + j] * inv);
+                    *(f16x4*)(Op + dv) = o;
+                }
+            }
+        if (LSE && g == 0) LSE[((int64_t)b * H + h) * Tq + t] = (m_run + log2f(l_run)) / LOG2E;
+    }
+}
+
+// ================================================================================== D = rowsum(dO * O)
+__global__ void attn_bwd_prep_kernel(const f16* O, const f16* dO, float* Dd, int H, int T, int d, int64_t n) {
+    // one thread per (b, t, h)
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int h = (int)(i % H);
+        const int64_t bt = i / H;
+        const int t = (int)(bt % T);
+        const int64_t b = bt / T;
+        const f16* o = O + bt * H * d + h * d;
+        const f16* g = dO + bt * H * d + h * d;
+        float s = 0.f;
+        for (int j = 0; j < d; j += 8) {
+            const f16x8 a = *(const f16x8*)(o + j), c = *(const f16x8*)(g + j);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s += (float)a[k] * (float)c[k];
+        }
+        Dd[(b * H + h) * T + t] = s;
+    }
+}
+
+// ================================================================================== dQ
+template <int D>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const f16* __restrict__ Q, const f16* __restrict__ K, const f16* __restrict__ V,
+                                                          const f16* __restrict__ Kt, const f16* __restrict__ dO,
+                                                          const float* __restrict__ LSE, const float* __restrict__ Dd, f16* __restrict__ dQ,
+                                                          int H, int Tq, int Tk, int Tkp, int kv_div, float scale) {
+    constexpr int DK = (D + 15) / 16 * 16, DV = (D + 31) / 32 * 32, DKP = DK + 8;
+    constexpr int NKS = DK / 16, NDV = DV / 32;
+    extern __shared__ __attribute__((aligned(16))) f16 smem[];
+    f16* Ks = smem;                // [64][DKP]
+    f16* Vs = Ks + 64 * DKP;       // [64][DKP]
+    f16* Kts = Vs + 64 * DKP;      // [DV][72]
+
+    const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 128;
+    const int bk = b / kv_div;
+    const int C = H * D;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ql = lane & 31, g = lane >> 5;
+    const int t = q0 + wave * 32 + ql;
+    const bool tvalid = t < Tq;
+
+    f16x8 qf[NKS], gf[NKS];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+        const int col = ks * 16 + g * 8;
+        qf[ks] = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
+        gf[ks] = qf[ks];
+        if (tvalid && col < D) {
+            qf[ks] = *(const f16x8*)(Q + ((int64_t)b * Tq + t) * C + h * D + col);
+            gf[ks] = *(const f16x8*)(dO + ((int64_t)b * Tq + t) * C + h * D + col);
+        }
+    }
+    const float lse2 = tvalid ? LSE[((int64_t)b * H + h) * Tq + t] * LOG2E : INFINITY;
+    const float dd = tvalid ? Dd[((int64_t)b * H + h) * Tq + t] : 0.f;
+    const float sl2 = scale * LOG2E;
+    f32x16 acc[NDV];
+#pragma unroll
+    for (int i = 0; i < NDV; ++i) acc[i] = zero16();
+
+    const f16* Kb = K + (int64_t)bk * Tk * C + h * D;
+    const f16* Vb = V + (int64_t)bk * Tk * C + h * D;
+    const f16* Ktb = Kt + ((int64_t)bk * C + h * D) * Tkp;
+
+    for (int k0 = 0; k0 < Tk; k0 += 64) {
+        __syncthreads();
+        stage_rows<64, D, DKP>(Ks, Kb, C, k0, Tk);
+        stage_rows<64, D, DKP>(Vs, Vb, C, k0, Tk);
+        stage_cols<D, DV>(Kts, Ktb, Tkp, k0, Tkp);
+        __syncthreads();
+        f16x8 dsf[4];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            f32x16 s = zero16(), dp = zero16();
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                const f16x8 kf = *(const f16x8*)(Ks + (kt * 32 + ql) * DKP + ks * 16 + g * 8);
+                const f16x8 vf = *(const f16x8*)(Vs + (kt * 32 + ql) * DKP + ks * 16 + g * 8);
+                s = mfma32(kf, qf[ks], s);
+                dp = mfma32(vf, gf[ks], dp);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = k0 + kt * 32 + crow(r, g);
+                float p = exp2f(s[r] * sl2 - lse2);
+                if (key >= Tk) p = 0.f;
+                dsf[kt * 2 + (r >> 3)][r & 7] = (f16)(p * (dp[r] - dd) * scale);
+            }
+        }
+#pragma unroll
+        for (int st = 0; st < 4; ++st)
+#pragma unroll
+            for (int i = 0; i < NDV; ++i) {
+                const f16x8 kf = read_perm(Kts, i * 32 + ql, st * 16, g);
+                acc[i] = mfma32(kf, dsf[st], acc[i]);
+            }
+    }
+    if (tvalid) {
+        f16* P = dQ + ((int64_t)b * Tq + t) * C + h * D;
+#pragma unroll
+        for (int i = 0; i < NDV; ++i)
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                const int dv = i * 32 + 8 * rq + 4 * g;
+                if (dv < D) {
+                    f16x4 o;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] = (f16)acc[i][rq * 4 + j];
+                    *(f16x4*)(P + dv) = o;
+                }
+            }
+    }
+}
+
+// ================================================================================== dK, dV
+// block = 128 keys (4 waves x 32), loops over 32-query tiles.  S[q][key] = Q.K^T with K,V rows in VGPRs.
+template <int D, bool ATOMIC>
+__global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const f16* __restrict__ Q, const f16* __restrict__ Qt, const f16* __restrict__ K,
+                                                            const f16* __restrict__ V, const f16* __restrict__ dO,
+                                                            const f16* __restrict__ dOt, const float* __restrict__ LSE,
+                                                            const float* __restrict__ Dd, void* __restrict__ dKo, void* __restrict__ dVo,
+                                                            int H, int Tq, int Tk, int kv_div, float scale) {
+    constexpr int DK = (D + 15) / 16 * 16, DV = (D + 31) / 32 * 32, DKP = DK + 8;
+    constexpr int NKS = DK / 16, NDV = DV / 32;
+    extern __shared__ __attribute__((aligned(16))) f16 smem[];
+    f16* Qs = smem;                 // [64][DKP]
+    f16* Gs = Qs + 64 * DKP;        // [64][DKP]  (dO rows)
+    f16* Qts = Gs + 64 * DKP;       // [DV][72]
+    f16* Gts = Qts + DV * 72;       // [DV][72]
+    float* lse_s = (float*)(Gts + DV * 72);  // [64]
+    float* dd_s = lse_s + 64;                // [64]
+
+    const int b = blockIdx.z, h = blockIdx.y, k0 = blockIdx.x * 128;
+    const int bk = b / kv_div;
+    const int C = H * D;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int kl = lane & 31, g = lane >> 5;
+    const int key = k0 + wave * 32 + kl;
+    const bool kvalid = key < Tk;
+
+    f16x8 kf[NKS], vf[NKS];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+        const int col = ks * 16 + g * 8;
+        kf[ks] = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
+        vf[ks] = kf[ks];
+        if (kvalid && col < D) {
+            kf[ks] = *(const f16x8*)(K + ((int64_t)bk * Tk + key) * C + h * D + col);
+            vf[ks] = *(const f16x8*)(V + ((int64_t)bk * Tk + key) * C + h * D + col);
+        }
+    }
+    f32x16 dk[NDV], dv[NDV];
+#pragma unroll
+    for (int i = 0; i < NDV; ++i) { dk[i] = zero16(); dv[i] = zero16(); }
+    const float sl2 = scale * LOG2E;
+
+    const f16* Qb = Q + (int64_t)b * Tq * C + h * D;
+    const f16* Gb = dO + (int64_t)b * Tq * C + h * D;
+    const f16* Qtb = Qt + ((int64_t)b * C + h * D) * Tq;
+    const f16* Gtb = dOt + ((int64_t)b * C + h * D) * Tq;
+    const float* Lb = LSE + ((int64_t)b * H + h) * Tq;
+    const float* Db = Dd + ((int64_t)b * H + h) * Tq;
+
+    for (int q0 = 0; q0 < Tq; q0 += 64) {
+        __syncthreads();
+        stage_rows<64, D, DKP>(Qs, Qb, C, q0, Tq);
+        stage_rows<64, D, DKP>(Gs, Gb, C, q0, Tq);
+        stage_cols<D, DV>(Qts, Qtb, Tq, q0, Tq);
+        stage_cols<D, DV>(Gts, Gtb, Tq, q0, Tq);
+        if (threadIdx.x < 64) {
+            const int tq = q0 + threadIdx.x;
+            lse_s[threadIdx.x] = tq < Tq ? Lb[tq] * LOG2E : INFINITY;
+            dd_s[threadIdx.x] = tq < Tq ? Db[tq] : 0.f;
+        }
+        __syncthreads();
+        f16x8 pf[4], dsf[4];
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            f32x16 s = zero16(), dp = zero16();
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                const f16x8 qa = *(const f16x8*)(Qs + (qt * 32 + kl) * DKP + ks * 16 + g * 8);
+                const f16x8 ga = *(const f16x8*)(Gs + (qt * 32 + kl) * DKP + ks * 16 + g * 8);
+                s = mfma32(qa, kf[ks], s);
+                dp = mfma32(ga, vf[ks], dp);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int qi = qt * 32 + crow(r, g);
+                float p = exp2f(s[r] * sl2 - lse_s[qi]);
+                if (!kvalid) p = 0.f;
+                pf[qt * 2 + (r >> 3)][r & 7] = (f16)p;
+                dsf[qt * 2 + (r >> 3)][r & 7] = (f16)(p * (dp[r] - dd_s[qi]) * scale);
+            }
+        }
+#pragma unroll
+        for (int st = 0; st < 4; ++st)
+#pragma unroll
+            for (int i = 0; i < NDV; ++i) {
+                const f16x8 ga = read_perm(Gts, i * 32 + kl, st * 16, g);
+                const f16x8 qa = read_perm(Qts, i * 32 + kl, st * 16, g);
+                dv[i] = mfma32(ga, pf[st], dv[i]);
+                dk[i] = mfma32(qa, dsf[st], dk[i]);
+            }
+    }
+    if (kvalid) {
+        const int64_t off = ((int64_t)bk * Tk + key) * C + h * D;
+#pragma unroll
+        for (int i = 0; i < NDV; ++i)
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                const int d0 = i * 32 + 8 * rq + 4 * g;
+                if (d0 < D) {
+                    if (ATOMIC) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            atomicAdd((float*)dKo + off + d0 + j, dk[i][rq * 4 + j]);
+                            atomicAdd((float*)dVo + off + d0 + j, dv[i][rq * 4 + j]);
+                        }
+                    } else {
+                        f16x4 a, c;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) { a[j] = (f16)dk[i][rq * 4 + j]; c[j] = (f16)dv[i][rq * 4 + j]; }
+                        *(f16x4*)((f16*)dKo + off + d0) = a;
+                        *(f16x4*)((f16*)dVo + off + d0) = c;
+                    }
+                }
+            }
+    }
+}
+
+// ================================================================================== host side
+template <int D> static constexpr size_t fwd_lds() { return (size_t)(64 * (((D + 15) / 16 * 16) + 8) + ((D + 31) / 32 * 32) * 72) * 2; }
+template <int D> static constexpr size_t dq_lds() { return (size_t)(2 * 64 * (((D + 15) / 16 * 16) + 8) + ((D + 31) / 32 * 32) * 72) * 2; }
+template <int D> static constexpr size_t dkdv_lds() {
+    return (size_t)(2 * 64 * (((D + 15) / 16 * 16) + 8) + 2 * ((D + 31) / 32 * 32) * 72) * 2 + 512;
+}
+
+#define FD_DISPATCH_D(d, CALL)                                                       \
+    switch (d) {                                                                     \
+        case 16: { CALL(16); break; }                                                \
+        case 32: { CALL(32); break; }                                                \
+        case 40: { CALL(40); break; }                                                \
+        case 64: { CALL(64); break; }                                                \
+        case 80: { CALL(80); break; }                                                \
+        case 128: { CALL(128); break; }                                              \
+        case 160: { CALL(160); break; }                                              \
+        default: fd_set_error("attention: unsupported head dim %d", d); return FD_ERR_ARG; \
+    }
+
+// raise the dynamic-LDS cap once per kernel instantiation (each macro expansion has its own static)
+#define ALLOW_LDS(kern, bytes)                                                                                   \
+    {                                                                                                            \
+        static bool once = false;                                                                                \
+        if (!once) {                                                                                             \
+            (void)hipFuncSetAttribute((const void*)(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)); \
+            once = true;                                                                                         \
+        }                                                                                                        \
+    }
+
+extern "C" int fd_attn_fwd(const void* q, const void* k, const void* vt, void* o, float* lse, int B, int H, int Tq, int Tk, int Tkp, int d,
+                           int kv_div, float scale, void* stream) {
+    FD_REQUIRE(B > 0 && H > 0 && Tq > 0 && Tk > 0 && Tkp >= Tk && (Tkp & 7) == 0 && kv_div >= 1, "fd_attn_fwd: bad shape");
+    dim3 grid((Tq + 127) / 128, H, B);
+#define CALL(DD)                                                                                                                      \
+    ALLOW_LDS(attn_fwd_kernel<DD>, fwd_lds<DD>());                                                                                    \
+    hipLaunchKernelGGL(attn_fwd_kernel<DD>, grid, dim3(256), fwd_lds<DD>(), (hipStream_t)stream, (const f16*)q, (const f16*)k,        \
+                       (const f16*)vt, (f16*)o, lse, H, Tq, Tk, Tkp, kv_div, scale)
+    FD_DISPATCH_D(d, CALL)
+#undef CALL
+    return fd_check_launch("fd_attn_fwd");
+}
+
+extern "C" int fd_attn_bwd_prep(const void* o, const void* d_o, float* D, int B, int H, int T, int d, void* stream) {
+    FD_REQUIRE((d & 7) == 0, "fd_attn_bwd_prep: d %% 8");
+    const int64_t n = (int64_t)B * T * H;
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const f16*)o, (const f16*)d_o, D, H, T, d, n);
+    return fd_check_launch("fd_attn_bwd_prep");
+}
+
+extern "C" int fd_attn_bwd_dq(const void* q, const void* k, const void* v, const void* kt, const void* d_o, const float* lse, const float* D,
+                              void* dq, int B, int H, int Tq, int Tk, int Tkp, int d, int kv_div, float scale, void* stream) {
+    FD_REQUIRE(B > 0 && H > 0 && Tq > 0 && Tk > 0 && Tkp >= Tk && (Tkp & 7) == 0 && kv_div >= 1, "fd_attn_bwd_dq: bad shape");
+    dim3 grid((Tq + 127) / 128, H, B);
+#define CALL(DD)                                                                                                                      \
+    ALLOW_LDS(attn_bwd_dq_kernel<DD>, dq_lds<DD>());                                                                                  \
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<DD>, grid, dim3(256), dq_lds<DD>(), (hipStream_t)stream, (const f16*)q, (const f16*)k,      \
+                       (const f16*)v, (const f16*)kt, (const f16*)d_o, lse, D, (f16*)dq, H, Tq, Tk, Tkp, kv_div, scale)
+    FD_DISPATCH_D(d, CALL)
+#undef CALL
+    return fd_check_launch("fd_attn_bwd_dq");
+}
+
+extern "C" int fd_attn_bwd_dkdv(const void* q, const void* qt, const void* k, const void* v, const void* d_o, const void* d_ot,
+                                const float* lse, const float* D, void* dk, void* dv, int B, int H, int Tq, int Tk, int d, int kv_div,
+                                float scale, void* stream) {
+    FD_REQUIRE(B > 0 && H > 0 && Tq > 0 && Tk > 0 && (Tq & 7) == 0 && kv_div >= 1, "fd_attn_bwd_dkdv: bad shape (Tq %% 8)");
+    dim3 grid((Tk + 127) / 128, H, B);
+#define CALL(DD)                                                                                                                       \
+    if (kv_div > 1) {                                                                                                                  \
+        ALLOW_LDS((attn_bwd_dkdv_kernel<DD, true>), dkdv_lds<DD>());                                                                     \
+        hipLaunchKernelGGL((attn_bwd_dkdv_kernel<DD, true>), grid, dim3(256), dkdv_lds<DD>(), (hipStream_t)stream, (const f16*)q,      \
+                           (const f16*)qt, (const f16*)k, (const f16*)v, (const f16*)d_o, (const f16*)d_ot, lse, D, dk, dv, H, Tq, Tk, \
+                           kv_div, scale);                                                                                             \
+    } else {                                                                                                                           \
+        ALLOW_LDS((attn_bwd_dkdv_kernel<DD, false>), dkdv_lds<DD>());                                                                    \
+        hipLaunchKernelGGL((attn_bwd_dkdv_kernel<DD, false>), grid, dim3(256), dkdv_lds<DD>(), (hipStream_t)stream, (const f16*)q,     \
+                           (const f16*)qt, (const f16*)k, (const f16*)v, (const f16*)d_o, (const f16*)d_ot, lse, D, dk, dv, H, Tq, Tk, \
+                           kv_div, scale);                                                                                             \
+    }
+    FD_DISPATCH_D(d, CALL)
+#undef CALL
+    return fd_check_launch("fd_attn_bwd_dkdv");
+}

@@ -1,0 +1,104 @@
+// Shared device helpers for the gfx950 (CDNA4, wave64) kernels of libfairdiff_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/fairdiff_hip.h"
+
+typedef _Float16 f16;
+typedef f16 f16x2 __attribute__((ext_vector_type(2)));
+typedef f16 f16x4 __attribute__((ext_vector_type(4)));
+typedef f16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define FD_WAVE 64
+
+void fd_set_error(const char* fmt, ...);
+int fd_check_launch(const char* what);
+
+#define FD_REQUIRE(cond, ...)                  \
+    do {                                       \
+        if (!(cond)) {                         \
+            fd_set_error(__VA_ARGS__);         \
+            return FD_ERR_ARG;                 \
+        }                                      \
+    } while (0)
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// block-wide sum for blockDim.x <= 1024 (multiple of 64); `red` holds >= 16 floats of LDS.
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    v = wave_sum(v);
+    const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[w] = v;
+    __syncthreads();
+    float t = 0.f;
+    for (int i = 0; i < nw; ++i) t += red[i];
+    return t;
+}
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.f + __expf(-x)); }
+__device__ __forceinline__ float silu_grad_f(float x) {
+    const float s = 1.f / (1.f + __expf(-x));
+    return s * (1.f + x * (1.f - s));
+}
+__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_erf_grad_f(float x) {
+    return 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+}
+__device__ __forceinline__ float quick_gelu_f(float x) { return x / (1.f + __expf(-1.702f * x)); }
+__device__ __forceinline__ float quick_gelu_grad_f(float x) {
+    const float s = 1.f / (1.f + __expf(-1.702f * x));
+    return s * (1.f + 1.702f * x * (1.f - s));
+}
+__device__ __forceinline__ float hardswish_f(float x) { return x * fminf(fmaxf(x + 3.f, 0.f), 6.f) * (1.f / 6.f); }
+__device__ __forceinline__ float hardswish_grad_f(float x) {
+    // torch: 0 for x < -3, grad*(x/3 + 0.5) for -3 <= x <= 3, grad for x > 3
+    if (x < -3.f) return 0.f;
+    if (x <= 3.f) return x * (1.f / 3.f) + 0.5f;
+    return 1.f;
+}
+__device__ __forceinline__ float hardsigmoid_f(float x) { return fminf(fmaxf(x + 3.f, 0.f), 6.f) * (1.f / 6.f); }
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+    switch (act) {
+        case FD_ACT_SILU: return silu_f(v);
+        case FD_ACT_QUICK_GELU: return quick_gelu_f(v);
+        case FD_ACT_GELU: return gelu_erf_f(v);
+        case FD_ACT_RELU: return fmaxf(v, 0.f);
+        case FD_ACT_HARDSWISH: return hardswish_f(v);
+        case FD_ACT_HARDSIGMOID: return hardsigmoid_f(v);
+        default: return v;
+    }
+}
+// derivative of act w.r.t. its pre-activation input z
+__device__ __forceinline__ float act_grad(float z, int act) {
+    switch (act) {
+        case FD_ACT_SILU: return silu_grad_f(z);
+        case FD_ACT_QUICK_GELU: return quick_gelu_grad_f(z);
+        case FD_ACT_GELU: return gelu_erf_grad_f(z);
+        case FD_ACT_RELU: return z > 0.f ? 1.f : 0.f;
+        case FD_ACT_HARDSWISH: return hardswish_grad_f(z);
+        case FD_ACT_HARDSIGMOID: return (z > -3.f && z < 3.f) ? (1.f / 6.f) : 0.f;
+        default: return 1.f;
+    }
+}
+
+// XCD-aware bijective remap of a linear workgroup id: consecutive remapped ids share an XCD's L2
+// (dispatcher places block b on XCD b % 8 -- speed only, never correctness).
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}

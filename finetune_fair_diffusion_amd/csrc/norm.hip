@@ -1,0 +1,341 @@
+// GroupNorm (channels-last, 2-source concat, fused SiLU) and LayerNorm, forward and backward.
+// HBM-bound kernels: 16-byte fp16 vectors, fp32 statistics, fixed reduction order (deterministic).
+#include "common.h"
+
+#define GN_MAX_CHUNKS 64
+
+struct GNArgs {
+    const f16* x1; const f16* x2; int C1, C2;
+    const f16* dy;
+    int B, HW, G, rows_per_chunk, nchunks;
+    float eps;
+    const float* gamma; const float* beta; const float* mean_rstd;
+    int silu;
+};
+
+__device__ __forceinline__ f16x8 gn_load(const GNArgs& a, int64_t pix, int c) {
+    if (c < a.C1) return *(const f16x8*)(a.x1 + pix * a.C1 + c);
+    return *(const f16x8*)(a.x2 + pix * a.C2 + (c - a.C1));
+}
+
+// MODE 0: per-group (sum x, sum x^2). MODE 1: per-group (sum dz*gamma, sum dz*gamma*xhat)
+template <int MODE>
+__global__ void gn_reduce_kernel(GNArgs a, float* partial /* [B,nchunks,G,2] */) {
+    extern __shared__ float sacc[];  // [G*2]
+    const int C = a.C1 + a.C2, V = C >> 3, cg = C / a.G;
+    const int b = blockIdx.y, chunk = blockIdx.x;
+    const int v = threadIdx.x % V, rsub = threadIdx.x / V, rpb = blockDim.x / V;
+    for (int i = threadIdx.x; i < a.G * 2; i += blockDim.x) sacc[i] = 0.f;
+    __syncthreads();
+    const int c0 = v * 8;
+    float s0[8], s1[8];
+    float gm[8], bt[8], mu[8], rs[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        s0[j] = s1[j] = 0.f;
+        if (MODE == 1) {
+            const int g = (c0 + j) / cg;
+            gm[j] = a.gamma[c0 + j];
+            bt[j] = a.beta[c0 + j];
+            mu[j] = a.mean_rstd[(b * a.G + g) * 2];
+            rs[j] = a.mean_rstd[(b * a.G + g) * 2 + 1];
+        }
+    }
+    const int r0 = chunk * a.rows_per_chunk;
+    const int r1 = min(r0 + a.rows_per_chunk, a.HW);
+    if (rsub < rpb) {
+        for (int r = r0 + rsub; r < r1; r += rpb) {
+            const int64_t pix = (int64_t)b * a.HW + r;
+            const f16x8 xv = gn_load(a, pix, c0);
+            if (MODE == 0) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float x = (float)xv[j];
+                    s0[j] += x;
+                    s1[j] += x * x;
+                }
+            } else {
+                const f16x8 dv = *(const f16x8*)(a.dy + pix * C + c0);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float xh = ((float)xv[j] - mu[j]) * rs[j];
+                    float dz = (float)dv[j];
+                    if (a.silu) dz *= silu_grad_f(xh * gm[j] + bt[j]);
+                    const float t = dz * gm[j];
+                    s0[j] += t;
+                    s1[j] += t * xh;
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int g = (c0 + j) / cg;
+            atomicAdd(&sacc[g * 2], s0[j]);
+            atomicAdd(&sacc[g * 2 + 1], s1[j]);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < a.G * 2; i += blockDim.x)
+        partial[((int64_t)(b * a.nchunks + chunk)) * a.G * 2 + i] = sacc[i];
+}
+
+// MODE 0: -> (mean, rstd).  MODE 1: -> (s1/n, s2/n)
+template <int MODE>
+__global__ void gn_finalize_kernel(const float* partial, float* out, int B, int G, int nchunks, float n, float eps) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * G) return;
+    const int b = i / G, g = i % G;
+    float a0 = 0.f, a1 = 0.f;
+    for (int c = 0; c < nchunks; ++c) {
+        a0 += partial[((int64_t)(b * nchunks + c) * G + g) * 2];
+        a1 += partial[((int64_t)(b * nchunks + c) * G + g) * 2 + 1];
+    }
+    if (MODE == 0) {
+        const float mean = a0 / n;
+        const float var = fmaxf(a1 / n - mean * mean, 0.f);
+        out[i * 2] = mean;
+        out[i * 2 + 1] = rsqrtf(var + eps);
+    } else {
+        out[i * 2] = a0 / n;
+        out[i * 2 + 1] = a1 / n;
+    }
+}
+
+__global__ void gn_apply_kernel(GNArgs a, f16* y) {
+    const int C = a.C1 + a.C2, V = C >> 3, cg = C / a.G;
+    const int b = blockIdx.y, chunk = blockIdx.x;
+    const int v = threadIdx.x % V, rsub = threadIdx.x / V, rpb = blockDim.x / V;
+    if (rsub >= rpb) return;
+    const int c0 = v * 8;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int g = (c0 + j) / cg;
+        const float mu = a.mean_rstd[(b * a.G + g) * 2], rs = a.mean_rstd[(b * a.G + g) * 2 + 1];
+        sc[j] = rs * a.gamma[c0 + j];
+        sh[j] = a.beta[c0 + j] - mu * sc[j];
+    }
+    const int r0 = chunk * a.rows_per_chunk;
+    const int r1 = min(r0 + a.rows_per_chunk, a.HW);
+    for (int r = r0 + rsub; r < r1; r += rpb) {
+        const int64_t pix = (int64_t)b * a.HW + r;
+        const f16x8 xv = gn_load(a, pix, c0);
+        f16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float z = (float)xv[j] * sc[j] + sh[j];
+            if (a.silu) z = silu_f(z);
+            o[j] = (f16)z;
+        }
+        *(f16x8*)(y + pix * C + c0) = o;
+    }
+}
+
+__global__ void gn_bwd_apply_kernel(GNArgs a, const float* s12, const f16* add1, const f16* add2, f16* dx1, f16* dx2) {
+    const int C = a.C1 + a.C2, V = C >> 3, cg = C / a.G;
+    const int b = blockIdx.y, chunk = blockIdx.x;
+    const int v = threadIdx.x % V, rsub = threadIdx.x / V, rpb = blockDim.x / V;
+    if (rsub >= rpb) return;
+    const int c0 = v * 8;
+    float gm[8], bt[8], mu[8], rs[8], m1[8], m2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int g = (c0 + j) / cg;
+        gm[j] = a.gamma[c0 + j];
+        bt[j] = a.beta[c0 + j];
+        mu[j] = a.mean_rstd[(b * a.G + g) * 2];
+        rs[j] = a.mean_rstd[(b * a.G + g) * 2 + 1];
+        m1[j] = s12[(b * a.G + g) * 2];
+        m2[j] = s12[(b * a.G + g) * 2 + 1];
+    }
+    const bool first = c0 < a.C1;
+    const int cc = first ? c0 : c0 - a.C1;
+    const int Cs = first ? a.C1 : a.C2;
+    f16* dxp = first ? dx1 : dx2;
+    const f16* addp = first ? add1 : add2;
+    const int r0 = chunk * a.rows_per_chunk;
+    const int r1 = min(r0 + a.rows_per_chunk, a.HW);
+    for (int r = r0 + rsub; r < r1; r += rpb) {
+        const int64_t pix = (int64_t)b * a.HW + r;
+        const f16x8 xv = gn_load(a, pix, c0);
+        const f16x8 dv = *(const f16x8*)(a.dy + pix * C + c0);
+        f16x8 av = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (addp) av = *(const f16x8*)(addp + pix * Cs + cc);
+        f16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float xh = ((float)xv[j] - mu[j]) * rs[j];
+            float dz = (float)dv[j];
+            if (a.silu) dz *= silu_grad_f(xh * gm[j] + bt[j]);
+            const float d = rs[j] * (dz * gm[j] - m1[j] - xh * m2[j]) + (float)av[j];
+            o[j] = (f16)d;
+        }
+        if (dxp) *(f16x8*)(dxp + pix * Cs + cc) = o;
+    }
+}
+
+static int gn_geometry(int C, int HW, int& threads, int& rows_per_chunk, int& nchunks) {
+    const int V = C / 8;
+    if (V > 1024) return -1;
+    const int rpb = V >= 256 ? 1 : (256 / V);
+    threads = V * rpb;
+    nchunks = HW < GN_MAX_CHUNKS * rpb ? (HW + rpb - 1) / rpb : GN_MAX_CHUNKS;
+    if (nchunks < 1) nchunks = 1;
+    rows_per_chunk = (HW + nchunks - 1) / nchunks;
+    nchunks = (HW + rows_per_chunk - 1) / rows_per_chunk;
+    return 0;
+}
+
+static int gn_check(int C1, int C2, int groups) {
+    const int C = C1 + C2;
+    if ((C1 & 7) || (C2 & 7) || C <= 0 || groups <= 0 || groups > 64 || C % groups) return -1;
+    return 0;
+}
+
+// scratch needed by stats/bwd: B * 64 * groups * 2 floats
+extern "C" int fd_groupnorm_stats(const void* x1, int C1, const void* x2, int C2, int B, int HW, int groups, float eps,
+                                  float* mean_rstd, float* scratch, void* stream) {
+    FD_REQUIRE(gn_check(C1, C2, groups) == 0, "fd_groupnorm_stats: bad channels C1=%d C2=%d groups=%d", C1, C2, groups);
+    GNArgs a = {};
+    a.x1 = (const f16*)x1; a.x2 = (const f16*)x2; a.C1 = C1; a.C2 = C2; a.B = B; a.HW = HW; a.G = groups; a.eps = eps;
+    int threads;
+    FD_REQUIRE(gn_geometry(C1 + C2, HW, threads, a.rows_per_chunk, a.nchunks) == 0, "fd_groupnorm: C too large");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(gn_reduce_kernel<0>, dim3(a.nchunks, B), dim3(threads), groups * 2 * sizeof(float), s, a, scratch);
+    const float n = (float)HW * (float)((C1 + C2) / groups);
+    hipLaunchKernelGGL(gn_finalize_kernel<0>, dim3((B * groups + 63) / 64), dim3(64), 0, s, scratch, mean_rstd, B, groups, a.nchunks, n, eps);
+    return fd_check_launch("fd_groupnorm_stats");
+}
+
+extern "C" int fd_groupnorm_apply(const void* x1, int C1, const void* x2, int C2, int B, int HW, int groups,
+                                  const float* mean_rstd, const float* gamma, const float* beta, int silu, void* y, void* stream) {
+    FD_REQUIRE(gn_check(C1, C2, groups) == 0, "fd_groupnorm_apply: bad channels");
+    GNArgs a = {};
+    a.x1 = (const f16*)x1; a.x2 = (const f16*)x2; a.C1 = C1; a.C2 = C2; a.B = B; a.HW = HW; a.G = groups;
+    a.gamma = gamma; a.beta = beta; a.mean_rstd = mean_rstd; a.silu = silu;
+    int threads;
+    FD_REQUIRE(gn_geometry(C1 + C2, HW, threads, a.rows_per_chunk, a.nchunks) == 0, "fd_groupnorm: C too large");
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(a.nchunks, B), dim3(threads), 0, (hipStream_t)stream, a, (f16*)y);
+    return fd_check_launch("fd_groupnorm_apply");
+}
+
+extern "C" int fd_groupnorm_bwd(const void* x1, int C1, const void* x2, int C2, const void* dy, int B, int HW, int groups,
+                                const float* mean_rstd, const float* gamma, const float* beta, int silu, float* scratch,
+                                const void* add1, const void* add2, void* dx1, void* dx2, void* stream) {
+    FD_REQUIRE(gn_check(C1, C2, groups) == 0, "fd_groupnorm_bwd: bad channels");
+    GNArgs a = {};
+    a.x1 = (const f16*)x1; a.x2 = (const f16*)x2; a.C1 = C1; a.C2 = C2; a.B = B; a.HW = HW; a.G = groups;
+    a.gamma = gamma; a.beta = beta; a.mean_rstd = mean_rstd; a.silu = silu; a.dy = (const f16*)dy;
+    int threads;
+    FD_REQUIRE(gn_geometry(C1 + C2, HW, threads, a.rows_per_chunk, a.nchunks) == 0, "fd_groupnorm: C too large");
+    hipStream_t s = (hipStream_t)stream;
+    float* s12 = scratch;                       // [B,G,2]
+    float* partial = scratch + (size_t)B * groups * 2;  // [B,nchunks,G,2]
+    hipLaunchKernelGGL(gn_reduce_kernel<1>, dim3(a.nchunks, B), dim3(threads), groups * 2 * sizeof(float), s, a, partial);
+    const float n = (float)HW * (float)((C1 + C2) / groups);
+    hipLaunchKernelGGL(gn_finalize_kernel<1>, dim3((B * groups + 63) / 64), dim3(64), 0, s, partial, s12, B, groups, a.nchunks, n, 0.f);
+    hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(a.nchunks, B), dim3(threads), 0, s, a, s12, (const f16*)add1, (const f16*)add2,
+                       (f16*)dx1, (f16*)dx2);
+    return fd_check_launch("fd_groupnorm_bwd");
+}
+
+// ------------------------------------------------------------------ LayerNorm: one wave per row
+template <bool BWD>
+__global__ __launch_bounds__(256) void layernorm_kernel(const f16* x, const f16* dy, const float* gamma, const float* beta,
+                                                        const f16* add, f16* out, float* mean_rstd, int M, int C, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int V = C >> 3;
+    constexpr int MAXV = 4;  // C <= 2048
+    f16x8 xv[MAXV], dv[MAXV];
+    float s0 = 0.f, s1 = 0.f;
+    if (!BWD) {
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int v = lane + i * 64;
+            if (v < V) {
+                xv[i] = *(const f16x8*)(x + (int64_t)row * C + v * 8);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) s0 += (float)xv[i][j];
+            }
+        }
+        const float mean = wave_sum(s0) / C;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int v = lane + i * 64;
+            if (v < V) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float d = (float)xv[i][j] - mean;
+                    s1 += d * d;
+                }
+            }
+        }
+        const float rstd = rsqrtf(wave_sum(s1) / C + eps);
+        if (mean_rstd && lane == 0) {
+            mean_rstd[row * 2] = mean;
+            mean_rstd[row * 2 + 1] = rstd;
+        }
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int v = lane + i * 64;
+            if (v < V) {
+                f16x8 o;
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    o[j] = (f16)(((float)xv[i][j] - mean) * rstd * gamma[v * 8 + j] + beta[v * 8 + j]);
+                *(f16x8*)(out + (int64_t)row * C + v * 8) = o;
+            }
+        }
+    } else {
+        const float mean = mean_rstd[row * 2], rstd = mean_rstd[row * 2 + 1];
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int v = lane + i * 64;
+            if (v < V) {
+                xv[i] = *(const f16x8*)(x + (int64_t)row * C + v * 8);
+                dv[i] = *(const f16x8*)(dy + (int64_t)row * C + v * 8);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float t = (float)dv[i][j] * gamma[v * 8 + j];
+                    s0 += t;
+                    s1 += t * ((float)xv[i][j] - mean) * rstd;
+                }
+            }
+        }
+        const float m1 = wave_sum(s0) / C, m2 = wave_sum(s1) / C;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int v = lane + i * 64;
+            if (v < V) {
+                f16x8 av = {0, 0, 0, 0, 0, 0, 0, 0};
+                if (add) av = *(const f16x8*)(add + (int64_t)row * C + v * 8);
+                f16x8 o;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float xh = ((float)xv[i][j] - mean) * rstd;
+                    const float t = (float)dv[i][j] * gamma[v * 8 + j];
+                    o[j] = (f16)(rstd * (t - m1 - xh * m2) + (float)av[j]);
+                }
+                *(f16x8*)(out + (int64_t)row * C + v * 8) = o;
+            }
+        }
+    }
+}
+
+extern "C" int fd_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean_rstd, int M, int C,
+                                float eps, void* stream) {
+    FD_REQUIRE((C & 7) == 0 && C <= 2048 && M > 0, "fd_layernorm_fwd: C=%d must be a multiple of 8 and <= 2048", C);
+    hipLaunchKernelGGL(layernorm_kernel<false>, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const f16*)x, (const f16*)nullptr,
+                       gamma, beta, (const f16*)nullptr, (f16*)y, mean_rstd, M, C, eps);
+    return fd_check_launch("fd_layernorm_fwd");
+}
+
+extern "C" int fd_layernorm_bwd(const void* x, const void* dy, const float* gamma, const float* mean_rstd, const void* add, void* dx,
+                                int M, int C, void* stream) {
+    FD_REQUIRE((C & 7) == 0 && C <= 2048 && M > 0 && mean_rstd, "fd_layernorm_bwd: bad args");
+    hipLaunchKernelGGL(layernorm_kernel<true>, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const f16*)x, (const f16*)dy, gamma,
+                       (const float*)nullptr, (const f16*)add, (f16*)dx, (float*)mean_rstd, M, C, 0.f);
+    return fd_check_launch("fd_layernorm_bwd");
+}

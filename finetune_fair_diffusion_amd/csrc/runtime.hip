@@ -1,0 +1,25 @@
+// Error plumbing shared by every entry point of libfairdiff_hip.so.
+#include "common.h"
+#include <stdarg.h>
+#include <stdio.h>
+
+static thread_local char g_err[512] = "";
+
+void fd_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int fd_check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        fd_set_error("%s: launch failed: %s", what, hipGetErrorString(e));
+        return FD_ERR_LAUNCH;
+    }
+    return FD_OK;
+}
+
+extern "C" const char* fd_last_error(void) { return g_err; }
+extern "C" int fd_version(void) { return 1; }

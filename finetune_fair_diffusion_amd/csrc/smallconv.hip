@@ -1,0 +1,310 @@
+// Direct (VALU) kernels for the thin ends of the path: tiny-channel convolutions (latent/pixel
+// side of the U-Net and VAE, classifier stem), depthwise convolutions + squeeze-excite pieces of the
+// MobileNetV3 face-attribute classifier, and the differentiable crop+bilinear-resize of the face chip.
+#include "common.h"
+
+static inline dim3 grid1d(int64_t n, int threads = 256) {
+    int64_t b = (n + threads - 1) / threads;
+    if (b > 65535) b = 65535;
+    if (b < 1) b = 1;
+    return dim3((unsigned)b);
+}
+
+// ------------------------------------------------------------------ conv with tiny Cin (<= 8), k in {1,3}, pad (k-1)/2
+// x: [B,Cin,H,W] (nchw) or [B,H,W,Cin]; fp32 or fp16.  w: fp32 [k*k*Cin][Cout].  y: fp16 [B,Ho,Wo,Cout]
+template <typename XT>
+__global__ void conv_small_cin_kernel(const XT* x, int nchw, const float* w, const float* bias, f16* y, int B, int H, int W, int Cin, int Cout,
+                                      int k, int stride, int Ho, int Wo, int act) {
+    const int64_t n = (int64_t)B * Ho * Wo * Cout;
+    const int pad = (k - 1) / 2;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int co = (int)(i % Cout);
+        int64_t p = i / Cout;
+        const int ox = (int)(p % Wo); p /= Wo;
+        const int oy = (int)(p % Ho);
+        const int b = (int)(p / Ho);
+        float acc = bias ? bias[co] : 0.f;
+        for (int ky = 0; ky < k; ++ky) {
+            const int iy = oy * stride + ky - pad;
+            if (iy < 0 || iy >= H) continue;
+            for (int kx = 0; kx < k; ++kx) {
+                const int ix = ox * stride + kx - pad;
+                if (ix < 0 || ix >= W) continue;
+                for (int ci = 0; ci < Cin; ++ci) {
+                    const float xv = nchw ? (float)x[(((int64_t)b * Cin + ci) * H + iy) * W + ix] : (float)x[(((int64_t)b * H + iy) * W + ix) * Cin + ci];
+                    acc += xv * w[((ky * k + kx) * Cin + ci) * Cout + co];
+                }
+            }
+        }
+        y[i] = (f16)apply_act(acc, act);
+    }
+}
+extern "C" int fd_conv_small_cin(const void* x, int x_is_f32, int nchw, const float* w, const float* bias, void* y, int B, int H, int W, int Cin,
+                                 int Cout, int ksize, int stride, int act, void* stream) {
+    FD_REQUIRE(Cin >= 1 && Cin <= 8 && (ksize == 1 || ksize == 3) && (stride == 1 || stride == 2), "fd_conv_small_cin: Cin<=8, k in {1,3}");
+    const int pad = (ksize - 1) / 2;
+    const int Ho = (H + 2 * pad - ksize) / stride + 1, Wo = (W + 2 * pad - ksize) / stride + 1;
+    const int64_t n = (int64_t)B * Ho * Wo * Cout;
+    if (x_is_f32)
+        hipLaunchKernelGGL(conv_small_cin_kernel<float>, grid1d(n), dim3(256), 0, (hipStream_t)stream, (const float*)x, nchw, w, bias, (f16*)y, B, H,
+                           W, Cin, Cout, ksize, stride, Ho, Wo, act);
+    else
+        hipLaunchKernelGGL(conv_small_cin_kernel<f16>, grid1d(n), dim3(256), 0, (hipStream_t)stream, (const f16*)x, nchw, w, bias, (f16*)y, B, H, W,
+                           Cin, Cout, ksize, stride, Ho, Wo, act);
+    return fd_check_launch("fd_conv_small_cin");
+}
+
+// data gradient of the above: dx[B,Cin,H,W] fp32 NCHW (overwritten) from dy [B,Ho,Wo,Cout] fp16
+__global__ void conv_small_cin_bwd_kernel(const f16* dy, const float* w, float* dx, int B, int H, int W, int Cin, int Cout, int k, int stride,
+                                          int Ho, int Wo, float scale) {
+    const int64_t n = (int64_t)B * H * W;
+    const int pad = (k - 1) / 2;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int xx = (int)(i % W);
+        int64_t p = i / W;
+        const int yy = (int)(p % H);
+        const int b = (int)(p / H);
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int ky = 0; ky < k; ++ky) {
+            const int ty = yy + pad - ky;
+            if (ty < 0 || ty % stride) continue;
+            const int oy = ty / stride;
+            if (oy >= Ho) continue;
+            for (int kx = 0; kx < k; ++kx) {
+                const int tx = xx + pad - kx;
+                if (tx < 0 || tx % stride) continue;
+                const int ox = tx / stride;
+                if (ox >= Wo) continue;
+                const f16* g = dy + (((int64_t)b * Ho + oy) * Wo + ox) * Cout;
+                for (int co = 0; co < Cout; ++co) {
+                    const float gv = (float)g[co];
+                    for (int ci = 0; ci < Cin; ++ci) acc[ci] += gv * w[((ky * k + kx) * Cin + ci) * Cout + co];
+                }
+            }
+        }
+        for (int ci = 0; ci < Cin; ++ci) dx[(((int64_t)b * Cin + ci) * H + yy) * W + xx] = acc[ci] * scale;
+    }
+}
+extern "C" int fd_conv_small_cin_bwd(const void* dy, const float* w, float* dx, int B, int H, int W, int Cin, int Cout, int ksize, int stride,
+                                     float scale, void* stream) {
+    FD_REQUIRE(Cin >= 1 && Cin <= 8 && (ksize == 1 || ksize == 3) && (stride == 1 || stride == 2), "fd_conv_small_cin_bwd: Cin<=8, k in {1,3}");
+    const int pad = (ksize - 1) / 2;
+    const int Ho = (H + 2 * pad - ksize) / stride + 1, Wo = (W + 2 * pad - ksize) / stride + 1;
+    hipLaunchKernelGGL(conv_small_cin_bwd_kernel, grid1d((int64_t)B * H * W), dim3(256), 0, (hipStream_t)stream, (const f16*)dy, w, dx, B, H, W, Cin,
+                       Cout, ksize, stride, Ho, Wo, scale);
+    return fd_check_launch("fd_conv_small_cin_bwd");
+}
+
+// ------------------------------------------------------------------ depthwise conv (channels-last, 8 channels per thread)
+// x [B,H,W,C] fp16, w fp32 [k*k][C], bias fp32 [C] -> y [B,Ho,Wo,C]; pad (k-1)/2
+__global__ void dwconv_fwd_kernel(const f16* x, const float* w, const float* bias, f16* y, int B, int H, int W, int C, int k, int stride, int Ho,
+                                  int Wo, int act) {
+    const int CV = C >> 3;
+    const int64_t n = (int64_t)B * Ho * Wo * CV;
+    const int pad = (k - 1) / 2;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % CV) * 8;
+        int64_t p = i / CV;
+        const int ox = (int)(p % Wo); p /= Wo;
+        const int oy = (int)(p % Ho);
+        const int b = (int)(p / Ho);
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = bias ? bias[c + j] : 0.f;
+        for (int ky = 0; ky < k; ++ky) {
+            const int iy = oy * stride + ky - pad;
+            if (iy < 0 || iy >= H) continue;
+            for (int kx = 0; kx < k; ++kx) {
+                const int ix = ox * stride + kx - pad;
+                if (ix < 0 || ix >= W) continue;
+                const f16x8 xv = *(const f16x8*)(x + (((int64_t)b * H + iy) * W + ix) * C + c);
+                const float* wp = w + (ky * k + kx) * C + c;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] += (float)xv[j] * wp[j];
+            }
+        }
+        f16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (f16)apply_act(acc[j], act);
+        *(f16x8*)(y + i * 8) = o;
+    }
+}
+__global__ void dwconv_bwd_kernel(const f16* dy, const float* w, f16* dx, int B, int H, int W, int C, int k, int stride, int Ho, int Wo) {
+    const int CV = C >> 3;
+    const int64_t n = (int64_t)B * H * W * CV;
+    const int pad = (k - 1) / 2;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % CV) * 8;
+        int64_t p = i / CV;
+        const int xx = (int)(p % W); p /= W;
+        const int yy = (int)(p % H);
+        const int b = (int)(p / H);
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int ky = 0; ky < k; ++ky) {
+            const int ty = yy + pad - ky;
+            if (ty < 0 || ty % stride) continue;
+            const int oy = ty / stride;
+            if (oy >= Ho) continue;
+            for (int kx = 0; kx < k; ++kx) {
+                const int tx = xx + pad - kx;
+                if (tx < 0 || tx % stride) continue;
+                const int ox = tx / stride;
+                if (ox >= Wo) continue;
+                const f16x8 g = *(const f16x8*)(dy + (((int64_t)b * Ho + oy) * Wo + ox) * C + c);
+                const float* wp = w + (ky * k + kx) * C + c;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] += (float)g[j] * wp[j];
+            }
+        }
+        f16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (f16)acc[j];
+        *(f16x8*)(dx + i * 8) = o;
+    }
+}
+extern "C" int fd_dwconv_fwd(const void* x, const float* w, const float* bias, void* y, int B, int H, int W, int C, int k, int stride, int act,
+                             void* stream) {
+    FD_REQUIRE((C & 7) == 0 && (k == 3 || k == 5) && (stride == 1 || stride == 2), "fd_dwconv_fwd: C%%8, k in {3,5}");
+    const int pad = (k - 1) / 2, Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
+    hipLaunchKernelGGL(dwconv_fwd_kernel, grid1d((int64_t)B * Ho * Wo * (C / 8)), dim3(256), 0, (hipStream_t)stream, (const f16*)x, w, bias, (f16*)y,
+                       B, H, W, C, k, stride, Ho, Wo, act);
+    return fd_check_launch("fd_dwconv_fwd");
+}
+extern "C" int fd_dwconv_bwd(const void* dy, const float* w, void* dx, int B, int H, int W, int C, int k, int stride, void* stream) {
+    FD_REQUIRE((C & 7) == 0 && (k == 3 || k == 5) && (stride == 1 || stride == 2), "fd_dwconv_bwd: C%%8, k in {3,5}");
+    const int pad = (k - 1) / 2, Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
+    hipLaunchKernelGGL(dwconv_bwd_kernel, grid1d((int64_t)B * H * W * (C / 8)), dim3(256), 0, (hipStream_t)stream, (const f16*)dy, w, (f16*)dx, B, H,
+                       W, C, k, stride, Ho, Wo);
+    return fd_check_launch("fd_dwconv_bwd");
+}
+
+// ------------------------------------------------------------------ global average pool over HW and its backward; SE channel scaling
+__global__ void avgpool_kernel(const f16* x, f16* y, int HW, int C) {  // grid (C/64.., B), block 256 = 64 ch x 4 row-groups
+    __shared__ float red[4][64];
+    const int b = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
+    float s = 0.f;
+    if (c < C)
+        for (int r = rg; r < HW; r += 4) s += (float)x[((int64_t)b * HW + r) * C + c];
+    red[rg][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (rg == 0 && c < C) y[(int64_t)b * C + c] = (f16)((red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]) / HW);
+}
+__global__ void avgpool_bwd_kernel(const f16* dy, const f16* add, f16* dx, int HW, int C, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const int64_t b = i / ((int64_t)HW * C);
+        dx[i] = (f16)((float)dy[b * C + c] / HW + (add ? (float)add[i] : 0.f));
+    }
+}
+__global__ void scale_channels_kernel(const f16* x, const f16* s, f16* y, int HW, int C, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const int64_t b = i / ((int64_t)HW * C);
+        y[i] = (f16)((float)x[i] * (float)s[b * C + c]);
+    }
+}
+// dx = dy * s ; ds[b,c] = sum_hw dy * x
+__global__ void scale_channels_bwd_kernel(const f16* x, const f16* s, const f16* dy, f16* dx, f16* ds, int HW, int C) {
+    __shared__ float red[4][64];
+    const int b = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
+    float acc = 0.f;
+    if (c < C) {
+        const float sv = (float)s[(int64_t)b * C + c];
+        for (int r = rg; r < HW; r += 4) {
+            const int64_t i = ((int64_t)b * HW + r) * C + c;
+            const float g = (float)dy[i];
+            acc += g * (float)x[i];
+            dx[i] = (f16)(g * sv);
+        }
+    }
+    red[rg][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (rg == 0 && c < C) ds[(int64_t)b * C + c] = (f16)(red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+extern "C" int fd_avgpool_hw(const void* x, void* y, int B, int HW, int C, void* stream) {
+    hipLaunchKernelGGL(avgpool_kernel, dim3((C + 63) / 64, B), dim3(256), 0, (hipStream_t)stream, (const f16*)x, (f16*)y, HW, C);
+    return fd_check_launch("fd_avgpool_hw");
+}
+extern "C" int fd_avgpool_hw_bwd(const void* dy, const void* add, void* dx, int B, int HW, int C, void* stream) {
+    const int64_t n = (int64_t)B * HW * C;
+    hipLaunchKernelGGL(avgpool_bwd_kernel, grid1d(n), dim3(256), 0, (hipStream_t)stream, (const f16*)dy, (const f16*)add, (f16*)dx, HW, C, n);
+    return fd_check_launch("fd_avgpool_hw_bwd");
+}
+extern "C" int fd_scale_channels(const void* x, const void* s, void* y, int B, int HW, int C, void* stream) {
+    const int64_t n = (int64_t)B * HW * C;
+    hipLaunchKernelGGL(scale_channels_kernel, grid1d(n), dim3(256), 0, (hipStream_t)stream, (const f16*)x, (const f16*)s, (f16*)y, HW, C, n);
+    return fd_check_launch("fd_scale_channels");
+}
+extern "C" int fd_scale_channels_bwd(const void* x, const void* s, const void* dy, void* dx, void* ds, int B, int HW, int C, void* stream) {
+    hipLaunchKernelGGL(scale_channels_bwd_kernel, dim3((C + 63) / 64, B), dim3(256), 0, (hipStream_t)stream, (const f16*)x, (const f16*)s,
+                       (const f16*)dy, (f16*)dx, (f16*)ds, HW, C);
+    return fd_check_launch("fd_scale_channels_bwd");
+}
+
+// ------------------------------------------------------------------ crop [x0,y0,x1,y1) + constant pad + bilinear resize to SxS
+// (torchvision Pad + Resize on tensors: align_corners=False, no antialias; 1-main-debias.py:267-290)
+__device__ __forceinline__ void bilinear_src(int o, int in_size, int out_size, int& i0, int& i1, float& lam) {
+    float src = ((float)o + 0.5f) * ((float)in_size / (float)out_size) - 0.5f;
+    if (src < 0.f) src = 0.f;
+    i0 = (int)src;
+    if (i0 > in_size - 1) i0 = in_size - 1;
+    i1 = i0 + (i0 < in_size - 1 ? 1 : 0);
+    lam = src - (float)i0;
+}
+// img [B,3,H,W] fp16 -> chips [B,3,S,S] fp16
+__global__ void crop_resize_fwd_kernel(const f16* img, const int32_t* boxes, float fill, f16* chips, int H, int W, int S, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int ox = (int)(i % S);
+        int64_t p = i / S;
+        const int oy = (int)(p % S); p /= S;
+        const int c = (int)(p % 3);
+        const int b = (int)(p / 3);
+        const int x0 = boxes[b * 4], y0 = boxes[b * 4 + 1], x1 = boxes[b * 4 + 2], y1 = boxes[b * 4 + 3];
+        int ya, yb, xa, xb;
+        float ly, lx;
+        bilinear_src(oy, y1 - y0, S, ya, yb, ly);
+        bilinear_src(ox, x1 - x0, S, xa, xb, lx);
+        const f16* ip = img + ((int64_t)b * 3 + c) * H * W;
+        auto at = [&](int py, int px) -> float {
+            const int yy = y0 + py, xx = x0 + px;
+            return (yy >= 0 && yy < H && xx >= 0 && xx < W) ? (float)ip[(int64_t)yy * W + xx] : fill;
+        };
+        const float v = (1.f - ly) * ((1.f - lx) * at(ya, xa) + lx * at(ya, xb)) + ly * ((1.f - lx) * at(yb, xa) + lx * at(yb, xb));
+        chips[i] = (f16)v;
+    }
+}
+// dchips [B,3,S,S] fp32 -> dimg [B,3,H,W] fp32 (atomically accumulated; caller zeroes dimg)
+__global__ void crop_resize_bwd_kernel(const float* dchips, const int32_t* boxes, float* dimg, int H, int W, int S, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int ox = (int)(i % S);
+        int64_t p = i / S;
+        const int oy = (int)(p % S); p /= S;
+        const int c = (int)(p % 3);
+        const int b = (int)(p / 3);
+        const int x0 = boxes[b * 4], y0 = boxes[b * 4 + 1], x1 = boxes[b * 4 + 2], y1 = boxes[b * 4 + 3];
+        int ya, yb, xa, xb;
+        float ly, lx;
+        bilinear_src(oy, y1 - y0, S, ya, yb, ly);
+        bilinear_src(ox, x1 - x0, S, xa, xb, lx);
+        float* ip = dimg + ((int64_t)b * 3 + c) * H * W;
+        const float g = dchips[i];
+        auto put = [&](int py, int px, float wgt) {
+            const int yy = y0 + py, xx = x0 + px;
+            if (yy >= 0 && yy < H && xx >= 0 && xx < W) atomicAdd(ip + (int64_t)yy * W + xx, g * wgt);
+        };
+        put(ya, xa, (1.f - ly) * (1.f - lx));
+        put(ya, xb, (1.f - ly) * lx);
+        put(yb, xa, ly * (1.f - lx));
+        put(yb, xb, ly * lx);
+    }
+}
+extern "C" int fd_crop_resize_fwd(const void* img, const int32_t* boxes, float fill, void* chips, int B, int H, int W, int S, void* stream) {
+    const int64_t n = (int64_t)B * 3 * S * S;
+    hipLaunchKernelGGL(crop_resize_fwd_kernel, grid1d(n), dim3(256), 0, (hipStream_t)stream, (const f16*)img, boxes, fill, (f16*)chips, H, W, S, n);
+    return fd_check_launch("fd_crop_resize_fwd");
+}
+extern "C" int fd_crop_resize_bwd(const float* dchips, const int32_t* boxes, float* dimg, int B, int H, int W, int S, void* stream) {
+    const int64_t n = (int64_t)B * 3 * S * S;
+    hipLaunchKernelGGL(crop_resize_bwd_kernel, grid1d(n), dim3(256), 0, (hipStream_t)stream, dchips, boxes, dimg, H, W, S, n);
+    return fd_check_launch("fd_crop_resize_bwd");
+}

@@ -1,0 +1,81 @@
+"""ctypes loader for libfairdiff_hip.so (the C-ABI in include/fairdiff_hip.h).
+
+The product path has NO fallback: if the shared library is missing this module raises,
+and every op in ``ops.py`` raises on a non-zero return code.  Prototypes (argtypes) are
+derived from the public header so the Python side cannot drift from the C-ABI.
+"""
+import ctypes
+import os
+import re
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfairdiff_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "fairdiff_hip.h")
+
+
+class GemmDesc(ctypes.Structure):
+    """Mirror of ``fd_gemm_desc`` (include/fairdiff_hip.h)."""
+    _fields_ = [
+        ("A", ctypes.c_void_p), ("lda", ctypes.c_int64),
+        ("B", ctypes.c_void_p), ("ldb", ctypes.c_int64),
+        ("A2", ctypes.c_void_p), ("lda2", ctypes.c_int64),
+        ("B2", ctypes.c_void_p), ("ldb2", ctypes.c_int64),
+        ("C", ctypes.c_void_p), ("ldc", ctypes.c_int64),
+        ("bias", ctypes.c_void_p),
+        ("rowbias", ctypes.c_void_p), ("ld_rowbias", ctypes.c_int64), ("rows_per_batch", ctypes.c_int32),
+        ("residual", ctypes.c_void_p), ("ldr", ctypes.c_int64),
+        ("alpha", ctypes.c_float),
+        ("M", ctypes.c_int32), ("N", ctypes.c_int32), ("K", ctypes.c_int32), ("K2", ctypes.c_int32),
+        ("act", ctypes.c_int32), ("out_dtype", ctypes.c_int32),
+        ("batch", ctypes.c_int32), ("sA", ctypes.c_int64), ("sB", ctypes.c_int64), ("sC", ctypes.c_int64), ("sR", ctypes.c_int64),
+        ("conv", ctypes.c_int32), ("conv_mode", ctypes.c_int32), ("Bn", ctypes.c_int32), ("H", ctypes.c_int32),
+        ("W", ctypes.c_int32), ("Cin", ctypes.c_int32), ("Ho", ctypes.c_int32), ("Wo", ctypes.c_int32),
+    ]
+
+
+_CTYPE = {"int": ctypes.c_int, "int32_t": ctypes.c_int32, "int64_t": ctypes.c_int64, "float": ctypes.c_float}
+
+
+def parse_header(path=HEADER_PATH):
+    """Return {name: (restype, [argtypes])} for every ``int fd_*(...)`` / ``const char* fd_*`` prototype."""
+    src = open(path).read()
+    src = re.sub(r"/\*.*?\*/", " ", src, flags=re.S)
+    protos = {}
+    for m in re.finditer(r"\b(int|const char\*)\s+(fd_\w+)\s*\(([^;{}]*?)\)\s*;", src, flags=re.S):
+        ret, name, args = m.group(1), m.group(2), m.group(3).strip()
+        argtypes = []
+        if args and args != "void":
+            for a in args.split(","):
+                a = " ".join(a.split())
+                if "fd_gemm_desc" in a:
+                    argtypes.append(ctypes.POINTER(GemmDesc))
+                elif "*" in a:
+                    argtypes.append(ctypes.c_void_p)
+                else:
+                    toks = a.replace("const ", "").split()
+                    argtypes.append(_CTYPE[toks[0]])
+        protos[name] = (ctypes.c_char_p if ret != "int" else ctypes.c_int, argtypes)
+    return protos
+
+
+def load():
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: the HIP extension is required (no fallback path). "
+            "Build it with `python -c 'import __graft_entry__ as g; g.build()'` or `make -C finetune_fair_diffusion_amd/csrc`.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (ret, argtypes) in parse_header().items():
+        fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
+        fn.restype = ret
+        fn.argtypes = argtypes
+    return lib
+
+
+_lib = None
+
+
+def get():
+    global _lib
+    if _lib is None:
+        _lib = load()
+    return _lib

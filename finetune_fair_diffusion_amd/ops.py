@@ -1,0 +1,384 @@
+"""Python wrappers over the C-ABI (include/fairdiff_hip.h): torch tensors in, raw device
+pointers + the current HIP stream out.  torch is plumbing here (device memory, streams);
+every op fails loudly if the HIP library is missing or a kernel reports an error.
+"""
+import ctypes
+import math
+
+import torch
+
+from . import lib as _lib
+
+ACT = dict(none=0, silu=1, quick_gelu=2, gelu=3, relu=4, hardswish=5, hardsigmoid=6)
+CONV_NORMAL, CONV_STRIDE2, CONV_UP2, CONV_TRANS2 = 0, 1, 2, 3
+F16, F32 = torch.float16, torch.float32
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    if t is None:
+        return None
+    assert t.is_cuda, "fairdiff ops need device tensors (no CPU path)"
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _call(name, *args):
+    L = _lib.get()
+    rc = getattr(L, name)(*args)
+    if rc != 0:
+        raise RuntimeError(f"{name} failed ({rc}): {L.fd_last_error().decode()}")
+
+
+def _chk(t, dtype=F16):
+    assert t.dtype == dtype and t.is_contiguous(), (t.dtype, t.shape, t.stride())
+    return t
+
+
+# ----------------------------------------------------------------------------- GEMM / conv
+def gemm(a, b, *, a2=None, b2=None, bias=None, rowbias=None, rows_per_batch=0, residual=None, act="none", alpha=1.0,
+         out=None, out_dtype=F16, n=None):
+    """C[M,N] = act(alpha*(a.b^T + a2.b2^T) + bias + rowbias) + residual.  a:[M,K] (row stride free), b:[N,K]."""
+    M, K = a.shape
+    N = b.shape[0] if n is None else n
+    assert b.shape[1] == K and a.stride(1) == 1 and b.stride(1) == 1
+    if out is None:
+        out = torch.empty((M, N), dtype=out_dtype, device=a.device)
+    d = _lib.GemmDesc()
+    d.A, d.lda, d.B, d.ldb = a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0)
+    if a2 is not None:
+        assert a2.shape[0] == M and a2.shape[1] == b2.shape[1] and a2.stride(1) == 1 and b2.stride(1) == 1
+        d.A2, d.lda2, d.B2, d.ldb2, d.K2 = a2.data_ptr(), a2.stride(0), b2.data_ptr(), b2.stride(0), a2.shape[1]
+    d.C, d.ldc = out.data_ptr(), out.stride(0)
+    if bias is not None:
+        d.bias = _chk(bias, F32).data_ptr()
+    if rowbias is not None:
+        d.rowbias, d.ld_rowbias, d.rows_per_batch = _chk(rowbias).data_ptr(), rowbias.stride(0), rows_per_batch
+    if residual is not None:
+        assert residual.dtype == F16 and residual.stride(1) == 1
+        d.residual, d.ldr = residual.data_ptr(), residual.stride(0)
+    d.alpha, d.M, d.N, d.K = alpha, M, N, K
+    d.act, d.out_dtype, d.batch = ACT[act], 1 if out.dtype == F32 else 0, 1
+    _call("fd_gemm", ctypes.byref(d), _stream())
+    return out
+
+
+def bgemm(a, b, *, alpha=1.0, out=None):
+    """Strided-batch C[z] = alpha * a[z] . b[z]^T ; a:[Z,M,K], b:[Z,N,K] contiguous fp16."""
+    Z, M, K = a.shape
+    N = b.shape[1]
+    _chk(a), _chk(b)
+    if out is None:
+        out = torch.empty((Z, M, N), dtype=F16, device=a.device)
+    d = _lib.GemmDesc()
+    d.A, d.lda, d.B, d.ldb, d.C, d.ldc = a.data_ptr(), K, b.data_ptr(), K, out.data_ptr(), N
+    d.alpha, d.M, d.N, d.K, d.batch = alpha, M, N, K, Z
+    d.sA, d.sB, d.sC = M * K, N * K, M * N
+    _call("fd_gemm", ctypes.byref(d), _stream())
+    return out
+
+
+def conv3x3(x, w, B, H, W, *, mode=CONV_NORMAL, bias=None, rowbias=None, residual=None, act="none", out=None):
+    """Implicit-GEMM 3x3 conv (pad 1).  x: [B*H*W, Cin] channels-last fp16, w: [Cout, 9*Cin] (ky,kx,ci order).
+    Returns ([B*Ho*Wo, Cout], Ho, Wo)."""
+    Cin = x.shape[1]
+    Cout = w.shape[0]
+    assert w.shape[1] == 9 * Cin and x.shape[0] == B * H * W
+    _chk(x), _chk(w)
+    if mode == CONV_NORMAL:
+        Ho, Wo = H, W
+    elif mode == CONV_STRIDE2:
+        Ho, Wo = (H + 1) // 2, (W + 1) // 2
+    else:
+        Ho, Wo = 2 * H, 2 * W
+    M = B * Ho * Wo
+    if out is None:
+        out = torch.empty((M, Cout), dtype=F16, device=x.device)
+    d = _lib.GemmDesc()
+    d.A, d.lda, d.B, d.ldb, d.C, d.ldc = x.data_ptr(), Cin, w.data_ptr(), 9 * Cin, out.data_ptr(), out.stride(0)
+    if bias is not None:
+        d.bias = _chk(bias, F32).data_ptr()
+    if rowbias is not None:
+        d.rowbias, d.ld_rowbias, d.rows_per_batch = _chk(rowbias).data_ptr(), rowbias.stride(0), Ho * Wo
+    if residual is not None:
+        d.residual, d.ldr = _chk(residual).data_ptr(), residual.stride(0)
+    d.alpha, d.M, d.N, d.K, d.act, d.batch = 1.0, M, Cout, 9 * Cin, ACT[act], 1
+    d.out_dtype = 1 if out.dtype == F32 else 0
+    d.conv, d.conv_mode, d.Bn, d.H, d.W, d.Cin, d.Ho, d.Wo = 1, mode, B, H, W, Cin, Ho, Wo
+    _call("fd_gemm", ctypes.byref(d), _stream())
+    return out, Ho, Wo
+
+
+def conv_small_cin(x, w, bias, B, H, W, Cin, Cout, k, stride=1, nchw=True, act="none"):
+    pad = (k - 1) // 2
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    y = torch.empty((B * Ho * Wo, Cout), dtype=F16, device=x.device)
+    assert x.is_contiguous() and x.dtype in (F16, F32)
+    _call("fd_conv_small_cin", _p(x), int(x.dtype == F32), int(nchw), _p(_chk(w, F32)), _p(bias), _p(y), B, H, W, Cin, Cout, k, stride,
+          ACT[act], _stream())
+    return y, Ho, Wo
+
+
+def conv_small_cin_bwd(dy, w, B, H, W, Cin, Cout, k, stride=1, scale=1.0):
+    dx = torch.empty((B, Cin, H, W), dtype=F32, device=dy.device)
+    _call("fd_conv_small_cin_bwd", _p(_chk(dy)), _p(_chk(w, F32)), _p(dx), B, H, W, Cin, Cout, k, stride, scale, _stream())
+    return dx
+
+
+def nhwc_to_nchw(x, B, HW, C, *, out_dtype=F32, scale=1.0, lo=-math.inf, hi=math.inf):
+    y = torch.empty((B, C, HW), dtype=out_dtype, device=x.device)
+    _call("fd_nhwc_to_nchw", _p(x), x.stride(0), _p(y), int(out_dtype == F32), B, HW, C, scale, lo, hi, _stream())
+    return y
+
+
+def clamp_bwd(pre, dimg, B, HW, C, lo=-1.0, hi=1.0):
+    out = torch.empty_like(dimg)
+    _call("fd_clamp_bwd", _p(pre), pre.stride(0), _p(_chk(dimg, F32)), _p(out), B, HW, C, lo, hi, _stream())
+    return out
+
+
+# ----------------------------------------------------------------------------- norms
+_scratch = {}
+
+
+def scratch(nfloats, device):
+    key = (device.index if device.index is not None else torch.cuda.current_device())
+    t = _scratch.get(key)
+    if t is None or t.numel() < nfloats:
+        t = torch.empty(max(nfloats, 1 << 22), dtype=F32, device=device)
+        _scratch[key] = t
+    return t
+
+
+def groupnorm_stats(x1, x2, B, HW, groups, eps):
+    C1, C2 = x1.shape[1], (x2.shape[1] if x2 is not None else 0)
+    st = torch.empty((B, groups, 2), dtype=F32, device=x1.device)
+    sc = scratch(B * 64 * groups * 2, x1.device)
+    _call("fd_groupnorm_stats", _p(_chk(x1)), C1, _p(x2), C2, B, HW, groups, eps, _p(st), _p(sc), _stream())
+    return st
+
+
+def groupnorm_apply(x1, x2, B, HW, groups, stats, gamma, beta, silu):
+    C1, C2 = x1.shape[1], (x2.shape[1] if x2 is not None else 0)
+    y = torch.empty((B * HW, C1 + C2), dtype=F16, device=x1.device)
+    _call("fd_groupnorm_apply", _p(x1), C1, _p(x2), C2, B, HW, groups, _p(stats), _p(gamma), _p(beta), int(silu), _p(y), _stream())
+    return y
+
+
+def groupnorm(x1, x2, B, HW, groups, eps, gamma, beta, silu):
+    st = groupnorm_stats(x1, x2, B, HW, groups, eps)
+    return groupnorm_apply(x1, x2, B, HW, groups, st, gamma, beta, silu), st
+
+
+def groupnorm_bwd(x1, x2, dy, B, HW, groups, stats, gamma, beta, silu, add1=None, add2=None, need_dx2=True):
+    C1, C2 = x1.shape[1], (x2.shape[1] if x2 is not None else 0)
+    dx1 = torch.empty_like(x1)
+    dx2 = torch.empty_like(x2) if (x2 is not None and need_dx2) else None
+    sc = scratch(B * 65 * groups * 2, x1.device)
+    _call("fd_groupnorm_bwd", _p(x1), C1, _p(x2), C2, _p(_chk(dy)), B, HW, groups, _p(stats), _p(gamma), _p(beta), int(silu), _p(sc),
+          _p(add1), _p(add2), _p(dx1), _p(dx2), _stream())
+    return dx1, dx2
+
+
+def layernorm(x, gamma, beta, eps=1e-5, save_stats=False):
+    M, C = x.shape
+    y = torch.empty_like(x)
+    st = torch.empty((M, 2), dtype=F32, device=x.device) if save_stats else None
+    _call("fd_layernorm_fwd", _p(_chk(x)), _p(gamma), _p(beta), _p(y), _p(st), M, C, eps, _stream())
+    return (y, st) if save_stats else y
+
+
+def layernorm_bwd(x, dy, gamma, stats, add=None):
+    M, C = x.shape
+    dx = torch.empty_like(x)
+    _call("fd_layernorm_bwd", _p(_chk(x)), _p(_chk(dy)), _p(gamma), _p(stats), _p(add), _p(dx), M, C, _stream())
+    return dx
+
+
+# ----------------------------------------------------------------------------- elementwise
+def geglu(proj):
+    M, F2 = proj.shape
+    y = torch.empty((M, F2 // 2), dtype=F16, device=proj.device)
+    _call("fd_geglu_fwd", _p(_chk(proj)), _p(y), M, F2 // 2, _stream())
+    return y
+
+
+def geglu_bwd(proj, dy):
+    M, F2 = proj.shape
+    d = torch.empty_like(proj)
+    _call("fd_geglu_bwd", _p(proj), _p(_chk(dy)), _p(d), M, F2 // 2, _stream())
+    return d
+
+
+def act_fwd(x, act):
+    y = torch.empty_like(x)
+    _call("fd_act_fwd", _p(_chk(x)), _p(y), x.numel(), ACT[act], _stream())
+    return y
+
+
+def act_bwd(z, dy, act):
+    dx = torch.empty_like(z)
+    _call("fd_act_bwd", _p(_chk(z)), _p(_chk(dy)), _p(dx), z.numel(), ACT[act], _stream())
+    return dx
+
+
+def add(a, b, sa=1.0, sb=1.0, out=None):
+    if out is None:
+        out = torch.empty_like(a)
+    _call("fd_add", _p(_chk(a)), _p(b), _p(out), a.numel(), sa, sb, _stream())
+    return out
+
+
+def copy_cols(src, dst, cols):
+    _call("fd_copy_cols", _p(src), src.stride(0), _p(dst), dst.stride(0), src.shape[0], cols, _stream())
+
+
+def transpose_btc(x, B, T, C, Tp=None):
+    Tp = Tp or ((T + 7) // 8 * 8)
+    y = torch.empty((B, C, Tp), dtype=F16, device=x.device)
+    _call("fd_transpose_btc", _p(_chk(x)), _p(y), B, T, C, Tp, _stream())
+    return y
+
+
+def downsum2x2(x, B, H, W, C):
+    y = torch.empty((B * H * W, C), dtype=F16, device=x.device)
+    _call("fd_downsum2x2", _p(_chk(x)), _p(y), B, H, W, C, _stream())
+    return y
+
+
+def softmax_rows(x, scale=1.0, mask=None, mask_t=0, mask_ht=0):
+    rows, cols = x.numel() // x.shape[-1], x.shape[-1]
+    y = torch.empty_like(x)
+    _call("fd_softmax_rows", _p(_chk(x)), _p(y), rows, cols, scale, _p(mask), mask_t, mask_ht, _stream())
+    return y
+
+
+def softmax_rows_bwd(p, dp, scale=1.0):
+    rows, cols = p.numel() // p.shape[-1], p.shape[-1]
+    ds = torch.empty_like(p)
+    _call("fd_softmax_rows_bwd", _p(_chk(p)), _p(_chk(dp)), _p(ds), rows, cols, scale, _stream())
+    return ds
+
+
+def to_f16(x, scale=1.0):
+    y = torch.empty(x.shape, dtype=F16, device=x.device)
+    _call("fd_cast_f32_to_f16", _p(_chk(x, F32)), _p(y), x.numel(), scale, _stream())
+    return y
+
+
+def to_f32(x, scale=1.0):
+    y = torch.empty(x.shape, dtype=F32, device=x.device)
+    _call("fd_cast_f16_to_f32", _p(_chk(x)), _p(y), x.numel(), scale, _stream())
+    return y
+
+
+# ----------------------------------------------------------------------------- attention
+def attn_fwd(q, k, vt, B, H, Tq, Tk, d, kv_div=1, scale=None, need_lse=False):
+    Tkp = vt.shape[-1]
+    o = torch.empty_like(q)
+    lse = torch.empty((B, H, Tq), dtype=F32, device=q.device) if need_lse else None
+    _call("fd_attn_fwd", _p(_chk(q)), _p(_chk(k)), _p(_chk(vt)), _p(o), _p(lse), B, H, Tq, Tk, Tkp, d, kv_div,
+          scale if scale is not None else d ** -0.5, _stream())
+    return (o, lse) if need_lse else o
+
+
+def attn_bwd(q, k, v, o, do, lse, B, H, Tq, Tk, d, kv_div=1, scale=None, kt=None, dk_acc=None, dv_acc=None):
+    """Returns (dq, dk, dv).  With kv_div>1 (shared K/V) dk/dv are accumulated into the fp32 buffers dk_acc/dv_acc."""
+    scale = scale if scale is not None else d ** -0.5
+    C = H * d
+    Dd = torch.empty((B, H, Tq), dtype=F32, device=q.device)
+    _call("fd_attn_bwd_prep", _p(_chk(o)), _p(_chk(do)), _p(Dd), B, H, Tq, d, _stream())
+    Bk = B // kv_div
+    if kt is None:
+        kt = transpose_btc(k, Bk, Tk, C)
+    Tkp = kt.shape[-1]
+    dq = torch.empty_like(q)
+    _call("fd_attn_bwd_dq", _p(_chk(q)), _p(_chk(k)), _p(_chk(v)), _p(kt), _p(do), _p(lse), _p(Dd), _p(dq), B, H, Tq, Tk, Tkp, d, kv_div,
+          scale, _stream())
+    qt = transpose_btc(q, B, Tq, C, Tq)
+    dot = transpose_btc(do, B, Tq, C, Tq)
+    if kv_div > 1:
+        dk, dv = dk_acc, dv_acc
+        assert dk.dtype == F32 and dv.dtype == F32
+    else:
+        dk, dv = torch.empty_like(k), torch.empty_like(v)
+    _call("fd_attn_bwd_dkdv", _p(q), _p(qt), _p(k), _p(v), _p(do), _p(dot), _p(lse), _p(Dd), _p(dk), _p(dv), B, H, Tq, Tk, d, kv_div, scale,
+          _stream())
+    return dq, dk, dv
+
+
+# ----------------------------------------------------------------------------- LoRA / scheduler / optimizer
+def lora_wgrad(X, T, G, sn, sr, R, scale=1.0):
+    M, N = X.shape
+    sc = scratch(1 << 22, X.device)
+    _call("fd_lora_wgrad", _p(X), X.stride(0), _p(T), T.stride(0), _p(G), sn, sr, M, N, R, scale, _p(sc), sc.numel(), _stream())
+
+
+def cfg_dpm_step(eps, guidance, lat, x0_prev, x0_out, alpha_t, sigma_t, c_x, c_d0, c_d1):
+    n = lat.numel()
+    assert eps.numel() == 2 * n
+    _call("fd_cfg_dpm_step", _p(_chk(eps, F32)), guidance, _p(_chk(lat, F32)), _p(x0_prev), _p(_chk(x0_out, F32)), alpha_t, sigma_t, c_x, c_d0,
+          c_d1, n, _stream())
+
+
+def grad_finite_scale(g, scale, flag):
+    _call("fd_grad_finite_scale", _p(_chk(g, F32)), g.numel(), scale, _p(flag), _stream())
+
+
+def adamw_ema(p, g, m, v, ema, lr, b1, b2, eps, wd, step, ema_omd):
+    _call("fd_adamw_ema", _p(p), _p(g), _p(m), _p(v), _p(ema), p.numel(), lr, b1, b2, eps, wd, step, ema_omd, _stream())
+
+
+# ----------------------------------------------------------------------------- classifier pieces
+def dwconv(x, w, bias, B, H, W, C, k, stride, act):
+    pad = (k - 1) // 2
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    y = torch.empty((B * Ho * Wo, C), dtype=F16, device=x.device)
+    _call("fd_dwconv_fwd", _p(_chk(x)), _p(w), _p(bias), _p(y), B, H, W, C, k, stride, ACT[act], _stream())
+    return y, Ho, Wo
+
+
+def dwconv_bwd(dy, w, B, H, W, C, k, stride):
+    dx = torch.empty((B * H * W, C), dtype=F16, device=dy.device)
+    _call("fd_dwconv_bwd", _p(_chk(dy)), _p(w), _p(dx), B, H, W, C, k, stride, _stream())
+    return dx
+
+
+def avgpool_hw(x, B, HW, C):
+    y = torch.empty((B, C), dtype=F16, device=x.device)
+    _call("fd_avgpool_hw", _p(_chk(x)), _p(y), B, HW, C, _stream())
+    return y
+
+
+def avgpool_hw_bwd(dy, B, HW, C, add=None):
+    dx = torch.empty((B * HW, C), dtype=F16, device=dy.device)
+    _call("fd_avgpool_hw_bwd", _p(_chk(dy)), _p(add), _p(dx), B, HW, C, _stream())
+    return dx
+
+
+def scale_channels(x, s, B, HW, C):
+    y = torch.empty_like(x)
+    _call("fd_scale_channels", _p(_chk(x)), _p(_chk(s)), _p(y), B, HW, C, _stream())
+    return y
+
+
+def scale_channels_bwd(x, s, dy, B, HW, C):
+    dx = torch.empty_like(x)
+    ds = torch.empty((B, C), dtype=F16, device=x.device)
+    _call("fd_scale_channels_bwd", _p(x), _p(s), _p(_chk(dy)), _p(dx), _p(ds), B, HW, C, _stream())
+    return dx, ds
+
+
+def crop_resize(img, boxes, fill, S):
+    B, _, H, W = img.shape
+    chips = torch.empty((B, 3, S, S), dtype=F16, device=img.device)
+    _call("fd_crop_resize_fwd", _p(_chk(img)), _p(boxes), fill, _p(chips), B, H, W, S, _stream())
+    return chips
+
+
+def crop_resize_bwd(dchips, boxes, B, H, W, S):
+    dimg = torch.zeros((B, 3, H, W), dtype=F32, device=dchips.device)
+    _call("fd_crop_resize_bwd", _p(_chk(dchips, F32)), _p(boxes), _p(dimg), B, H, W, S, _stream())
+    return dimg

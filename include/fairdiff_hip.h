@@ -1,0 +1,153 @@
+/* libfairdiff_hip.so -- C-ABI of the MI355X (gfx950) fairness-finetuning hot path.
+ *
+ * The reference (sail-sg/finetune-fair-diffusion) has no FFI/plugin interface: its hot
+ * path is Python calling un-vendored diffusers/transformers/torchvision modules
+ * (SURVEY.md section 8b).  Each entry point below names the reference interface whose
+ * arithmetic it replaces (file:line into /root/reference) so a maintainer can bind it
+ * from the reference side with ctypes.
+ *
+ * Conventions: every pointer is a DEVICE pointer unless stated; `stream` is a
+ * hipStream_t passed as void*; the caller owns all buffers (kernels never allocate);
+ * functions return FD_OK (0) or a negative FD_ERR_* code and are re-entrant (no global
+ * mutable state except the thread-local last-error string).  Activations are fp16
+ * ("wd" in SURVEY 8a), channels-last: an image tensor is [B, H, W, C] == a token matrix
+ * [B*H*W, C]; LoRA/optimizer state and all reductions are fp32.
+ */
+#ifndef FAIRDIFF_HIP_H
+#define FAIRDIFF_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FD_OK 0
+#define FD_ERR_ARG (-1)
+#define FD_ERR_LAUNCH (-2)
+
+enum { FD_ACT_NONE = 0, FD_ACT_SILU = 1, FD_ACT_QUICK_GELU = 2, FD_ACT_GELU = 3, FD_ACT_RELU = 4,
+       FD_ACT_HARDSWISH = 5, FD_ACT_HARDSIGMOID = 6 };
+enum { FD_OUT_F16 = 0, FD_OUT_F32 = 1 };
+enum { FD_CONV_NORMAL = 0, FD_CONV_STRIDE2 = 1, FD_CONV_UP2 = 2, FD_CONV_TRANS2 = 3 };
+
+const char* fd_last_error(void);
+int fd_version(void);
+
+/* ---- MFMA GEMM  C[M,N] = act(alpha * (A[M,K] . B[N,K]^T + A2[M,K2] . B2[N,K2]^T) + bias + rowbias) + residual
+ * Replaces torch.nn.Linear / 1x1 Conv2d inside diffusers Attention/FeedForward/Transformer2DModel/
+ * ResnetBlock2D (called through unet(...) at exp-1-debias-gender/1-main-debias.py:1046-1050,1118-1122)
+ * and the LoRA rank update of LoRAAttnProcessor (injected at :798-818): the second (A2,B2) slab
+ * carries t = x.down^T and the up matrix so the rank update is accumulated in the same MFMA tile.
+ * The A operand may instead be gathered as an implicit-GEMM 3x3 convolution (conv != 0):
+ * A is then a channels-last image [B,H,W,Cin] and K = 9*Cin with k = (ky*3+kx)*Cin + ci.        */
+typedef struct fd_gemm_desc {
+    const void* A;  int64_t lda;        /* fp16 [M,K] row-major (or image when conv) */
+    const void* B;  int64_t ldb;        /* fp16 [N,K] row-major */
+    const void* A2; int64_t lda2;       /* optional second K-slab (LoRA / channel-concat) */
+    const void* B2; int64_t ldb2;
+    void* C;        int64_t ldc;        /* fp16 or fp32 [M,N] */
+    const float* bias;                  /* fp32 [N] or NULL */
+    const void* rowbias; int64_t ld_rowbias; int32_t rows_per_batch; /* fp16 [M/rows_per_batch, N] or NULL */
+    const void* residual; int64_t ldr;  /* fp16 [M,N] or NULL */
+    float alpha;
+    int32_t M, N, K, K2;
+    int32_t act, out_dtype;
+    int32_t batch; int64_t sA, sB, sC, sR; /* strided batching (batch>=1), element strides */
+    /* implicit-GEMM convolution gather (conv: 0 = dense A, 1 = 3x3 pad 1) */
+    int32_t conv, conv_mode, Bn, H, W, Cin, Ho, Wo;
+} fd_gemm_desc;
+int fd_gemm(const fd_gemm_desc* d, void* stream);
+
+/* Direct convolution for tiny channel counts (conv_in 4->320, conv_out dgrad, VAE post_quant 1x1,
+ * classifier stem).  x: [B,Cin,H,W] (nchw!=0) or [B,H,W,Cin]; w: fp32 [k*k*Cin, Cout]; y: fp16 [B,Ho,Wo,Cout]. */
+int fd_conv_small_cin(const void* x, int x_is_f32, int nchw, const float* w, const float* bias, void* y,
+                      int B, int H, int W, int Cin, int Cout, int ksize, int stride, int act, void* stream);
+/* y[B,C,HW] (fp32 or fp16) <- clamp(scale * x[B,HW,ldx>=C] fp16, lo, hi)  (eps for the scheduler; images.clamp(-1,1) :1059,:1134) */
+int fd_nhwc_to_nchw(const void* x, int64_t ldx, void* y, int y_is_f32, int B, int HW, int C, float scale, float lo, float hi, void* stream);
+/* backward of the clamp: dpre[B,C,HW] fp32 = (lo <= pre <= hi) ? dimg : 0 */
+int fd_clamp_bwd(const void* pre, int64_t ldx, const float* dimg, float* dpre, int B, int HW, int C, float lo, float hi, void* stream);
+
+/* ---- GroupNorm (32 groups, channels-last, optional 2-source channel concat, optional fused SiLU).
+ * Replaces torch.nn.GroupNorm(+SiLU) in ResnetBlock2D / Transformer2DModel / conv_norm_out.          */
+/* scratch: B*64*groups*2 floats (stats) / B*65*groups*2 floats (bwd) */
+int fd_groupnorm_stats(const void* x1, int C1, const void* x2, int C2, int B, int HW, int groups, float eps,
+                       float* mean_rstd /* [B,groups,2] */, float* scratch, void* stream);
+int fd_groupnorm_apply(const void* x1, int C1, const void* x2, int C2, int B, int HW, int groups,
+                       const float* mean_rstd, const float* gamma, const float* beta, int silu, void* y, void* stream);
+/* backward: dx = d/dx [ act(GN(x)) ] . dy ; writes the two channel slices to dx1/dx2, optionally adding add1/add2 */
+int fd_groupnorm_bwd(const void* x1, int C1, const void* x2, int C2, const void* dy, int B, int HW, int groups,
+                     const float* mean_rstd, const float* gamma, const float* beta, int silu,
+                     float* scratch, const void* add1, const void* add2, void* dx1, void* dx2, void* stream);
+
+/* ---- LayerNorm over the last dim of [M,C] (BasicTransformerBlock.norm1/2/3, CLIP layer norms). */
+int fd_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean_rstd /* [M,2] or NULL */,
+                     int M, int C, float eps, void* stream);
+int fd_layernorm_bwd(const void* x, const void* dy, const float* gamma, const float* mean_rstd, const void* add /* or NULL */,
+                     void* dx, int M, int C, void* stream);
+
+/* ---- elementwise */
+int fd_geglu_fwd(const void* proj /* [M,2F] */, void* y /* [M,F] */, int M, int F, void* stream);
+int fd_geglu_bwd(const void* proj, const void* dy, void* dproj, int M, int F, void* stream);
+int fd_act_fwd(const void* x, void* y, int64_t n, int act, void* stream);
+int fd_act_bwd(const void* z, const void* dy, void* dx, int64_t n, int act, void* stream);
+int fd_add(const void* a, const void* b, void* y, int64_t n, float sa, float sb, void* stream);      /* y = sa*a + sb*b (fp16) */
+int fd_copy_cols(const void* src, int64_t lds, void* dst, int64_t ldd, int64_t M, int cols, void* stream); /* strided 2-D copy, fp16 */
+int fd_transpose_btc(const void* x /* [B,T,C] */, void* y /* [B,C,Tp] */, int B, int T, int C, int Tp, void* stream);
+int fd_downsum2x2(const void* x /* [B,2H,2W,C] */, void* y /* [B,H,W,C] */, int B, int H, int W, int C, void* stream);
+/* y = softmax(scale*x + mask); mask fp32 [.., mask_t, cols], mask row = (row / mask_ht) * mask_t + row % mask_t, or NULL */
+int fd_softmax_rows(const void* x, void* y, int64_t rows, int cols, float scale, const float* mask, int mask_t, int mask_ht, void* stream);
+int fd_softmax_rows_bwd(const void* p, const void* dp, void* ds, int64_t rows, int cols, float scale, void* stream);
+int fd_cast_f32_to_f16(const float* x, void* y, int64_t n, float scale, void* stream);
+int fd_cast_f16_to_f32(const void* x, float* y, int64_t n, float scale, void* stream);
+
+/* ---- fused attention (diffusers Attention.get_attention_scores + bmm, LoRAAttnProcessor.__call__)
+ * q:[B,Tq,H*d]  k:[Bk,Tk,H*d]  vt:[Bk,H*d,Tkp] (V transposed, keys contiguous, Tkp>=Tk, Tkp%8==0)
+ * sample b uses kv batch b / kv_div (cross-attention K/V are shared by each CFG half).
+ * o:[B,Tq,H*d] fp16, lse:[B,H,Tq] fp32 (natural-log sum-exp of the scaled scores).                 */
+int fd_attn_fwd(const void* q, const void* k, const void* vt, void* o, float* lse, int B, int H, int Tq, int Tk,
+                int Tkp, int d, int kv_div, float scale, void* stream);
+/* D[b,h,t] = sum_j dO*O */
+int fd_attn_bwd_prep(const void* o, const void* d_o, float* D, int B, int H, int T, int d, void* stream);
+/* dq from (q, k, v, kt:[Bk,H*d,Tkp], dO, lse, D) */
+int fd_attn_bwd_dq(const void* q, const void* k, const void* v, const void* kt, const void* d_o, const float* lse,
+                   const float* D, void* dq, int B, int H, int Tq, int Tk, int Tkp, int d, int kv_div, float scale, void* stream);
+/* dk,dv from (q, qt:[B,H*d,Tq], k, v, dO, dOt:[B,H*d,Tq], lse, D). When kv_div>1 the kv batch is shared by
+ * kv_div consecutive samples; dk/dv are then fp32 [Bk,Tk,H*d] accumulated with atomics, else fp16. */
+int fd_attn_bwd_dkdv(const void* q, const void* qt, const void* k, const void* v, const void* d_o, const void* d_ot,
+                     const float* lse, const float* D, void* dk, void* dv, int B, int H, int Tq, int Tk, int d,
+                     int kv_div, float scale, void* stream);
+
+/* ---- LoRA weight gradients: G[n, r] (+)= sum_m X[m, n] * T[m, r]  (fp16 X,T; fp32 G with strides) */
+int fd_lora_wgrad(const void* X, int64_t ldx, const void* T, int64_t ldt, float* G, int64_t g_stride_n, int64_t g_stride_r,
+                  int M, int N, int R, float scale, float* scratch, int64_t scratch_elems, void* stream);
+
+/* ---- scheduler / CFG (DPMSolverMultistepScheduler.step + CFG combine, 1-main-debias.py:1051-1056,1123-1131)
+ * eps:[2N,4,HW] fp32 NCHW (uncond first); x0_prev/x0_out fp32; lat fp32 updated in place.
+ * x0 = (lat - sigma*e)/alpha ; lat' = c_x*lat - c_d0*x0 - c_d1*(x0 - x0_prev)                        */
+int fd_cfg_dpm_step(const float* eps, float guidance, float* lat, const float* x0_prev, float* x0_out,
+                    float alpha_t, float sigma_t, float c_x, float c_d0, float c_d1, int64_t n, void* stream);
+
+/* ---- optimizer: flat fp32 buffers (1-main-debias.py:1998-2029) */
+int fd_grad_finite_scale(float* g, int64_t n, float scale, int32_t* nonfinite_flag, void* stream);
+int fd_adamw_ema(float* p, const float* g, float* m, float* v, float* ema, int64_t n, float lr, float beta1, float beta2,
+                 float eps, float weight_decay, int32_t step, float ema_one_minus_decay, void* stream);
+
+/* ---- classifier pieces (torchvision mobilenet_v3_large, 1-main-debias.py:929-935,1369) */
+int fd_dwconv_fwd(const void* x, const float* w /* [k,k,C] */, const float* bias, void* y, int B, int H, int W, int C,
+                  int k, int stride, int act, void* stream);
+int fd_dwconv_bwd(const void* dy, const float* w, void* dx, int B, int H, int W, int C, int k, int stride, void* stream);
+int fd_avgpool_hw(const void* x, void* y, int B, int HW, int C, void* stream);              /* [B,HW,C] -> [B,C] */
+int fd_avgpool_hw_bwd(const void* dy /* [B,C] */, const void* add /* [B,HW,C] or NULL */, void* dx, int B, int HW, int C, void* stream);
+int fd_scale_channels(const void* x, const void* s, void* y, int B, int HW, int C, void* stream); /* y = x * s[b,c] */
+int fd_scale_channels_bwd(const void* x, const void* s, const void* dy, void* dx, void* ds /* fp16 [B,C] */, int B, int HW, int C, void* stream);
+int fd_conv_small_cin_bwd(const void* dy /* [B,Ho,Wo,Cout] */, const float* w, float* dx /* fp32 [B,Cin,H,W], overwritten */,
+                          int B, int H, int W, int Cin, int Cout, int ksize, int stride, float scale, void* stream);
+/* crop [x0,y0,x1,y1) (may exceed the image -> fill) + bilinear resize (align_corners=False, no antialias):
+ * img [B,3,H,W] fp16 NCHW -> chips [B,3,S,S] fp16 NCHW. */
+int fd_crop_resize_fwd(const void* img, const int32_t* boxes, float fill, void* chips, int B, int H, int W, int S, void* stream);
+int fd_crop_resize_bwd(const float* dchips /* [B,3,S,S] */, const int32_t* boxes, float* dimg /* [B,3,H,W] (+=) */,
+                       int B, int H, int W, int S, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,336 @@
+"""Kernel-level parity (GPU): every HIP kernel vs a plain fp32 PyTorch statement of the same op,
+called through the C-ABI (ops.py -> libfairdiff_hip.so).  Tolerances are fp16-output tolerances:
+|err| <= tol * max|ref| with tol stated per test."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def relerr(a, b):
+    a, b = a.float(), b.float()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-12))
+
+
+def check(name, a, b, tol):
+    e = relerr(a, b)
+    print(f"[{name}] rel max err {e:.3e} (tol {tol:.1e})")
+    assert math.isfinite(e) and e <= tol, f"{name}: {e} > {tol}"
+
+
+def rnd(*shape, dev, scale=1.0, dtype=torch.float16, seed=None):
+    g = torch.Generator(device="cpu")
+    g.manual_seed(seed if seed is not None else (hash(shape) & 0xFFFF))
+    return (torch.randn(*shape, generator=g) * scale).to(dev).to(dtype)
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from finetune_fair_diffusion_amd import ops
+    return ops
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 320, 320), (4096, 320, 1280), (1000, 4, 2880), (65, 1280, 40), (2048, 2560, 320)])
+def test_gemm_plain(ops, dev, M, N, K):
+    a, b = rnd(M, K, dev=dev, seed=1), rnd(N, K, dev=dev, seed=2)
+    c = ops.gemm(a, b)
+    check(f"gemm {M}x{N}x{K}", c, a.float() @ b.float().t(), 2e-3)
+
+
+def test_gemm_epilogue_and_lora_slab(ops, dev):
+    M, N, K, R = 777, 640, 320, 8
+    a, b = rnd(M, K, dev=dev, seed=1), rnd(N, K, dev=dev, scale=0.1, seed=2)
+    a2, b2 = rnd(M, R, dev=dev, seed=3), rnd(N, R, dev=dev, seed=4)
+    bias = rnd(N, dev=dev, dtype=torch.float32, seed=5)
+    res = rnd(M, N, dev=dev, seed=6)
+    rb = rnd(7, N, dev=dev, seed=7)
+    ref = a.float() @ b.float().t() + a2.float() @ b2.float().t() + bias
+    ref = ref + rb.float().repeat_interleave(111, 0)
+    ref = F.silu(ref) + res.float()
+    c = ops.gemm(a, b, a2=a2, b2=b2, bias=bias, rowbias=rb, rows_per_batch=111, residual=res, act="silu")
+    check("gemm epilogue", c, ref, 2e-3)
+    c32 = ops.gemm(a, b, bias=bias, alpha=0.5, out_dtype=torch.float32, act="gelu")
+    check("gemm f32 out gelu", c32, F.gelu(0.5 * (a.float() @ b.float().t()) + bias), 1e-3)
+    c3 = ops.gemm(a, b, act="quick_gelu")
+    z = a.float() @ b.float().t()
+    check("gemm quick_gelu", c3, z * torch.sigmoid(1.702 * z), 2e-3)
+
+
+def test_bgemm(ops, dev):
+    a, b = rnd(6, 200, 64, dev=dev, seed=1), rnd(6, 136, 64, dev=dev, seed=2)
+    check("bgemm", ops.bgemm(a, b, alpha=0.25), 0.25 * torch.einsum("zmk,znk->zmn", a.float(), b.float()), 2e-3)
+
+
+def _nhwc(x):  # [B,C,H,W] -> [B*H*W, C]
+    B, C, H, W = x.shape
+    return x.permute(0, 2, 3, 1).reshape(B * H * W, C).contiguous()
+
+
+def _nchw(y, B, H, W):
+    return y.reshape(B, H, W, -1).permute(0, 3, 1, 2)
+
+
+@pytest.mark.parametrize("B,H,Cin,Cout", [(2, 16, 64, 96), (3, 8, 320, 320), (1, 32, 32, 4)])
+def test_conv3x3_modes(ops, dev, B, H, Cin, Cout):
+    x = rnd(B, Cin, H, H, dev=dev, seed=1)
+    w = rnd(Cout, Cin, 3, 3, dev=dev, scale=0.05, seed=2)
+    bias = rnd(Cout, dev=dev, dtype=torch.float32, seed=3)
+    wk = w.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin).contiguous()
+    y, Ho, Wo = ops.conv3x3(_nhwc(x), wk, B, H, H, bias=bias)
+    check("conv normal", _nchw(y, B, Ho, Wo), F.conv2d(x.float(), w.float(), bias, padding=1), 2e-3)
+    y, Ho, Wo = ops.conv3x3(_nhwc(x), wk, B, H, H, mode=ops.CONV_STRIDE2, bias=bias)
+    check("conv stride2", _nchw(y, B, Ho, Wo), F.conv2d(x.float(), w.float(), bias, stride=2, padding=1), 2e-3)
+    y, Ho, Wo = ops.conv3x3(_nhwc(x), wk, B, H, H, mode=ops.CONV_UP2, bias=bias)
+    check("conv up2", _nchw(y, B, Ho, Wo), F.conv2d(F.interpolate(x.float(), scale_factor=2.0, mode="nearest"), w.float(), bias, padding=1), 2e-3)
+    # data gradients: flipped/transposed weights [Cin, (ky,kx,co)]
+    wd = w.flip(2, 3).permute(1, 2, 3, 0).reshape(Cin, 9 * Cout).contiguous()
+    if Cout % 32 == 0:
+        xx = x.float().requires_grad_(True)
+        o = F.conv2d(xx, w.float(), None, padding=1)
+        g = rnd(*o.shape, dev=dev, seed=4)
+        o.backward(g.float())
+        dx, _, _ = ops.conv3x3(_nhwc(g), wd, B, H, H)
+        check("conv dgrad", _nchw(dx, B, H, H), xx.grad, 2e-3)
+        xx = x.float().requires_grad_(True)
+        o = F.conv2d(xx, w.float(), None, stride=2, padding=1)
+        g = rnd(*o.shape, dev=dev, seed=5)
+        o.backward(g.float())
+        dx, Ho, Wo = ops.conv3x3(_nhwc(g), wd, B, H // 2, H // 2, mode=ops.CONV_TRANS2)
+        check("conv stride2 dgrad", _nchw(dx, B, Ho, Wo), xx.grad, 2e-3)
+
+
+@pytest.mark.parametrize("B,HW,C1,C2,silu", [(2, 256, 320, 0, True), (3, 64, 1280, 640, True), (2, 1024, 128, 0, False), (2, 100, 640, 320, False)])
+def test_groupnorm(ops, dev, B, HW, C1, C2, silu):
+    G, eps = 32, 1e-5
+    x1 = rnd(B * HW, C1, dev=dev, seed=1) * 2 + 0.5
+    x2 = (rnd(B * HW, C2, dev=dev, seed=2) - 0.3) if C2 else None
+    C = C1 + C2
+    gamma = rnd(C, dev=dev, dtype=torch.float32, seed=3) * 0.2 + 1
+    beta = rnd(C, dev=dev, dtype=torch.float32, seed=4) * 0.2
+    xc = (torch.cat([x1, x2], 1) if C2 else x1).float().reshape(B, HW, C).permute(0, 2, 1).requires_grad_(True)
+    ref = F.group_norm(xc, G, gamma, beta, eps)
+    if silu:
+        ref = F.silu(ref)
+    y, st = ops.groupnorm(x1, x2, B, HW, G, eps, gamma, beta, silu)
+    check("groupnorm fwd", y.reshape(B, HW, C).permute(0, 2, 1), ref, 2e-3)
+    dy = rnd(B * HW, C, dev=dev, seed=5)
+    ref.backward(dy.float().reshape(B, HW, C).permute(0, 2, 1))
+    add1 = rnd(B * HW, C1, dev=dev, seed=6)
+    dx1, dx2 = ops.groupnorm_bwd(x1, x2, dy, B, HW, G, st, gamma, beta, silu, add1=add1)
+    gref = xc.grad.permute(0, 2, 1).reshape(B * HW, C)
+    check("groupnorm bwd dx1", dx1, gref[:, :C1] + add1.float(), 3e-3)
+    if C2:
+        check("groupnorm bwd dx2", dx2, gref[:, C1:], 3e-3)
+
+
+@pytest.mark.parametrize("M,C", [(1000, 320), (333, 1280), (64, 768)])
+def test_layernorm(ops, dev, M, C):
+    x = rnd(M, C, dev=dev, seed=1) * 3 + 1
+    gamma = rnd(C, dev=dev, dtype=torch.float32, seed=2) * 0.2 + 1
+    beta = rnd(C, dev=dev, dtype=torch.float32, seed=3) * 0.2
+    xr = x.float().requires_grad_(True)
+    ref = F.layer_norm(xr, (C,), gamma, beta, 1e-5)
+    y, st = ops.layernorm(x, gamma, beta, 1e-5, save_stats=True)
+    check("layernorm fwd", y, ref, 2e-3)
+    dy = rnd(M, C, dev=dev, seed=4)
+    ref.backward(dy.float())
+    add = rnd(M, C, dev=dev, seed=5)
+    check("layernorm bwd", ops.layernorm_bwd(x, dy, gamma, st, add=add), xr.grad + add.float(), 3e-3)
+
+
+def test_elementwise(ops, dev):
+    M, Fh = 300, 1280
+    proj = rnd(M, 2 * Fh, dev=dev, seed=1)
+    pr = proj.float().requires_grad_(True)
+    a, g = pr.chunk(2, dim=-1)
+    ref = a * F.gelu(g)
+    check("geglu fwd", ops.geglu(proj), ref, 2e-3)
+    dy = rnd(M, Fh, dev=dev, seed=2)
+    ref.backward(dy.float())
+    check("geglu bwd", ops.geglu_bwd(proj, dy), pr.grad, 3e-3)
+    x = rnd(1003, dev=dev, seed=3) * 3
+    for act, fn in [("silu", F.silu), ("relu", F.relu), ("hardswish", F.hardswish), ("hardsigmoid", F.hardsigmoid),
+                    ("quick_gelu", lambda t: t * torch.sigmoid(1.702 * t)), ("gelu", F.gelu)]:
+        xr = x.float().requires_grad_(True)
+        r = fn(xr)
+        check(f"act {act}", ops.act_fwd(x, act), r, 2e-3)
+        r.backward(torch.ones_like(r) * 0.5)
+        check(f"act_bwd {act}", ops.act_bwd(x, torch.full_like(x, 0.5), act), xr.grad, 3e-3)
+    a, b = rnd(999, dev=dev, seed=4), rnd(999, dev=dev, seed=5)
+    check("add", ops.add(a, b, 0.5, -2.0), 0.5 * a.float() - 2 * b.float(), 2e-3)
+    x = rnd(3, 100, 320, dev=dev, seed=6)
+    yt = ops.transpose_btc(x.reshape(300, 320), 3, 100, 320)
+    assert yt.shape == (3, 320, 104)
+    check("transpose", yt[:, :, :100], x.permute(0, 2, 1), 0)
+    assert float(yt[:, :, 100:].abs().max()) == 0
+    x = rnd(2, 8, 8, 64, dev=dev, seed=7)
+    check("downsum", ops.downsum2x2(x.reshape(-1, 64), 2, 4, 4, 64).reshape(2, 4, 4, 64),
+          x.float().reshape(2, 4, 2, 4, 2, 64).sum(dim=(2, 4)), 2e-3)
+    x = rnd(50, 77, dev=dev, seed=8) * 4
+    check("softmax", ops.softmax_rows(x, 0.5), torch.softmax(0.5 * x.float(), -1), 2e-3)
+    x = rnd(20, 4096, dev=dev, seed=9) * 4
+    p = ops.softmax_rows(x, 0.1)
+    check("softmax 4096", p, torch.softmax(0.1 * x.float(), -1), 2e-3)
+    dp = rnd(20, 4096, dev=dev, seed=10)
+    xr = x.float().requires_grad_(True)
+    torch.softmax(0.1 * xr, -1).backward(dp.float())
+    check("softmax bwd", ops.softmax_rows_bwd(p, dp, 0.1), xr.grad, 5e-3)
+    src = rnd(64, 48, dev=dev, seed=11)
+    dst = torch.zeros(64, 80, dtype=torch.float16, device=dev)
+    ops.copy_cols(src, dst[:, 32:], 48)
+    check("copy_cols", dst[:, 32:], src, 0)
+
+
+def _attn_ref(q, k, v, H, kv_div=1):
+    B, T, C = q.shape
+    d = C // H
+    kk, vv = k.repeat_interleave(kv_div, 0), v.repeat_interleave(kv_div, 0)
+    def sp(t):
+        return t.reshape(t.shape[0], t.shape[1], H, d).permute(0, 2, 1, 3)
+    s = sp(q) @ sp(kk).transpose(-1, -2) * d ** -0.5
+    o = torch.softmax(s, -1) @ sp(vv)
+    return o.permute(0, 2, 1, 3).reshape(B, T, C), torch.logsumexp(s, -1)
+
+
+@pytest.mark.parametrize("B,H,Tq,Tk,d,kv_div", [(2, 8, 1024, 1024, 40, 1), (2, 8, 256, 256, 80, 1), (2, 4, 256, 256, 160, 1),
+                                                 (1, 2, 64, 64, 160, 1), (4, 8, 1024, 13, 40, 2), (2, 2, 200, 77, 64, 1),
+                                                 (2, 4, 64, 16, 32, 2), (1, 8, 4096, 4096, 40, 1)])
+def test_attention_fwd_bwd(ops, dev, B, H, Tq, Tk, d, kv_div):
+    C = H * d
+    Bk = B // kv_div
+    q, k, v = rnd(B, Tq, C, dev=dev, seed=1), rnd(Bk, Tk, C, dev=dev, seed=2), rnd(Bk, Tk, C, dev=dev, seed=3)
+    qr, kr, vr = (t.float().requires_grad_(True) for t in (q, k, v))
+    oref, lref = _attn_ref(qr, kr, vr, H, kv_div)
+    vt = ops.transpose_btc(v.reshape(Bk * Tk, C), Bk, Tk, C)
+    o, lse = ops.attn_fwd(q.reshape(B * Tq, C), k.reshape(Bk * Tk, C), vt, B, H, Tq, Tk, d, kv_div, need_lse=True)
+    check("attn fwd", o.reshape(B, Tq, C), oref, 3e-3)
+    check("attn lse", lse, lref, 1e-3)
+    if Tq % 8:
+        return
+    do = rnd(B, Tq, C, dev=dev, seed=4)
+    oref.backward(do.float())
+    dk_acc = torch.zeros(Bk * Tk, C, dtype=torch.float32, device=dev) if kv_div > 1 else None
+    dv_acc = torch.zeros_like(dk_acc) if kv_div > 1 else None
+    dq, dk, dv = ops.attn_bwd(q.reshape(B * Tq, C), k.reshape(Bk * Tk, C), v.reshape(Bk * Tk, C), o, do.reshape(B * Tq, C), lse, B, H, Tq, Tk, d,
+                              kv_div, dk_acc=dk_acc, dv_acc=dv_acc)
+    check("attn dq", dq.reshape(B, Tq, C), qr.grad, 5e-3)
+    check("attn dk", dk.reshape(Bk, Tk, C), kr.grad, 5e-3)
+    check("attn dv", dv.reshape(Bk, Tk, C), vr.grad, 5e-3)
+
+
+@pytest.mark.parametrize("M,N,R", [(4096, 320, 4), (1000, 1280, 50), (777, 768, 16)])
+def test_lora_wgrad(ops, dev, M, N, R):
+    RP = (R + 7) // 8 * 8
+    RP = 8 if R <= 8 else 16 if R <= 16 else 32 if R <= 32 else 64
+    X = rnd(M, N, dev=dev, seed=1)
+    T = torch.zeros(M, RP, dtype=torch.float16, device=dev)
+    T[:, :R] = rnd(M, R, dev=dev, seed=2)
+    G = torch.ones(N, R, dtype=torch.float32, device=dev)
+    ops.lora_wgrad(X, T, G, R, 1, R, scale=0.5)
+    check("lora wgrad [N,R]", G, 1 + 0.5 * X.float().t() @ T[:, :R].float(), 1e-3)
+    G2 = torch.zeros(R, N, dtype=torch.float32, device=dev)
+    ops.lora_wgrad(X, T, G2, 1, N, R)
+    check("lora wgrad [R,N]", G2, T[:, :R].float().t() @ X.float(), 1e-3)
+
+
+def test_cfg_dpm_and_adamw(ops, dev):
+    n = 2 * 4 * 64
+    eps = rnd(2 * n, dev=dev, dtype=torch.float32, seed=1)
+    lat = rnd(n, dev=dev, dtype=torch.float32, seed=2)
+    x0p = rnd(n, dev=dev, dtype=torch.float32, seed=3)
+    x0o = torch.empty_like(lat)
+    l0 = lat.clone()
+    ops.cfg_dpm_step(eps, 7.5, lat, x0p, x0o, 0.9, 0.43, 0.8, -0.3, 0.11)
+    e = eps[:n] + 7.5 * (eps[n:] - eps[:n])
+    x0 = (l0 - 0.43 * e) / 0.9
+    check("dpm x0", x0o, x0, 1e-5)
+    check("dpm lat", lat, 0.8 * l0 + 0.3 * x0 - 0.11 * (x0 - x0p), 1e-5)
+    p = rnd(5000, dev=dev, dtype=torch.float32, seed=4)
+    pr = p.clone().requires_grad_(True)
+    opt = torch.optim.AdamW([pr], lr=5e-3, betas=(0.9, 0.999), weight_decay=1e-2, eps=1e-8)
+    m, v, ema = torch.zeros_like(p), torch.zeros_like(p), p.clone()
+    for step in range(1, 4):
+        g = rnd(5000, dev=dev, dtype=torch.float32, seed=10 + step)
+        pr.grad = g.clone()
+        opt.step()
+        ops.adamw_ema(p, g, m, v, ema, 5e-3, 0.9, 0.999, 1e-8, 1e-2, step, 0.25)
+    check("adamw", p, pr.detach(), 1e-5)
+    flag = torch.zeros(1, dtype=torch.int32, device=dev)
+    g = rnd(1000, dev=dev, dtype=torch.float32, seed=20)
+    g0 = g.clone()
+    ops.grad_finite_scale(g, 0.5, flag)
+    assert int(flag.item()) == 0
+    check("grad scale", g, 0.5 * g0, 1e-6)
+    g[17] = float("inf")
+    ops.grad_finite_scale(g, 1.0, flag)
+    assert int(flag.item()) == 1
+
+
+def test_small_convs_and_classifier_pieces(ops, dev):
+    B, H, Cin, Cout = 2, 16, 4, 64
+    x = rnd(B, Cin, H, H, dev=dev, dtype=torch.float32, seed=1)
+    w = rnd(Cout, Cin, 3, 3, dev=dev, dtype=torch.float32, scale=0.2, seed=2)
+    bias = rnd(Cout, dev=dev, dtype=torch.float32, seed=3)
+    wk = w.permute(2, 3, 1, 0).reshape(9 * Cin, Cout).contiguous()
+    for stride in (1, 2):
+        y, Ho, Wo = ops.conv_small_cin(x, wk, bias, B, H, H, Cin, Cout, 3, stride)
+        xr = x.clone().requires_grad_(True)
+        ref = F.conv2d(xr, w, bias, stride=stride, padding=1)
+        check(f"small conv s{stride}", _nchw(y, B, Ho, Wo), ref, 2e-3)
+        g = rnd(*ref.shape, dev=dev, seed=4)
+        ref.backward(g.float())
+        dx = ops.conv_small_cin_bwd(_nhwc(g), wk, B, H, H, Cin, Cout, 3, stride)
+        check(f"small conv bwd s{stride}", dx, xr.grad, 2e-3)
+    w1 = rnd(4, 4, 1, 1, dev=dev, dtype=torch.float32, seed=5)
+    y, _, _ = ops.conv_small_cin(x.half(), w1.permute(2, 3, 1, 0).reshape(4, 4).contiguous(), None, B, H, H, 4, 4, 1)
+    check("1x1 conv", _nchw(y, B, H, H), F.conv2d(x.half().float(), w1), 2e-3)
+    # depthwise
+    C = 72
+    for k, s in [(3, 1), (3, 2), (5, 1), (5, 2)]:
+        xd = rnd(B, C, 14, 14, dev=dev, seed=6)
+        wd = rnd(C, 1, k, k, dev=dev, dtype=torch.float32, scale=0.3, seed=7)
+        bd = rnd(C, dev=dev, dtype=torch.float32, seed=8)
+        xr = xd.float().requires_grad_(True)
+        ref = F.hardswish(F.conv2d(xr, wd, bd, stride=s, padding=(k - 1) // 2, groups=C))
+        wkk = wd.reshape(C, k * k).t().contiguous()
+        y, Ho, Wo = ops.dwconv(_nhwc(xd), wkk, bd, B, 14, 14, C, k, s, "hardswish")
+        check(f"dwconv k{k}s{s}", _nchw(y, B, Ho, Wo), ref, 2e-3)
+        lin = F.conv2d(xr, wd, None, stride=s, padding=(k - 1) // 2, groups=C)
+        g = rnd(*lin.shape, dev=dev, seed=9)
+        xr.grad = None
+        lin.backward(g.float())
+        check(f"dwconv bwd k{k}s{s}", _nchw(ops.dwconv_bwd(_nhwc(g), wkk, B, 14, 14, C, k, s), B, 14, 14), xr.grad, 3e-3)
+    xa = rnd(B, 49, 120, dev=dev, seed=10)
+    check("avgpool", ops.avgpool_hw(xa.reshape(-1, 120), B, 49, 120), xa.float().mean(1), 2e-3)
+    s = rnd(B, 120, dev=dev, seed=11)
+    check("scale ch", ops.scale_channels(xa.reshape(-1, 120), s, B, 49, 120).reshape(B, 49, 120), xa.float() * s.float()[:, None], 2e-3)
+    dy = rnd(B, 49, 120, dev=dev, seed=12)
+    dx, ds = ops.scale_channels_bwd(xa.reshape(-1, 120), s, dy.reshape(-1, 120), B, 49, 120)
+    check("scale ch dx", dx.reshape(B, 49, 120), dy.float() * s.float()[:, None], 2e-3)
+    check("scale ch ds", ds, (dy.float() * xa.float()).sum(1), 3e-3)
+    check("avgpool bwd", ops.avgpool_hw_bwd(s, B, 49, 120).reshape(B, 49, 120), (s.float() / 49)[:, None].expand(B, 49, 120), 2e-3)
+    # crop + resize, incl. a box leaving the image
+    img = rnd(B, 3, 64, 64, dev=dev, seed=13)
+    boxes = torch.tensor([[8, 8, 56, 56], [-6, 10, 40, 70]], dtype=torch.int32, device=dev)
+    chips = ops.crop_resize(img, boxes, -1.0, 28)
+    for i, bb in enumerate(boxes.tolist()):
+        im = img[i].float().requires_grad_(True)
+        l, r, bt, tp = max(bb[0], 0), min(bb[2], 64), max(bb[1], 0), min(bb[3], 64)
+        face = F.pad(im[:, bt:tp, l:r], [max(-bb[0], 0), max(bb[2] - 64, 0), max(-bb[1], 0), max(bb[3] - 64, 0)], value=-1.0)
+        ref = F.interpolate(face[None], size=[28, 28], mode="bilinear", align_corners=False)[0]
+        check(f"crop_resize {i}", chips[i], ref, 2e-3)
+        g = rnd(3, 28, 28, dev=dev, dtype=torch.float32, seed=14 + i)
+        ref.backward(g)
+        gfull = torch.zeros(B, 3, 28, 28, device=dev)
+        gfull[i] = g
+        dimg = ops.crop_resize_bwd(gfull, boxes, B, 64, 64, 28)
+        check(f"crop_resize bwd {i}", dimg[i], im.grad, 1e-4)
+    pre = rnd(B * 16, 4, dev=dev, seed=20) * 2
+    y = ops.nhwc_to_nchw(pre, B, 16, 3, out_dtype=torch.float16, lo=-1.0, hi=1.0)
+    check("nhwc_to_nchw clamp", y, pre[:, :3].float().reshape(B, 16, 3).permute(0, 2, 1).clamp(-1, 1), 1e-3)
+    dimg = rnd(B, 3, 16, dev=dev, dtype=torch.float32, seed=21)
+    pm = pre[:, :3].float().reshape(B, 16, 3).permute(0, 2, 1)
+    check("clamp bwd", ops.clamp_bwd(pre, dimg, B, 16, 3), dimg * ((pm >= -1) & (pm <= 1)), 1e-6)
