@@ -64,9 +64,9 @@ __device__ __forceinline__ float quick_gelu_grad_f(float x) {
 }
 __device__ __forceinline__ float hardswish_f(float x) { return x * fminf(fmaxf(x + 3.f, 0.f), 6.f) * (1.f / 6.f); }
 __device__ __forceinline__ float hardswish_grad_f(float x) {
-    // torch: 0 for x < -3, grad*(x/3 + 0.5) for -3 <= x <= 3, grad for x > 3
-    if (x < -3.f) return 0.f;
-    if (x <= 3.f) return x * (1.f / 3.f) + 0.5f;
+    // sub-gradient convention at the kinks follows torch (2.10): 0 for x <= -3, x/3 + 0.5 inside, 1 for x >= 3
+    if (x <= -3.f) return 0.f;
+    if (x < 3.f) return x * (1.f / 3.f) + 0.5f;
     return 1.f;
 }
 __device__ __forceinline__ float hardsigmoid_f(float x) { return fminf(fmaxf(x + 3.f, 0.f), 6.f) * (1.f / 6.f); }

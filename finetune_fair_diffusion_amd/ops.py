@@ -101,7 +101,8 @@ def conv3x3(x, w, B, H, W, *, mode=CONV_NORMAL, bias=None, rowbias=None, residua
     if bias is not None:
         d.bias = _chk(bias, F32).data_ptr()
     if rowbias is not None:
-        d.rowbias, d.ld_rowbias, d.rows_per_batch = _chk(rowbias).data_ptr(), rowbias.stride(0), Ho * Wo
+        # one row per image, or a single row shared by the whole batch (time embedding: same t for all samples)
+        d.rowbias, d.ld_rowbias, d.rows_per_batch = _chk(rowbias).data_ptr(), rowbias.stride(0), (M if rowbias.shape[0] == 1 else Ho * Wo)
     if residual is not None:
         d.residual, d.ldr = _chk(residual).data_ptr(), residual.stride(0)
     d.alpha, d.M, d.N, d.K, d.act, d.batch = 1.0, M, Cout, 9 * Cin, ACT[act], 1
@@ -382,3 +383,17 @@ def crop_resize_bwd(dchips, boxes, B, H, W, S):
     dimg = torch.zeros((B, 3, H, W), dtype=F32, device=dchips.device)
     _call("fd_crop_resize_bwd", _p(_chk(dchips, F32)), _p(boxes), _p(dimg), B, H, W, S, _stream())
     return dimg
+
+
+# ----------------------------------------------------------------------------- text-encoder attention
+def small_attn_fwd(q, k, v, key_valid, B, H, T, d, scale, causal=True, save_p=False):
+    o = torch.empty_like(q)
+    P = torch.empty((B, H, T, T), dtype=F32, device=q.device) if save_p else None
+    _call("fd_small_attn_fwd", _p(_chk(q)), _p(_chk(k)), _p(_chk(v)), _p(o), _p(P), _p(key_valid), B, H, T, d, scale, int(causal), _stream())
+    return (o, P) if save_p else o
+
+
+def small_attn_bwd(q, k, v, P, do, B, H, T, d, scale):
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    _call("fd_small_attn_bwd", _p(q), _p(k), _p(v), _p(_chk(P, F32)), _p(_chk(do)), _p(dq), _p(dk), _p(dv), B, H, T, d, scale, _stream())
+    return dq, dk, dv

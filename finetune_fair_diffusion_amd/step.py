@@ -1,0 +1,215 @@
+"""The fairness-finetuning training step on one MI355X rank -- the hot path of
+exp-1-debias-gender/1-main-debias.py:1746-2029 re-designed for this hardware:
+
+* R1 / R2: no-grad CFG rollouts (``generate_image_no_gradient`` :998-1061) of the finetuned and the
+  frozen original models: S fused U-Net forwards on the 2N CFG batch, one fused CFG+DPM-Solver++
+  update kernel per step, VAE decode.
+* R3: ``generate_image_w_gradient`` (:1063-1136) as *recompute-backward*: the forward rollout only
+  keeps the S input latents [N,4,64,64]; dL/dx_final is obtained once (classifier + VAE backward),
+  and because the U-Net input is detached at every step the gradient of eps_i is the scalar
+  ``grad_coef_i * c_i`` times dL/dx_final (scheduler.chain_coefs) -- each timestep is then
+  recomputed with recording and back-propagated independently, O(1) activation memory in S.
+* all micro-batches of the reference (``train_GPU_batch_size`` chunks, :1889) run as ONE batch with
+  per-image weights 1/n_j (identical gradient, see fairness.microbatch_weights).
+* gradient sync: one RCCL all-reduce of the flat fp32 LoRA-gradient buffer + fused scale/finite
+  check + one AdamW+EMA launch (replaces the 400 per-tensor collectives/launches of :1998-2029).
+
+The loss is the distributional-alignment term (``loss_fair``); the CLIP/DINO/face regularisers are
+SURVEY.md 8f "next" rows.
+"""
+import math
+
+import torch
+import torch.distributed as dist
+
+from . import ops
+from .fairness import SyntheticFaceProvider, fair_loss_and_grad, generate_dynamic_targets, microbatch_weights
+from .layers import F16, F32
+
+
+def _pow2_scale(amax, target):
+    if not math.isfinite(amax) or amax <= 0:
+        return 1.0
+    return float(2.0 ** round(math.log2(target / amax)))
+
+
+class EMAState:
+    """diffusers ``EMAModel`` decay schedule (no warm-up flag): decay_n = min(decay, (1+n)/(10+n)), first step copies."""
+
+    def __init__(self, decay):
+        self.decay, self.optimization_step = decay, 0
+
+    def next_one_minus_decay(self):
+        self.optimization_step += 1
+        step = max(0, self.optimization_step - 1)
+        d = 0.0 if step <= 0 else min((1 + step) / (10 + step), self.decay)
+        return 1.0 - d
+
+
+class FairnessTrainer:
+    def __init__(self, args, text_encoder, unet, vae, classifier, scheduler, eval_text_encoder=None, eval_unet=None,
+                 face_provider=None, attr_cols=(40, 42), rank=0, world_size=1, device=None):
+        self.args = args
+        self.te, self.unet, self.vae, self.clf, self.sch = text_encoder, unet, vae, classifier, scheduler
+        self.eval_te = eval_text_encoder if eval_text_encoder is not None else text_encoder
+        self.eval_unet = eval_unet if eval_unet is not None else unet
+        self.faces = face_provider or SyntheticFaceProvider()
+        self.attr_cols = attr_cols
+        self.rank, self.world = rank, world_size
+        self.device = device or unet.device
+        self.banks = []
+        if getattr(args, "train_unet", False):
+            self.banks.append(unet.lora_bank)
+        if getattr(args, "train_text_encoder", False):
+            self.banks.append(text_encoder.lora_bank)
+        self.ema = [EMAState(args.EMA_decay) for _ in self.banks]
+        self.opt_step = 0
+        self.flag = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self.clf_gscale = 1024.0
+        self.timers = None
+
+    # ------------------------------------------------------------------ pieces
+    def encode_pair(self, te, tokens, record=False):
+        """tokens = (prompt_ids [L], prompt_mask [L], uncond_ids [L], uncond_mask [L]) -> enc [2,L,D] fp16, uncond first (:1035)."""
+        pid, pm, uid, um = tokens
+        ids = torch.stack([uid, pid]).to(self.device)
+        mask = torch.stack([um, pm]).to(self.device)
+        return te.forward(ids, mask, record=record)[0]
+
+    def rollout(self, unet, enc, noises, S, keep_inputs=False, record_prompt=False):
+        """CFG denoising rollout (:1038-1056).  noises [N,4,h,w] fp32 on device.  Returns (x_final, [x_i])."""
+        N = noises.shape[0]
+        self.sch.set_timesteps(S)
+        unet.prepare_timesteps(self.sch.timesteps)
+        unet.prepare_prompt(enc, record=record_prompt)
+        lat = noises.clone()
+        state, inputs = {}, []
+        gs = self.args.guidance_scale
+        for i in range(S):
+            if keep_inputs:
+                inputs.append(lat.clone())
+            x = ops.to_f16(lat).repeat(2, 1, 1, 1)
+            eps = unet.forward_step(x, i)
+            self.sch.cfg_step(i, eps, gs, lat, state)
+        return lat, inputs
+
+    def decode(self, lat, record=False):
+        return self.vae.decode_images(lat * (1.0 / self.vae.config.scaling_factor), record=record)
+
+    def classify(self, images, record=False):
+        """get_face + get_face_gender (:1794-1795): returns indicators, boxes, preds, probs(-1 filled), logits_attr."""
+        N = images.shape[0]
+        ind, boxes = self.faces(images)
+        S = self.args.size_face
+        a, b = self.attr_cols
+        probs = torch.full((N, b - a), -1.0)
+        preds = torch.full((N,), -1, dtype=torch.long)
+        logits_attr = torch.full((N, b - a), -1.0)
+        sel = ind.nonzero().view(-1)
+        if len(sel):
+            chips = ops.crop_resize(images[sel.to(images.device)].contiguous() if len(sel) != N else images, boxes[sel].to(self.device).contiguous(), -1.0, S)
+            logits = self.clf.forward(chips, record=record)
+            la = logits[:, a:b].float().cpu()
+            logits_attr[sel] = la
+            p = torch.softmax(la, dim=-1)
+            probs[sel] = p
+            preds[sel] = p.max(dim=-1).indices
+        return ind, boxes, preds, probs, logits_attr
+
+    # ------------------------------------------------------------------ the step
+    def train_step(self, tokens, noises, S):
+        args = self.args
+        dev = self.device
+        B = noises.shape[0]
+        noises = noises.to(dev, F32)
+        out = {}
+        for bank in self.banks:
+            bank.grad.zero_()
+        vb = args.val_GPU_batch_size
+        # ---- R1: images from the model being finetuned (:1786-1795)
+        enc = self.encode_pair(self.te, tokens)
+        images = torch.cat([self.decode(self.rollout(self.unet, enc, noises[j:j + vb], S)[0]) for j in range(0, B, vb)])
+        ind, boxes, preds, probs, _ = self.classify(images)
+        # ---- dynamic targets from the global batch (:1805-1837)
+        if self.world > 1:
+            allp = [torch.empty_like(probs) for _ in range(self.world)]
+            pg = probs.to(dev)
+            gl = [torch.empty_like(pg) for _ in range(self.world)]
+            dist.all_gather(gl, pg)
+            probs_all = torch.cat([t.cpu() for t in gl])
+        else:
+            probs_all = probs
+        targets_all, unc_all = generate_dynamic_targets(probs_all, w_uncertainty=True)
+        targets_all[unc_all > args.uncertainty_threshold] = -1
+        targets = targets_all[B * self.rank:B * (self.rank + 1)]
+        out.update(images=images, probs=probs, preds=preds, targets=targets, uncertainty=unc_all[B * self.rank:B * (self.rank + 1)])
+        # ---- R2: images from the frozen original models (:1844-1858)
+        enc_ori = self.encode_pair(self.eval_te, tokens) if self.eval_te is not self.te else enc
+        images_ori = torch.cat([self.decode(self.rollout(self.eval_unet, enc_ori, noises[j:j + vb], S)[0]) for j in range(0, B, vb)])
+        ind_o, boxes_o, preds_o, probs_o, _ = self.classify(images_ori)
+        out.update(images_ori=images_ori, preds_ori=preds_o, probs_ori=probs_o)
+        # ---- R3: rollout with gradient (:1889-1933), all micro-batches at once with weights 1/n_j
+        train_te = getattr(args, "train_text_encoder", False) and self.te.lora_bank is not None
+        train_unet = getattr(args, "train_unet", False) and self.unet.lora_bank is not None
+        w, N_backward = microbatch_weights(B, args.train_GPU_batch_size)
+        enc_g = self.encode_pair(self.te, tokens, record=train_te)
+        x_final, inputs = self.rollout(self.unet, enc_g, noises, S, keep_inputs=True, record_prompt=True)
+        images_g = self.decode(x_final, record=True)
+        ind_g, boxes_g, _, _, logits_g = self.classify(images_g, record=True)
+        loss_fair, dl = fair_loss_and_grad(logits_g, targets, ind_g, w)
+        out.update(loss_fair=loss_fair, images_grad=images_g, N_backward=N_backward)
+        sel = ind_g.nonzero().view(-1)
+        if len(sel) and float(dl.abs().sum()) > 0:
+            a, b = self.attr_cols
+            dlog = torch.zeros((len(sel), self.clf.num_classes), dtype=F32)
+            dlog[:, a:b] = dl[sel]
+            dchips = self.clf.backward(dlog.to(dev), self.clf_gscale)
+            full = dchips
+            if len(sel) != B:
+                full = torch.zeros((B,) + tuple(dchips.shape[1:]), dtype=F32, device=dev)
+                full[sel.to(dev)] = dchips
+            bx = boxes_g.clone()
+            bx[~ind_g] = 0
+            Himg, Wimg = images_g.shape[2], images_g.shape[3]
+            d_img = ops.crop_resize_bwd(full.contiguous(), bx.to(dev).contiguous(), B, Himg, Wimg, args.size_face)
+            vscale = _pow2_scale(float(d_img.abs().max()), 64.0)
+            dz = self.vae.backward_images(d_img, vscale)
+            g = dz * (1.0 / self.vae.config.scaling_factor)          # dL/dx_final  [B,4,h,w] fp32
+            coefs = self.sch.grad_coefs() * self.sch.chain_coefs()   # hook (:1128) x scheduler recurrence (:1131)
+            gs = args.guidance_scale
+            gscale = _pow2_scale(float(g.abs().max()) * float(abs(coefs).max()) * max(abs(gs), abs(1 - gs)), 64.0)
+            out.update(g=g, coefs=coefs, gscale=gscale)
+            if train_unet or train_te:
+                for i in range(S):
+                    x = ops.to_f16(inputs[i]).repeat(2, 1, 1, 1)
+                    self.unet.forward_step(x, i, record=True)
+                    d = g * float(coefs[i] * gscale)
+                    self.unet.backward_step(torch.cat([d * (1.0 - gs), d * gs]), gscale)
+                denc = self.unet.finish_prompt_backward(gscale, need_denc=train_te)
+                if train_te:
+                    L = enc_g.shape[1]
+                    self.te.backward(denc.view(2, L, -1), gscale)
+        else:
+            self.vae._ctx = self.clf._ctx = None
+        # ---- gradient sync, guard, update (:1998-2029)
+        out["grad_is_finite"] = self.sync_and_update(N_backward)
+        return out
+
+    def sync_and_update(self, N_backward, apply=True):
+        args = self.args
+        self.flag.zero_()
+        for bank in self.banks:
+            if self.world > 1:
+                dist.all_reduce(bank.grad, op=dist.ReduceOp.SUM)
+            ops.grad_finite_scale(bank.grad, 1.0 / (self.world * N_backward), self.flag)
+        finite = int(self.flag.item()) == 0  # checked after the all-reduce so every rank takes the same branch
+        if finite and apply:
+            self.opt_step += 1
+            for bank, ema in zip(self.banks, self.ema):
+                ops.adamw_ema(bank.flat, bank.grad, bank.exp_avg, bank.exp_avg_sq, bank.ema, args.learning_rate, args.adam_beta1,
+                              args.adam_beta2, args.adam_epsilon, args.adam_weight_decay, self.opt_step, ema.next_one_minus_decay())
+            if getattr(args, "train_unet", False):
+                self.unet.refresh_lora()
+            if getattr(args, "train_text_encoder", False):
+                self.te.refresh_lora()
+        return finite

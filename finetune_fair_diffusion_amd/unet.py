@@ -1,0 +1,404 @@
+"""MI355X-native mirror of diffusers ``UNet2DConditionModel`` + ``LoRAAttnProcessor`` for the
+reference's call ``unet(latent_model_input, t, encoder_hidden_states=prompt_embeds).sample``
+(exp-1-debias-gender/1-main-debias.py:1046-1050, :1118-1122; LoRA injection :798-818).
+
+Execution model (not autograd): ``forward(..., record=True)`` keeps exactly the tensors the explicit
+``backward`` needs; base weights are frozen so backward computes data gradients only, plus the
+fp32 LoRA weight gradients, which are accumulated straight into the flat ``ParamBank.grad`` buffer.
+Because the reference detaches the U-Net input at every denoising step (:1115) each timestep's
+backward is independent given dL/d(eps_i) -- the training step (step.py) therefore re-runs this
+forward per timestep with ``record=True`` (gradient-checkpointed recompute) and frees it again.
+
+Workload structure exploited: cross-attention K/V depend only on the
+prompt -> computed once per rollout for the 2 distinct sequences (uncond, cond) and shared by
+every sample of that CFG half (``kv_div``); the 22 time-embedding projections depend only on t ->
+one stacked GEMM per rollout for all S timesteps.
+"""
+import math
+
+import torch
+
+from . import ops
+from .layers import (F16, F32, Conv3x3, Linear, LoRAPair, Norm, ParamBank, ResnetBlock, lora_linear_bwd, lora_linear_fwd)
+from .weights import UNetConfig, unet_attn_names, unet_lora_param_shapes, unet_param_shapes
+
+
+class _Out:
+    def __init__(self, sample):
+        self.sample = sample
+
+
+class AttnLoRA:
+    """The four LoRALinearLayers of one LoRAAttnProcessor."""
+
+    def __init__(self, bank, name):
+        self.q, self.k, self.v, self.out = (LoRAPair(bank, f"{name}.{p}_lora.down.weight", f"{name}.{p}_lora.up.weight")
+                                            for p in ("to_q", "to_k", "to_v", "to_out"))
+
+    def refresh(self):
+        for p in (self.q, self.k, self.v, self.out):
+            p.refresh()
+        # stacked down matrices: one skinny GEMM gives t for q,k,v of self-attention
+        if self.q.K == self.k.K:
+            self.down_qkv16 = torch.cat([self.q.down16, self.k.down16, self.v.down16], 0).contiguous()
+        self.down_kv16 = torch.cat([self.k.down16, self.v.down16], 0).contiguous()
+
+
+class TransformerBlock:
+    """Transformer2DModel with one BasicTransformerBlock (norm -> proj_in -> [LN, attn1, LN, attn2, LN, GEGLU-FF] -> proj_out)."""
+
+    def __init__(self, sd, p, dev, C, heads, groups, xdim):
+        self.C, self.heads, self.d, self.groups, self.xdim = C, heads, C // heads, groups, xdim
+        self.p = p
+        self.norm = Norm(sd, p + "norm", dev)
+        self.proj_in = Linear(sd, p + "proj_in", dev, conv1x1=True)
+        self.proj_out = Linear(sd, p + "proj_out", dev, conv1x1=True)
+        b = p + "transformer_blocks.0."
+        self.ln1, self.ln2, self.ln3 = Norm(sd, b + "norm1", dev), Norm(sd, b + "norm2", dev), Norm(sd, b + "norm3", dev)
+        self.q1, self.k1, self.v1, self.o1 = (Linear(sd, b + "attn1." + n, dev) for n in ("to_q", "to_k", "to_v", "to_out.0"))
+        self.q2, self.k2, self.v2, self.o2 = (Linear(sd, b + "attn2." + n, dev) for n in ("to_q", "to_k", "to_v", "to_out.0"))
+        self.ff1, self.ff2 = Linear(sd, b + "ff.net.0.proj", dev), Linear(sd, b + "ff.net.2", dev)
+        self.lora1 = self.lora2 = None  # AttnLoRA for attn1 / attn2
+        self.name1, self.name2 = b + "attn1.processor", b + "attn2.processor"
+        self.cross = None  # per-rollout cross-attention K/V cache
+
+    # -- cross-attention K/V for the rollout's prompt embeddings (timestep invariant) ------------
+    def prepare_cross(self, enc, Bk, L, record):
+        """enc: [Bk*L, xdim] fp16.  Caches K [Bk*L,C], V, K^T, V^T ([Bk,C,Lp])."""
+        lo = self.lora2
+        te = ops.gemm(enc, lo.down_kv16) if lo is not None else None
+        rp = lo.k.rp if lo is not None else 0
+        if lo is not None:
+            K = ops.gemm(enc, self.k2.w, a2=te[:, :rp], b2=lo.k.up16)
+            V = ops.gemm(enc, self.v2.w, a2=te[:, rp:], b2=lo.v.up16)
+        else:
+            K, V = ops.gemm(enc, self.k2.w), ops.gemm(enc, self.v2.w)
+        self.cross = dict(K=K, V=V, Vt=ops.transpose_btc(V, Bk, L, self.C), Bk=Bk, L=L, enc=enc, te=te)
+        if record:
+            self.cross["Kt"] = ops.transpose_btc(K, Bk, L, self.C)
+            self.cross["dK"] = torch.zeros((Bk * L, self.C), dtype=F32, device=enc.device)
+            self.cross["dV"] = torch.zeros((Bk * L, self.C), dtype=F32, device=enc.device)
+
+    def finish_cross_backward(self, gscale, need_denc):
+        """Backward of prepare_cross from the accumulated (over steps and samples) dK/dV."""
+        c, lo = self.cross, self.lora2
+        dK, dV = ops.to_f16(c["dK"]), ops.to_f16(c["dV"])
+        rp = lo.k.rp if lo is not None else 0
+        te = c["te"]
+        denc = lora_linear_bwd(dK, c["enc"], te[:, :rp] if te is not None else None, self.k2, lo.k if lo else None, gscale, need_dx=need_denc)
+        denc = lora_linear_bwd(dV, c["enc"], te[:, rp:] if te is not None else None, self.v2, lo.v if lo else None, gscale, residual=denc,
+                               need_dx=need_denc)
+        return denc
+
+    # -- forward -------------------------------------------------------------------------------
+    def forward(self, x, B, H, W, ctx=None):
+        HW, M, C, h, d = H * W, B * H * W, self.C, self.heads, self.d
+        rec = ctx is not None
+        g, st = ops.groupnorm(x, None, B, HW, self.groups, 1e-6, self.norm.gamma, self.norm.beta, False)
+        h0 = ops.gemm(g, self.proj_in.w, bias=self.proj_in.bias)
+        n1, ln1 = ops.layernorm(h0, self.ln1.gamma, self.ln1.beta, 1e-5, save_stats=True)  # stats are 8 B/row: always kept
+        l1 = self.lora1
+        if l1 is not None:
+            rp = l1.q.rp
+            t1 = ops.gemm(n1, l1.down_qkv16)
+            q = ops.gemm(n1, self.q1.w, a2=t1[:, :rp], b2=l1.q.up16)
+            k = ops.gemm(n1, self.k1.w, a2=t1[:, rp:2 * rp], b2=l1.k.up16)
+            v = ops.gemm(n1, self.v1.w, a2=t1[:, 2 * rp:], b2=l1.v.up16)
+        else:
+            t1 = None
+            q, k, v = ops.gemm(n1, self.q1.w), ops.gemm(n1, self.k1.w), ops.gemm(n1, self.v1.w)
+        vt = ops.transpose_btc(v, B, HW, C)
+        o, lse = ops.attn_fwd(q, k, vt, B, h, HW, HW, d, 1, need_lse=True)
+        h1, to1 = lora_linear_fwd(o, self.o1, l1.out if l1 else None, residual=h0)
+        n2, ln2 = ops.layernorm(h1, self.ln2.gamma, self.ln2.beta, 1e-5, save_stats=True)
+        l2 = self.lora2
+        q2, tq2 = lora_linear_fwd(n2, self.q2, l2.q if l2 else None)
+        cr = self.cross
+        kv_div = B // cr["Bk"]
+        o2, lse2 = ops.attn_fwd(q2, cr["K"], cr["Vt"], B, h, HW, cr["L"], d, kv_div, need_lse=True)
+        h2, to2 = lora_linear_fwd(o2, self.o2, l2.out if l2 else None, residual=h1)
+        n3, ln3 = ops.layernorm(h2, self.ln3.gamma, self.ln3.beta, 1e-5, save_stats=True)
+        proj = ops.gemm(n3, self.ff1.w, bias=self.ff1.bias)
+        gg = ops.geglu(proj)
+        h3 = ops.gemm(gg, self.ff2.w, bias=self.ff2.bias, residual=h2)
+        out = ops.gemm(h3, self.proj_out.w, bias=self.proj_out.bias, residual=x)
+        if rec:
+            ctx.append(dict(x=x, st=st, h0=h0, ln1=ln1, n1=n1, t1=t1, q=q, k=k, v=v, o=o, lse=lse, to1=to1, h1=h1, ln2=ln2, n2=n2,
+                            tq2=tq2, q2=q2, o2=o2, lse2=lse2, to2=to2, h2=h2, ln3=ln3, proj=proj))
+        return out
+
+    # -- backward ------------------------------------------------------------------------------
+    def backward(self, d_out, B, H, W, c, gscale):
+        HW, C, h, d = H * W, self.C, self.heads, self.d
+        l1, l2 = self.lora1, self.lora2
+        dh3 = ops.gemm(d_out, self.proj_out.wT)
+        dgg = ops.gemm(dh3, self.ff2.wT)
+        dproj = ops.geglu_bwd(c["proj"], dgg)
+        dn3 = ops.gemm(dproj, self.ff1.wT)
+        dh2 = ops.layernorm_bwd(c["h2"], dn3, self.ln3.gamma, c["ln3"], add=dh3)
+        # attn2 (cross)
+        do2 = lora_linear_bwd(dh2, c["o2"], c["to2"], self.o2, l2.out if l2 else None, gscale)
+        cr = self.cross
+        kv_div = B // cr["Bk"]
+        if kv_div > 1:
+            dq2, _, _ = ops.attn_bwd(c["q2"], cr["K"], cr["V"], c["o2"], do2, c["lse2"], B, h, HW, cr["L"], d, kv_div, kt=cr["Kt"],
+                                     dk_acc=cr["dK"], dv_acc=cr["dV"])
+        else:
+            dq2, dk2, dv2 = ops.attn_bwd(c["q2"], cr["K"], cr["V"], c["o2"], do2, c["lse2"], B, h, HW, cr["L"], d, 1, kt=cr["Kt"])
+            cr["dK"] += dk2.float()
+            cr["dV"] += dv2.float()
+        dn2 = lora_linear_bwd(dq2, c["n2"], c["tq2"], self.q2, l2.q if l2 else None, gscale)
+        dh1 = ops.layernorm_bwd(c["h1"], dn2, self.ln2.gamma, c["ln2"], add=dh2)
+        # attn1 (self)
+        do1 = lora_linear_bwd(dh1, c["o"], c["to1"], self.o1, l1.out if l1 else None, gscale)
+        dq, dk, dv = ops.attn_bwd(c["q"], c["k"], c["v"], c["o"], do1, c["lse"], B, h, HW, HW, d, 1)
+        t1 = c["t1"]
+        rp = l1.q.rp if l1 else 0
+        sl = (lambda i: t1[:, i * rp:(i + 1) * rp]) if l1 else (lambda i: None)
+        dn1 = lora_linear_bwd(dq, c["n1"], sl(0), self.q1, l1.q if l1 else None, gscale)
+        dn1 = lora_linear_bwd(dk, c["n1"], sl(1), self.k1, l1.k if l1 else None, gscale, residual=dn1)
+        dn1 = lora_linear_bwd(dv, c["n1"], sl(2), self.v1, l1.v if l1 else None, gscale, residual=dn1)
+        dh0 = ops.layernorm_bwd(c["h0"], dn1, self.ln1.gamma, c["ln1"], add=dh1)
+        dg = ops.gemm(dh0, self.proj_in.wT)
+        dx, _ = ops.groupnorm_bwd(c["x"], None, dg, B, HW, self.groups, c["st"], self.norm.gamma, self.norm.beta, False, add1=d_out)
+        return dx
+
+
+class UNet2DConditionModel:
+    def __init__(self, cfg: UNetConfig, state_dict, device):
+        self.config, self.device = cfg, device
+        shapes = unet_param_shapes(cfg)
+        missing = [k for k in shapes if k not in state_dict]
+        if missing:
+            raise KeyError(f"UNet state_dict is missing {len(missing)} tensors, e.g. {missing[:3]}")
+        sd, dev = state_dict, device
+        boc, g, heads, xdim, n = cfg.block_out_channels, cfg.norm_num_groups, cfg.attention_head_dim, cfg.cross_attention_dim, cfg.layers_per_block
+        self.temb_dim = boc[0] * 4
+        w = sd["conv_in.weight"].to(dev, F32)
+        self.conv_in_w = w.permute(2, 3, 1, 0).reshape(9 * cfg.in_channels, boc[0]).contiguous()
+        self.conv_in_b = sd["conv_in.bias"].to(dev, F32).contiguous()
+        self.time1, self.time2 = Linear(sd, "time_embedding.linear_1", dev), Linear(sd, "time_embedding.linear_2", dev)
+        self.resnets, self.transformers = [], []
+
+        def res(p):
+            r = ResnetBlock(sd, p, dev, g, 1e-5)
+            self.resnets.append(r)
+            return r
+
+        def tr(p, c):
+            t = TransformerBlock(sd, p, dev, c, heads, g, xdim)
+            self.transformers.append(t)
+            return t
+
+        self.down = []
+        cout = boc[0]
+        for i, t in enumerate(cfg.down_block_types):
+            cout = boc[i]
+            blk = dict(res=[res(f"down_blocks.{i}.resnets.{j}.") for j in range(n)],
+                       attn=[tr(f"down_blocks.{i}.attentions.{j}.", cout) for j in range(n)] if t.startswith("CrossAttn") else None,
+                       down=Conv3x3(sd, f"down_blocks.{i}.downsamplers.0.conv", dev) if i != len(boc) - 1 else None)
+            self.down.append(blk)
+        c = boc[-1]
+        self.mid = dict(res=[res("mid_block.resnets.0."), res("mid_block.resnets.1.")], attn=[tr("mid_block.attentions.0.", c)])
+        self.up = []
+        rev = list(reversed(boc))
+        for i, t in enumerate(cfg.up_block_types):
+            cout = rev[i]
+            blk = dict(res=[res(f"up_blocks.{i}.resnets.{j}.") for j in range(n + 1)],
+                       attn=[tr(f"up_blocks.{i}.attentions.{j}.", cout) for j in range(n + 1)] if t.startswith("CrossAttn") else None,
+                       up=Conv3x3(sd, f"up_blocks.{i}.upsamplers.0.conv", dev) if i != len(boc) - 1 else None)
+            self.up.append(blk)
+        self.norm_out = Norm(sd, "conv_norm_out", dev)
+        self.conv_out = Conv3x3(sd, "conv_out", dev)
+        wo = sd["conv_out.weight"].to(dev, F32)  # data-gradient as a small-Cin direct conv: [k*k*Cout_as_in, Cin_as_out]
+        self.conv_out_wd = wo.flip(2, 3).permute(2, 3, 0, 1).reshape(9 * cfg.out_channels, boc[0]).contiguous()
+        # stacked time-embedding projections of all resnets: one GEMM per rollout
+        ws, bs, off = [], [], 0
+        for r in self.resnets:
+            ws.append(r.temb_w.to(dev, F16))
+            bs.append(r.temb_b.to(dev, F32))
+            r.temb_slice = (off, off + ws[-1].shape[0])
+            off += ws[-1].shape[0]
+        self.temb_proj_w = torch.cat(ws, 0).contiguous()
+        self.temb_proj_b = torch.cat(bs, 0).contiguous()
+        self.lora_bank = None
+        self._tr_by_name = {}
+        for t in self.transformers:
+            self._tr_by_name[t.name1] = (t, 1)
+            self._tr_by_name[t.name2] = (t, 2)
+        self.temb_table = None
+        self._ctx = None
+
+    # ------------------------------------------------------------------ diffusers-compatible surface
+    @property
+    def attn_processors(self):
+        return {n: (getattr(self._tr_by_name[n][0], f"lora{self._tr_by_name[n][1]}")) for n in unet_attn_names(self.config)}
+
+    def enable_gradient_checkpointing(self):  # always on: the step recomputes per timestep
+        return None
+
+    def train(self, mode=True):
+        return self
+
+    def eval(self):
+        return self
+
+    def requires_grad_(self, flag=False):
+        return self
+
+    def add_lora(self, rank, state_dict=None, seed=0):
+        """Create the 32 LoRAAttnProcessors (rank r) in one flat fp32 ParamBank (:798-818)."""
+        shapes = unet_lora_param_shapes(self.config, rank)
+        self.lora_bank = ParamBank(shapes, self.device)
+        if state_dict is None:
+            from .weights import synthetic_state_dict
+            state_dict = synthetic_state_dict(shapes, seed=seed)
+        self.lora_bank.load_state_dict(state_dict)
+        for name, (t, which) in self._tr_by_name.items():
+            setattr(t, f"lora{which}", AttnLoRA(self.lora_bank, name))
+        self.refresh_lora()
+        return self.lora_bank
+
+    def refresh_lora(self):
+        for t in self.transformers:
+            for lo in (t.lora1, t.lora2):
+                if lo is not None:
+                    lo.refresh()
+
+    def load_state_dict(self, sd, strict=False):
+        """LoRA tensors by diffusers key (gen-images.py:520-521 calls exactly this with strict=False)."""
+        if self.lora_bank is not None:
+            self.lora_bank.load_state_dict(sd, strict=strict)
+            self.refresh_lora()
+
+    # ------------------------------------------------------------------ per-rollout preparation
+    def prepare_timesteps(self, timesteps):
+        """temb table [S, sum(Cout)] for all S timesteps: sinusoid -> MLP -> SiLU -> 22 stacked projections."""
+        c0 = self.config.block_out_channels[0]
+        half = c0 // 2
+        t = torch.as_tensor(timesteps, dtype=F32).reshape(-1, 1)
+        freq = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=F32) / half)[None]
+        emb = torch.cat([torch.cos(t * freq), torch.sin(t * freq)], -1).to(F16).to(self.device)  # flip_sin_to_cos, cast to wd
+        h = ops.gemm(emb, self.time1.w, bias=self.time1.bias, act="silu")
+        temb = ops.gemm(h, self.time2.w, bias=self.time2.bias, act="silu")  # SiLU(temb) feeds every time_emb_proj
+        self.temb_table = ops.gemm(temb, self.temb_proj_w, bias=self.temb_proj_b)
+        self.timesteps = [int(v) for v in torch.as_tensor(timesteps).reshape(-1).tolist()]
+
+    def prepare_prompt(self, enc, record=False):
+        """enc: [Bk, L, xdim] fp16 (Bk = 2 for the shared CFG pair, or 2N for per-sample embeddings)."""
+        Bk, L, X = enc.shape
+        e2 = enc.reshape(Bk * L, X).to(F16).contiguous()
+        for t in self.transformers:
+            t.prepare_cross(e2, Bk, L, record)
+
+    def finish_prompt_backward(self, gscale, need_denc=False):
+        denc = None
+        for t in self.transformers:
+            d = t.finish_cross_backward(gscale, need_denc)
+            if need_denc:
+                denc = d if denc is None else ops.add(denc, d)
+        return denc
+
+    # ------------------------------------------------------------------ forward / backward
+    def forward_step(self, sample, step_index, record=False):
+        """sample: [B,4,H,W] NCHW (fp32 or fp16; cast to wd as the reference does :1043).
+        Returns eps [B,4,H*W] fp32 (values are fp16-rounded, then upcast like :1051)."""
+        cfg = self.config
+        B, Cin, H, W = sample.shape
+        boc = cfg.block_out_channels
+        trow = self.temb_table[step_index:step_index + 1]
+        ctx = [] if record else None
+
+        def temb(r):
+            a, b = r.temb_slice
+            return trow[:, a:b]
+
+        x16 = sample if sample.dtype == F16 else ops.to_f16(sample.contiguous())
+        x, _, _ = ops.conv_small_cin(x16.contiguous(), self.conv_in_w, self.conv_in_b, B, H, W, Cin, boc[0], 3, 1, nchw=True)
+        skips = [(x, H, W)]
+        for blk in self.down:
+            for j, r in enumerate(blk["res"]):
+                x = r.forward(x, None, B, H, W, temb(r), ctx)
+                if blk["attn"] is not None:
+                    x = blk["attn"][j].forward(x, B, H, W, ctx)
+                skips.append((x, H, W))
+            if blk["down"] is not None:
+                x, H, W = ops.conv3x3(x, blk["down"].wk, B, H, W, mode=ops.CONV_STRIDE2, bias=blk["down"].bias)
+                skips.append((x, H, W))
+        x = self.mid["res"][0].forward(x, None, B, H, W, temb(self.mid["res"][0]), ctx)
+        x = self.mid["attn"][0].forward(x, B, H, W, ctx)
+        x = self.mid["res"][1].forward(x, None, B, H, W, temb(self.mid["res"][1]), ctx)
+        for blk in self.up:
+            for j, r in enumerate(blk["res"]):
+                s, _, _ = skips.pop()
+                x = r.forward(x, s, B, H, W, temb(r), ctx)
+                if blk["attn"] is not None:
+                    x = blk["attn"][j].forward(x, B, H, W, ctx)
+            if blk["up"] is not None:
+                x, H, W = ops.conv3x3(x, blk["up"].wk, B, H, W, mode=ops.CONV_UP2, bias=blk["up"].bias)
+        g, st = ops.groupnorm(x, None, B, H * W, cfg.norm_num_groups, 1e-5, self.norm_out.gamma, self.norm_out.beta, True)
+        y, _, _ = ops.conv3x3(g, self.conv_out.wk, B, H, W, bias=self.conv_out.bias)
+        eps = ops.nhwc_to_nchw(y, B, H * W, cfg.out_channels, out_dtype=F32)
+        if record:
+            self._ctx = dict(blocks=ctx, x_out=x, st_out=st, B=B, H=H, W=W)
+        return eps
+
+    def backward_step(self, d_eps, gscale):
+        """d_eps: [B,4,H,W] fp32 = gscale * dL/d(eps).  Accumulates LoRA grads; returns nothing
+        (the U-Net input is detached in the reference, so no gradient flows to the latents)."""
+        cfg, c = self.config, self._ctx
+        B, H, W = c["B"], c["H"], c["W"]
+        boc = cfg.block_out_channels
+        blocks = c["blocks"]
+        dg, _, _ = ops.conv_small_cin(d_eps.contiguous(), self.conv_out_wd, None, B, H, W, cfg.out_channels, boc[0], 3, 1, nchw=True)
+        dx, _ = ops.groupnorm_bwd(c["x_out"], None, dg, B, H * W, cfg.norm_num_groups, c["st_out"], self.norm_out.gamma, self.norm_out.beta, True)
+        dskips = []
+        # up blocks, reversed
+        for bi in range(len(self.up) - 1, -1, -1):
+            blk = self.up[bi]
+            if blk["up"] is not None:
+                dxu, _, _ = ops.conv3x3(dx, blk["up"].wd, B, H, W)            # grad at the upsampled resolution
+                H, W = H // 2, W // 2
+                dx = ops.downsum2x2(dxu, B, H, W, dxu.shape[1])              # nearest-upsample backward
+            for j in range(len(blk["res"]) - 1, -1, -1):
+                if blk["attn"] is not None:
+                    dx = blk["attn"][j].backward(dx, B, H, W, blocks.pop(), gscale)
+                dx, dsk = blk["res"][j].backward(dx, B, H, W, blocks.pop())
+                dskips.append(dsk)
+        # mid
+        dx, _ = self.mid["res"][1].backward(dx, B, H, W, blocks.pop())
+        dx = self.mid["attn"][0].backward(dx, B, H, W, blocks.pop(), gscale)
+        dx, _ = self.mid["res"][0].backward(dx, B, H, W, blocks.pop())
+        # down blocks, reversed: every forward output that was pushed as a skip gets its skip-gradient added.
+        # The up path popped skips last-in-first-out and we walked it backwards, so dskips[k] already pairs
+        # with forward skip index k (skip 0 = conv_in output).
+        first_attn = next(i for i, b in enumerate(self.down) if b["attn"] is not None)
+        k = len(dskips) - 1
+        done = False
+        for bi in range(len(self.down) - 1, -1, -1):
+            blk = self.down[bi]
+            if blk["down"] is not None:
+                dx = ops.add(dx, dskips[k]); k -= 1
+                dx, H, W = ops.conv3x3(dx, blk["down"].wd, B, H, W, mode=ops.CONV_TRANS2)
+            for j in range(len(blk["res"]) - 1, -1, -1):
+                dx = ops.add(dx, dskips[k]); k -= 1
+                if blk["attn"] is not None:
+                    dx = blk["attn"][j].backward(dx, B, H, W, blocks.pop(), gscale)
+                last = (bi == first_attn and j == 0)
+                if last:
+                    done = True  # nothing trainable upstream of the first attention: stop here
+                    break
+                dx, _ = blk["res"][j].backward(dx, B, H, W, blocks.pop())
+            if done:
+                break
+        self._ctx = None
+
+    # ------------------------------------------------------------------ drop-in call
+    def __call__(self, sample, timestep, encoder_hidden_states=None):
+        """diffusers-compatible call: per-sample ``encoder_hidden_states`` [B,L,D]; returns obj.sample [B,4,H,W] (wd)."""
+        t = int(timestep)
+        self.prepare_timesteps([t])
+        self.prepare_prompt(encoder_hidden_states, record=False)
+        B, _, H, W = sample.shape
+        eps = self.forward_step(sample, 0, record=False)
+        return _Out(eps.reshape(B, -1, H, W).to(F16))

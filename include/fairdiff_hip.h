@@ -116,6 +116,13 @@ int fd_attn_bwd_dkdv(const void* q, const void* qt, const void* k, const void* v
                      const float* lse, const float* D, void* dk, void* dv, int B, int H, int Tq, int Tk, int d,
                      int kv_div, float scale, void* stream);
 
+/* ---- masked attention of the CLIP text encoder (transformers CLIPAttention; reference call sites :1011-1014, :1078-1081).
+ * q,k,v,o: [B,T,H*d] fp16, T<=128, d<=128; key_valid [B,T] int32 or NULL; P [B,H,T,T] fp32 (saved probabilities) or NULL */
+int fd_small_attn_fwd(const void* q, const void* k, const void* v, void* o, float* P, const int32_t* key_valid, int B, int H, int T,
+                      int d, float scale, int causal, void* stream);
+int fd_small_attn_bwd(const void* q, const void* k, const void* v, const float* P, const void* d_o, void* dq, void* dk, void* dv,
+                      int B, int H, int T, int d, float scale, void* stream);
+
 /* ---- LoRA weight gradients: G[n, r] (+)= sum_m X[m, n] * T[m, r]  (fp16 X,T; fp32 G with strides) */
 int fd_lora_wgrad(const void* X, int64_t ldx, const void* T, int64_t ldt, float* G, int64_t g_stride_n, int64_t g_stride_r,
                   int M, int N, int R, float scale, float* scratch, int64_t scratch_elems, void* stream);

@@ -1,0 +1,108 @@
+"""Builds matching (oracle, product) model pairs from the SAME synthetic state dicts (test helper)."""
+import copy
+import types
+
+import torch
+
+from finetune_fair_diffusion_amd import weights as W
+
+TINY_UNET = dict(block_out_channels=(64, 128, 256, 256), attention_head_dim=4, cross_attention_dim=64, sample_size=32)
+TINY_VAE = dict(block_out_channels=(32, 64, 64, 64))
+TINY_CLIP = dict(vocab_size=1000, hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=2)
+
+
+def tiny_tokens(L=7, vocab=1000):
+    ids = torch.tensor([vocab - 1] + list(range(5, 5 + L - 2)) + [vocab - 2])
+    mask = torch.ones(L, dtype=torch.long)
+    uids = torch.tensor([vocab - 1] + [vocab - 2] * (L - 1))
+    umask = torch.tensor([1, 1] + [0] * (L - 2))
+    return ids, mask, uids, umask
+
+
+def make_args(**kw):
+    d = dict(train_unet=True, train_text_encoder=False, rank=4, guidance_scale=7.5, train_GPU_batch_size=3, val_GPU_batch_size=8,
+             uncertainty_threshold=0.2, factor1=0.2, factor2=0.2, size_face=64, learning_rate=5e-5, adam_beta1=0.9, adam_beta2=0.999,
+             adam_weight_decay=1e-2, adam_epsilon=1e-8, EMA_decay=0.996)
+    d.update(kw)
+    return types.SimpleNamespace(**d)
+
+
+def oracle_models(rank=4, train_unet=True, train_te=False, num_classes=80, lora_up_std=0.02, seed=0):
+    """Returns dict of oracle modules + the state dicts they were loaded from."""
+    from oracle import nn_clip, nn_mobilenet, nn_unet, nn_vae
+    from oracle.dpm_solver import DPMSolverMultistepScheduler
+    ucfg, vcfg, ccfg = nn_unet.UNetConfig(**TINY_UNET), nn_vae.VAEConfig(**TINY_VAE), nn_clip.CLIPTextConfig(**TINY_CLIP)
+    sds = dict(
+        unet=W.synthetic_state_dict(W.unet_param_shapes(W.UNetConfig(**TINY_UNET)), seed=seed + 1),
+        vae=W.synthetic_state_dict(W.vae_param_shapes(W.VAEConfig(**TINY_VAE)), seed=seed + 2),
+        clip=W.synthetic_state_dict(W.clip_param_shapes(W.CLIPTextConfig(**TINY_CLIP)), seed=seed + 3),
+        clf=W.synthetic_state_dict(W.mobilenet_param_shapes(num_classes), seed=seed + 4, gain=1.4),
+    )
+    # the frozen models are cast to fp16 in the reference (:761-763): make the oracle see fp16-representable weights
+    for k in ("unet", "vae", "clip", "clf"):
+        for n, t in sds[k].items():
+            if t.is_floating_point():
+                sds[k][n] = t.half().float()
+    unet = nn_unet.UNet2DConditionModel(ucfg)
+    unet.load_state_dict(sds["unet"], strict=True)
+    eval_unet = copy.deepcopy(unet)
+    vae = nn_vae.AutoencoderKLDecoder(vcfg)
+    vae.load_state_dict(sds["vae"], strict=True)
+    te = nn_clip.CLIPTextModel(ccfg)
+    te.load_state_dict(sds["clip"], strict=True)
+    eval_te = copy.deepcopy(te)
+    clf = nn_mobilenet.MobileNetV3Large(num_classes).eval()
+    clf.load_state_dict(sds["clf"], strict=True)
+    for m in (unet, eval_unet, vae, te, eval_te, clf):
+        m.requires_grad_(False)
+    out = dict(unet=unet, eval_unet=eval_unet, vae=vae, text_encoder=te, eval_text_encoder=eval_te, classifier=clf,
+               scheduler=DPMSolverMultistepScheduler(), sds=sds, lora_params=[])
+    g = torch.Generator().manual_seed(seed + 10)
+    if train_unet:
+        layers = nn_unet.make_unet_lora(unet, rank)
+        sd = W.synthetic_state_dict(W.unet_lora_param_shapes(W.UNetConfig(**TINY_UNET), rank), seed=seed + 5)
+        for n in sd:
+            if ".up." in n:
+                sd[n] = torch.randn(sd[n].shape, generator=g) * lora_up_std
+        layers.load_named(sd)
+        sds["unet_lora"] = sd
+        out["unet_lora_layers"] = layers
+        for p in layers.parameters():
+            p.requires_grad_(True)
+        out["lora_params"] += list(layers.parameters())
+    if train_te:
+        params = nn_clip.modify_text_encoder(te, rank)
+        sd = W.synthetic_state_dict(W.clip_lora_param_shapes(W.CLIPTextConfig(**TINY_CLIP), rank), seed=seed + 6)
+        for n in sd:
+            if ".up." in n:
+                sd[n] = torch.randn(sd[n].shape, generator=g) * lora_up_std
+        missing, unexpected = te.load_state_dict(sd, strict=False)
+        assert not unexpected, unexpected
+        sds["te_lora"] = sd
+        for p in params:
+            p.requires_grad_(True)
+        out["lora_params"] += params
+        out["te_lora_named"] = {n: p for n, p in te.named_parameters() if "lora_linear_layer" in n}
+    return out
+
+
+def product_models(sds, dev, rank=4, train_unet=True, train_te=False, num_classes=80):
+    from finetune_fair_diffusion_amd.classifier import MobileNetV3Large
+    from finetune_fair_diffusion_amd.scheduler import DPMSolverMultistepScheduler
+    from finetune_fair_diffusion_amd.text_encoder import CLIPTextModel
+    from finetune_fair_diffusion_amd.unet import UNet2DConditionModel
+    from finetune_fair_diffusion_amd.vae import AutoencoderKL
+    ucfg, vcfg, ccfg = W.UNetConfig(**TINY_UNET), W.VAEConfig(**TINY_VAE), W.CLIPTextConfig(**TINY_CLIP)
+    unet = UNet2DConditionModel(ucfg, sds["unet"], dev)
+    eval_unet = UNet2DConditionModel(ucfg, sds["unet"], dev) if train_unet else None
+    vae = AutoencoderKL(vcfg, sds["vae"], dev)
+    te = CLIPTextModel(ccfg, sds["clip"], dev)
+    eval_te = CLIPTextModel(ccfg, sds["clip"], dev) if train_te else None
+    clf = MobileNetV3Large(sds["clf"], dev, num_classes)
+    if train_unet:
+        unet.add_lora(rank, sds["unet_lora"])
+    if train_te:
+        # oracle keys carry the PatchedLoraProjection naming of the export format
+        te.add_lora(rank, sds["te_lora"])
+    return dict(unet=unet, eval_unet=eval_unet, vae=vae, text_encoder=te, eval_text_encoder=eval_te, classifier=clf,
+                scheduler=DPMSolverMultistepScheduler())
