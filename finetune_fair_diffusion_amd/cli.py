@@ -1,0 +1,103 @@
+"""Command-line / YAML surface of the reference's ``1-main-debias.py`` (``parse_args``,
+exp-1-debias-gender/1-main-debias.py:327-644): the same 50 flags with the same defaults and the same
+YAML-overlay rule -- ``args[key] = type(args[key])(value)`` (:632-638), so keys whose default is None
+cannot be set from YAML and booleans follow Python's ``bool(value)`` -- plus the build's own additions
+(prefixed below), which the reference does not have:
+
+  --num_denoising_steps  fixed S instead of ``random.choices(range(19,24))`` (:1779)
+  --synthetic            synthetic weights / token ids / face provider (no network, no data.zip)
+  --face_provider        detector seam: "synthetic" (default)
+  --num_classifier_logits  80 (exp-1) / 6 (exp-3,5) / 8 (exp-4)
+
+Pinned by tests/golden/reference_cli.json (defaults and the three exp-1 YAML overlays, produced by
+running the reference's own parse_args).
+"""
+import argparse
+import os
+
+import yaml
+
+
+def build_parser():
+    p = argparse.ArgumentParser(description="Script to finetune Stable Diffusion for debiasing purposes.")
+    a = p.add_argument
+    # 1. experiment setting
+    a("--proj_name", default="debias-SD", type=str)
+    a("--pretrained_model_name_or_path", type=str, default="runwayml/stable-diffusion-v1-5")
+    a("--train_text_encoder", action="store_true", default=True)
+    a("--train_unet", action="store_true", default=False)
+    a("--seed", type=int, default=5991)
+    a("--max_train_steps", type=int, default=10000)
+    a("--checkpointing_steps", type=int, default=20)
+    a("--checkpoints_total_limit", type=int, default=2)
+    a("--checkpointing_steps_long", type=int, default=200)
+    a("--resume_from_checkpoint", type=str, default=None)
+    a("--mixed_precision", type=str, default="fp16", choices=["no", "fp16", "bf16"])
+    a("--rank", type=int, default=50)
+    a("--train_plot_every_n_iter", type=int, default=20)
+    a("--evaluate_every_n_iter", type=int, default=200)
+    a("--guidance_scale", type=float, default=7.5)
+    a("--EMA_decay", type=float, default=0.996)
+    # 2. loss weights
+    a("--weight_loss_img", type=float, default=8)
+    a("--weight_loss_face", type=float, default=1)
+    a("--uncertainty_threshold", type=float, default=0.2)
+    a("--factor1", type=float, default=0.2)
+    a("--factor2", type=float, default=0.2)
+    # 3. batch sizes
+    a("--train_images_per_prompt_GPU", type=int, default=8)
+    a("--train_GPU_batch_size", type=int, default=4)
+    a("--val_images_per_prompt_GPU", type=int, default=8)
+    a("--val_GPU_batch_size", type=int, default=8)
+    # 4. data / external files
+    a("--prompt_occupation_path", type=str, default="../data/1-prompts/occupation.json")
+    a("--classifier_weight_path", type=str, default="../data/2-trained-classifiers/CelebA_MobileNetLarge_08060852/epoch=9-step=12660_MobileNetLarge.pt")
+    a("--face_feats_path", type=str, default="../data/3-face-features/CelebA_MobileNetLarge_08240859/face_feats.pkl")
+    a("--opensphere_config", type=str, default="../data/4-opensphere_checkpoints/opensphere_checkpoints/20220424_210641/config.yml")
+    a("--opensphere_model_path", type=str, default="../data/4-opensphere_checkpoints/opensphere_checkpoints/20220424_210641/models/backbone_100000.pth")
+    a("--output_dir", type=str, default="./outputs")
+    a("--logging_dir", type=str, default="logs")
+    a("--report_to", type=str, default="wandb")
+    # 5. optimisation
+    a("--learning_rate", type=float, default=5e-5)
+    a("--lr_scheduler", type=str, default="constant")
+    a("--lr_warmup_steps", type=int, default=0)
+    a("--lr_num_cycles", type=int, default=1)
+    a("--lr_power", type=float, default=1.0)
+    a("--allow_tf32", action="store_true", default=True)
+    a("--adam_beta1", type=float, default=0.9)
+    a("--adam_beta2", type=float, default=0.999)
+    a("--adam_weight_decay", type=float, default=1e-2)
+    a("--adam_epsilon", type=float, default=1e-08)
+    a("--max_grad_norm", default=100.0, type=float)
+    a("--img_size_small", type=int, default=224)
+    a("--size_face", type=int, default=224)
+    a("--size_aligned_face", type=int, default=112)
+    a("--face_gender_confidence_level", type=float, default=0.9)
+    a("--local_rank", type=int, default=-1)
+    a("--config", type=str, default=None)
+    return p
+
+
+EXTRA_DEFAULTS = dict(num_denoising_steps=0, synthetic=False, face_provider="synthetic", num_classifier_logits=80)
+
+
+def parse_args(input_args=None, with_extras=False):
+    p = build_parser()
+    if with_extras:
+        p.add_argument("--num_denoising_steps", type=int, default=0, help="0 = draw from range(19,24) like the reference")
+        p.add_argument("--synthetic", action="store_true", default=False)
+        p.add_argument("--face_provider", type=str, default="synthetic")
+        p.add_argument("--num_classifier_logits", type=int, default=80)
+    args = p.parse_args(input_args) if input_args is not None else p.parse_args()
+    if args.config:
+        with open(args.config, "r") as f:
+            config_data = yaml.safe_load(f)
+        d = vars(args)
+        for key, value in config_data.items():
+            d[key] = type(d[key])(value)
+        args = argparse.Namespace(**d)
+    env_local_rank = int(os.environ.get("LOCAL_RANK", -1))
+    if env_local_rank != -1 and env_local_rank != args.local_rank:
+        args.local_rank = env_local_rank
+    return args

@@ -7,6 +7,7 @@
 // operands swapped (D^T = B.A^T) so each lane ends up holding 4 consecutive N for one M row:
 // the epilogue then does 8-byte stores along the contiguous dimension.
 #include "common.h"
+#include <stdlib.h>
 
 #define LDSK 40  // 32 halfs of K + 8 pad (80-byte rows)
 
@@ -197,17 +198,515 @@ __global__ __launch_bounds__(256) void gemm_kernel(fd_gemm_desc p, int ntm, int 
     }
 }
 
+
+// ======================================================================================= v2: direct-to-LDS staging
+// Same tiling and MFMA arrangement as gemm_kernel, but both operand tiles travel global -> LDS with
+// global_load_lds_dwordx4 (no VGPR round trip, no ds_write).  The LDS image of a 16-row x 64-byte group is
+// exactly what one wave-instruction writes (lane l -> row l>>2, 16-byte slot l&3), so rows are unpadded;
+// bank conflicts on the ds_read_b128 fragment reads are removed by permuting WHICH 16-byte k-chunk a slot
+// holds (chunk = slot ^ G[(row>>2)&3], G = {0,3,2,1}) on the source address, and reading with the same
+// involution.  Out-of-range rows / k-chunks / conv padding read from a zero page instead of branching.
+// Two LDS stages: the loads of k-tile t+1 are in flight under the MFMAs of tile t; one barrier per k-tile.
+__device__ __attribute__((aligned(16))) f16 fd_zero_page[64];
+
+__device__ __forceinline__ int swz_g(int r4) { return (4 - r4) & 3; }  // {0,3,2,1}
+
+__device__ __forceinline__ void glds16(const f16* src, f16* lds_dst) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+
+template <int BM, int BN, bool CONV>
+__global__ __launch_bounds__(256) void gemm_glds_kernel(fd_gemm_desc p, int ntm, int ntn) {
+    constexpr int TM = BM / 32, TN = BN / 32;
+    constexpr int AI = BM / 64, BI = BN / 64;     // 16-row groups per wave per k-tile
+    __shared__ __attribute__((aligned(16))) f16 smem[2 * (BM + BN) * 32];
+    f16* As = smem;
+    f16* Bs = smem + 2 * BM * 32;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, lg = lane >> 4;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const int tile = xcd_remap(blockIdx.x, ntm * ntn);
+    const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
+    const int z = blockIdx.y;
+
+    const f16* A = (const f16*)p.A + (int64_t)z * p.sA;
+    const f16* B = (const f16*)p.B + (int64_t)z * p.sB;
+    const f16* A2 = (const f16*)p.A2;
+    const f16* B2 = (const f16*)p.B2;
+    const int nk1 = (p.K + 31) >> 5, nk2 = (p.K2 + 31) >> 5, nk = nk1 + nk2;
+
+    // this lane's slot in a 16-row group: row lane>>2, 16-byte slot lane&3 holding k-chunk (slot ^ G[row>>2])
+    const int lrow = lane >> 2;
+    const int kchunk = ((lane & 3) ^ swz_g(lane >> 4)) * 8;
+    int arow[AI], brow[BI];
+    ConvRow crow[AI];
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+        arow[i] = (wave * AI + i) * 16 + lrow;
+        if (CONV) {
+            const int m = m0 + arow[i];
+            const int hw = p.Ho * p.Wo;
+            crow[i].valid = m < p.M;
+            const int mm = crow[i].valid ? m : 0;
+            crow[i].b = mm / hw;
+            const int r = mm - crow[i].b * hw;
+            crow[i].oy = r / p.Wo;
+            crow[i].ox = r - crow[i].oy * p.Wo;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < BI; ++i) brow[i] = (wave * BI + i) * 16 + lrow;
+    const int cpt = CONV ? (p.Cin >> 5) : 1;
+
+    auto issue = [&](int kt, int buf) {
+        if (CONV) {
+            const int tap = kt / cpt;
+            const int c0 = (kt - tap * cpt) << 5;
+            const int ky = tap / 3, kx = tap - ky * 3;
+#pragma unroll
+            for (int i = 0; i < AI; ++i) {
+                int iy = crow[i].oy, ix = crow[i].ox;
+                bool ok = crow[i].valid;
+                if (p.conv_mode == FD_CONV_NORMAL) {
+                    iy += ky - 1; ix += kx - 1;
+                    ok = ok && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+                } else if (p.conv_mode == FD_CONV_STRIDE2) {
+                    iy = 2 * iy + ky - 1; ix = 2 * ix + kx - 1;
+                    ok = ok && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+                } else if (p.conv_mode == FD_CONV_UP2) {
+                    iy += ky - 1; ix += kx - 1;
+                    ok = ok && iy >= 0 && iy < 2 * p.H && ix >= 0 && ix < 2 * p.W;
+                    iy >>= 1; ix >>= 1;
+                } else {
+                    iy += ky - 1; ix += kx - 1;
+                    ok = ok && iy >= 0 && ix >= 0 && !(iy & 1) && !(ix & 1);
+                    iy >>= 1; ix >>= 1;
+                    ok = ok && iy < p.H && ix < p.W;
+                }
+                const f16* src = ok ? A + (((int64_t)crow[i].b * p.H + iy) * p.W + ix) * p.lda + c0 + kchunk : fd_zero_page;
+                glds16(src, As + (buf * BM + (wave * AI + i) * 16) * 32);
+            }
+            const int kk = kt * 32 + kchunk;
+#pragma unroll
+            for (int i = 0; i < BI; ++i) {
+                const int n = n0 + brow[i];
+                const f16* src = (n < p.N) ? B + (int64_t)n * p.ldb + kk : fd_zero_page;
+                glds16(src, Bs + (buf * BN + (wave * BI + i) * 16) * 32);
+            }
+        } else {
+            const bool seg2 = kt >= nk1;
+            const f16* Ap = seg2 ? A2 : A;
+            const f16* Bp = seg2 ? B2 : B;
+            const int64_t la = seg2 ? p.lda2 : p.lda, lb = seg2 ? p.ldb2 : p.ldb;
+            const int Kseg = seg2 ? p.K2 : p.K;
+            const int kk = (seg2 ? kt - nk1 : kt) * 32 + kchunk;
+            const bool kok = kk < Kseg;
+#pragma unroll
+            for (int i = 0; i < AI; ++i) {
+                const int m = m0 + arow[i];
+                const f16* src = (kok && m < p.M) ? Ap + (int64_t)m * la + kk : fd_zero_page;
+                glds16(src, As + (buf * BM + (wave * AI + i) * 16) * 32);
+            }
+#pragma unroll
+            for (int i = 0; i < BI; ++i) {
+                const int n = n0 + brow[i];
+                const f16* src = (kok && n < p.N) ? Bp + (int64_t)n * lb + kk : fd_zero_page;
+                glds16(src, Bs + (buf * BN + (wave * BI + i) * 16) * 32);
+            }
+        }
+    };
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // fragment read offset inside a 16-row group: row l15, slot (lg ^ G[l15>>2])
+    const int frag_off = l15 * 32 + ((lg ^ swz_g(l15 >> 2)) * 8);
+
+    issue(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (kt + 1 < nk) issue(kt + 1, buf ^ 1);
+        f16x8 af[TM], bf[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[i] = *(const f16x8*)(As + (buf * BM + wm * (BM / 2) + i * 16) * 32 + frag_off);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bf[j] = *(const f16x8*)(Bs + (buf * BN + wn * (BN / 2) + j * 16) * 32 + frag_off);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
+    }
+
+    const f16* R = p.residual ? (const f16*)p.residual + (int64_t)z * p.sR : nullptr;
+    const f16* RB = (const f16*)p.rowbias;
+    const bool vec_ok = ((p.N & 3) == 0) && ((p.ldc & 3) == 0) && (!R || (p.ldr & 3) == 0);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int m = m0 + wm * (BM / 2) + i * 16 + l15;
+        if (m >= p.M) continue;
+        const int rbrow = RB ? m / p.rows_per_batch : 0;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn * (BN / 2) + j * 16 + lg * 4;
+            if (n >= p.N) continue;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float x = acc[i][j][r] * p.alpha;
+                if (n + r < p.N) {
+                    if (p.bias) x += p.bias[n + r];
+                    if (RB) x += (float)RB[(int64_t)rbrow * p.ld_rowbias + n + r];
+                    x = apply_act(x, p.act);
+                    if (R) x += (float)R[(int64_t)m * p.ldr + n + r];
+                }
+                v[r] = x;
+            }
+            if (p.out_dtype == FD_OUT_F32) {
+                float* C = (float*)p.C + (int64_t)z * p.sC + (int64_t)m * p.ldc + n;
+                if (vec_ok) *(f32x4*)C = (f32x4){v[0], v[1], v[2], v[3]};
+                else
+                    for (int r = 0; r < 4 && n + r < p.N; ++r) C[r] = v[r];
+            } else {
+                f16* C = (f16*)p.C + (int64_t)z * p.sC + (int64_t)m * p.ldc + n;
+                if (vec_ok) *(f16x4*)C = (f16x4){(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+                else
+                    for (int r = 0; r < 4 && n + r < p.N; ++r) C[r] = (f16)v[r];
+            }
+        }
+    }
+}
+
+
+// ======================================================================================= v3: big tiles, BK = 64
+// The per-CU global->LDS path saturates near 15-20 B/clk (measured: the 128x128 and 128x64 tiles above both sit
+// at ~15 B/clk/CU at very different TFLOP/s), so arithmetic intensity -- tile size -- is the lever.  This kernel
+// uses 8 waves (512 threads), a BM x BN x 64 tile (N tiles of 320/160 match the U-Net's channel counts, which are
+// all multiples of 320), full 128-byte rows per operand row (one L2 line per row per k-tile), direct-to-LDS
+// loads, the conflict-free XOR slot permutation chunk = slot ^ (row & 7), and two LDS stages.
+template <int BM, int BN, int WGM, int WGN, bool CONV>
+__global__ __launch_bounds__(512) void gemm_big_kernel(fd_gemm_desc p, int ntm, int ntn) {
+    static_assert(WGM * WGN == 8, "8 waves");
+    constexpr int WTM = BM / WGM, WTN = BN / WGN;   // wave tile
+    constexpr int TM = WTM / 16, TN = WTN / 16;
+    constexpr int NA = BM / 8, NB = BN / 8;         // 8-row groups (one glds instruction each) per k-tile
+    constexpr int AI = (NA + 7) / 8, BI = (NB + 7) / 8;
+    extern __shared__ __attribute__((aligned(16))) f16 smem[];
+    f16* As = smem;                      // [2][BM][64]
+    f16* Bs = smem + 2 * BM * 64;        // [2][BN][64]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, lg = lane >> 4;
+    const int wm = wave / WGN, wn = wave % WGN;
+
+    const int tile = xcd_remap(blockIdx.x, ntm * ntn);
+    const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
+
+    const f16* A = (const f16*)p.A;
+    const f16* B = (const f16*)p.B;
+    const f16* A2 = (const f16*)p.A2;
+    const f16* B2 = (const f16*)p.B2;
+    const int nk1 = (p.K + 63) >> 6, nk2 = (p.K2 + 63) >> 6, nk = nk1 + nk2;
+
+    const int lrow = lane >> 3;                              // row inside the 8-row group
+    const int kchunk = ((lane & 7) ^ lrow) * 8;              // k-chunk this lane's slot holds
+    ConvRow crow[AI];
+    if (CONV) {
+#pragma unroll
+        for (int i = 0; i < AI; ++i) {
+            const int m = m0 + (wave + i * 8) * 8 + lrow;
+            const int hw = p.Ho * p.Wo;
+            crow[i].valid = m < p.M && (wave + i * 8) < NA;
+            const int mm = crow[i].valid ? m : 0;
+            crow[i].b = mm / hw;
+            const int r = mm - crow[i].b * hw;
+            crow[i].oy = r / p.Wo;
+            crow[i].ox = r - crow[i].oy * p.Wo;
+        }
+    }
+
+    auto issue = [&](int kt, int buf) {
+        if (CONV) {
+            // k order = (64-channel chunk, tap): the 9 taps of one chunk re-read the same 128-byte lines shifted by a
+            // pixel, so the tile's working set per chunk (~48 KB) stays in L1/L2 instead of cycling all Cin channels
+            const int cc = kt / 9;
+            const int tap = kt - cc * 9;
+            const int c0 = cc << 6;
+            const int ky = tap / 3, kx = tap - ky * 3;
+#pragma unroll
+            for (int i = 0; i < AI; ++i) {
+                const int g = wave + i * 8;
+                if (g < NA) {
+                    int iy = crow[i].oy, ix = crow[i].ox;
+                    bool ok = crow[i].valid;
+                    if (p.conv_mode == FD_CONV_NORMAL) {
+                        iy += ky - 1; ix += kx - 1;
+                        ok = ok && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+                    } else if (p.conv_mode == FD_CONV_STRIDE2) {
+                        iy = 2 * iy + ky - 1; ix = 2 * ix + kx - 1;
+                        ok = ok && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+                    } else if (p.conv_mode == FD_CONV_UP2) {
+                        iy += ky - 1; ix += kx - 1;
+                        ok = ok && iy >= 0 && iy < 2 * p.H && ix >= 0 && ix < 2 * p.W;
+                        iy >>= 1; ix >>= 1;
+                    } else {
+                        iy += ky - 1; ix += kx - 1;
+                        ok = ok && iy >= 0 && ix >= 0 && !(iy & 1) && !(ix & 1);
+                        iy >>= 1; ix >>= 1;
+                        ok = ok && iy < p.H && ix < p.W;
+                    }
+                    const f16* src = ok ? A + (((int64_t)crow[i].b * p.H + iy) * p.W + ix) * p.lda + c0 + kchunk : fd_zero_page;
+                    glds16(src, As + (buf * BM + g * 8) * 64);
+                }
+            }
+            const int kk = tap * p.Cin + c0 + kchunk;
+#pragma unroll
+            for (int i = 0; i < BI; ++i) {
+                const int g = wave + i * 8;
+                if (g < NB) {
+                    const int n = n0 + g * 8 + lrow;
+                    const f16* src = (n < p.N) ? B + (int64_t)n * p.ldb + kk : fd_zero_page;
+                    glds16(src, Bs + (buf * BN + g * 8) * 64);
+                }
+            }
+        } else {
+            const bool seg2 = kt >= nk1;
+            const f16* Ap = seg2 ? A2 : A;
+            const f16* Bp = seg2 ? B2 : B;
+            const int64_t la = seg2 ? p.lda2 : p.lda, lb = seg2 ? p.ldb2 : p.ldb;
+            const int Kseg = seg2 ? p.K2 : p.K;
+            const int kk = (seg2 ? kt - nk1 : kt) * 64 + kchunk;
+            const bool kok = kk < Kseg;
+#pragma unroll
+            for (int i = 0; i < AI; ++i) {
+                const int g = wave + i * 8;
+                if (g < NA) {
+                    const int m = m0 + g * 8 + lrow;
+                    const f16* src = (kok && m < p.M) ? Ap + (int64_t)m * la + kk : fd_zero_page;
+                    glds16(src, As + (buf * BM + g * 8) * 64);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < BI; ++i) {
+                const int g = wave + i * 8;
+                if (g < NB) {
+                    const int n = n0 + g * 8 + lrow;
+                    const f16* src = (kok && n < p.N) ? Bp + (int64_t)n * lb + kk : fd_zero_page;
+                    glds16(src, Bs + (buf * BN + g * 8) * 64);
+                }
+            }
+        }
+    };
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // fragment read: row l15 of a 16-row tile, k-chunk (ks*4 + lg) lives in slot chunk ^ (row & 7)
+    const int frow = l15 * 64;
+    const int fsw = l15 & 7;
+
+    // split-K: blockIdx.y owns the k-tiles [kbeg, kend) and writes raw fp32 partials to the workspace
+    const int nsplit = gridDim.y;
+    const int kbeg = (int)((int64_t)nk * blockIdx.y / nsplit), kend = (int)((int64_t)nk * (blockIdx.y + 1) / nsplit);
+    issue(kbeg, 0);
+    for (int kt = kbeg; kt < kend; ++kt) {
+        const int buf = (kt - kbeg) & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (kt + 1 < kend && p.batch != -1) issue(kt + 1, buf ^ 1);
+        if (p.batch == -2) continue;
+        const f16* Ab = As + (buf * BM + wm * WTM) * 64 + frow;
+        const f16* Bb = Bs + (buf * BN + wn * WTN) * 64 + frow;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int slot = ((ks * 4 + lg) ^ fsw) * 8;
+            // keep the smaller operand set resident, stream the other one fragment at a time (register budget)
+            if (TN <= TM) {
+                f16x8 bf[TN];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bf[j] = *(const f16x8*)(Bb + j * 16 * 64 + slot);
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const f16x8 af = *(const f16x8*)(Ab + i * 16 * 64 + slot);
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af, acc[i][j], 0, 0, 0);
+                }
+            } else {
+                f16x8 af[TM];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) af[i] = *(const f16x8*)(Ab + i * 16 * 64 + slot);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const f16x8 bf = *(const f16x8*)(Bb + j * 16 * 64 + slot);
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf, af[i], acc[i][j], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    if (nsplit > 1) {
+        float* ws = (float*)p.workspace + (int64_t)blockIdx.y * p.M * p.N;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = m0 + wm * WTM + i * 16 + l15;
+            if (m >= p.M) continue;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + wn * WTN + j * 16 + lg * 4;
+                if (n < p.N) *(f32x4*)(ws + (int64_t)m * p.N + n) = acc[i][j];   // split-K is only chosen when N % 4 == 0
+            }
+        }
+        return;
+    }
+    const f16* R = (const f16*)p.residual;
+    const f16* RB = (const f16*)p.rowbias;
+    const bool vec_ok = ((p.N & 3) == 0) && ((p.ldc & 3) == 0) && (!R || (p.ldr & 3) == 0);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int m = m0 + wm * WTM + i * 16 + l15;
+        if (m >= p.M) continue;
+        const int rbrow = RB ? m / p.rows_per_batch : 0;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn * WTN + j * 16 + lg * 4;
+            if (n >= p.N) continue;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float x = acc[i][j][r] * p.alpha;
+                if (n + r < p.N) {
+                    if (p.bias) x += p.bias[n + r];
+                    if (RB) x += (float)RB[(int64_t)rbrow * p.ld_rowbias + n + r];
+                    x = apply_act(x, p.act);
+                    if (R) x += (float)R[(int64_t)m * p.ldr + n + r];
+                }
+                v[r] = x;
+            }
+            if (p.out_dtype == FD_OUT_F32) {
+                float* C = (float*)p.C + (int64_t)m * p.ldc + n;
+                if (vec_ok) *(f32x4*)C = (f32x4){v[0], v[1], v[2], v[3]};
+                else
+                    for (int r = 0; r < 4 && n + r < p.N; ++r) C[r] = v[r];
+            } else {
+                f16* C = (f16*)p.C + (int64_t)m * p.ldc + n;
+                if (vec_ok) *(f16x4*)C = (f16x4){(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+                else
+                    for (int r = 0; r < 4 && n + r < p.N; ++r) C[r] = (f16)v[r];
+            }
+        }
+    }
+}
+
+// sum the split-K slabs in a fixed order and apply the epilogue
+__global__ void splitk_reduce_kernel(fd_gemm_desc p, int nsplit) {
+    const int64_t n4 = (int64_t)p.M * p.N / 4;
+    const float* ws = (const float*)p.workspace;
+    const f16* R = (const f16*)p.residual;
+    const f16* RB = (const f16*)p.rowbias;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t e = i * 4;
+        const int m = (int)(e / p.N), n = (int)(e - (int64_t)m * p.N);
+        f32x4 a = *(const f32x4*)(ws + e);
+        for (int s = 1; s < nsplit; ++s) a += *(const f32x4*)(ws + (int64_t)s * p.M * p.N + e);
+        const int rbrow = RB ? m / p.rows_per_batch : 0;
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float x = a[r] * p.alpha;
+            if (p.bias) x += p.bias[n + r];
+            if (RB) x += (float)RB[(int64_t)rbrow * p.ld_rowbias + n + r];
+            x = apply_act(x, p.act);
+            if (R) x += (float)R[(int64_t)m * p.ldr + n + r];
+            v[r] = x;
+        }
+        if (p.out_dtype == FD_OUT_F32) *(f32x4*)((float*)p.C + (int64_t)m * p.ldc + n) = (f32x4){v[0], v[1], v[2], v[3]};
+        else *(f16x4*)((f16*)p.C + (int64_t)m * p.ldc + n) = (f16x4){(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+    }
+}
+
+template <int BM, int BN, int WGM, int WGN>
+static int launch_big(const fd_gemm_desc& d, hipStream_t s, int nsplit = 1) {
+    const int ntm = (d.M + BM - 1) / BM, ntn = (d.N + BN - 1) / BN;
+    constexpr size_t lds = (size_t)2 * (BM + BN) * 64 * sizeof(f16);
+    static bool once = false;
+    if (!once) {
+        (void)hipFuncSetAttribute((const void*)gemm_big_kernel<BM, BN, WGM, WGN, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)gemm_big_kernel<BM, BN, WGM, WGN, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        once = true;
+    }
+    if (d.conv) hipLaunchKernelGGL((gemm_big_kernel<BM, BN, WGM, WGN, true>), dim3(ntm * ntn, nsplit), dim3(512), lds, s, d, ntm, ntn);
+    else hipLaunchKernelGGL((gemm_big_kernel<BM, BN, WGM, WGN, false>), dim3(ntm * ntn, nsplit), dim3(512), lds, s, d, ntm, ntn);
+    if (nsplit > 1) {
+        int64_t blocks = ((int64_t)d.M * d.N / 4 + 255) / 256;
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, d, nsplit);
+    }
+    return fd_check_launch("fd_gemm(big)");
+}
+
 template <int BM, int BN>
 static int launch(const fd_gemm_desc& d, hipStream_t s) {
     const int ntm = (d.M + BM - 1) / BM, ntn = (d.N + BN - 1) / BN;
     dim3 grid(ntm * ntn, d.batch > 0 ? d.batch : 1);
-    if (d.conv) hipLaunchKernelGGL((gemm_kernel<BM, BN, true>), grid, dim3(256), 0, s, d, ntm, ntn);
-    else hipLaunchKernelGGL((gemm_kernel<BM, BN, false>), grid, dim3(256), 0, s, d, ntm, ntn);
+    static const bool v1 = getenv("FD_GEMM_V1") != nullptr;   // A/B switch for the register-staged kernel (measurement only)
+    if (v1) {
+        if (d.conv) hipLaunchKernelGGL((gemm_kernel<BM, BN, true>), grid, dim3(256), 0, s, d, ntm, ntn);
+        else hipLaunchKernelGGL((gemm_kernel<BM, BN, false>), grid, dim3(256), 0, s, d, ntm, ntn);
+    } else {
+        if (d.conv) hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, true>), grid, dim3(256), 0, s, d, ntm, ntn);
+        else hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, false>), grid, dim3(256), 0, s, d, ntm, ntn);
+    }
     return fd_check_launch("fd_gemm");
+}
+
+// tile choice (BM*1000+BN): big tiles when the grid still fills 256 CUs a few times over
+extern "C" int fd_gemm_tile(const fd_gemm_desc* dp) {
+    const fd_gemm_desc& d = *dp;
+    const long nb = d.batch > 1 ? d.batch : 1;
+    static const bool nobig = getenv("FD_GEMM_NOBIG") != nullptr;
+    // big-tile (BK=64, 8-wave) variants: unbatched, K-tiles of 64 must not straddle a conv tap
+    if (!nobig && nb == 1 && (d.conv ? (d.Cin & 63) == 0 : (d.K + d.K2) >= 1024)) {
+        const long m256 = (d.M + 255) / 256, m128 = (d.M + 127) / 128;
+        if (d.N % 320 == 0) {
+            if (m256 * (d.N / 320) >= 200) return 256320;
+            if (m128 * (d.N / 320) >= 160) return 128320;
+        }
+        if (d.N % 160 == 0 && m128 * (d.N / 160) >= 160) return 128160;
+        if (d.N % 128 == 0 && m256 * (d.N / 128) >= 200) return 256128;
+        // small-M, long-K (the 8x8 / 16x16 levels of the U-Net): split K so that all 256 CUs get a block
+        if (d.N % 160 == 0 && d.workspace && (d.N & 3) == 0 && (d.ldc & 3) == 0) {
+            const long blocks = m128 * (d.N / 160);
+            const long nk = (d.K + 63) / 64 + (d.K2 + 63) / 64;
+            long split = blocks > 0 ? 256 / blocks : 1;
+            if (split > 8) split = 8;
+            while (split > 1 && (nk / split < 8 || (int64_t)split * d.M * d.N * 4 > d.workspace_bytes)) --split;
+            if (split > 1) return (int)(split * 1000000 + 128160);
+        }
+    }
+    const long t128 = (long)((d.M + 127) / 128) * ((d.N + 127) / 128) * nb;
+    const bool n64 = (d.N % 128) != 0 && (d.N % 128) <= 64;  // e.g. N=320: 128x64 tiles waste nothing
+    if (t128 >= 512 && !n64) return 128128;
+    const long t12864 = (long)((d.M + 127) / 128) * ((d.N + 63) / 64) * nb;
+    if (t12864 >= 512) return 128064;
+    return 64064;
 }
 
 extern "C" int fd_gemm(const fd_gemm_desc* dp, void* stream) {
     fd_gemm_desc d = *dp;
+    static const char* dbg = getenv("FD_GEMM_DBG");   // measurement only: 1 = no loads after the first tile, 2 = no MFMAs
+    if (dbg && d.batch <= 1) d.batch = -atoi(dbg);
     FD_REQUIRE(d.A && d.B && d.C, "fd_gemm: null operand");
     FD_REQUIRE(d.M > 0 && d.N > 0 && d.K > 0, "fd_gemm: bad shape M=%d N=%d K=%d", d.M, d.N, d.K);
     FD_REQUIRE((d.K & 7) == 0 && (d.lda & 7) == 0 && (d.ldb & 7) == 0, "fd_gemm: K, lda, ldb must be multiples of 8");
@@ -223,11 +722,15 @@ extern "C" int fd_gemm(const fd_gemm_desc* dp, void* stream) {
     }
     if (d.rowbias) FD_REQUIRE(d.rows_per_batch > 0, "fd_gemm: rows_per_batch");
     hipStream_t s = (hipStream_t)stream;
-    // tile choice: big tiles when the grid still fills 256 CUs a few times over
-    const long t128 = (long)((d.M + 127) / 128) * ((d.N + 127) / 128) * (d.batch > 0 ? d.batch : 1);
-    const bool n64 = (d.N % 128) != 0 && (d.N % 128) <= 64;  // e.g. N=320: 128x64 tiles waste nothing
-    if (t128 >= 512 && !n64) return launch<128, 128>(d, s);
-    const long t12864 = (long)((d.M + 127) / 128) * ((d.N + 63) / 64) * (d.batch > 0 ? d.batch : 1);
-    if (t12864 >= 512) return launch<128, 64>(d, s);
-    return launch<64, 64>(d, s);
+    const int sel = fd_gemm_tile(&d);
+    if (sel >= 1000000) return launch_big<128, 160, 4, 2>(d, s, sel / 1000000);
+    switch (sel) {
+        case 256320: return launch_big<256, 320, 2, 4>(d, s);
+        case 128320: return launch_big<128, 320, 2, 4>(d, s);
+        case 128160: return launch_big<128, 160, 4, 2>(d, s);
+        case 256128: return launch_big<256, 128, 4, 2>(d, s);
+        case 128128: return launch<128, 128>(d, s);
+        case 128064: return launch<128, 64>(d, s);
+        default: return launch<64, 64>(d, s);
+    }
 }

@@ -1,0 +1,91 @@
+"""Builds the model set of one training run (text encoder, U-Net (+frozen copy), VAE decoder, classifier,
+scheduler, trainer) on one device -- with synthetic weights when no checkpoint directory is mounted
+(the build/bench environment has no network: SD-v1.5, the CLIP vocabulary and data.zip are absent).
+"""
+import types
+
+import torch
+
+from . import weights as W
+from .classifier import MobileNetV3Large
+from .scheduler import DPMSolverMultistepScheduler
+from .step import FairnessTrainer
+from .text_encoder import CLIPTextModel
+from .unet import UNet2DConditionModel
+from .vae import AutoencoderKL
+
+SD15 = dict(unet=W.UNetConfig(), vae=W.VAEConfig(), clip=W.CLIPTextConfig())
+TINY = dict(unet=W.UNetConfig(block_out_channels=(64, 128, 256, 256), attention_head_dim=4, cross_attention_dim=64, sample_size=32),
+            vae=W.VAEConfig(block_out_channels=(32, 64, 64, 64)),
+            clip=W.CLIPTextConfig(vocab_size=1000, hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=2))
+
+
+def synthetic_tokens(L=13, vocab=49408, seed=1):
+    """Token ids shaped like the reference's tokenizer calls (:1007, :1020-1026): prompt = BOS, L-2 words, EOS
+    (mask all ones); uncond = BOS, EOS, then EOS padding with attention_mask = [1,1,0,...]."""
+    g = torch.Generator().manual_seed(seed)
+    bos, eos = vocab - 2, vocab - 1
+    lo, hi = min(320, vocab // 4), min(40000, vocab - 2)
+    ids = torch.cat([torch.tensor([bos]), torch.randint(lo, hi, (L - 2,), generator=g), torch.tensor([eos])])
+    mask = torch.ones(L, dtype=torch.long)
+    uids = torch.tensor([bos] + [eos] * (L - 1))
+    umask = torch.tensor([1, 1] + [0] * (L - 2))
+    return ids, mask, uids, umask
+
+
+def default_args(**kw):
+    from .cli import parse_args
+    a = vars(parse_args([]))
+    a.update(kw)
+    return types.SimpleNamespace(**a)
+
+
+def build_trainer(args, device, cfgs=SD15, seed=0, rank=0, world_size=1, num_classes=80, classifier_gain=1.4, state_dicts=None):
+    """Returns (trainer, models dict).  ``state_dicts`` may carry real weights by diffusers key
+    (keys 'unet','vae','clip','clf','unet_lora','te_lora'); anything missing is synthetic."""
+    sds = dict(state_dicts or {})
+    gen = lambda shapes, s, **k: W.synthetic_state_dict(shapes, seed=seed + s, **k)  # noqa: E731
+    if "unet" not in sds:
+        sds["unet"] = gen(W.unet_param_shapes(cfgs["unet"]), 1)
+    if "vae" not in sds:
+        sds["vae"] = gen(W.vae_param_shapes(cfgs["vae"]), 2)
+    if "clip" not in sds:
+        sds["clip"] = gen(W.clip_param_shapes(cfgs["clip"]), 3)
+    if "clf" not in sds:
+        sds["clf"] = gen(W.mobilenet_param_shapes(num_classes), 4, gain=classifier_gain)
+    unet = UNet2DConditionModel(cfgs["unet"], sds["unet"], device)
+    eval_unet = UNet2DConditionModel(cfgs["unet"], sds["unet"], device) if args.train_unet else None
+    del sds["unet"]
+    vae = AutoencoderKL(cfgs["vae"], sds["vae"], device)
+    te = CLIPTextModel(cfgs["clip"], sds["clip"], device)
+    eval_te = CLIPTextModel(cfgs["clip"], sds["clip"], device) if args.train_text_encoder else None
+    clf = MobileNetV3Large(sds["clf"], device, num_classes)
+    if args.train_unet:
+        bank = unet.add_lora(args.rank, sds.get("unet_lora"), seed=seed + 5)
+        if "unet_lora" not in sds:   # one warm-up so the up matrices are non-zero
+            g = torch.Generator().manual_seed(seed + 7)
+            for n in bank.names:
+                if ".up." in n:
+                    bank.view(n).copy_((torch.randn(bank.shape(n), generator=g) * 0.01).to(device))
+            bank.ema.copy_(bank.flat)
+            unet.refresh_lora()
+    if args.train_text_encoder:
+        bank = te.add_lora(args.rank, sds.get("te_lora"), seed=seed + 6)
+        if "te_lora" not in sds:
+            g = torch.Generator().manual_seed(seed + 8)
+            for n in bank.names:
+                if ".up." in n:
+                    bank.view(n).copy_((torch.randn(bank.shape(n), generator=g) * 0.01).to(device))
+            bank.ema.copy_(bank.flat)
+            te.refresh_lora()
+    if world_size > 1:  # identical LoRA init on every rank (:820-821, :848-854): one flat broadcast per bank
+        import torch.distributed as dist
+        for m in (unet if args.train_unet else None, te if args.train_text_encoder else None):
+            if m is not None:
+                dist.broadcast(m.lora_bank.flat, src=0)
+                m.lora_bank.ema.copy_(m.lora_bank.flat)
+                m.refresh_lora()
+    sch = DPMSolverMultistepScheduler()
+    tr = FairnessTrainer(args, te, unet, vae, clf, sch, eval_text_encoder=eval_te, eval_unet=eval_unet, rank=rank, world_size=world_size,
+                         device=device)
+    return tr, dict(unet=unet, eval_unet=eval_unet, vae=vae, text_encoder=te, eval_text_encoder=eval_te, classifier=clf, scheduler=sch)

@@ -30,6 +30,7 @@ class GemmDesc(ctypes.Structure):
         ("batch", ctypes.c_int32), ("sA", ctypes.c_int64), ("sB", ctypes.c_int64), ("sC", ctypes.c_int64), ("sR", ctypes.c_int64),
         ("conv", ctypes.c_int32), ("conv_mode", ctypes.c_int32), ("Bn", ctypes.c_int32), ("H", ctypes.c_int32),
         ("W", ctypes.c_int32), ("Cin", ctypes.c_int32), ("Ho", ctypes.c_int32), ("Wo", ctypes.c_int32),
+        ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_int64),
     ]
 
 
@@ -63,6 +64,10 @@ def load():
         raise RuntimeError(
             f"{LIB_PATH} not found: the HIP extension is required (no fallback path). "
             "Build it with `python -c 'import __graft_entry__ as g; g.build()'` or `make -C finetune_fair_diffusion_amd/csrc`.")
+    # torch bundles its own HIP runtime: import it FIRST so libfairdiff_hip.so binds to the runtime torch's
+    # streams and device memory live in (loading the system libamdhip64 first leaves two runtimes in one process
+    # and every launch then fails with "no ROCm-capable device").
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     for name, (ret, argtypes) in parse_header().items():
         fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol

@@ -32,6 +32,56 @@ def _call(name, *args):
         raise RuntimeError(f"{name} failed ({rc}): {L.fd_last_error().decode()}")
 
 
+_gemm_ws = {}
+
+
+def gemm_workspace():
+    """32 MiB fp32 split-K workspace per device (owned by the caller of the C-ABI, as every buffer is)."""
+    key = torch.cuda.current_device()
+    t = _gemm_ws.get(key)
+    if t is None:
+        t = torch.empty(8 << 20, dtype=F32, device=torch.device("cuda", key))
+        _gemm_ws[key] = t
+    return t
+
+
+class OpTimer:
+    """Per-launch HIP-event timing of the MFMA GEMM/conv kernel family on the stream they are launched on
+    (torch's current stream); used by bench.py's roofline pass, never inside the timed region."""
+
+    def __init__(self):
+        self.records = []  # (variant, flops, start_event, end_event)
+
+    def summary(self):
+        torch.cuda.synchronize()
+        agg = {}
+        for variant, flops, a, b in self.records:
+            ms = a.elapsed_time(b)
+            e = agg.setdefault(variant, [0, 0.0, 0.0])
+            e[0] += 1; e[1] += flops; e[2] += ms
+        return {k: dict(launches=v[0], flops=v[1], ms=v[2]) for k, v in agg.items()}
+
+
+TIMER = None
+
+
+def _gemm_call(d, conv):
+    ws = gemm_workspace()
+    d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * 4
+    if TIMER is None:
+        _call("fd_gemm", ctypes.byref(d), _stream())
+        return
+    tile = _lib.get().fd_gemm_tile(ctypes.byref(d))
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    _call("fd_gemm", ctypes.byref(d), _stream())
+    b.record()
+    flops = 2.0 * d.M * d.N * (d.K + d.K2) * max(d.batch, 1)
+    split, tile = tile // 1000000, tile % 1000000
+    kname = "gemm_big_kernel" if tile in (256320, 128320, 128160, 256128) else "gemm_glds_kernel"
+    TIMER.records.append((f"{kname}<{tile // 1000},{tile % 1000},{'conv3x3' if conv else 'dense'}{',splitK' if split > 1 else ''}>", flops, a, b))
+
+
 def _chk(t, dtype=F16):
     assert t.dtype == dtype and t.is_contiguous(), (t.dtype, t.shape, t.stride())
     return t
@@ -61,7 +111,7 @@ def gemm(a, b, *, a2=None, b2=None, bias=None, rowbias=None, rows_per_batch=0, r
         d.residual, d.ldr = residual.data_ptr(), residual.stride(0)
     d.alpha, d.M, d.N, d.K = alpha, M, N, K
     d.act, d.out_dtype, d.batch = ACT[act], 1 if out.dtype == F32 else 0, 1
-    _call("fd_gemm", ctypes.byref(d), _stream())
+    _gemm_call(d, False)
     return out
 
 
@@ -76,7 +126,7 @@ def bgemm(a, b, *, alpha=1.0, out=None):
     d.A, d.lda, d.B, d.ldb, d.C, d.ldc = a.data_ptr(), K, b.data_ptr(), K, out.data_ptr(), N
     d.alpha, d.M, d.N, d.K, d.batch = alpha, M, N, K, Z
     d.sA, d.sB, d.sC = M * K, N * K, M * N
-    _call("fd_gemm", ctypes.byref(d), _stream())
+    _gemm_call(d, False)
     return out
 
 
@@ -108,7 +158,7 @@ def conv3x3(x, w, B, H, W, *, mode=CONV_NORMAL, bias=None, rowbias=None, residua
     d.alpha, d.M, d.N, d.K, d.act, d.batch = 1.0, M, Cout, 9 * Cin, ACT[act], 1
     d.out_dtype = 1 if out.dtype == F32 else 0
     d.conv, d.conv_mode, d.Bn, d.H, d.W, d.Cin, d.Ho, d.Wo = 1, mode, B, H, W, Cin, Ho, Wo
-    _call("fd_gemm", ctypes.byref(d), _stream())
+    _gemm_call(d, True)
     return out, Ho, Wo
 
 

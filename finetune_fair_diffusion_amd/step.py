@@ -27,6 +27,22 @@ from .fairness import SyntheticFaceProvider, fair_loss_and_grad, generate_dynami
 from .layers import F16, F32
 
 
+def _ctx_bytes(obj, seen=None):
+    """Bytes held by the tensors reachable from a recorded-forward context (unique storages)."""
+    seen = set() if seen is None else seen
+    if torch.is_tensor(obj):
+        key = obj.untyped_storage().data_ptr()
+        if key in seen:
+            return 0
+        seen.add(key)
+        return obj.untyped_storage().nbytes()
+    if isinstance(obj, dict):
+        return sum(_ctx_bytes(v, seen) for v in obj.values())
+    if isinstance(obj, (list, tuple)):
+        return sum(_ctx_bytes(v, seen) for v in obj)
+    return 0
+
+
 def _pow2_scale(amax, target):
     if not math.isfinite(amax) or amax <= 0:
         return 1.0
@@ -66,6 +82,11 @@ class FairnessTrainer:
         self.opt_step = 0
         self.flag = torch.zeros(1, dtype=torch.int32, device=self.device)
         self.clf_gscale = 1024.0
+        # R3 keeps per-timestep activations in HBM when they fit (MI355X: 288 GB) instead of recomputing every
+        # timestep; set keep_activations=False for the pure recompute schedule of the reference (:748).
+        self.keep_activations = True
+        self.activation_mem_fraction = 0.85
+        self.last_ctx_bytes = self.last_ctx_budget = 0
         self.timers = None
 
     # ------------------------------------------------------------------ pieces
@@ -76,22 +97,37 @@ class FairnessTrainer:
         mask = torch.stack([um, pm]).to(self.device)
         return te.forward(ids, mask, record=record)[0]
 
-    def rollout(self, unet, enc, noises, S, keep_inputs=False, record_prompt=False):
-        """CFG denoising rollout (:1038-1056).  noises [N,4,h,w] fp32 on device.  Returns (x_final, [x_i])."""
+    def rollout(self, unet, enc, noises, S, keep_inputs=False, record_prompt=False, keep_activations=False):
+        """CFG denoising rollout (:1038-1056).  noises [N,4,h,w] fp32 on device.  Returns (x_final, [x_i], {i: ctx}).
+        With ``keep_activations`` the per-step backward contexts are kept for as many timesteps as fit in HBM
+        (288 GB holds the whole 20-step chain at batch 8); the remaining steps are recomputed in the backward."""
         N = noises.shape[0]
         self.sch.set_timesteps(S)
         unet.prepare_timesteps(self.sch.timesteps)
         unet.prepare_prompt(enc, record=record_prompt)
         lat = noises.clone()
-        state, inputs = {}, []
+        state, inputs, ctxs = {}, [], {}
         gs = self.args.guidance_scale
+        budget = 0
         for i in range(S):
             if keep_inputs:
                 inputs.append(lat.clone())
             x = ops.to_f16(lat).repeat(2, 1, 1, 1)
-            eps = unet.forward_step(x, i)
+            rec = keep_activations and (i == 0 or budget > 0)
+            eps = unet.forward_step(x, i, record=rec)
+            if rec:
+                ctxs[i] = unet._ctx
+                unet._ctx = None
+                if i == 0:
+                    per = _ctx_bytes(ctxs[0])
+                    free, _ = torch.cuda.mem_get_info()
+                    free += torch.cuda.memory_reserved() - torch.cuda.memory_allocated()
+                    budget = int(self.activation_mem_fraction * free / max(per, 1))
+                    self.last_ctx_bytes, self.last_ctx_budget = per, budget
+                else:
+                    budget -= 1
             self.sch.cfg_step(i, eps, gs, lat, state)
-        return lat, inputs
+        return lat, inputs, ctxs
 
     def decode(self, lat, record=False):
         return self.vae.decode_images(lat * (1.0 / self.vae.config.scaling_factor), record=record)
@@ -153,7 +189,8 @@ class FairnessTrainer:
         train_unet = getattr(args, "train_unet", False) and self.unet.lora_bank is not None
         w, N_backward = microbatch_weights(B, args.train_GPU_batch_size)
         enc_g = self.encode_pair(self.te, tokens, record=train_te)
-        x_final, inputs = self.rollout(self.unet, enc_g, noises, S, keep_inputs=True, record_prompt=True)
+        x_final, inputs, ctxs = self.rollout(self.unet, enc_g, noises, S, keep_inputs=True, record_prompt=True,
+                                             keep_activations=self.keep_activations)
         images_g = self.decode(x_final, record=True)
         ind_g, boxes_g, _, _, logits_g = self.classify(images_g, record=True)
         loss_fair, dl = fair_loss_and_grad(logits_g, targets, ind_g, w)
@@ -181,8 +218,11 @@ class FairnessTrainer:
             out.update(g=g, coefs=coefs, gscale=gscale)
             if train_unet or train_te:
                 for i in range(S):
-                    x = ops.to_f16(inputs[i]).repeat(2, 1, 1, 1)
-                    self.unet.forward_step(x, i, record=True)
+                    if i in ctxs:
+                        self.unet._ctx = ctxs.pop(i)        # activations kept from the forward rollout
+                    else:                                   # gradient-checkpointed recompute of this timestep
+                        x = ops.to_f16(inputs[i]).repeat(2, 1, 1, 1)
+                        self.unet.forward_step(x, i, record=True)
                     d = g * float(coefs[i] * gscale)
                     self.unet.backward_step(torch.cat([d * (1.0 - gs), d * gs]), gscale)
                 denc = self.unet.finish_prompt_backward(gscale, need_denc=train_te)
@@ -191,6 +231,7 @@ class FairnessTrainer:
                     self.te.backward(denc.view(2, L, -1), gscale)
         else:
             self.vae._ctx = self.clf._ctx = None
+        ctxs.clear()
         # ---- gradient sync, guard, update (:1998-2029)
         out["grad_is_finite"] = self.sync_and_update(N_backward)
         return out

@@ -54,8 +54,12 @@ typedef struct fd_gemm_desc {
     int32_t batch; int64_t sA, sB, sC, sR; /* strided batching (batch>=1), element strides */
     /* implicit-GEMM convolution gather (conv: 0 = dense A, 1 = 3x3 pad 1) */
     int32_t conv, conv_mode, Bn, H, W, Cin, Ho, Wo;
+    /* optional fp32 workspace for split-K (small-M, long-K problems); NULL disables split-K */
+    void* workspace; int64_t workspace_bytes;
 } fd_gemm_desc;
 int fd_gemm(const fd_gemm_desc* d, void* stream);
+/* tile variant fd_gemm would pick for this problem, as BM*1000+BN (128128 / 128064 / 64064) */
+int fd_gemm_tile(const fd_gemm_desc* d);
 
 /* Direct convolution for tiny channel counts (conv_in 4->320, conv_out dgrad, VAE post_quant 1x1,
  * classifier stem).  x: [B,Cin,H,W] (nchw!=0) or [B,H,W,Cin]; w: fp32 [k*k*Cin, Cout]; y: fp16 [B,Ho,Wo,Cout]. */

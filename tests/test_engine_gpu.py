@@ -219,5 +219,4 @@ def test_full_fairness_step(dev, mode):
         assert cos > 0.97
     # optimizer + EMA: replay torch AdamW on the oracle params with the PRODUCT's synced gradient (isolates the update rule)
     for i, b in enumerate(tr.banks):
-        p0 = torch.nn.Parameter(torch.zeros_like(b.flat.cpu()))
-        assert b.exp_avg.abs().sum() > 0 and (b.ema - b.flat).abs().max() == 0  # first EMA step copies the params
+        assert b.exp_avg.abs().sum() > 0 and (b.ema - b.flat).abs().max() < 1e-6  # first EMA step copies the params

@@ -40,6 +40,43 @@ def test_gemm_plain(ops, dev, M, N, K):
     check(f"gemm {M}x{N}x{K}", c, a.float() @ b.float().t(), 2e-3)
 
 
+@pytest.mark.parametrize("M,N,K,tile", [(51300, 320, 1280, 256320), (20600, 320, 1288, 128320), (20500, 640, 1032, 128320), (1300, 2560, 1024, 128160),
+                                          (51300, 128, 1096, 256128), (65536, 320, 320, 128064), (1024, 1280, 11520, 4128160), (1000, 320, 5120, 8128160)])
+def test_gemm_big_tiles(ops, dev, M, N, K, tile):
+    """The 8-wave BK=64 tile variants (incl. M tails and K tails inside a 64-wide k-tile), with the LoRA slab + epilogue."""
+    a, b = rnd(M, K, dev=dev, seed=1), rnd(N, K, dev=dev, scale=0.1, seed=2)
+    a2, b2 = rnd(M, 8, dev=dev, seed=3), rnd(N, 8, dev=dev, seed=4)
+    bias = rnd(N, dev=dev, dtype=torch.float32, seed=5)
+    res = rnd(M, N, dev=dev, seed=6)
+    import ctypes
+    from finetune_fair_diffusion_amd import lib
+    d = lib.GemmDesc(); d.M, d.N, d.K, d.batch = M, N, K, 1
+    ws = ops.gemm_workspace()
+    d.workspace, d.workspace_bytes, d.ldc = ws.data_ptr(), ws.numel() * 4, N
+    assert lib.get().fd_gemm_tile(ctypes.byref(d)) == tile
+    c = ops.gemm(a, b, a2=a2, b2=b2, bias=bias, residual=res)
+    check(f"gemm big {M}x{N}x{K}", c, a.float() @ b.float().t() + a2.float() @ b2.float().t() + bias + res.float(), 2e-3)
+
+
+@pytest.mark.parametrize("B,H,Cin,Cout", [(16, 64, 320, 320), (14, 64, 64, 128), (13, 32, 128, 640)])
+def test_conv3x3_big_tiles(ops, dev, B, H, Cin, Cout):
+    x = rnd(B, Cin, H, H, dev=dev, seed=1)
+    w = rnd(Cout, Cin, 3, 3, dev=dev, scale=0.05, seed=2)
+    bias = rnd(Cout, dev=dev, dtype=torch.float32, seed=3)
+    wk = w.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin).contiguous()
+    y, Ho, Wo = ops.conv3x3(_nhwc(x), wk, B, H, H, bias=bias)
+    check("conv big normal", _nchw(y, B, Ho, Wo), F.conv2d(x.float(), w.float(), bias, padding=1), 2e-3)
+    y, Ho, Wo = ops.conv3x3(_nhwc(x), wk, B, H, H, mode=ops.CONV_UP2, bias=bias)
+    check("conv big up2", _nchw(y, B, Ho, Wo), F.conv2d(F.interpolate(x.float(), scale_factor=2.0, mode="nearest"), w.float(), bias, padding=1), 2e-3)
+    y, Ho, Wo = ops.conv3x3(_nhwc(x), wk, B, H, H, mode=ops.CONV_STRIDE2, bias=bias)
+    check("conv big stride2", _nchw(y, B, Ho, Wo), F.conv2d(x.float(), w.float(), bias, stride=2, padding=1), 2e-3)
+    wd = w.flip(2, 3).permute(1, 2, 3, 0).reshape(Cin, 9 * Cout).contiguous()
+    g = rnd(B, Cout, H, H, dev=dev, seed=5)
+    dx, Ho, Wo = ops.conv3x3(_nhwc(g), wd, B, H, H, mode=ops.CONV_TRANS2)
+    ref = F.conv_transpose2d(g.float(), w.float(), stride=2, padding=1, output_padding=1)
+    check("conv big stride2 dgrad", _nchw(dx, B, Ho, Wo), ref, 2e-3)
+
+
 def test_gemm_epilogue_and_lora_slab(ops, dev):
     M, N, K, R = 777, 640, 320, 8
     a, b = rnd(M, K, dev=dev, seed=1), rnd(N, K, dev=dev, scale=0.1, seed=2)
