@@ -152,6 +152,23 @@ class FairnessTrainer:
             preds[sel] = p.max(dim=-1).indices
         return ind, boxes, preds, probs, logits_attr
 
+    # ------------------------------------------------------------------ the two exchange points of the step
+    def gather_probs(self, probs):
+        """(1) all-gather of the per-rank class probabilities [B,k] so every rank derives identical global targets
+        (:1805-1837; the reference also gathers images/boxes/preds for plotting only)."""
+        if self.world == 1:
+            return probs
+        pg = probs.to(self.device).contiguous()
+        gl = [torch.empty_like(pg) for _ in range(self.world)]
+        dist.all_gather(gl, pg)
+        return torch.cat([t.cpu() for t in gl])
+
+    def allreduce_grads(self):
+        """(2) ONE all-reduce(SUM) per flat fp32 LoRA-gradient buffer (RCCL over xGMI on the GPU box)."""
+        if self.world > 1:
+            for bank in self.banks:
+                dist.all_reduce(bank.grad, op=dist.ReduceOp.SUM)
+
     # ------------------------------------------------------------------ the step
     def train_step(self, tokens, noises, S):
         args = self.args
@@ -167,14 +184,7 @@ class FairnessTrainer:
         images = torch.cat([self.decode(self.rollout(self.unet, enc, noises[j:j + vb], S)[0]) for j in range(0, B, vb)])
         ind, boxes, preds, probs, _ = self.classify(images)
         # ---- dynamic targets from the global batch (:1805-1837)
-        if self.world > 1:
-            allp = [torch.empty_like(probs) for _ in range(self.world)]
-            pg = probs.to(dev)
-            gl = [torch.empty_like(pg) for _ in range(self.world)]
-            dist.all_gather(gl, pg)
-            probs_all = torch.cat([t.cpu() for t in gl])
-        else:
-            probs_all = probs
+        probs_all = self.gather_probs(probs)
         targets_all, unc_all = generate_dynamic_targets(probs_all, w_uncertainty=True)
         targets_all[unc_all > args.uncertainty_threshold] = -1
         targets = targets_all[B * self.rank:B * (self.rank + 1)]
@@ -239,9 +249,8 @@ class FairnessTrainer:
     def sync_and_update(self, N_backward, apply=True):
         args = self.args
         self.flag.zero_()
+        self.allreduce_grads()
         for bank in self.banks:
-            if self.world > 1:
-                dist.all_reduce(bank.grad, op=dist.ReduceOp.SUM)
             ops.grad_finite_scale(bank.grad, 1.0 / (self.world * N_backward), self.flag)
         finite = int(self.flag.item()) == 0  # checked after the all-reduce so every rank takes the same branch
         if finite and apply:
