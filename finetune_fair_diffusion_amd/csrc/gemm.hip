@@ -393,12 +393,13 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(fd_gemm_desc p, int ntm,
 // all multiples of 320), full 128-byte rows per operand row (one L2 line per row per k-tile), direct-to-LDS
 // loads, the conflict-free XOR slot permutation chunk = slot ^ (row & 7), and two LDS stages.
 template <int BM, int BN, int WGM, int WGN, bool CONV>
-__global__ __launch_bounds__(512) void gemm_big_kernel(fd_gemm_desc p, int ntm, int ntn) {
-    static_assert(WGM * WGN == 8, "8 waves");
+__global__ __launch_bounds__(WGM * WGN * 64) void gemm_big_kernel(fd_gemm_desc p, int ntm, int ntn) {
+    constexpr int NW = WGM * WGN;                   // 8 or 16 waves
+    static_assert(NW == 8 || NW == 16, "8 or 16 waves");
     constexpr int WTM = BM / WGM, WTN = BN / WGN;   // wave tile
     constexpr int TM = WTM / 16, TN = WTN / 16;
     constexpr int NA = BM / 8, NB = BN / 8;         // 8-row groups (one glds instruction each) per k-tile
-    constexpr int AI = (NA + 7) / 8, BI = (NB + 7) / 8;
+    constexpr int AI = (NA + NW - 1) / NW, BI = (NB + NW - 1) / NW;
     extern __shared__ __attribute__((aligned(16))) f16 smem[];
     f16* As = smem;                      // [2][BM][64]
     f16* Bs = smem + 2 * BM * 64;        // [2][BN][64]
@@ -418,22 +419,24 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(fd_gemm_desc p, int ntm, 
 
     const int lrow = lane >> 3;                              // row inside the 8-row group
     const int kchunk = ((lane & 7) ^ lrow) * 8;              // k-chunk this lane's slot holds
-    ConvRow crow[AI];
+    // per staged row: image index and packed (oy, ox); rows beyond M get coordinates that fail every bounds check
+    int crow_b[AI], crow_yx[AI];
     if (CONV) {
 #pragma unroll
         for (int i = 0; i < AI; ++i) {
-            const int m = m0 + (wave + i * 8) * 8 + lrow;
+            const int m = m0 + (wave + i * NW) * 8 + lrow;
             const int hw = p.Ho * p.Wo;
-            crow[i].valid = m < p.M && (wave + i * 8) < NA;
-            const int mm = crow[i].valid ? m : 0;
-            crow[i].b = mm / hw;
-            const int r = mm - crow[i].b * hw;
-            crow[i].oy = r / p.Wo;
-            crow[i].ox = r - crow[i].oy * p.Wo;
+            const bool valid = m < p.M && (wave + i * NW) < NA;
+            const int mm = valid ? m : 0;
+            const int b = mm / hw;
+            const int r = mm - b * hw;
+            const int oy = r / p.Wo;
+            const int ox = r - oy * p.Wo;
+            crow_b[i] = b;
+            crow_yx[i] = valid ? ((oy << 16) | ox) : (int)0x80008000u;   // (-32768, -32768)
         }
     }
-
-    auto issue = [&](int kt, int buf) {
+    auto issue = [&](int kt, int buf, int part) {
         if (CONV) {
             // k order = (64-channel chunk, tap): the 9 taps of one chunk re-read the same 128-byte lines shifted by a
             // pixel, so the tile's working set per chunk (~48 KB) stays in L1/L2 instead of cycling all Cin channels
@@ -443,10 +446,10 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(fd_gemm_desc p, int ntm, 
             const int ky = tap / 3, kx = tap - ky * 3;
 #pragma unroll
             for (int i = 0; i < AI; ++i) {
-                const int g = wave + i * 8;
-                if (g < NA) {
-                    int iy = crow[i].oy, ix = crow[i].ox;
-                    bool ok = crow[i].valid;
+                const int g = wave + i * NW;
+                if (g < NA && (part & 1)) {
+                    int iy = crow_yx[i] >> 16, ix = (int)(short)(crow_yx[i] & 0xffff);
+                    bool ok = true;
                     if (p.conv_mode == FD_CONV_NORMAL) {
                         iy += ky - 1; ix += kx - 1;
                         ok = ok && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
@@ -463,15 +466,15 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(fd_gemm_desc p, int ntm, 
                         iy >>= 1; ix >>= 1;
                         ok = ok && iy < p.H && ix < p.W;
                     }
-                    const f16* src = ok ? A + (((int64_t)crow[i].b * p.H + iy) * p.W + ix) * p.lda + c0 + kchunk : fd_zero_page;
+                    const f16* src = ok ? A + (((int64_t)crow_b[i] * p.H + iy) * p.W + ix) * p.lda + c0 + kchunk : fd_zero_page;
                     glds16(src, As + (buf * BM + g * 8) * 64);
                 }
             }
             const int kk = tap * p.Cin + c0 + kchunk;
 #pragma unroll
             for (int i = 0; i < BI; ++i) {
-                const int g = wave + i * 8;
-                if (g < NB) {
+                const int g = wave + i * NW;
+                if (g < NB && (part & 2)) {
                     const int n = n0 + g * 8 + lrow;
                     const f16* src = (n < p.N) ? B + (int64_t)n * p.ldb + kk : fd_zero_page;
                     glds16(src, Bs + (buf * BN + g * 8) * 64);
@@ -487,8 +490,8 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(fd_gemm_desc p, int ntm, 
             const bool kok = kk < Kseg;
 #pragma unroll
             for (int i = 0; i < AI; ++i) {
-                const int g = wave + i * 8;
-                if (g < NA) {
+                const int g = wave + i * NW;
+                if (g < NA && (part & 1)) {
                     const int m = m0 + g * 8 + lrow;
                     const f16* src = (kok && m < p.M) ? Ap + (int64_t)m * la + kk : fd_zero_page;
                     glds16(src, As + (buf * BM + g * 8) * 64);
@@ -496,8 +499,8 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(fd_gemm_desc p, int ntm, 
             }
 #pragma unroll
             for (int i = 0; i < BI; ++i) {
-                const int g = wave + i * 8;
-                if (g < NB) {
+                const int g = wave + i * NW;
+                if (g < NB && (part & 2)) {
                     const int n = n0 + g * 8 + lrow;
                     const f16* src = (kok && n < p.N) ? Bp + (int64_t)n * lb + kk : fd_zero_page;
                     glds16(src, Bs + (buf * BN + g * 8) * 64);
@@ -519,12 +522,13 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(fd_gemm_desc p, int ntm, 
     // split-K: blockIdx.y owns the k-tiles [kbeg, kend) and writes raw fp32 partials to the workspace
     const int nsplit = gridDim.y;
     const int kbeg = (int)((int64_t)nk * blockIdx.y / nsplit), kend = (int)((int64_t)nk * (blockIdx.y + 1) / nsplit);
-    issue(kbeg, 0);
+    issue(kbeg, 0, 3);
     for (int kt = kbeg; kt < kend; ++kt) {
         const int buf = (kt - kbeg) & 1;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (kt + 1 < kend && p.batch != -1) issue(kt + 1, buf ^ 1);
+        // (issuing the B half between the two k-steps was measured: it pushes the 16-wave variant into scratch, 8x slower)
+        if (kt + 1 < kend && p.batch != -1) issue(kt + 1, buf ^ 1, 3);
         if (p.batch == -2) continue;
         const f16* Ab = As + (buf * BM + wm * WTM) * 64 + frow;
         const f16* Bb = Bs + (buf * BN + wn * WTN) * 64 + frow;
@@ -646,8 +650,8 @@ static int launch_big(const fd_gemm_desc& d, hipStream_t s, int nsplit = 1) {
         (void)hipFuncSetAttribute((const void*)gemm_big_kernel<BM, BN, WGM, WGN, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         once = true;
     }
-    if (d.conv) hipLaunchKernelGGL((gemm_big_kernel<BM, BN, WGM, WGN, true>), dim3(ntm * ntn, nsplit), dim3(512), lds, s, d, ntm, ntn);
-    else hipLaunchKernelGGL((gemm_big_kernel<BM, BN, WGM, WGN, false>), dim3(ntm * ntn, nsplit), dim3(512), lds, s, d, ntm, ntn);
+    if (d.conv) hipLaunchKernelGGL((gemm_big_kernel<BM, BN, WGM, WGN, true>), dim3(ntm * ntn, nsplit), dim3(WGM * WGN * 64), lds, s, d, ntm, ntn);
+    else hipLaunchKernelGGL((gemm_big_kernel<BM, BN, WGM, WGN, false>), dim3(ntm * ntn, nsplit), dim3(WGM * WGN * 64), lds, s, d, ntm, ntn);
     if (nsplit > 1) {
         int64_t blocks = ((int64_t)d.M * d.N / 4 + 255) / 256;
         if (blocks > 2048) blocks = 2048;
@@ -722,11 +726,12 @@ extern "C" int fd_gemm(const fd_gemm_desc* dp, void* stream) {
     }
     if (d.rowbias) FD_REQUIRE(d.rows_per_batch > 0, "fd_gemm: rows_per_batch");
     hipStream_t s = (hipStream_t)stream;
+    static const bool w16 = getenv("FD_GEMM_W8") == nullptr;   // 16-wave variants by default (A/B switch for measurement)
     const int sel = fd_gemm_tile(&d);
     if (sel >= 1000000) return launch_big<128, 160, 4, 2>(d, s, sel / 1000000);
     switch (sel) {
-        case 256320: return launch_big<256, 320, 2, 4>(d, s);
-        case 128320: return launch_big<128, 320, 2, 4>(d, s);
+        case 256320: return (w16 && !d.conv) ? launch_big<256, 320, 4, 4>(d, s) : launch_big<256, 320, 2, 4>(d, s);
+        case 128320: return w16 ? launch_big<128, 320, 4, 4>(d, s) : launch_big<128, 320, 2, 4>(d, s);
         case 128160: return launch_big<128, 160, 4, 2>(d, s);
         case 256128: return launch_big<256, 128, 4, 2>(d, s);
         case 128128: return launch<128, 128>(d, s);
