@@ -25,32 +25,68 @@ __device__ __forceinline__ f32x16 zero16() {
 // row index inside a 32x32 C/D tile for accumulator register r of lane-half g
 __device__ __forceinline__ int crow(int r, int g) { return (r & 3) + 8 * (r >> 2) + 4 * g; }
 
-// stage a row-major [rows x D] fp16 tile (global row stride ld) into LDS [rows][DKP], zero padded
-template <int ROWS, int D, int DKP>
-__device__ __forceinline__ void stage_rows(f16* dst, const f16* src, int64_t ld, int row0, int nrows_valid) {
-    constexpr int CH = DKP / 8;  // chunks per LDS row (incl. pad columns beyond D up to DK)
-    for (int c = threadIdx.x; c < ROWS * CH; c += 256) {
-        const int r = c / CH, cc = (c - r * CH) * 8;
-        f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (row0 + r < nrows_valid && cc < D) v = *(const f16x8*)(src + (int64_t)(row0 + r) * ld + cc);
-        *(f16x8*)(dst + r * DKP + cc) = v;
-    }
-}
-// stage a transposed tile: global [D rows (channels) x T] (row stride ldt) -> LDS [DV][72], cols col0..col0+63
-template <int D, int DV>
-__device__ __forceinline__ void stage_cols(f16* dst, const f16* src, int64_t ldt, int col0, int ncols_valid) {
-    for (int c = threadIdx.x; c < DV * 8; c += 256) {
-        const int r = c >> 3, cc = (c & 7) * 8;
-        f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (r < D && col0 + cc < ncols_valid) v = *(const f16x8*)(src + (int64_t)r * ldt + col0 + cc);
-        *(f16x8*)(dst + r * 72 + cc) = v;
-    }
-}
 // the permuted-k A operand from a key-contiguous LDS tile [.][72]: keys base + 4g + {0..3} and base + 8 + 4g + {0..3}
 __device__ __forceinline__ f16x8 read_perm(const f16* tile, int row, int base, int g) {
     const f16x4 lo = *(const f16x4*)(tile + row * 72 + base + 4 * g);
     const f16x4 hi = *(const f16x4*)(tile + row * 72 + base + 8 + 4 * g);
     return (f16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+
+
+// ---- register-staged tiles with the load split from the LDS write (issue the next tile's global loads before
+// computing the current one, write them to LDS after the barrier): hides the HBM/L2 latency under the MFMAs.
+template <int D> struct TileRegs { f16x8 r[(64 * (D / 8) + 255) / 256]; };
+
+template <int D>
+__device__ __forceinline__ void load_rows(TileRegs<D>& t, const f16* src, int64_t ld, int row0, int nrows_valid) {
+    constexpr int CH = D / 8, N = 64 * CH, NCH = (N + 255) / 256;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c = threadIdx.x + i * 256;
+        const int r = c / CH, cc = (c - r * CH) * 8;
+        t.r[i] = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
+        if (c < N && row0 + r < nrows_valid) t.r[i] = *(const f16x8*)(src + (int64_t)(row0 + r) * ld + cc);
+    }
+}
+template <int D, int DKP>
+__device__ __forceinline__ void store_rows(const TileRegs<D>& t, f16* dst) {
+    constexpr int CH = D / 8, N = 64 * CH, NCH = (N + 255) / 256;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c = threadIdx.x + i * 256;
+        const int r = c / CH, cc = (c - r * CH) * 8;
+        if (c < N) *(f16x8*)(dst + r * DKP + cc) = t.r[i];
+    }
+}
+template <int D>
+__device__ __forceinline__ void load_cols(TileRegs<D>& t, const f16* src, int64_t ldt, int col0, int ncols_valid) {
+    constexpr int N = D * 8, NCH = (64 * (D / 8) + 255) / 256;   // D rows x 8 chunks == 64 * D/8
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c = threadIdx.x + i * 256;
+        const int r = c >> 3, cc = (c & 7) * 8;
+        t.r[i] = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
+        if (c < N && col0 + cc < ncols_valid) t.r[i] = *(const f16x8*)(src + (int64_t)r * ldt + col0 + cc);
+    }
+}
+template <int D>
+__device__ __forceinline__ void store_cols(const TileRegs<D>& t, f16* dst) {
+    constexpr int N = D * 8, NCH = (64 * (D / 8) + 255) / 256;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c = threadIdx.x + i * 256;
+        const int r = c >> 3, cc = (c & 7) * 8;
+        if (c < N) *(f16x8*)(dst + r * 72 + cc) = t.r[i];
+    }
+}
+// zero the padding that staging never touches: columns [D, DKP) of a row tile / rows [D, DV) of a column tile
+template <int D, int DKP>
+__device__ __forceinline__ void zero_row_pad(f16* dst) {
+    for (int c = threadIdx.x; c < 64 * (DKP - D); c += 256) dst[(c / (DKP - D)) * DKP + D + c % (DKP - D)] = (f16)0;
+}
+template <int D, int DV>
+__device__ __forceinline__ void zero_col_pad(f16* dst) {
+    for (int c = threadIdx.x; c < (DV - D) * 72; c += 256) dst[D * 72 + c] = (f16)0;
 }
 
 // ================================================================================== forward
@@ -88,11 +124,20 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const f16* __restrict__ Q
     const f16* Kb = K + (int64_t)bk * Tk * C + h * D;
     const f16* Vtb = Vt + ((int64_t)bk * C + h * D) * Tkp;
 
+    TileRegs<D> kreg, vreg;
+    zero_row_pad<D, DKP>(Ks);
+    zero_col_pad<D, DV>(Vts);
+    load_rows<D>(kreg, Kb, C, 0, Tk);
+    load_cols<D>(vreg, Vtb, Tkp, 0, Tkp);
     for (int k0 = 0; k0 < Tk; k0 += 64) {
         __syncthreads();
-        stage_rows<64, D, DKP>(Ks, Kb, C, k0, Tk);
-        stage_cols<D, DV>(Vts, Vtb, Tkp, k0, Tkp);
+        store_rows<D, DKP>(kreg, Ks);
+        store_cols<D>(vreg, Vts);
         __syncthreads();
+        if (k0 + 64 < Tk) {            // next tile's loads fly under this tile's MFMAs
+            load_rows<D>(kreg, Kb, C, k0 + 64, Tk);
+            load_cols<D>(vreg, Vtb, Tkp, k0 + 64, Tkp);
+        }
 
         f32x16 s[2];
 #pragma unroll
@@ -104,38 +149,43 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const f16* __restrict__ Q
                 s[kt] = mfma32(kf, qf[ks], s[kt]);
             }
         }
-        // scale, mask, online softmax
+        // online softmax on the raw scores: p = exp2(s*sl2 - m*sl2) is one FMA + one v_exp per element; the
+        // key mask only exists in the last (partial) tile, a wave-uniform branch
+        if (k0 + 64 > Tk) {
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (k0 + kt * 32 + crow(r, g) >= Tk) s[kt][r] = -INFINITY;
+        }
         float mx = -INFINITY;
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = k0 + kt * 32 + crow(r, g);
-                float v = s[kt][r] * sl2;
-                if (key >= Tk) v = -INFINITY;
-                s[kt][r] = v;
-                mx = fmaxf(mx, v);
-            }
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kt][r]);
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run, mx);
-        const float alpha = exp2f(m_run - m_new);
+        const float m_new = fmaxf(m_run, mx);          // running max of the RAW scores
+        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * sl2);
+        const float nm = -m_new * sl2;
         float rs = 0.f;
         f16x8 pf[4];
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float p = exp2f(s[kt][r] - m_new);
+                const float p = __builtin_amdgcn_exp2f(fmaf(s[kt][r], sl2, nm));
                 rs += p;
                 pf[kt * 2 + (r >> 3)][r & 7] = (f16)p;
             }
         rs += __shfl_xor(rs, 32, 64);
         l_run = l_run * alpha + rs;
+        if (__any(m_new != m_run)) {                   // rescale O only when some row's max moved
+#pragma unroll
+            for (int i = 0; i < NDV; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
+        }
         m_run = m_new;
-#pragma unroll
-        for (int i = 0; i < NDV; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
 #pragma unroll
         for (int st = 0; st < 4; ++st)
 #pragma unroll
@@ -159,7 +209,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const f16* __restrict__ Q
                     *(f16x4*)(Op + dv) = o;
                 }
             }
-        if (LSE && g == 0) LSE[((int64_t)b * H + h) * Tq + t] = (m_run + log2f(l_run)) / LOG2E;
+        if (LSE && g == 0) LSE[((int64_t)b * H + h) * Tq + t] = m_run * scale + log2f(l_run) / LOG2E;
     }
 }
 
@@ -226,12 +276,32 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const f16* __restrict_
     const f16* Vb = V + (int64_t)bk * Tk * C + h * D;
     const f16* Ktb = Kt + ((int64_t)bk * C + h * D) * Tkp;
 
+    constexpr bool PF = D <= 80;      // register prefetch where the register file has room
+    TileRegs<D> kreg, vreg, ktreg;
+    zero_row_pad<D, DKP>(Ks);
+    zero_row_pad<D, DKP>(Vs);
+    zero_col_pad<D, DV>(Kts);
+    if (PF) {
+        load_rows<D>(kreg, Kb, C, 0, Tk);
+        load_rows<D>(vreg, Vb, C, 0, Tk);
+        load_cols<D>(ktreg, Ktb, Tkp, 0, Tkp);
+    }
     for (int k0 = 0; k0 < Tk; k0 += 64) {
         __syncthreads();
-        stage_rows<64, D, DKP>(Ks, Kb, C, k0, Tk);
-        stage_rows<64, D, DKP>(Vs, Vb, C, k0, Tk);
-        stage_cols<D, DV>(Kts, Ktb, Tkp, k0, Tkp);
+        if (!PF) {
+            load_rows<D>(kreg, Kb, C, k0, Tk);
+            load_rows<D>(vreg, Vb, C, k0, Tk);
+            load_cols<D>(ktreg, Ktb, Tkp, k0, Tkp);
+        }
+        store_rows<D, DKP>(kreg, Ks);
+        store_rows<D, DKP>(vreg, Vs);
+        store_cols<D>(ktreg, Kts);
         __syncthreads();
+        if (PF && k0 + 64 < Tk) {
+            load_rows<D>(kreg, Kb, C, k0 + 64, Tk);
+            load_rows<D>(vreg, Vb, C, k0 + 64, Tk);
+            load_cols<D>(ktreg, Ktb, Tkp, k0 + 64, Tkp);
+        }
         f16x8 dsf[4];
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
@@ -245,10 +315,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const f16* __restrict_
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int key = k0 + kt * 32 + crow(r, g);
-                float p = exp2f(s[r] * sl2 - lse2);
-                if (key >= Tk) p = 0.f;
-                dsf[kt * 2 + (r >> 3)][r & 7] = (f16)(p * (dp[r] - dd) * scale);
+                float p = __builtin_amdgcn_exp2f(fmaf(s[r], sl2, -lse2));
+                if (k0 + 64 > Tk && k0 + kt * 32 + crow(r, g) >= Tk) p = 0.f;
+                dsf[kt * 2 + (r >> 3)][r & 7] = (f16)(p * (dp[r] - dd));   // the softmax scale is applied once to the accumulator
             }
         }
 #pragma unroll
@@ -269,7 +338,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const f16* __restrict_
                 if (dv < D) {
                     f16x4 o;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) o[j] = (f16)acc[i][rq * 4 + j];
+                    for (int j = 0; j < 4; ++j) o[j] = (f16)(acc[i][rq * 4 + j] * scale);
                     *(f16x4*)(P + dv) = o;
                 }
             }
@@ -325,18 +394,42 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const f16* __restric
     const float* Lb = LSE + ((int64_t)b * H + h) * Tq;
     const float* Db = Dd + ((int64_t)b * H + h) * Tq;
 
+    constexpr bool PF = D <= 80;
+    TileRegs<D> qreg, greg, qtreg, gtreg;
+    zero_row_pad<D, DKP>(Qs);
+    zero_row_pad<D, DKP>(Gs);
+    zero_col_pad<D, DV>(Qts);
+    zero_col_pad<D, DV>(Gts);
+    if (PF) {
+        load_rows<D>(qreg, Qb, C, 0, Tq);
+        load_rows<D>(greg, Gb, C, 0, Tq);
+        load_cols<D>(qtreg, Qtb, Tq, 0, Tq);
+        load_cols<D>(gtreg, Gtb, Tq, 0, Tq);
+    }
     for (int q0 = 0; q0 < Tq; q0 += 64) {
         __syncthreads();
-        stage_rows<64, D, DKP>(Qs, Qb, C, q0, Tq);
-        stage_rows<64, D, DKP>(Gs, Gb, C, q0, Tq);
-        stage_cols<D, DV>(Qts, Qtb, Tq, q0, Tq);
-        stage_cols<D, DV>(Gts, Gtb, Tq, q0, Tq);
+        if (!PF) {
+            load_rows<D>(qreg, Qb, C, q0, Tq);
+            load_rows<D>(greg, Gb, C, q0, Tq);
+            load_cols<D>(qtreg, Qtb, Tq, q0, Tq);
+            load_cols<D>(gtreg, Gtb, Tq, q0, Tq);
+        }
+        store_rows<D, DKP>(qreg, Qs);
+        store_rows<D, DKP>(greg, Gs);
+        store_cols<D>(qtreg, Qts);
+        store_cols<D>(gtreg, Gts);
         if (threadIdx.x < 64) {
             const int tq = q0 + threadIdx.x;
             lse_s[threadIdx.x] = tq < Tq ? Lb[tq] * LOG2E : INFINITY;
             dd_s[threadIdx.x] = tq < Tq ? Db[tq] : 0.f;
         }
         __syncthreads();
+        if (PF && q0 + 64 < Tq) {
+            load_rows<D>(qreg, Qb, C, q0 + 64, Tq);
+            load_rows<D>(greg, Gb, C, q0 + 64, Tq);
+            load_cols<D>(qtreg, Qtb, Tq, q0 + 64, Tq);
+            load_cols<D>(gtreg, Gtb, Tq, q0 + 64, Tq);
+        }
         f16x8 pf[4], dsf[4];
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) {
@@ -351,10 +444,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const f16* __restric
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int qi = qt * 32 + crow(r, g);
-                float p = exp2f(s[r] * sl2 - lse_s[qi]);
+                float p = __builtin_amdgcn_exp2f(fmaf(s[r], sl2, -lse_s[qi]));
                 if (!kvalid) p = 0.f;
                 pf[qt * 2 + (r >> 3)][r & 7] = (f16)p;
-                dsf[qt * 2 + (r >> 3)][r & 7] = (f16)(p * (dp[r] - dd_s[qi]) * scale);
+                dsf[qt * 2 + (r >> 3)][r & 7] = (f16)(p * (dp[r] - dd_s[qi]));   // scale applied to dK at the end
             }
         }
 #pragma unroll
@@ -378,13 +471,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const f16* __restric
                     if (ATOMIC) {
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
-                            atomicAdd((float*)dKo + off + d0 + j, dk[i][rq * 4 + j]);
+                            atomicAdd((float*)dKo + off + d0 + j, dk[i][rq * 4 + j] * scale);
                             atomicAdd((float*)dVo + off + d0 + j, dv[i][rq * 4 + j]);
                         }
                     } else {
                         f16x4 a, c;
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) { a[j] = (f16)dk[i][rq * 4 + j]; c[j] = (f16)dv[i][rq * 4 + j]; }
+                        for (int j = 0; j < 4; ++j) { a[j] = (f16)(dk[i][rq * 4 + j] * scale); c[j] = (f16)dv[i][rq * 4 + j]; }
                         *(f16x4*)((f16*)dKo + off + d0) = a;
                         *(f16x4*)((f16*)dVo + off + d0) = c;
                     }

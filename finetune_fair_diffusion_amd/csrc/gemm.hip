@@ -1,207 +1,21 @@
 // MFMA GEMM / implicit-GEMM 3x3 convolution for gfx950.
 //   C[M,N] = act(alpha*(A.B^T + A2.B2^T) + bias + rowbias) + residual       (fp16 in, fp32 acc)
-// Tile BMxBNx32, 256 threads = 4 waves (2x2), each wave (BM/2)x(BN/2) of v_mfma_f32_16x16x32_f16.
-// Operands are staged global -> VGPR -> LDS (16 B per lane, rows padded to 80 B so the
-// ds_read_b128 fragment reads are at most 2-way conflicted), double-buffered in LDS with the next
-// k-tile's global loads in flight under the current tile's MFMAs.  The MFMA is issued with the
-// operands swapped (D^T = B.A^T) so each lane ends up holding 4 consecutive N for one M row:
-// the epilogue then does 8-byte stores along the contiguous dimension.
+// Two kernel families, both staging operands global -> LDS with global_load_lds_dwordx4 (no VGPR round trip) into
+// unpadded rows whose 16-byte slots are XOR-permuted so the ds_read_b128 fragment reads are bank-conflict free, and
+// both issuing v_mfma_f32_16x16x32_f16 with the operands swapped (D^T = B.A^T) so a lane ends up holding 4
+// consecutive N of one M row (8-byte epilogue stores along the contiguous dimension):
+//   gemm_glds_kernel  4 waves, BK = 32, tiles 128x128 / 128x64 / 64x64  (short K, small problems, strided batch)
+//   gemm_big_kernel   8 or 16 waves, BK = 64, tiles 256x320 / 128x320 / 128x160 / 256x128, optional split-K
 #include "common.h"
 #include <stdlib.h>
-
-#define LDSK 40  // 32 halfs of K + 8 pad (80-byte rows)
 
 struct ConvRow {
     int b, oy, ox;
     bool valid;
 };
 
-template <int BM, int BN, bool CONV>
-__global__ __launch_bounds__(256) void gemm_kernel(fd_gemm_desc p, int ntm, int ntn) {
-    constexpr int TM = BM / 32, TN = BN / 32;     // 16x16 tiles per wave in M / N
-    constexpr int AI = BM / 64, BI = BN / 64;     // 16-byte chunks per thread per k-tile
-    __shared__ __attribute__((aligned(16))) f16 smem[2 * (BM + BN) * LDSK];
-    f16* As = smem;
-    f16* Bs = smem + 2 * BM * LDSK;
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int l15 = lane & 15, lg = lane >> 4;
-    const int wm = wave >> 1, wn = wave & 1;
-
-    const int tile = xcd_remap(blockIdx.x, ntm * ntn);
-    const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
-    const int z = blockIdx.y;
-
-    const f16* A = (const f16*)p.A + (int64_t)z * p.sA;
-    const f16* B = (const f16*)p.B + (int64_t)z * p.sB;
-    const f16* A2 = (const f16*)p.A2;
-    const f16* B2 = (const f16*)p.B2;
-
-    const int nk1 = (p.K + 31) >> 5;
-    const int nk2 = (p.K2 + 31) >> 5;
-    const int nk = nk1 + nk2;
-
-    // per-thread chunk coordinates
-    int arow[AI], brow[BI];
-    const int kc = tid & 3;
-    ConvRow crow[AI];
-#pragma unroll
-    for (int i = 0; i < AI; ++i) {
-        arow[i] = (tid >> 2) + i * 64;
-        if (CONV) {
-            const int m = m0 + arow[i];
-            const int hw = p.Ho * p.Wo;
-            crow[i].valid = m < p.M;
-            const int mm = crow[i].valid ? m : 0;
-            crow[i].b = mm / hw;
-            const int r = mm - crow[i].b * hw;
-            crow[i].oy = r / p.Wo;
-            crow[i].ox = r - crow[i].oy * p.Wo;
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < BI; ++i) brow[i] = (tid >> 2) + i * 64;
-
-    const int cpt = CONV ? (p.Cin >> 5) : 1;  // k-tiles per filter tap
-
-    f16x8 ra[AI], rb[BI];
-    const f16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
-
-    auto load_tiles = [&](int kt) {
-        if (CONV) {
-            const int tap = kt / cpt;
-            const int c0 = (kt - tap * cpt) << 5;
-            const int ky = tap / 3, kx = tap - ky * 3;
-#pragma unroll
-            for (int i = 0; i < AI; ++i) {
-                int iy = crow[i].oy, ix = crow[i].ox;
-                bool ok = crow[i].valid;
-                if (p.conv_mode == FD_CONV_NORMAL) {
-                    iy += ky - 1; ix += kx - 1;
-                    ok = ok && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-                } else if (p.conv_mode == FD_CONV_STRIDE2) {
-                    iy = 2 * iy + ky - 1; ix = 2 * ix + kx - 1;
-                    ok = ok && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-                } else if (p.conv_mode == FD_CONV_UP2) {
-                    iy += ky - 1; ix += kx - 1;
-                    ok = ok && iy >= 0 && iy < 2 * p.H && ix >= 0 && ix < 2 * p.W;
-                    iy >>= 1; ix >>= 1;
-                } else {  // FD_CONV_TRANS2: data-gradient of the stride-2 conv (weights pre-flipped)
-                    iy += ky - 1; ix += kx - 1;
-                    ok = ok && iy >= 0 && ix >= 0 && !(iy & 1) && !(ix & 1);
-                    iy >>= 1; ix >>= 1;
-                    ok = ok && iy < p.H && ix < p.W;
-                }
-                ra[i] = zero8;
-                if (ok) ra[i] = *(const f16x8*)(A + (((int64_t)crow[i].b * p.H + iy) * p.W + ix) * p.lda + c0 + kc * 8);
-            }
-            const int kk = kt * 32 + kc * 8;
-#pragma unroll
-            for (int i = 0; i < BI; ++i) {
-                const int n = n0 + brow[i];
-                rb[i] = zero8;
-                if (n < p.N) rb[i] = *(const f16x8*)(B + (int64_t)n * p.ldb + kk);
-            }
-        } else {
-            const bool seg2 = kt >= nk1;
-            const f16* Ap = seg2 ? A2 : A;
-            const f16* Bp = seg2 ? B2 : B;
-            const int64_t la = seg2 ? p.lda2 : p.lda, lb = seg2 ? p.ldb2 : p.ldb;
-            const int Kseg = seg2 ? p.K2 : p.K;
-            const int kk = (seg2 ? kt - nk1 : kt) * 32 + kc * 8;
-            const bool kok = kk < Kseg;
-#pragma unroll
-            for (int i = 0; i < AI; ++i) {
-                const int m = m0 + arow[i];
-                ra[i] = zero8;
-                if (kok && m < p.M) ra[i] = *(const f16x8*)(Ap + (int64_t)m * la + kk);
-            }
-#pragma unroll
-            for (int i = 0; i < BI; ++i) {
-                const int n = n0 + brow[i];
-                rb[i] = zero8;
-                if (kok && n < p.N) rb[i] = *(const f16x8*)(Bp + (int64_t)n * lb + kk);
-            }
-        }
-    };
-    auto store_tiles = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < AI; ++i) *(f16x8*)(As + (buf * BM + arow[i]) * LDSK + kc * 8) = ra[i];
-#pragma unroll
-        for (int i = 0; i < BI; ++i) *(f16x8*)(Bs + (buf * BN + brow[i]) * LDSK + kc * 8) = rb[i];
-    };
-
-    f32x4 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    load_tiles(0);
-    store_tiles(0);
-    __syncthreads();
-
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) load_tiles(kt + 1);
-        f16x8 af[TM], bf[TN];
-#pragma unroll
-        for (int i = 0; i < TM; ++i) af[i] = *(const f16x8*)(As + (buf * BM + wm * (BM / 2) + i * 16 + l15) * LDSK + lg * 8);
-#pragma unroll
-        for (int j = 0; j < TN; ++j) bf[j] = *(const f16x8*)(Bs + (buf * BN + wn * (BN / 2) + j * 16 + l15) * LDSK + lg * 8);
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
-        if (kt + 1 < nk) store_tiles(buf ^ 1);
-        __syncthreads();
-    }
-
-    // ---- epilogue: lane holds C[m][n..n+3], m = m0+wm*BM/2+i*16+l15, n = n0+wn*BN/2+j*16+lg*4
-    const f16* R = p.residual ? (const f16*)p.residual + (int64_t)z * p.sR : nullptr;
-    const f16* RB = (const f16*)p.rowbias;
-    const bool vec_ok = ((p.N & 3) == 0) && ((p.ldc & 3) == 0) && (!R || (p.ldr & 3) == 0);
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int m = m0 + wm * (BM / 2) + i * 16 + l15;
-        if (m >= p.M) continue;
-        const int rbrow = RB ? m / p.rows_per_batch : 0;
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int n = n0 + wn * (BN / 2) + j * 16 + lg * 4;
-            if (n >= p.N) continue;
-            float v[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float x = acc[i][j][r] * p.alpha;
-                if (n + r < p.N) {
-                    if (p.bias) x += p.bias[n + r];
-                    if (RB) x += (float)RB[(int64_t)rbrow * p.ld_rowbias + n + r];
-                    x = apply_act(x, p.act);
-                    if (R) x += (float)R[(int64_t)m * p.ldr + n + r];
-                }
-                v[r] = x;
-            }
-            if (p.out_dtype == FD_OUT_F32) {
-                float* C = (float*)p.C + (int64_t)z * p.sC + (int64_t)m * p.ldc + n;
-                if (vec_ok) *(f32x4*)C = (f32x4){v[0], v[1], v[2], v[3]};
-                else
-                    for (int r = 0; r < 4 && n + r < p.N; ++r) C[r] = v[r];
-            } else {
-                f16* C = (f16*)p.C + (int64_t)z * p.sC + (int64_t)m * p.ldc + n;
-                if (vec_ok) *(f16x4*)C = (f16x4){(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
-                else
-                    for (int r = 0; r < 4 && n + r < p.N; ++r) C[r] = (f16)v[r];
-            }
-        }
-    }
-}
-
-
-// ======================================================================================= v2: direct-to-LDS staging
-// Same tiling and MFMA arrangement as gemm_kernel, but both operand tiles travel global -> LDS with
-// global_load_lds_dwordx4 (no VGPR round trip, no ds_write).  The LDS image of a 16-row x 64-byte group is
+// ======================================================================================= 4-wave, BK = 32
+// Both operand tiles travel global -> LDS with global_load_lds_dwordx4 (no VGPR round trip, no ds_write).  The LDS image of a 16-row x 64-byte group is
 // exactly what one wave-instruction writes (lane l -> row l>>2, 16-byte slot l&3), so rows are unpadded;
 // bank conflicts on the ds_read_b128 fragment reads are removed by permuting WHICH 16-byte k-chunk a slot
 // holds (chunk = slot ^ G[(row>>2)&3], G = {0,3,2,1}) on the source address, and reading with the same
@@ -386,7 +200,7 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(fd_gemm_desc p, int ntm,
 }
 
 
-// ======================================================================================= v3: big tiles, BK = 64
+// ======================================================================================= 8/16-wave, BK = 64
 // The per-CU global->LDS path saturates near 15-20 B/clk (measured: the 128x128 and 128x64 tiles above both sit
 // at ~15 B/clk/CU at very different TFLOP/s), so arithmetic intensity -- tile size -- is the lever.  This kernel
 // uses 8 waves (512 threads), a BM x BN x 64 tile (N tiles of 320/160 match the U-Net's channel counts, which are
@@ -664,14 +478,8 @@ template <int BM, int BN>
 static int launch(const fd_gemm_desc& d, hipStream_t s) {
     const int ntm = (d.M + BM - 1) / BM, ntn = (d.N + BN - 1) / BN;
     dim3 grid(ntm * ntn, d.batch > 0 ? d.batch : 1);
-    static const bool v1 = getenv("FD_GEMM_V1") != nullptr;   // A/B switch for the register-staged kernel (measurement only)
-    if (v1) {
-        if (d.conv) hipLaunchKernelGGL((gemm_kernel<BM, BN, true>), grid, dim3(256), 0, s, d, ntm, ntn);
-        else hipLaunchKernelGGL((gemm_kernel<BM, BN, false>), grid, dim3(256), 0, s, d, ntm, ntn);
-    } else {
-        if (d.conv) hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, true>), grid, dim3(256), 0, s, d, ntm, ntn);
-        else hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, false>), grid, dim3(256), 0, s, d, ntm, ntn);
-    }
+    if (d.conv) hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, true>), grid, dim3(256), 0, s, d, ntm, ntn);
+    else hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, false>), grid, dim3(256), 0, s, d, ntm, ntn);
     return fd_check_launch("fd_gemm");
 }
 
@@ -681,7 +489,8 @@ extern "C" int fd_gemm_tile(const fd_gemm_desc* dp) {
     const long nb = d.batch > 1 ? d.batch : 1;
     static const bool nobig = getenv("FD_GEMM_NOBIG") != nullptr;
     // big-tile (BK=64, 8-wave) variants: unbatched, K-tiles of 64 must not straddle a conv tap
-    if (!nobig && nb == 1 && (d.conv ? (d.Cin & 63) == 0 : (d.K + d.K2) >= 1024)) {
+    static const int bigk = getenv("FD_GEMM_BIGK") ? atoi(getenv("FD_GEMM_BIGK")) : 512;
+    if (!nobig && nb == 1 && (d.conv ? (d.Cin & 63) == 0 : (d.K + d.K2) >= bigk)) {
         const long m256 = (d.M + 255) / 256, m128 = (d.M + 127) / 128;
         if (d.N % 320 == 0) {
             if (m256 * (d.N / 320) >= 200) return 256320;
