@@ -349,26 +349,41 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_big_kernel(fd_gemm_desc p
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const int slot = ((ks * 4 + lg) ^ fsw) * 8;
-            // keep the smaller operand set resident, stream the other one fragment at a time (register budget)
+            // keep the smaller operand set resident and stream the other one with a 2-deep register prefetch, the
+            // ds_read of fragment i+2 pinned in front of the MFMAs of fragment i (LDS latency hidden under 2x TN MFMAs)
             if (TN <= TM) {
                 f16x8 bf[TN];
 #pragma unroll
                 for (int j = 0; j < TN; ++j) bf[j] = *(const f16x8*)(Bb + j * 16 * 64 + slot);
+                f16x8 a0 = *(const f16x8*)(Ab + slot);
+                f16x8 a1 = *(const f16x8*)(Ab + (TM > 1 ? 1 : 0) * 16 * 64 + slot);
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
-                    const f16x8 af = *(const f16x8*)(Ab + i * 16 * 64 + slot);
+                    f16x8 a2 = a1;
+                    if (i + 2 < TM) a2 = *(const f16x8*)(Ab + (i + 2) * 16 * 64 + slot);
 #pragma unroll
-                    for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af, acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], a0, acc[i][j], 0, 0, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, TN, 0);
+                    a0 = a1;
+                    a1 = a2;
                 }
             } else {
                 f16x8 af[TM];
 #pragma unroll
                 for (int i = 0; i < TM; ++i) af[i] = *(const f16x8*)(Ab + i * 16 * 64 + slot);
+                f16x8 b0 = *(const f16x8*)(Bb + slot);
+                f16x8 b1 = *(const f16x8*)(Bb + (TN > 1 ? 1 : 0) * 16 * 64 + slot);
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
-                    const f16x8 bf = *(const f16x8*)(Bb + j * 16 * 64 + slot);
+                    f16x8 b2 = b1;
+                    if (j + 2 < TN) b2 = *(const f16x8*)(Bb + (j + 2) * 16 * 64 + slot);
 #pragma unroll
-                    for (int i = 0; i < TM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf, af[i], acc[i][j], 0, 0, 0);
+                    for (int i = 0; i < TM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b0, af[i], acc[i][j], 0, 0, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, TM, 0);
+                    b0 = b1;
+                    b1 = b2;
                 }
             }
         }
@@ -496,16 +511,25 @@ extern "C" int fd_gemm_tile(const fd_gemm_desc* dp) {
             if (m256 * (d.N / 320) >= 200) return 256320;
             if (m128 * (d.N / 320) >= 160) return 128320;
         }
-        if (d.N % 160 == 0 && m128 * (d.N / 160) >= 160) return 128160;
-        if (d.N % 128 == 0 && m256 * (d.N / 128) >= 200) return 256128;
-        // small-M, long-K (the 8x8 / 16x16 levels of the U-Net): split K so that all 256 CUs get a block
-        if (d.N % 160 == 0 && d.workspace && (d.N & 3) == 0 && (d.ldc & 3) == 0) {
-            const long blocks = m128 * (d.N / 160);
-            const long nk = (d.K + 63) / 64 + (d.K2 + 63) / 64;
+        const bool can_split = d.workspace && (d.N & 3) == 0 && (d.ldc & 3) == 0;
+        const long nk = (d.K + 63) / 64 + (d.K2 + 63) / 64;
+        auto split_for = [&](long blocks, int tilecode) -> int {   // split K so ~256 blocks exist, >= 8 k-tiles each
             long split = blocks > 0 ? 256 / blocks : 1;
             if (split > 8) split = 8;
             while (split > 1 && (nk / split < 8 || (int64_t)split * d.M * d.N * 4 > d.workspace_bytes)) --split;
-            if (split > 1) return (int)(split * 1000000 + 128160);
+            return split > 1 ? (int)(split * 1000000 + tilecode) : 0;
+        };
+        // mid-size M with long K (16x16 level): the 128x320 tile split over K beats 128x160 without a split (intensity 91 vs 71 FLOP/B)
+        if (can_split && d.N % 320 == 0 && m128 * (d.N / 320) >= 32) {
+            const int c = split_for(m128 * (d.N / 320), 128320);
+            if (c) return c;
+        }
+        if (d.N % 160 == 0 && m128 * (d.N / 160) >= 160) return 128160;
+        if (d.N % 128 == 0 && m256 * (d.N / 128) >= 200) return 256128;
+        // small-M, long-K (8x8 level): split K so that all 256 CUs get a block
+        if (can_split && d.N % 160 == 0) {
+            const int c = split_for(m128 * (d.N / 160), 128160);
+            if (c) return c;
         }
     }
     const long t128 = (long)((d.M + 127) / 128) * ((d.N + 127) / 128) * nb;
@@ -537,7 +561,8 @@ extern "C" int fd_gemm(const fd_gemm_desc* dp, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     static const bool w16 = getenv("FD_GEMM_W8") == nullptr;   // 16-wave variants by default (A/B switch for measurement)
     const int sel = fd_gemm_tile(&d);
-    if (sel >= 1000000) return launch_big<128, 160, 4, 2>(d, s, sel / 1000000);
+    if (sel >= 1000000)
+        return (sel % 1000000 == 128320) ? launch_big<128, 320, 4, 4>(d, s, sel / 1000000) : launch_big<128, 160, 4, 2>(d, s, sel / 1000000);
     switch (sel) {
         case 256320: return (w16 && !d.conv) ? launch_big<256, 320, 4, 4>(d, s) : launch_big<256, 320, 2, 4>(d, s);
         case 128320: return w16 ? launch_big<128, 320, 4, 4>(d, s) : launch_big<128, 320, 2, 4>(d, s);

@@ -36,11 +36,11 @@ _gemm_ws = {}
 
 
 def gemm_workspace():
-    """32 MiB fp32 split-K workspace per device (owned by the caller of the C-ABI, as every buffer is)."""
+    """64 MiB fp32 split-K workspace per device (owned by the caller of the C-ABI, as every buffer is)."""
     key = torch.cuda.current_device()
     t = _gemm_ws.get(key)
     if t is None:
-        t = torch.empty(8 << 20, dtype=F32, device=torch.device("cuda", key))
+        t = torch.empty(16 << 20, dtype=F32, device=torch.device("cuda", key))
         _gemm_ws[key] = t
     return t
 
