@@ -520,7 +520,7 @@ extern "C" int fd_gemm_tile(const fd_gemm_desc* dp) {
             return split > 1 ? (int)(split * 1000000 + tilecode) : 0;
         };
         // mid-size M with long K (16x16 level): the 128x320 tile split over K beats 128x160 without a split (intensity 91 vs 71 FLOP/B)
-        if (can_split && d.N % 320 == 0 && m128 * (d.N / 320) >= 32) {
+        if (can_split && nk >= 64 && d.N % 320 == 0 && m128 * (d.N / 320) >= 32) {
             const int c = split_for(m128 * (d.N / 320), 128320);
             if (c) return c;
         }
