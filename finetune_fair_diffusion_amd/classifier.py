@@ -65,7 +65,13 @@ class MobileNetV3Large:
             cin = cout
         self.last = _PW(*_fold(sd, "features.16.", dev))
         self.fc1 = _PW(sd["classifier.0.weight"].to(dev, F32), sd["classifier.0.bias"].to(dev))
-        self.fc2 = _PW(sd["classifier.3.weight"].to(dev, F32), sd["classifier.3.bias"].to(dev))
+        # head padded to a multiple of 8 logits (16-byte GEMM rows); the pad columns are zero weights, sliced off on return
+        self.ncls_pad = (num_classes + 7) // 8 * 8
+        w2 = torch.zeros(self.ncls_pad, 1280, dtype=F32, device=dev)
+        b2 = torch.zeros(self.ncls_pad, dtype=F32, device=dev)
+        w2[:num_classes] = sd["classifier.3.weight"].to(dev, F32)
+        b2[:num_classes] = sd["classifier.3.bias"].to(dev, F32)
+        self.fc2 = _PW(w2, b2)
         self._ctx = None
 
     def forward(self, chips, record=False):
@@ -122,7 +128,7 @@ class MobileNetV3Large:
         logits, _ = pw(h, self.fc2, "none")
         if record:
             self._ctx = dict(blocks=ctx, zl=zl, zf=zf, HWl=HWl, B=B)
-        return logits
+        return logits[:, :self.num_classes]
 
     __call__ = forward
 
@@ -130,7 +136,11 @@ class MobileNetV3Large:
         """d_logits: [B, num_classes] fp32 = dL/dlogits.  Returns dL/dchips [B,3,S,S] fp32."""
         c = self._ctx
         B, blocks = c["B"], c["blocks"]
-        d = ops.to_f16(d_logits.contiguous(), gscale)
+        dl = d_logits
+        if self.ncls_pad != self.num_classes:
+            dl = torch.zeros((B, self.ncls_pad), dtype=F32, device=d_logits.device)
+            dl[:, :self.num_classes] = d_logits
+        d = ops.to_f16(dl.contiguous(), gscale)
         d = ops.gemm(d, self.fc2.wT)
         d = ops.act_bwd(c["zf"], d, "hardswish")
         d = ops.gemm(d, self.fc1.wT)                                   # [B, 960] grad of the pooled features

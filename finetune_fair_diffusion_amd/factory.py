@@ -40,9 +40,11 @@ def default_args(**kw):
     return types.SimpleNamespace(**a)
 
 
-def build_trainer(args, device, cfgs=SD15, seed=0, rank=0, world_size=1, num_classes=80, classifier_gain=1.4, state_dicts=None):
+def build_trainer(args, device, cfgs=SD15, seed=0, rank=0, world_size=1, experiment="exp-1", classifier_gain=1.4, state_dicts=None):
     """Returns (trainer, models dict).  ``state_dicts`` may carry real weights by diffusers key
     (keys 'unet','vae','clip','clf','unet_lora','te_lora'); anything missing is synthetic."""
+    from .fairness import EXPERIMENT_ATTRS
+    num_classes = EXPERIMENT_ATTRS[experiment][0]
     sds = dict(state_dicts or {})
     gen = lambda shapes, s, **k: W.synthetic_state_dict(shapes, seed=seed + s, **k)  # noqa: E731
     if "unet" not in sds:
@@ -86,6 +88,6 @@ def build_trainer(args, device, cfgs=SD15, seed=0, rank=0, world_size=1, num_cla
                 m.lora_bank.ema.copy_(m.lora_bank.flat)
                 m.refresh_lora()
     sch = DPMSolverMultistepScheduler()
-    tr = FairnessTrainer(args, te, unet, vae, clf, sch, eval_text_encoder=eval_te, eval_unet=eval_unet, rank=rank, world_size=world_size,
-                         device=device)
+    tr = FairnessTrainer(args, te, unet, vae, clf, sch, eval_text_encoder=eval_te, eval_unet=eval_unet, experiment=experiment, rank=rank,
+                         world_size=world_size, device=device)
     return tr, dict(unet=unet, eval_unet=eval_unet, vae=vae, text_encoder=te, eval_text_encoder=eval_te, classifier=clf, scheduler=sch)

@@ -99,7 +99,7 @@ def fair_loss_and_grad(logits_attr, targets, face_indicators, weights):
     lg = logits_attr.detach().float().cpu()
     n = lg.shape[0]
     loss = torch.full([n], -1.0)
-    dl = torch.zeros(n, 2)
+    dl = torch.zeros(n, lg.shape[1])
     sel = (face_indicators.cpu() & (targets.cpu() != -1)).nonzero().view(-1)
     if len(sel):
         lp = torch.log_softmax(lg[sel], dim=-1)
@@ -109,3 +109,99 @@ def fair_loss_and_grad(logits_attr, targets, face_indicators, weights):
         g[torch.arange(len(sel)), t] -= 1.0
         dl[sel] = g * weights[sel][:, None]
     return loss, dl
+
+
+# ------------------------------------------------------------------------------------------ multi-attribute (exp-3/4/5)
+def _ot_assign(M, counts):
+    """Optimal transport from N unit-mass sources to integer-capacity sinks (sum(counts) == N) -- what the reference
+    solves with ``ot.emd(ones(N), counts, M)`` (POT, not installable here).  With unit sources and integer sinks the
+    LP has an integral optimum: an assignment problem on the sink-replicated cost matrix."""
+    from scipy.optimize import linear_sum_assignment
+    N, K = M.shape
+    cols = np.repeat(np.arange(K), counts)
+    assert len(cols) == N
+    r, c = linear_sum_assignment(M[:, cols])
+    T = np.zeros((N, K))
+    T[r, cols[c]] = 1.0
+    return T
+
+
+def _cells(attr_sizes):
+    """Cell index = mixed-radix number over the attributes in order (exp-3: g*4+r `:1510`; exp-4: g*8+r*2+a `exp-4:1522`)."""
+    import itertools as it
+    return list(it.product(*[range(k) for k in attr_sizes]))
+
+
+@torch.no_grad()
+def generate_dynamic_targets_multi(probs_list, class_cdfs, num_samples_per_device=100, generator=None, allreduce=None,
+                                   age_asymmetric=False):
+    """Dynamic targets for several attributes at once (exp-3-debias-gender-race/1-main-debias.py:1459-1569,
+    exp-4-debias-gender-race-age/1-main-debias.py:1477-1615).
+
+    probs_list: per attribute a CPU tensor [n, k_a] (-1 rows = no face).  class_cdfs: per attribute the upper CDF
+    edges used to turn a uniform draw into a class (gender [0.5, 1], race [.25,.5,.75,1], age [.75, 1]).
+    For each of ``num_samples_per_device`` Monte-Carlo draws of a balanced class assignment the faces are optimally
+    transported onto the drawn cell counts; the plans are summed (and all-reduced over ranks, ``allreduce`` callable),
+    normalised, marginalised per attribute.  Returns [(targets [n] long, uncertainty [n])] per attribute.
+    ``age_asymmetric``: exp-4's cost doubles the first age coordinate when the target is the second class (`exp-4:1551-1556`)."""
+    n = probs_list[0].shape[0]
+    sizes = [p.shape[1] for p in probs_list]
+    idx = torch.ones(n, dtype=torch.bool)
+    for p in probs_list:
+        idx &= (p != -1).all(dim=-1)
+    out_t = [torch.full([n], -1, dtype=torch.long) for _ in sizes]
+    out_u = [torch.full([n], -1.0, dtype=torch.float32) for _ in sizes]
+    N = int(idx.sum())
+    if N == 0:
+        return list(zip(out_t, out_u))
+    P = [p[idx].float().numpy() for p in probs_list]
+    cells = _cells(sizes)
+    K = len(cells)
+    # Monte-Carlo class draws (`:1492-1512`)
+    draws = []
+    for cdf in class_cdfs:
+        u = torch.rand([num_samples_per_device, N], generator=generator)
+        cls = torch.zeros_like(u, dtype=torch.long)
+        lo = 0.0
+        for c, hi in enumerate(cdf):
+            if c > 0:
+                cls[(u > lo) & (u <= hi)] = c
+            lo = hi
+        draws.append(cls.numpy())
+    radix = np.array([int(np.prod(sizes[a + 1:])) for a in range(len(sizes))])
+    # cost matrix: distance of the probability vectors to the one-hot corners of each cell (`:1514-1531`)
+    M = np.zeros((N, K))
+    for j, cell in enumerate(cells):
+        sq = np.zeros(N)
+        for a, c in enumerate(cell):
+            onehot = np.zeros(sizes[a]); onehot[c] = 1.0
+            d = P[a] - onehot
+            if age_asymmetric and a == len(sizes) - 1 and c == 1:
+                d = d.copy(); d[:, 0] *= 2.0
+            sq += (d ** 2).sum(axis=1)
+        M[:, j] = np.sqrt(sq)
+    tp = np.zeros((N, K))
+    for s in range(num_samples_per_device):
+        cell_idx = sum(draws[a][s] * radix[a] for a in range(len(sizes)))
+        counts = np.bincount(cell_idx, minlength=K)
+        tp += _ot_assign(M, counts)
+    tp = torch.tensor(tp, dtype=torch.float32)
+    if allreduce is not None:
+        tp = allreduce(tp)
+    tp = tp / tp[0, :].sum()
+    for a in range(len(sizes)):
+        marg = torch.zeros(N, sizes[a])
+        for j, cell in enumerate(cells):
+            marg[:, cell[a]] += tp[:, j]
+        out_t[a][idx] = marg.argmax(dim=-1)
+        out_u[a][idx] = 1 - marg.max(dim=-1).values
+    return list(zip(out_t, out_u))
+
+
+EXPERIMENT_ATTRS = {
+    # name: (classifier logits, [(attribute, first logit column, width)], class CDF edges, exp-4 age asymmetry)
+    "exp-1": (80, [("gender", 40, 2)], None, False),
+    "exp-3": (6, [("gender", 0, 2), ("race", 2, 4)], [[0.5, 1.0], [0.25, 0.5, 0.75, 1.0]], False),
+    "exp-4": (8, [("gender", 0, 2), ("race", 2, 4), ("age", 6, 2)], [[0.5, 1.0], [0.25, 0.5, 0.75, 1.0], [0.75, 1.0]], True),
+    "exp-5": (6, [("gender", 0, 2), ("race", 2, 4)], [[0.5, 1.0], [0.25, 0.5, 0.75, 1.0]], False),
+}

@@ -23,7 +23,8 @@ import torch
 import torch.distributed as dist
 
 from . import ops
-from .fairness import SyntheticFaceProvider, fair_loss_and_grad, generate_dynamic_targets, microbatch_weights
+from .fairness import (EXPERIMENT_ATTRS, SyntheticFaceProvider, fair_loss_and_grad, generate_dynamic_targets,
+                       generate_dynamic_targets_multi, microbatch_weights)
 from .layers import F16, F32
 
 
@@ -64,13 +65,16 @@ class EMAState:
 
 class FairnessTrainer:
     def __init__(self, args, text_encoder, unet, vae, classifier, scheduler, eval_text_encoder=None, eval_unet=None,
-                 face_provider=None, attr_cols=(40, 42), rank=0, world_size=1, device=None):
+                 face_provider=None, experiment="exp-1", rank=0, world_size=1, device=None):
         self.args = args
         self.te, self.unet, self.vae, self.clf, self.sch = text_encoder, unet, vae, classifier, scheduler
         self.eval_te = eval_text_encoder if eval_text_encoder is not None else text_encoder
         self.eval_unet = eval_unet if eval_unet is not None else unet
         self.faces = face_provider or SyntheticFaceProvider()
-        self.attr_cols = attr_cols
+        # which classifier columns carry which attribute (exp-1: CelebA attr 20 of 40x2 logits `:1370`; exp-3/5: 2+4; exp-4: 2+4+2)
+        self.experiment = experiment
+        _, self.attrs, self.class_cdfs, self.age_asym = EXPERIMENT_ATTRS[experiment]
+        self.target_rng = torch.Generator().manual_seed(1234 + rank)
         self.rank, self.world = rank, world_size
         self.device = device or unet.device
         self.banks = []
@@ -133,24 +137,52 @@ class FairnessTrainer:
         return self.vae.decode_images(lat * (1.0 / self.vae.config.scaling_factor), record=record)
 
     def classify(self, images, record=False):
-        """get_face + get_face_gender (:1794-1795): returns indicators, boxes, preds, probs(-1 filled), logits_attr."""
+        """get_face + get_face_gender[_race[_age]] (:1794-1795; exp-3 :1387-1457; exp-4 :1378-1475).
+        Returns indicators, boxes and per attribute (preds [N], probs [N,k] (-1 filled), logits [N,k])."""
         N = images.shape[0]
         ind, boxes = self.faces(images)
         S = self.args.size_face
-        a, b = self.attr_cols
-        probs = torch.full((N, b - a), -1.0)
-        preds = torch.full((N,), -1, dtype=torch.long)
-        logits_attr = torch.full((N, b - a), -1.0)
+        per = []
         sel = ind.nonzero().view(-1)
+        logits = None
         if len(sel):
             chips = ops.crop_resize(images[sel.to(images.device)].contiguous() if len(sel) != N else images, boxes[sel].to(self.device).contiguous(), -1.0, S)
-            logits = self.clf.forward(chips, record=record)
-            la = logits[:, a:b].float().cpu()
-            logits_attr[sel] = la
-            p = torch.softmax(la, dim=-1)
-            probs[sel] = p
-            preds[sel] = p.max(dim=-1).indices
-        return ind, boxes, preds, probs, logits_attr
+            logits = self.clf.forward(chips, record=record).float().cpu()
+        for name, c0, k in self.attrs:
+            probs = torch.full((N, k), -1.0)
+            preds = torch.full((N,), -1, dtype=torch.long)
+            la_full = torch.full((N, k), -1.0)
+            if logits is not None:
+                la = logits[:, c0:c0 + k]
+                la_full[sel] = la
+                p = torch.softmax(la, dim=-1)
+                probs[sel] = p
+                preds[sel] = p.max(dim=-1).indices
+            per.append(dict(name=name, preds=preds, probs=probs, logits=la_full))
+        return ind, boxes, per
+
+    def dynamic_targets(self, per, B):
+        """Global dynamic targets for this rank's B images from the gathered probabilities of all ranks (:1831-1837;
+        exp-3 :2016-2025).  Returns per attribute (targets [B], uncertainty [B])."""
+        args = self.args
+        gathered = [self.gather_probs(a["probs"]) for a in per]
+        if len(per) == 1:
+            t, u = generate_dynamic_targets(gathered[0], w_uncertainty=True)
+            res = [(t, u)]
+        else:
+            def allreduce(tp):   # exchange point c11: sum of the per-rank Monte-Carlo transport plans
+                if self.world == 1:
+                    return tp
+                t = tp.to(self.device)
+                dist.all_reduce(t, op=dist.ReduceOp.SUM)
+                return t.cpu()
+            res = generate_dynamic_targets_multi(gathered, self.class_cdfs, 100, self.target_rng, allreduce, self.age_asym)
+        out = []
+        for t, u in res:
+            t = t.clone()
+            t[u > args.uncertainty_threshold] = -1
+            out.append((t[B * self.rank:B * (self.rank + 1)], u[B * self.rank:B * (self.rank + 1)]))
+        return out
 
     # ------------------------------------------------------------------ the two exchange points of the step (SURVEY 8e)
     def gather_probs(self, probs):
@@ -182,18 +214,17 @@ class FairnessTrainer:
         # ---- R1: images from the model being finetuned (:1786-1795)
         enc = self.encode_pair(self.te, tokens)
         images = torch.cat([self.decode(self.rollout(self.unet, enc, noises[j:j + vb], S)[0]) for j in range(0, B, vb)])
-        ind, boxes, preds, probs, _ = self.classify(images)
+        ind, boxes, per = self.classify(images)
         # ---- dynamic targets from the global batch (:1805-1837)
-        probs_all = self.gather_probs(probs)
-        targets_all, unc_all = generate_dynamic_targets(probs_all, w_uncertainty=True)
-        targets_all[unc_all > args.uncertainty_threshold] = -1
-        targets = targets_all[B * self.rank:B * (self.rank + 1)]
-        out.update(images=images, probs=probs, preds=preds, targets=targets, uncertainty=unc_all[B * self.rank:B * (self.rank + 1)])
+        tgt = self.dynamic_targets(per, B)
+        targets = tgt[0][0]
+        out.update(images=images, probs=per[0]["probs"], preds=per[0]["preds"], targets=targets, uncertainty=tgt[0][1],
+                   targets_by_attr={a["name"]: t for a, (t, _) in zip(per, tgt)})
         # ---- R2: images from the frozen original models (:1844-1858)
         enc_ori = self.encode_pair(self.eval_te, tokens) if self.eval_te is not self.te else enc
         images_ori = torch.cat([self.decode(self.rollout(self.eval_unet, enc_ori, noises[j:j + vb], S)[0]) for j in range(0, B, vb)])
-        ind_o, boxes_o, preds_o, probs_o, _ = self.classify(images_ori)
-        out.update(images_ori=images_ori, preds_ori=preds_o, probs_ori=probs_o)
+        ind_o, boxes_o, per_o = self.classify(images_ori)
+        out.update(images_ori=images_ori, preds_ori=per_o[0]["preds"], probs_ori=per_o[0]["probs"])
         # ---- R3: rollout with gradient (:1889-1933), all micro-batches at once with weights 1/n_j
         train_te = getattr(args, "train_text_encoder", False) and self.te.lora_bank is not None
         train_unet = getattr(args, "train_unet", False) and self.unet.lora_bank is not None
@@ -202,14 +233,18 @@ class FairnessTrainer:
         x_final, inputs, ctxs = self.rollout(self.unet, enc_g, noises, S, keep_inputs=True, record_prompt=True,
                                              keep_activations=self.keep_activations)
         images_g = self.decode(x_final, record=True)
-        ind_g, boxes_g, _, _, logits_g = self.classify(images_g, record=True)
-        loss_fair, dl = fair_loss_and_grad(logits_g, targets, ind_g, w)
-        out.update(loss_fair=loss_fair, images_grad=images_g, N_backward=N_backward)
+        ind_g, boxes_g, per_g = self.classify(images_g, record=True)
+        dlog_full = torch.zeros((B, self.clf.num_classes), dtype=F32)
+        loss_by_attr = {}
+        for (name, c0, k), a, (t_a, _) in zip(self.attrs, per_g, tgt):      # loss_ij = sum over attributes (:1932; exp-3 :2146)
+            lf, dl = fair_loss_and_grad(a["logits"], t_a, ind_g, w)
+            loss_by_attr[name] = lf
+            dlog_full[:, c0:c0 + k] = dl
+        loss_fair = loss_by_attr[self.attrs[0][0]]
+        out.update(loss_fair=loss_fair, loss_fair_by_attr=loss_by_attr, images_grad=images_g, N_backward=N_backward)
         sel = ind_g.nonzero().view(-1)
-        if len(sel) and float(dl.abs().sum()) > 0:
-            a, b = self.attr_cols
-            dlog = torch.zeros((len(sel), self.clf.num_classes), dtype=F32)
-            dlog[:, a:b] = dl[sel]
+        if len(sel) and float(dlog_full.abs().sum()) > 0:
+            dlog = dlog_full[sel]
             dchips = self.clf.backward(dlog.to(dev), self.clf_gscale)
             full = dchips
             if len(sel) != B:

@@ -106,6 +106,74 @@ def generate_dynamic_targets(probs, target_ratio=0.5, w_uncertainty=False):  # :
     return targets_all, unc_all
 
 
+@torch.no_grad()
+def generate_dynamic_targets_multi(probs_list, class_cdfs, num_samples=100, generator=None, age_asymmetric=False):
+    """exp-3-debias-gender-race/1-main-debias.py:1459-1569 and exp-4-debias-gender-race-age/1-main-debias.py:1477-1615
+    restated with the transport problem solved as a *linear program* (scipy HiGHS) -- ``ot.emd`` (POT 0.9.3,
+    environment.yml:172) is not installable here, so this piece is PARITY UNPINNED; it is an independent solver from the
+    product's assignment formulation, compared on the averaged plan as SURVEY.md 8c prescribes."""
+    import itertools as it
+    from scipy.optimize import linprog
+    n = probs_list[0].shape[0]
+    sizes = [p.shape[1] for p in probs_list]
+    idx = torch.ones(n, dtype=torch.bool)
+    for p in probs_list:
+        idx &= (p != -1).all(dim=-1)
+    N = int(idx.sum())
+    res_t = [torch.full([n], -1, dtype=torch.long) for _ in sizes]
+    res_u = [torch.full([n], -1.0) for _ in sizes]
+    if N == 0:
+        return list(zip(res_t, res_u))
+    P = [p[idx].double().numpy() for p in probs_list]
+    cells = list(it.product(*[range(k) for k in sizes]))
+    K = len(cells)
+    draws = []
+    for cdf in class_cdfs:
+        u = torch.rand([num_samples, N], generator=generator)
+        cls = torch.zeros_like(u, dtype=torch.long)
+        lo = 0.0
+        for c, hi in enumerate(cdf):
+            if c > 0:
+                cls[(u > lo) & (u <= hi)] = c
+            lo = hi
+        draws.append(cls.numpy())
+    M = np.zeros((N, K))
+    for j, cell in enumerate(cells):
+        for i in range(N):
+            sq = 0.0
+            for a, c in enumerate(cell):
+                tgt = np.zeros(sizes[a]); tgt[c] = 1.0
+                if age_asymmetric and a == len(sizes) - 1 and c == 1:
+                    sq += ((P[a][i][0] - 0) * 2) ** 2 + (P[a][i][1] - 1) ** 2
+                else:
+                    sq += np.linalg.norm(P[a][i] - tgt) ** 2
+            M[i, j] = sq ** 0.5
+    # equality constraints: rows sum to 1, columns sum to the drawn counts
+    A_eq = np.zeros((N + K, N * K))
+    for i in range(N):
+        A_eq[i, i * K:(i + 1) * K] = 1
+    for j in range(K):
+        A_eq[N + j, j::K] = 1
+    tp = np.zeros((N, K))
+    for s_ in range(num_samples):
+        counts = np.zeros(K)
+        for i in range(N):
+            j = 0
+            for a in range(len(sizes)):
+                j = j * sizes[a] + draws[a][s_][i]
+            counts[j] += 1
+        r = linprog(M.reshape(-1), A_eq=A_eq, b_eq=np.concatenate([np.ones(N), counts]), bounds=(0, None), method="highs")
+        tp += r.x.reshape(N, K)
+    tp = torch.tensor(tp / tp[0].sum(), dtype=torch.float32)
+    for a in range(len(sizes)):
+        marg = torch.zeros(N, sizes[a])
+        for j, cell in enumerate(cells):
+            marg[:, cell[a]] += tp[:, j]
+        res_t[a][idx] = marg.argmax(dim=-1)
+        res_u[a][idx] = 1 - marg.max(dim=-1).values
+    return list(zip(res_t, res_u)), tp
+
+
 def apply_grad_hook_face(images, face_bboxs, face_bboxs_ori, targets, preds_ori, factor=0.1):  # :1584-1617
     out = []
     for image, bb, bbo, target, pred_ori in itertools.zip_longest(images, face_bboxs, face_bboxs_ori, targets, preds_ori):
@@ -222,7 +290,7 @@ class EMAModel:
             s.sub_(omd * (s - p))
 
 
-def fairness_step(models, tokens, noises, S, cfg, world=None):
+def fairness_step(models, tokens, noises, S, cfg, world=None, attrs=None, targets_by_attr=None):
     """One training step (:1746-2029) on one rank, synthetic face provider,
     loss = loss_fair only (CLIP/DINO/face terms are SURVEY 8f "next" rows).
 
@@ -278,3 +346,31 @@ def fairness_step(models, tokens, noises, S, cfg, world=None):
         images_g.append(img.detach())
     out.update(loss_fair=loss_fair, N_backward=N_backward, images_grad=torch.cat(images_g))
     return out
+
+
+def fairness_step_multi(models, tokens, noises, S, cfg, attrs, targets_by_attr):
+    """Multi-attribute variant of the R3 part (exp-3 `:2079-2155`): loss_ij = sum_a CE_a with -1 sentinels; the dynamic
+    targets are passed in (they come from a Monte-Carlo OT procedure, tested separately).  attrs: [(name, col0, width)]."""
+    te, unet, vae, clf, sch = (models[k] for k in ("text_encoder", "unet", "vae", "classifier", "scheduler"))
+    faces = SyntheticFaceProvider(cfg.get("size_face", 224))
+    gs, B, tb = cfg.get("guidance_scale", 7.5), noises.shape[0], cfg["train_GPU_batch_size"]
+    N_backward = math.ceil(B / tb)
+    losses = {a[0]: torch.ones(B) * (-1) for a in attrs}
+    for j in range(N_backward):
+        idx = list(range(B))[j * tb:(j + 1) * tb]
+        img = generate_image_w_gradient(tokens, noises[idx], S, te, unet, vae, sch, gs)
+        ind_j, _, chips_j = faces(img)
+        logits = clf(chips_j[ind_j])
+        loss_ij = 0
+        for name, c0, k in attrs:
+            la = torch.ones(len(idx), k) * (-1)
+            la[ind_j] = logits[:, c0:c0 + k]
+            t = targets_by_attr[name][idx]
+            lf = torch.ones(len(idx)) * (-1)
+            w = ((ind_j == True) * (t != -1)).nonzero().view([-1])  # noqa: E712
+            lf[w] = F.cross_entropy(la[w], t[w], reduction="none")
+            losses[name][idx] = lf.detach()
+            loss_ij = loss_ij + lf
+        if torch.is_tensor(loss_ij) and loss_ij.requires_grad:
+            loss_ij.mean().backward()
+    return dict(losses=losses, N_backward=N_backward)

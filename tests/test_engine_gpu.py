@@ -220,3 +220,41 @@ def test_full_fairness_step(dev, mode):
     # optimizer + EMA: replay torch AdamW on the oracle params with the PRODUCT's synced gradient (isolates the update rule)
     for i, b in enumerate(tr.banks):
         assert b.exp_avg.abs().sum() > 0 and (b.ema - b.flat).abs().max() < 1e-6  # first EMA step copies the params
+
+
+def test_full_step_multi_attribute_exp3(dev):
+    """exp-3 mode (gender x race, 6-logit head, OT dynamic targets, loss = CE_gender + CE_race): losses and LoRA gradient
+    vs the oracle's autograd with the same targets."""
+    from oracle import fair_step as fs
+    from finetune_fair_diffusion_amd.fairness import EXPERIMENT_ATTRS
+    from finetune_fair_diffusion_amd.step import FairnessTrainer
+    om = U.oracle_models(train_unet=True, train_te=False, lora_up_std=0.05, num_classes=6)
+    pm = U.product_models(om["sds"], dev, train_unet=True, train_te=False, num_classes=6)
+    args = U.make_args(train_unet=True, train_text_encoder=False, uncertainty_threshold=0.6)
+    tokens = U.tiny_tokens()
+    B, S = 4, 3
+    noises = torch.randn(B, 4, 32, 32, generator=torch.Generator().manual_seed(7))
+    tr = FairnessTrainer(args, pm["text_encoder"], pm["unet"], pm["vae"], pm["classifier"], pm["scheduler"], eval_unet=pm["eval_unet"],
+                         experiment="exp-3", device=dev)
+    grads = {}
+    apply = tr.sync_and_update
+
+    def spy(N_backward, apply_=True):
+        grads[0] = tr.banks[0].grad.clone()
+        return apply(N_backward)
+    tr.sync_and_update = spy
+    out = tr.train_step(tokens, noises, S)
+    tg = out["targets_by_attr"]
+    assert set(tg) == {"gender", "race"} and any((t != -1).any() for t in tg.values())
+    models_o = dict(text_encoder=om["text_encoder"], unet=om["unet"], vae=om["vae"], classifier=om["classifier"], scheduler=om["scheduler"])
+    for p in om["lora_params"]:
+        p.grad = None
+    ref = fs.fairness_step_multi(models_o, tokens, noises, S, dict(train_GPU_batch_size=3, size_face=64), EXPERIMENT_ATTRS["exp-3"][1], tg)
+    for name in ("gender", "race"):
+        check(f"loss_fair_{name}", out["loss_fair_by_attr"][name], ref["losses"][name], 2e-2)
+    names = list(om["unet_lora_layers"].state_dict().keys())
+    refg = torch.cat([p.grad.flatten() for p in om["unet_lora_layers"].parameters()])
+    got = torch.cat([tr.banks[0].view(n, grads[0]).flatten() for n in names])
+    cos = F.cosine_similarity(got.cpu().double(), refg.double(), dim=0)
+    print("cosine(exp-3 unet grads) =", float(cos))
+    assert cos > 0.97
