@@ -38,6 +38,8 @@ def main():
     ap.add_argument("--S", type=int, default=20, help="denoising steps")
     ap.add_argument("--rank", type=int, default=4, help="LoRA rank")
     ap.add_argument("--tiny", action="store_true", help="tiny model config (plumbing check only; not a valid bench line)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU plumbing checks)")
+    ap.add_argument("--share_gpu0", action="store_true", help="plumbing check: every rank uses cuda:0")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_roofline", action="store_true")
     a = ap.parse_args()
@@ -48,10 +50,15 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}"
+    if a.share_gpu0:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(a.backend)
 
     from finetune_fair_diffusion_amd import factory, ops
     args = factory.default_args(train_unet=True, train_text_encoder=False, rank=a.rank, train_images_per_prompt_GPU=a.batch,
@@ -117,6 +124,17 @@ def main():
                             "avg_launch_us": 1e3 * s["ms"] / s["launches"], "algorithmic_flop_per_launch": s["flops"] / s["launches"],
                             "family": {k: {"launches": v["launches"], "ms": round(v["ms"], 2), "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1)}
                                        for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"])}}
+    if world == 1 and not a.no_roofline:
+        # informational only (NOT the headline value): the same step when R3 consumes R1's recorded forward instead of
+        # recomputing the bit-identical rollout; measured after the timed region
+        tr.share_r1_r3 = True
+        one_step()
+        fence()
+        t1 = time.perf_counter()
+        one_step()
+        fence()
+        line["config"]["images_per_s_if_r3_shares_r1_forward"] = a.batch / (time.perf_counter() - t1)
+        tr.share_r1_r3 = False
     if world > 1:
         dist.barrier()
 

@@ -21,12 +21,10 @@ __device__ __forceinline__ f16x8 gn_load(const GNArgs& a, int64_t pix, int c) {
 // MODE 0: per-group (sum x, sum x^2). MODE 1: per-group (sum dz*gamma, sum dz*gamma*xhat)
 template <int MODE>
 __global__ void gn_reduce_kernel(GNArgs a, float* partial /* [B,nchunks,G,2] */) {
-    extern __shared__ float sacc[];  // [G*2]
+    extern __shared__ float part[];  // [blockDim.x][16]: per-thread per-channel partial sums (fixed-order reduction below)
     const int C = a.C1 + a.C2, V = C >> 3, cg = C / a.G;
     const int b = blockIdx.y, chunk = blockIdx.x;
     const int v = threadIdx.x % V, rsub = threadIdx.x / V, rpb = blockDim.x / V;
-    for (int i = threadIdx.x; i < a.G * 2; i += blockDim.x) sacc[i] = 0.f;
-    __syncthreads();
     const int c0 = v * 8;
     float s0[8], s1[8];
     float gm[8], bt[8], mu[8], rs[8];
@@ -43,40 +41,49 @@ __global__ void gn_reduce_kernel(GNArgs a, float* partial /* [B,nchunks,G,2] */)
     }
     const int r0 = chunk * a.rows_per_chunk;
     const int r1 = min(r0 + a.rows_per_chunk, a.HW);
-    if (rsub < rpb) {
-        for (int r = r0 + rsub; r < r1; r += rpb) {
-            const int64_t pix = (int64_t)b * a.HW + r;
-            const f16x8 xv = gn_load(a, pix, c0);
-            if (MODE == 0) {
+    for (int r = r0 + rsub; r < r1; r += rpb) {
+        const int64_t pix = (int64_t)b * a.HW + r;
+        const f16x8 xv = gn_load(a, pix, c0);
+        if (MODE == 0) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float x = (float)xv[j];
-                    s0[j] += x;
-                    s1[j] += x * x;
-                }
-            } else {
-                const f16x8 dv = *(const f16x8*)(a.dy + pix * C + c0);
+            for (int j = 0; j < 8; ++j) {
+                const float x = (float)xv[j];
+                s0[j] += x;
+                s1[j] += x * x;
+            }
+        } else {
+            const f16x8 dv = *(const f16x8*)(a.dy + pix * C + c0);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float xh = ((float)xv[j] - mu[j]) * rs[j];
-                    float dz = (float)dv[j];
-                    if (a.silu) dz *= silu_grad_f(xh * gm[j] + bt[j]);
-                    const float t = dz * gm[j];
-                    s0[j] += t;
-                    s1[j] += t * xh;
-                }
+            for (int j = 0; j < 8; ++j) {
+                const float xh = ((float)xv[j] - mu[j]) * rs[j];
+                float dz = (float)dv[j];
+                if (a.silu) dz *= silu_grad_f(xh * gm[j] + bt[j]);
+                const float t = dz * gm[j];
+                s0[j] += t;
+                s1[j] += t * xh;
             }
         }
+    }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int g = (c0 + j) / cg;
-            atomicAdd(&sacc[g * 2], s0[j]);
-            atomicAdd(&sacc[g * 2 + 1], s1[j]);
-        }
+    for (int j = 0; j < 8; ++j) {
+        part[threadIdx.x * 16 + j] = s0[j];
+        part[threadIdx.x * 16 + 8 + j] = s1[j];
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < a.G * 2; i += blockDim.x)
-        partial[((int64_t)(b * a.nchunks + chunk)) * a.G * 2 + i] = sacc[i];
+    // one thread per group sums its channels over all row sub-groups in a fixed order (bit-reproducible, no atomics)
+    if (threadIdx.x < a.G) {
+        const int g = threadIdx.x;
+        float t0 = 0.f, t1 = 0.f;
+        for (int c = g * cg; c < (g + 1) * cg; ++c) {
+            const int tv = c >> 3, j = c & 7;
+            for (int rr = 0; rr < rpb; ++rr) {
+                t0 += part[(rr * V + tv) * 16 + j];
+                t1 += part[(rr * V + tv) * 16 + 8 + j];
+            }
+        }
+        partial[((int64_t)(b * a.nchunks + chunk)) * a.G * 2 + g * 2] = t0;
+        partial[((int64_t)(b * a.nchunks + chunk)) * a.G * 2 + g * 2 + 1] = t1;
+    }
 }
 
 // MODE 0: -> (mean, rstd).  MODE 1: -> (s1/n, s2/n)
@@ -201,7 +208,7 @@ extern "C" int fd_groupnorm_stats(const void* x1, int C1, const void* x2, int C2
     int threads;
     FD_REQUIRE(gn_geometry(C1 + C2, HW, threads, a.rows_per_chunk, a.nchunks) == 0, "fd_groupnorm: C too large");
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(gn_reduce_kernel<0>, dim3(a.nchunks, B), dim3(threads), groups * 2 * sizeof(float), s, a, scratch);
+    hipLaunchKernelGGL(gn_reduce_kernel<0>, dim3(a.nchunks, B), dim3(threads), threads * 16 * sizeof(float), s, a, scratch);
     const float n = (float)HW * (float)((C1 + C2) / groups);
     hipLaunchKernelGGL(gn_finalize_kernel<0>, dim3((B * groups + 63) / 64), dim3(64), 0, s, scratch, mean_rstd, B, groups, a.nchunks, n, eps);
     return fd_check_launch("fd_groupnorm_stats");
@@ -231,7 +238,7 @@ extern "C" int fd_groupnorm_bwd(const void* x1, int C1, const void* x2, int C2, 
     hipStream_t s = (hipStream_t)stream;
     float* s12 = scratch;                       // [B,G,2]
     float* partial = scratch + (size_t)B * groups * 2;  // [B,nchunks,G,2]
-    hipLaunchKernelGGL(gn_reduce_kernel<1>, dim3(a.nchunks, B), dim3(threads), groups * 2 * sizeof(float), s, a, partial);
+    hipLaunchKernelGGL(gn_reduce_kernel<1>, dim3(a.nchunks, B), dim3(threads), threads * 16 * sizeof(float), s, a, partial);
     const float n = (float)HW * (float)((C1 + C2) / groups);
     hipLaunchKernelGGL(gn_finalize_kernel<1>, dim3((B * groups + 63) / 64), dim3(64), 0, s, partial, s12, B, groups, a.nchunks, n, 0.f);
     hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(a.nchunks, B), dim3(threads), 0, s, a, s12, (const f16*)add1, (const f16*)add2,
