@@ -30,11 +30,121 @@ __device__ __forceinline__ void glds16(const f16* src, f16* lds_dst) {
                                      (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
 }
 
+
+// ---- shared epilogue: lane holds C[m][n..n+3] per 16x16 tile (swapped-operand MFMA layout).  Bias / row-bias / residual
+// are fetched as one vector per tile (the epilogue of a short-K GEMM is otherwise more VMEM instructions than its main loop).
+template <int TM, int TN>
+__device__ __forceinline__ void gemm_epilogue(const fd_gemm_desc& p, f32x4 (&acc)[TM][TN], int mbase, int nbase, int l15, int lg,
+                                              int64_t zC, int64_t zR) {
+    const f16* R = p.residual ? (const f16*)p.residual + zR : nullptr;
+    const f16* RB = (const f16*)p.rowbias;
+    const bool vec_ok = ((p.N & 3) == 0) && ((p.ldc & 3) == 0) && (!R || (p.ldr & 3) == 0) && (!RB || (p.ld_rowbias & 3) == 0);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = nbase + j * 16 + lg * 4;
+        if (n >= p.N) continue;
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias) {
+            if (vec_ok) bv = *(const f32x4*)(p.bias + n);
+            else
+                for (int r = 0; r < 4 && n + r < p.N; ++r) bv[r] = p.bias[n + r];
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = mbase + i * 16 + l15;
+            if (m >= p.M) continue;
+            float v[4];
+            f16x4 rbv = {0, 0, 0, 0}, resv = {0, 0, 0, 0};
+            if (vec_ok) {
+                if (RB) rbv = *(const f16x4*)(RB + (int64_t)(m / p.rows_per_batch) * p.ld_rowbias + n);
+                if (R) resv = *(const f16x4*)(R + (int64_t)m * p.ldr + n);
+            } else {
+                for (int r = 0; r < 4 && n + r < p.N; ++r) {
+                    if (RB) rbv[r] = RB[(int64_t)(m / p.rows_per_batch) * p.ld_rowbias + n + r];
+                    if (R) resv[r] = R[(int64_t)m * p.ldr + n + r];
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float x = acc[i][j][r] * p.alpha + bv[r] + (float)rbv[r];
+                x = apply_act(x, p.act);
+                v[r] = x + (float)resv[r];
+            }
+            if (p.out_dtype == FD_OUT_F32) {
+                float* C = (float*)p.C + zC + (int64_t)m * p.ldc + n;
+                if (vec_ok) *(f32x4*)C = (f32x4){v[0], v[1], v[2], v[3]};
+                else
+                    for (int r = 0; r < 4 && n + r < p.N; ++r) C[r] = v[r];
+            } else {
+                f16* C = (f16*)p.C + zC + (int64_t)m * p.ldc + n;
+                if (vec_ok) *(f16x4*)C = (f16x4){(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+                else
+                    for (int r = 0; r < 4 && n + r < p.N; ++r) C[r] = (f16)v[r];
+            }
+        }
+    }
+}
+
+
+// ---- LDS-staged epilogue (fp16 output): the accumulator layout gives each lane 4 consecutive N (8 bytes), i.e. 32-byte
+// row segments per store instruction; short-K GEMMs are bound by exactly that store path.  Here each wave parks its
+// WTM x WTN tile in LDS (bias / row-bias / activation already applied) and re-reads it as 16 bytes per lane so that a
+// store instruction covers whole 128-byte row segments; the residual is added on the way out with 16-byte loads.
+template <int TM, int TN>
+__device__ __forceinline__ void gemm_epilogue_lds(const fd_gemm_desc& p, f32x4 (&acc)[TM][TN], f16* wave_lds, int mbase, int nbase,
+                                                  int lane, int64_t zC, int64_t zR) {
+    constexpr int WTN = TN * 16, WTM = TM * 16, LDW = WTN + 4;   // +4 halfs: 8-byte aligned rows, spreads the ds_write_b64 banks
+    const int l15 = lane & 15, lg = lane >> 4;
+    const f16* RB = (const f16*)p.rowbias;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = nbase + j * 16 + lg * 4;
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias && n < p.N) bv = *(const f32x4*)(p.bias + n);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = mbase + i * 16 + l15;
+            f16x4 rbv = {0, 0, 0, 0};
+            if (RB && m < p.M && n < p.N) rbv = *(const f16x4*)(RB + (int64_t)(m / p.rows_per_batch) * p.ld_rowbias + n);
+            f16x4 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = (f16)apply_act(acc[i][j][r] * p.alpha + bv[r] + (float)rbv[r], p.act);
+            *(f16x4*)(wave_lds + (i * 16 + l15) * LDW + j * 16 + lg * 4) = o;
+        }
+    }
+    // wave-private region: no block barrier needed, only this wave's own LDS writes must have landed
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    const f16* R = p.residual ? (const f16*)p.residual + zR : nullptr;
+    constexpr int CPR = WTN / 8;                 // 16-byte chunks per row
+    constexpr int RPI = 64 / CPR;                // rows per store instruction
+    const int cr = lane / CPR, cc = (lane % CPR) * 8;
+#pragma unroll
+    for (int r0 = 0; r0 < WTM; r0 += RPI) {
+        const int row = r0 + cr;
+        const int m = mbase + row, n = nbase + cc;
+        if (row < WTM && m < p.M && n < p.N) {
+            // LDS rows are 8-byte aligned (LDW*2 bytes is a multiple of 8): two 8-byte reads
+            const f16x4 lo = *(const f16x4*)(wave_lds + row * LDW + cc);
+            const f16x4 hi = *(const f16x4*)(wave_lds + row * LDW + cc + 4);
+            f16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            if (R) {
+                const f16x8 rv = *(const f16x8*)(R + (int64_t)m * p.ldr + n);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = (f16)((float)v[k] + (float)rv[k]);
+            }
+            *(f16x8*)((f16*)p.C + zC + (int64_t)m * p.ldc + n) = v;
+        }
+    }
+}
+
 template <int BM, int BN, bool CONV>
 __global__ __launch_bounds__(256) void gemm_glds_kernel(fd_gemm_desc p, int ntm, int ntn) {
     constexpr int TM = BM / 32, TN = BN / 32;
     constexpr int AI = BM / 64, BI = BN / 64;     // 16-row groups per wave per k-tile
-    __shared__ __attribute__((aligned(16))) f16 smem[2 * (BM + BN) * 32];
+    constexpr int EPI_HALFS = 4 * (BM / 2) * (BN / 2 + 4);           // 4 waves x (wave tile + row pad)
+    constexpr int OPS_HALFS = 2 * (BM + BN) * 32;
+    __shared__ __attribute__((aligned(16))) f16 smem[OPS_HALFS > EPI_HALFS ? OPS_HALFS : EPI_HALFS];
     f16* As = smem;
     f16* Bs = smem + 2 * BM * 32;
 
@@ -160,45 +270,16 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(fd_gemm_desc p, int ntm,
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
     }
 
-    const f16* R = p.residual ? (const f16*)p.residual + (int64_t)z * p.sR : nullptr;
-    const f16* RB = (const f16*)p.rowbias;
-    const bool vec_ok = ((p.N & 3) == 0) && ((p.ldc & 3) == 0) && (!R || (p.ldr & 3) == 0);
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int m = m0 + wm * (BM / 2) + i * 16 + l15;
-        if (m >= p.M) continue;
-        const int rbrow = RB ? m / p.rows_per_batch : 0;
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int n = n0 + wn * (BN / 2) + j * 16 + lg * 4;
-            if (n >= p.N) continue;
-            float v[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float x = acc[i][j][r] * p.alpha;
-                if (n + r < p.N) {
-                    if (p.bias) x += p.bias[n + r];
-                    if (RB) x += (float)RB[(int64_t)rbrow * p.ld_rowbias + n + r];
-                    x = apply_act(x, p.act);
-                    if (R) x += (float)R[(int64_t)m * p.ldr + n + r];
-                }
-                v[r] = x;
-            }
-            if (p.out_dtype == FD_OUT_F32) {
-                float* C = (float*)p.C + (int64_t)z * p.sC + (int64_t)m * p.ldc + n;
-                if (vec_ok) *(f32x4*)C = (f32x4){v[0], v[1], v[2], v[3]};
-                else
-                    for (int r = 0; r < 4 && n + r < p.N; ++r) C[r] = v[r];
-            } else {
-                f16* C = (f16*)p.C + (int64_t)z * p.sC + (int64_t)m * p.ldc + n;
-                if (vec_ok) *(f16x4*)C = (f16x4){(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
-                else
-                    for (int r = 0; r < 4 && n + r < p.N; ++r) C[r] = (f16)v[r];
-            }
-        }
+    const bool lds_epi = p.out_dtype == FD_OUT_F16 && (p.N & 7) == 0 && (p.ldc & 7) == 0 && (!p.residual || (p.ldr & 7) == 0) &&
+                         (!p.rowbias || (p.ld_rowbias & 3) == 0);
+    if (lds_epi) {
+        __syncthreads();   // every wave is done reading the operand stages before they are reused as epilogue staging
+        gemm_epilogue_lds<TM, TN>(p, acc, smem + wave * (BM / 2) * (BN / 2 + 4), m0 + wm * (BM / 2), n0 + wn * (BN / 2), lane,
+                                  (int64_t)z * p.sC, (int64_t)z * p.sR);
+    } else {
+        gemm_epilogue<TM, TN>(p, acc, m0 + wm * (BM / 2), n0 + wn * (BN / 2), l15, lg, (int64_t)z * p.sC, (int64_t)z * p.sR);
     }
 }
-
 
 // ======================================================================================= 8/16-wave, BK = 64
 // The per-CU global->LDS path saturates near 15-20 B/clk (measured: the 128x128 and 128x64 tiles above both sit
@@ -403,43 +484,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_big_kernel(fd_gemm_desc p
         }
         return;
     }
-    const f16* R = (const f16*)p.residual;
-    const f16* RB = (const f16*)p.rowbias;
-    const bool vec_ok = ((p.N & 3) == 0) && ((p.ldc & 3) == 0) && (!R || (p.ldr & 3) == 0);
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int m = m0 + wm * WTM + i * 16 + l15;
-        if (m >= p.M) continue;
-        const int rbrow = RB ? m / p.rows_per_batch : 0;
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int n = n0 + wn * WTN + j * 16 + lg * 4;
-            if (n >= p.N) continue;
-            float v[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float x = acc[i][j][r] * p.alpha;
-                if (n + r < p.N) {
-                    if (p.bias) x += p.bias[n + r];
-                    if (RB) x += (float)RB[(int64_t)rbrow * p.ld_rowbias + n + r];
-                    x = apply_act(x, p.act);
-                    if (R) x += (float)R[(int64_t)m * p.ldr + n + r];
-                }
-                v[r] = x;
-            }
-            if (p.out_dtype == FD_OUT_F32) {
-                float* C = (float*)p.C + (int64_t)m * p.ldc + n;
-                if (vec_ok) *(f32x4*)C = (f32x4){v[0], v[1], v[2], v[3]};
-                else
-                    for (int r = 0; r < 4 && n + r < p.N; ++r) C[r] = v[r];
-            } else {
-                f16* C = (f16*)p.C + (int64_t)m * p.ldc + n;
-                if (vec_ok) *(f16x4*)C = (f16x4){(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
-                else
-                    for (int r = 0; r < 4 && n + r < p.N; ++r) C[r] = (f16)v[r];
-            }
-        }
-    }
+    gemm_epilogue<TM, TN>(p, acc, m0 + wm * WTM, n0 + wn * WTN, l15, lg, 0, 0);
 }
 
 // sum the split-K slabs in a fixed order and apply the epilogue
