@@ -42,13 +42,17 @@ __global__ __launch_bounds__(256) void lora_wgrad_partial(const f16* __restrict_
     }
 }
 
-__global__ void lora_wgrad_final(const float* partial, float* G, int64_t sn, int64_t sr, int N, int R, int RP, int nsplit, float scale) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N * R) return;
-    const int n = i / R, r = i % R;
+// one wave per output element (n, r): lanes stride over the splits in a fixed order, then a fixed-shape wave reduction
+__global__ __launch_bounds__(256) void lora_wgrad_final(const float* partial, float* G, int64_t sn, int64_t sr, int N, int R, int RP, int nsplit,
+                                                        float scale) {
+    const int o = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (o >= N * R) return;
+    const int lane = threadIdx.x & 63;
+    const int n = o / R, r = o % R;
     float s = 0.f;
-    for (int k = 0; k < nsplit; ++k) s += partial[((int64_t)k * N + n) * RP + r];
-    G[n * sn + r * sr] += scale * s;
+    for (int k = lane; k < nsplit; k += 64) s += partial[((int64_t)k * N + n) * RP + r];
+    s = wave_sum(s);
+    if (lane == 0) G[n * sn + r * sr] += scale * s;
 }
 
 extern "C" int fd_lora_wgrad(const void* X, int64_t ldx, const void* T, int64_t ldt, float* G, int64_t g_stride_n, int64_t g_stride_r, int M,
@@ -57,7 +61,7 @@ extern "C" int fd_lora_wgrad(const void* X, int64_t ldx, const void* T, int64_t 
     const int RP = R <= 8 ? 8 : (R <= 16 ? 16 : (R <= 32 ? 32 : 64));
     FD_REQUIRE(ldt >= RP && (ldt & 7) == 0, "fd_lora_wgrad: T must be padded to %d columns (ldt=%ld)", RP, (long)ldt);
     const int ncb = (N + 63) / 64;
-    int nsplit = (1024 + ncb - 1) / ncb;
+    int nsplit = (768 + ncb - 1) / ncb;
     if (nsplit > (M + 63) / 64) nsplit = (M + 63) / 64;
     while (nsplit > 1 && (int64_t)nsplit * N * RP > scratch_elems) nsplit >>= 1;
     FD_REQUIRE((int64_t)nsplit * N * RP <= scratch_elems, "fd_lora_wgrad: scratch too small");
@@ -72,6 +76,6 @@ extern "C" int fd_lora_wgrad(const void* X, int64_t ldx, const void* T, int64_t 
         case 32: hipLaunchKernelGGL(lora_wgrad_partial<32>, grid, dim3(256), 0, s, (const f16*)X, ldx, (const f16*)T, ldt, scratch, M, N, rows); break;
         default: hipLaunchKernelGGL(lora_wgrad_partial<64>, grid, dim3(256), 0, s, (const f16*)X, ldx, (const f16*)T, ldt, scratch, M, N, rows); break;
     }
-    hipLaunchKernelGGL(lora_wgrad_final, dim3((N * R + 255) / 256), dim3(256), 0, s, scratch, G, g_stride_n, g_stride_r, N, R, RP, nsplit, scale);
+    hipLaunchKernelGGL(lora_wgrad_final, dim3((N * R + 3) / 4), dim3(256), 0, s, scratch, G, g_stride_n, g_stride_r, N, R, RP, nsplit, scale);
     return fd_check_launch("fd_lora_wgrad");
 }

@@ -86,39 +86,45 @@ __global__ void gn_reduce_kernel(GNArgs a, float* partial /* [B,nchunks,G,2] */)
     }
 }
 
-// MODE 0: -> (mean, rstd).  MODE 1: -> (s1/n, s2/n)
+// every apply block reduces the (<= 64) chunk partials of its image itself: saves a separate finalize launch per GroupNorm
 template <int MODE>
-__global__ void gn_finalize_kernel(const float* partial, float* out, int B, int G, int nchunks, float n, float eps) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= B * G) return;
-    const int b = i / G, g = i % G;
-    float a0 = 0.f, a1 = 0.f;
-    for (int c = 0; c < nchunks; ++c) {
-        a0 += partial[((int64_t)(b * nchunks + c) * G + g) * 2];
-        a1 += partial[((int64_t)(b * nchunks + c) * G + g) * 2 + 1];
+__device__ __forceinline__ void gn_block_stats(const GNArgs& a, const float* partial, int b, float n, float* st /* LDS [G*2] */,
+                                               float* out /* global [B,G,2] or nullptr */) {
+    if (threadIdx.x < a.G) {
+        const int g = threadIdx.x;
+        float a0 = 0.f, a1 = 0.f;
+        for (int c = 0; c < a.nchunks; ++c) {
+            a0 += partial[((int64_t)(b * a.nchunks + c) * a.G + g) * 2];
+            a1 += partial[((int64_t)(b * a.nchunks + c) * a.G + g) * 2 + 1];
+        }
+        float v0, v1;
+        if (MODE == 0) {
+            v0 = a0 / n;
+            v1 = rsqrtf(fmaxf(a1 / n - v0 * v0, 0.f) + a.eps);
+        } else {
+            v0 = a0 / n;
+            v1 = a1 / n;
+        }
+        st[g * 2] = v0;
+        st[g * 2 + 1] = v1;
+        if (out) { out[(b * a.G + g) * 2] = v0; out[(b * a.G + g) * 2 + 1] = v1; }
     }
-    if (MODE == 0) {
-        const float mean = a0 / n;
-        const float var = fmaxf(a1 / n - mean * mean, 0.f);
-        out[i * 2] = mean;
-        out[i * 2 + 1] = rsqrtf(var + eps);
-    } else {
-        out[i * 2] = a0 / n;
-        out[i * 2 + 1] = a1 / n;
-    }
+    __syncthreads();
 }
 
-__global__ void gn_apply_kernel(GNArgs a, f16* y) {
+__global__ void gn_apply_kernel(GNArgs a, f16* y, const float* partial, float n, float* stats_out) {
+    __shared__ float st[128];
     const int C = a.C1 + a.C2, V = C >> 3, cg = C / a.G;
     const int b = blockIdx.y, chunk = blockIdx.x;
     const int v = threadIdx.x % V, rsub = threadIdx.x / V, rpb = blockDim.x / V;
+    gn_block_stats<0>(a, partial, b, n, st, chunk == 0 ? stats_out : nullptr);
     if (rsub >= rpb) return;
     const int c0 = v * 8;
     float sc[8], sh[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int g = (c0 + j) / cg;
-        const float mu = a.mean_rstd[(b * a.G + g) * 2], rs = a.mean_rstd[(b * a.G + g) * 2 + 1];
+        const float mu = st[g * 2], rs = st[g * 2 + 1];
         sc[j] = rs * a.gamma[c0 + j];
         sh[j] = a.beta[c0 + j] - mu * sc[j];
     }
@@ -138,10 +144,12 @@ __global__ void gn_apply_kernel(GNArgs a, f16* y) {
     }
 }
 
-__global__ void gn_bwd_apply_kernel(GNArgs a, const float* s12, const f16* add1, const f16* add2, f16* dx1, f16* dx2) {
+__global__ void gn_bwd_apply_kernel(GNArgs a, const float* partial, float n, const f16* add1, const f16* add2, f16* dx1, f16* dx2) {
+    __shared__ float s12[128];
     const int C = a.C1 + a.C2, V = C >> 3, cg = C / a.G;
     const int b = blockIdx.y, chunk = blockIdx.x;
     const int v = threadIdx.x % V, rsub = threadIdx.x / V, rpb = blockDim.x / V;
+    gn_block_stats<1>(a, partial, b, n, s12, nullptr);
     if (rsub >= rpb) return;
     const int c0 = v * 8;
     float gm[8], bt[8], mu[8], rs[8], m1[8], m2[8];
@@ -152,8 +160,8 @@ __global__ void gn_bwd_apply_kernel(GNArgs a, const float* s12, const f16* add1,
         bt[j] = a.beta[c0 + j];
         mu[j] = a.mean_rstd[(b * a.G + g) * 2];
         rs[j] = a.mean_rstd[(b * a.G + g) * 2 + 1];
-        m1[j] = s12[(b * a.G + g) * 2];
-        m2[j] = s12[(b * a.G + g) * 2 + 1];
+        m1[j] = s12[g * 2];
+        m2[j] = s12[g * 2 + 1];
     }
     const bool first = c0 < a.C1;
     const int cc = first ? c0 : c0 - a.C1;
@@ -199,31 +207,21 @@ static int gn_check(int C1, int C2, int groups) {
     return 0;
 }
 
-// scratch needed by stats/bwd: B * 64 * groups * 2 floats
-extern "C" int fd_groupnorm_stats(const void* x1, int C1, const void* x2, int C2, int B, int HW, int groups, float eps,
-                                  float* mean_rstd, float* scratch, void* stream) {
-    FD_REQUIRE(gn_check(C1, C2, groups) == 0, "fd_groupnorm_stats: bad channels C1=%d C2=%d groups=%d", C1, C2, groups);
+// GroupNorm forward: y = act(GN(x)); writes the (mean, rstd) it used to mean_rstd [B,groups,2] for the backward.
+// scratch: B * 64 * groups * 2 floats.
+extern "C" int fd_groupnorm_fwd(const void* x1, int C1, const void* x2, int C2, int B, int HW, int groups, float eps, const float* gamma,
+                                const float* beta, int silu, void* y, float* mean_rstd, float* scratch, void* stream) {
+    FD_REQUIRE(gn_check(C1, C2, groups) == 0, "fd_groupnorm_fwd: bad channels C1=%d C2=%d groups=%d", C1, C2, groups);
     GNArgs a = {};
     a.x1 = (const f16*)x1; a.x2 = (const f16*)x2; a.C1 = C1; a.C2 = C2; a.B = B; a.HW = HW; a.G = groups; a.eps = eps;
+    a.gamma = gamma; a.beta = beta; a.silu = silu;
     int threads;
     FD_REQUIRE(gn_geometry(C1 + C2, HW, threads, a.rows_per_chunk, a.nchunks) == 0, "fd_groupnorm: C too large");
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(gn_reduce_kernel<0>, dim3(a.nchunks, B), dim3(threads), threads * 16 * sizeof(float), s, a, scratch);
     const float n = (float)HW * (float)((C1 + C2) / groups);
-    hipLaunchKernelGGL(gn_finalize_kernel<0>, dim3((B * groups + 63) / 64), dim3(64), 0, s, scratch, mean_rstd, B, groups, a.nchunks, n, eps);
-    return fd_check_launch("fd_groupnorm_stats");
-}
-
-extern "C" int fd_groupnorm_apply(const void* x1, int C1, const void* x2, int C2, int B, int HW, int groups,
-                                  const float* mean_rstd, const float* gamma, const float* beta, int silu, void* y, void* stream) {
-    FD_REQUIRE(gn_check(C1, C2, groups) == 0, "fd_groupnorm_apply: bad channels");
-    GNArgs a = {};
-    a.x1 = (const f16*)x1; a.x2 = (const f16*)x2; a.C1 = C1; a.C2 = C2; a.B = B; a.HW = HW; a.G = groups;
-    a.gamma = gamma; a.beta = beta; a.mean_rstd = mean_rstd; a.silu = silu;
-    int threads;
-    FD_REQUIRE(gn_geometry(C1 + C2, HW, threads, a.rows_per_chunk, a.nchunks) == 0, "fd_groupnorm: C too large");
-    hipLaunchKernelGGL(gn_apply_kernel, dim3(a.nchunks, B), dim3(threads), 0, (hipStream_t)stream, a, (f16*)y);
-    return fd_check_launch("fd_groupnorm_apply");
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(a.nchunks, B), dim3(threads), 0, s, a, (f16*)y, (const float*)scratch, n, mean_rstd);
+    return fd_check_launch("fd_groupnorm_fwd");
 }
 
 extern "C" int fd_groupnorm_bwd(const void* x1, int C1, const void* x2, int C2, const void* dy, int B, int HW, int groups,
@@ -236,13 +234,10 @@ extern "C" int fd_groupnorm_bwd(const void* x1, int C1, const void* x2, int C2, 
     int threads;
     FD_REQUIRE(gn_geometry(C1 + C2, HW, threads, a.rows_per_chunk, a.nchunks) == 0, "fd_groupnorm: C too large");
     hipStream_t s = (hipStream_t)stream;
-    float* s12 = scratch;                       // [B,G,2]
-    float* partial = scratch + (size_t)B * groups * 2;  // [B,nchunks,G,2]
-    hipLaunchKernelGGL(gn_reduce_kernel<1>, dim3(a.nchunks, B), dim3(threads), threads * 16 * sizeof(float), s, a, partial);
+    hipLaunchKernelGGL(gn_reduce_kernel<1>, dim3(a.nchunks, B), dim3(threads), threads * 16 * sizeof(float), s, a, scratch);
     const float n = (float)HW * (float)((C1 + C2) / groups);
-    hipLaunchKernelGGL(gn_finalize_kernel<1>, dim3((B * groups + 63) / 64), dim3(64), 0, s, partial, s12, B, groups, a.nchunks, n, 0.f);
-    hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(a.nchunks, B), dim3(threads), 0, s, a, s12, (const f16*)add1, (const f16*)add2,
-                       (f16*)dx1, (f16*)dx2);
+    hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(a.nchunks, B), dim3(threads), 0, s, a, (const float*)scratch, n, (const f16*)add1,
+                       (const f16*)add2, (f16*)dx1, (f16*)dx2);
     return fd_check_launch("fd_groupnorm_bwd");
 }
 

@@ -203,24 +203,14 @@ def scratch(nfloats, device):
     return t
 
 
-def groupnorm_stats(x1, x2, B, HW, groups, eps):
+def groupnorm(x1, x2, B, HW, groups, eps, gamma, beta, silu):
+    """y = act(GroupNorm(cat(x1, x2))) over channels-last [B*HW, C]; returns (y, stats [B,groups,2] for the backward)."""
     C1, C2 = x1.shape[1], (x2.shape[1] if x2 is not None else 0)
     st = torch.empty((B, groups, 2), dtype=F32, device=x1.device)
-    sc = scratch(B * 64 * groups * 2, x1.device)
-    _call("fd_groupnorm_stats", _p(_chk(x1)), C1, _p(x2), C2, B, HW, groups, eps, _p(st), _p(sc), _stream())
-    return st
-
-
-def groupnorm_apply(x1, x2, B, HW, groups, stats, gamma, beta, silu):
-    C1, C2 = x1.shape[1], (x2.shape[1] if x2 is not None else 0)
     y = torch.empty((B * HW, C1 + C2), dtype=F16, device=x1.device)
-    _call("fd_groupnorm_apply", _p(x1), C1, _p(x2), C2, B, HW, groups, _p(stats), _p(gamma), _p(beta), int(silu), _p(y), _stream())
-    return y
-
-
-def groupnorm(x1, x2, B, HW, groups, eps, gamma, beta, silu):
-    st = groupnorm_stats(x1, x2, B, HW, groups, eps)
-    return groupnorm_apply(x1, x2, B, HW, groups, st, gamma, beta, silu), st
+    sc = scratch(B * 64 * groups * 2, x1.device)
+    _call("fd_groupnorm_fwd", _p(_chk(x1)), C1, _p(x2), C2, B, HW, groups, eps, _p(gamma), _p(beta), int(silu), _p(y), _p(st), _p(sc), _stream())
+    return y, st
 
 
 def groupnorm_bwd(x1, x2, dy, B, HW, groups, stats, gamma, beta, silu, add1=None, add2=None, need_dx2=True):

@@ -72,11 +72,9 @@ int fd_clamp_bwd(const void* pre, int64_t ldx, const float* dimg, float* dpre, i
 
 /* ---- GroupNorm (32 groups, channels-last, optional 2-source channel concat, optional fused SiLU).
  * Replaces torch.nn.GroupNorm(+SiLU) in ResnetBlock2D / Transformer2DModel / conv_norm_out.          */
-/* scratch: B*64*groups*2 floats (stats) / B*65*groups*2 floats (bwd) */
-int fd_groupnorm_stats(const void* x1, int C1, const void* x2, int C2, int B, int HW, int groups, float eps,
-                       float* mean_rstd /* [B,groups,2] */, float* scratch, void* stream);
-int fd_groupnorm_apply(const void* x1, int C1, const void* x2, int C2, int B, int HW, int groups,
-                       const float* mean_rstd, const float* gamma, const float* beta, int silu, void* y, void* stream);
+/* y = act(GN(x)); mean_rstd [B,groups,2] receives the statistics for the backward; scratch: B*64*groups*2 floats */
+int fd_groupnorm_fwd(const void* x1, int C1, const void* x2, int C2, int B, int HW, int groups, float eps, const float* gamma,
+                     const float* beta, int silu, void* y, float* mean_rstd, float* scratch, void* stream);
 /* backward: dx = d/dx [ act(GN(x)) ] . dy ; writes the two channel slices to dx1/dx2, optionally adding add1/add2 */
 int fd_groupnorm_bwd(const void* x1, int C1, const void* x2, int C2, const void* dy, int B, int HW, int groups,
                      const float* mean_rstd, const float* gamma, const float* beta, int silu,
