@@ -1,0 +1,134 @@
+"""Trainer-state checkpoints and the exported LoRA files, in the reference's public format.
+
+The reference writes rolling ``checkpoint_tmp-{step}`` / long-cadence ``checkpoint-{step}`` directories with
+``accelerator.save_state`` (exp-1-debias-gender/1-main-debias.py:2050-2068, clean-up :120-137) and later converts one
+of them with ``2-export-checkpoint.py:619-642`` into four files -- ``{text_encoder,unet}_lora{,_EMA}.pth`` -- each a
+``torch.save``d ``dict[str, Tensor]`` (fp32, CPU) keyed by the diffusers LoRA names.  ``gen-images.py``
+consumes exactly those four files.
+
+Here a checkpoint directory *is* the exported format plus one extra file:
+
+    checkpoint-{step}/unet_lora.pth, unet_lora_EMA.pth, text_encoder_lora.pth, text_encoder_lora_EMA.pth
+    checkpoint-{step}/trainer_state.pth   Adam moments (flat fp32 per bank), optimiser / EMA / lr step counters, RNG states
+
+so the reference's export step becomes a file copy (``export_checkpoint``), and files exported by the reference load
+back into the banks by key (``load_lora_files``).  Raw ``accelerate.save_state`` directories are not read.
+"""
+import os
+import random
+import shutil
+
+import numpy as np
+import torch
+
+BANK_FILES = {"unet": ("unet_lora.pth", "unet_lora_EMA.pth"), "text_encoder": ("text_encoder_lora.pth", "text_encoder_lora_EMA.pth")}
+
+
+def clean_checkpoint(ckpts_save_dir, name, checkpoints_total_limit):
+    """:120-137 -- before saving, keep at most ``limit - 1`` directories called ``{name}-{step}`` (oldest removed first)."""
+    ck = [d for d in os.listdir(ckpts_save_dir) if d.startswith(name + "-") and d.split("-")[1].isdigit()]   # "<ckpt>_exported" dirs stay
+    ck = sorted(ck, key=lambda x: int(x.split("-")[1]))
+    removed = []
+    if len(ck) >= checkpoints_total_limit:
+        removed = ck[0:len(ck) - checkpoints_total_limit + 1]
+        for d in removed:
+            shutil.rmtree(os.path.join(ckpts_save_dir, d))
+    return removed
+
+
+def trainer_banks(trainer):
+    out = {}
+    if getattr(trainer.args, "train_unet", False):
+        out["unet"] = trainer.unet.lora_bank
+    if getattr(trainer.args, "train_text_encoder", False):
+        out["text_encoder"] = trainer.te.lora_bank
+    return out
+
+
+def save_lora_files(banks, path):
+    """The four-file export (2-export-checkpoint.py:619-642): live and EMA weights by diffusers key, fp32 on CPU."""
+    os.makedirs(path, exist_ok=True)
+    for which, bank in banks.items():
+        live, ema = BANK_FILES[which]
+        torch.save(bank.state_dict(ema=False), os.path.join(path, live))
+        torch.save(bank.state_dict(ema=True), os.path.join(path, ema))
+
+
+def load_lora_files(banks, path, strict=True):
+    """Loads ``*_lora.pth`` into the live weights and ``*_lora_EMA.pth`` (when present) into the EMA shadow."""
+    for which, bank in banks.items():
+        live, ema = BANK_FILES[which]
+        sd = torch.load(os.path.join(path, live), map_location="cpu")
+        missing = [n for n in bank.names if n not in sd]
+        unexpected = [k for k in sd if k not in bank.offsets]
+        if strict and (missing or unexpected):
+            raise KeyError(f"{live}: missing {missing[:3]}... unexpected {unexpected[:3]}...")
+        for n in bank.names:
+            if n in sd:
+                if tuple(sd[n].shape) != tuple(bank.shape(n)):
+                    raise ValueError(f"{live}: {n} has shape {tuple(sd[n].shape)}, expected {tuple(bank.shape(n))}")
+                bank.view(n).copy_(sd[n].to(bank.flat.device, torch.float32))
+        bank.ema.copy_(bank.flat)
+        p = os.path.join(path, ema)
+        if os.path.exists(p):
+            sde = torch.load(p, map_location="cpu")
+            for n in bank.names:
+                if n in sde:
+                    bank.view(n, bank.ema).copy_(sde[n].to(bank.flat.device, torch.float32))
+
+
+def save_state(trainer, save_path, global_step, extra=None):
+    """What ``accelerator.save_state`` preserves for this loop: parameters, AdamW moments, scheduler position,
+    the registered EMA models and the RNG streams (:1654-1659, :2058)."""
+    banks = trainer_banks(trainer)
+    save_lora_files(banks, save_path)
+    st = dict(global_step=int(global_step), opt_step=int(trainer.opt_step), lr_step=int(getattr(trainer, "lr_step", 0)),
+              ema_steps=[e.optimization_step for e in trainer.ema], bank_order=list(banks.keys()),
+              exp_avg={k: b.exp_avg.detach().cpu() for k, b in banks.items()},
+              exp_avg_sq={k: b.exp_avg_sq.detach().cpu() for k, b in banks.items()},
+              rng=dict(python=random.getstate(), numpy=np.random.get_state(), torch=torch.get_rng_state(),
+                       targets=trainer.target_rng.get_state()),
+              extra=extra or {})
+    torch.save(st, os.path.join(save_path, "trainer_state.pth"))
+    return save_path
+
+
+def load_state(trainer, path):
+    """Inverse of save_state; returns the global step (the reference parses it from the directory name, :1708)."""
+    banks = trainer_banks(trainer)
+    load_lora_files(banks, path)
+    st = torch.load(os.path.join(path, "trainer_state.pth"), map_location="cpu", weights_only=False)
+    if st["bank_order"] != list(banks.keys()):
+        raise ValueError(f"checkpoint trains {st['bank_order']}, this run trains {list(banks.keys())}")
+    for k, b in banks.items():
+        b.exp_avg.copy_(st["exp_avg"][k].to(b.flat.device))
+        b.exp_avg_sq.copy_(st["exp_avg_sq"][k].to(b.flat.device))
+    trainer.opt_step = st["opt_step"]
+    trainer.lr_step = st["lr_step"]
+    for e, n in zip(trainer.ema, st["ema_steps"]):
+        e.optimization_step = n
+    random.setstate(st["rng"]["python"])
+    np.random.set_state(st["rng"]["numpy"])
+    torch.set_rng_state(st["rng"]["torch"])
+    trainer.target_rng.set_state(st["rng"]["targets"])
+    if getattr(trainer.args, "train_unet", False):
+        trainer.unet.refresh_lora()
+    if getattr(trainer.args, "train_text_encoder", False):
+        trainer.te.refresh_lora()
+    return st["global_step"]
+
+
+def export_checkpoint(resume_from_checkpoint):
+    """2-export-checkpoint.py:598-642: ``<ckpt>`` -> ``<ckpt>_exported/`` holding only the LoRA files."""
+    if not resume_from_checkpoint or not os.path.exists(resume_from_checkpoint):
+        raise ValueError(f"{resume_from_checkpoint}' does not exist.")
+    out = resume_from_checkpoint.rstrip("/") + "_exported"
+    os.makedirs(out, exist_ok=True)
+    done = []
+    for files in BANK_FILES.values():
+        for f in files:
+            src = os.path.join(resume_from_checkpoint, f)
+            if os.path.exists(src):
+                shutil.copyfile(src, os.path.join(out, f))
+                done.append(f)
+    return out, done

@@ -9,8 +9,12 @@ cannot be set from YAML and booleans follow Python's ``bool(value)`` -- plus the
   --face_provider        detector seam: "synthetic" (default)
   --num_classifier_logits  80 (exp-1) / 6 (exp-3,5) / 8 (exp-4)
 
-Pinned by tests/golden/reference_cli.json (defaults and the three exp-1 YAML overlays, produced by
-running the reference's own parse_args).
+The multi-attribute experiments change a few flags and defaults (exp-3-debias-gender-race/1-main-debias.py:343-660,
+exp-4-debias-gender-race-age/...:343-672, exp-5-...:343-690): ``factor{1,2}`` split per attribute,
+``face_gender[_race[_age]]_confidence_level``, bigger batches, three more prompt files in exp-5 -- ``EXPERIMENT_CLI``.
+
+Pinned by tests/golden/reference_cli.json and reference_cli_multi.json (defaults and every YAML overlay of
+exp-1/3/4/5, produced by running the reference's own parse_args).
 """
 import argparse
 import os
@@ -18,9 +22,41 @@ import os
 import yaml
 
 
-def build_parser():
+_FF = "../data/2-trained-classifiers/fairface_MobileNetLarge_"
+_MULTI = dict(max_train_steps=15000, weight_loss_face=0.1, uncertainty_threshold=0.4, val_images_per_prompt_GPU=24,
+              face_feats_path="../data/3-face-features/FairFace_MobileNetLarge_GenderRace4_09041634/face_feats.pkl")
+_GR = dict(factor1_gender=0.2, factor1_race=0.6, factor2_gender=0.2, factor2_race=0.3)
+# experiment -> (changed defaults, removed flags, added float flags, added str flags)
+EXPERIMENT_CLI = {
+    "exp-1": ({}, [], {}, {}),
+    "exp-3": (dict(_MULTI, train_images_per_prompt_GPU=16, classifier_weight_path=_FF + "GenderRace4_09041216/epoch=9-step=3380_MobileNetLarge.pt"),
+              ["factor1", "factor2", "face_gender_confidence_level"], dict(_GR, face_gender_race_confidence_level=0.8), {}),
+    "exp-4": (dict(_MULTI, train_images_per_prompt_GPU=20, classifier_weight_path=_FF + "GenderRace4Age2_09151907/epoch=9-step=3380_MobileNetLarge.pt"),
+              ["factor1", "factor2", "face_gender_confidence_level"],
+              dict(_GR, factor1_age=0.6, factor2_age=0.3, face_gender_race_age_confidence_level=0.75), {}),
+    "exp-5": (dict(_MULTI, train_images_per_prompt_GPU=16, classifier_weight_path=_FF + "GenderRace4_09041216/epoch=9-step=3380_MobileNetLarge.pt"),
+              ["factor1", "factor2", "face_gender_confidence_level"], dict(_GR, face_gender_race_confidence_level=0.8),
+              dict(prompt_occupation_w_style_and_context_path="../data/1-prompts/occupation_w_style_and_context.json",
+                   prompt_personal_descroptor_path="../data/1-prompts/personal_descriptor.json",   # (sic) the reference's spelling
+                   prompt_sports_path="../data/1-prompts/sports.json")),
+}
+
+
+def build_parser(experiment="exp-1"):
     p = argparse.ArgumentParser(description="Script to finetune Stable Diffusion for debiasing purposes.")
-    a = p.add_argument
+    changed, removed, add_f, add_s = EXPERIMENT_CLI[experiment]
+
+    def a(flag, **kw):
+        name = flag.lstrip("-")
+        if name in removed:
+            return
+        if name in changed:
+            kw["default"] = changed[name]
+        p.add_argument(flag, **kw)
+    for k, v in add_f.items():
+        p.add_argument("--" + k, type=float, default=v)
+    for k, v in add_s.items():
+        p.add_argument("--" + k, type=str, default=v)
     # 1. experiment setting
     a("--proj_name", default="debias-SD", type=str)
     a("--pretrained_model_name_or_path", type=str, default="runwayml/stable-diffusion-v1-5")
@@ -82,8 +118,8 @@ def build_parser():
 EXTRA_DEFAULTS = dict(num_denoising_steps=0, synthetic=False, face_provider="synthetic", num_classifier_logits=80)
 
 
-def parse_args(input_args=None, with_extras=False):
-    p = build_parser()
+def parse_args(input_args=None, with_extras=False, experiment="exp-1"):
+    p = build_parser(experiment)
     if with_extras:
         p.add_argument("--num_denoising_steps", type=int, default=0, help="0 = draw from range(19,24) like the reference")
         p.add_argument("--synthetic", action="store_true", default=False)

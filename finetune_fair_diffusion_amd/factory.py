@@ -40,9 +40,11 @@ def default_args(**kw):
     return types.SimpleNamespace(**a)
 
 
-def build_trainer(args, device, cfgs=SD15, seed=0, rank=0, world_size=1, experiment="exp-1", classifier_gain=1.4, state_dicts=None):
+def build_trainer(args, device, cfgs=SD15, seed=0, rank=0, world_size=1, experiment="exp-1", classifier_gain=1.4, state_dicts=None,
+                  frozen_copies=True):
     """Returns (trainer, models dict).  ``state_dicts`` may carry real weights by diffusers key
-    (keys 'unet','vae','clip','clf','unet_lora','te_lora'); anything missing is synthetic."""
+    (keys 'unet','vae','clip','clf','unet_lora','te_lora'); anything missing is synthetic.
+    ``frozen_copies=False`` skips the original-model replicas of R2 (inference-only consumers such as generate.py)."""
     from .fairness import EXPERIMENT_ATTRS
     num_classes = EXPERIMENT_ATTRS[experiment][0]
     sds = dict(state_dicts or {})
@@ -56,11 +58,11 @@ def build_trainer(args, device, cfgs=SD15, seed=0, rank=0, world_size=1, experim
     if "clf" not in sds:
         sds["clf"] = gen(W.mobilenet_param_shapes(num_classes), 4, gain=classifier_gain)
     unet = UNet2DConditionModel(cfgs["unet"], sds["unet"], device)
-    eval_unet = UNet2DConditionModel(cfgs["unet"], sds["unet"], device) if args.train_unet else None
+    eval_unet = UNet2DConditionModel(cfgs["unet"], sds["unet"], device) if (args.train_unet and frozen_copies) else None
     del sds["unet"]
     vae = AutoencoderKL(cfgs["vae"], sds["vae"], device)
     te = CLIPTextModel(cfgs["clip"], sds["clip"], device)
-    eval_te = CLIPTextModel(cfgs["clip"], sds["clip"], device) if args.train_text_encoder else None
+    eval_te = CLIPTextModel(cfgs["clip"], sds["clip"], device) if (args.train_text_encoder and frozen_copies) else None
     clf = MobileNetV3Large(sds["clf"], device, num_classes)
     if args.train_unet:
         bank = unet.add_lora(args.rank, sds.get("unet_lora"), seed=seed + 5)

@@ -4,11 +4,12 @@ exp-1-debias-gender/1-main-debias.py:1746-2029 re-designed for this hardware:
 * R1 / R2: no-grad CFG rollouts (``generate_image_no_gradient`` :998-1061) of the finetuned and the
   frozen original models: S fused U-Net forwards on the 2N CFG batch, one fused CFG+DPM-Solver++
   update kernel per step, VAE decode.
-* R3: ``generate_image_w_gradient`` (:1063-1136) as *recompute-backward*: the forward rollout only
-  keeps the S input latents [N,4,64,64]; dL/dx_final is obtained once (classifier + VAE backward),
-  and because the U-Net input is detached at every step the gradient of eps_i is the scalar
-  ``grad_coef_i * c_i`` times dL/dx_final (scheduler.chain_coefs) -- each timestep is then
-  recomputed with recording and back-propagated independently, O(1) activation memory in S.
+* R3: ``generate_image_w_gradient`` (:1063-1136) without an autograd graph: dL/dx_final is obtained once
+  (classifier + VAE backward), and because the U-Net input is detached at every step the gradient of eps_i is
+  the scalar ``grad_coef_i * c_i`` times dL/dx_final (scheduler.chain_coefs) -- every timestep is back-propagated
+  independently.  The forward rollout keeps each timestep's activations in HBM when they fit (7.8 GB per
+  timestep at batch 8; all 20 fit in 288 GB) and otherwise only its input latent [N,4,64,64], in which case the
+  timestep is recomputed with recording right before its backward (the reference's gradient checkpointing, :748).
 * all micro-batches of the reference (``train_GPU_batch_size`` chunks, :1889) run as ONE batch with
   per-image weights 1/n_j (identical gradient, see fairness.microbatch_weights).
 * gradient sync: one RCCL all-reduce of the flat fp32 LoRA-gradient buffer + fused scale/finite
@@ -26,6 +27,7 @@ from . import ops
 from .fairness import (EXPERIMENT_ATTRS, SyntheticFaceProvider, fair_loss_and_grad, generate_dynamic_targets,
                        generate_dynamic_targets_multi, microbatch_weights)
 from .layers import F16, F32
+from .lr_schedule import lr_lambda
 
 
 def _ctx_bytes(obj, seen=None):
@@ -84,6 +86,7 @@ class FairnessTrainer:
             self.banks.append(text_encoder.lora_bank)
         self.ema = [EMAState(args.EMA_decay) for _ in self.banks]
         self.opt_step = 0
+        self.lr_step = 0      # lr_scheduler.step() count: advances every step, also when the update is skipped (:2023)
         self.flag = torch.zeros(1, dtype=torch.int32, device=self.device)
         self.clf_gscale = 1024.0
         # R3 keeps per-timestep activations in HBM when they fit (MI355X: 288 GB) instead of recomputing every
@@ -307,10 +310,15 @@ class FairnessTrainer:
         for bank in self.banks:
             ops.grad_finite_scale(bank.grad, 1.0 / (self.world * N_backward), self.flag)
         finite = int(self.flag.item()) == 0  # checked after the all-reduce so every rank takes the same branch
+        self.last_lr = args.learning_rate * lr_lambda(getattr(args, "lr_scheduler", "constant"), self.lr_step,
+                                                      getattr(args, "lr_warmup_steps", 0), getattr(args, "max_train_steps", 1),
+                                                      getattr(args, "lr_num_cycles", 1), getattr(args, "lr_power", 1.0), args.learning_rate)
+        if apply:
+            self.lr_step += 1
         if finite and apply:
             self.opt_step += 1
             for bank, ema in zip(self.banks, self.ema):
-                ops.adamw_ema(bank.flat, bank.grad, bank.exp_avg, bank.exp_avg_sq, bank.ema, args.learning_rate, args.adam_beta1,
+                ops.adamw_ema(bank.flat, bank.grad, bank.exp_avg, bank.exp_avg_sq, bank.ema, self.last_lr, args.adam_beta1,
                               args.adam_beta2, args.adam_epsilon, args.adam_weight_decay, self.opt_step, ema.next_one_minus_decay())
             if getattr(args, "train_unet", False):
                 self.unet.refresh_lora()

@@ -25,8 +25,8 @@ REF = "/root/reference/exp-1-debias-gender/1-main-debias.py"
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def lift(names):
-    src = open(REF).read()
+def lift(names, ref=None):
+    src = open(ref or REF).read()
     tree = ast.parse(src)
     found = {}
     for node in ast.walk(tree):
@@ -34,7 +34,7 @@ def lift(names):
             node.decorator_list = []
             found[node.name] = ast.get_source_segment(src, node)
     ns = dict(torch=torch, np=np, scipy=scipy, itertools=itertools, math=math, argparse=argparse, yaml=yaml, os=os)
-    for n in ["make_grad_hook"] + [x for x in names if x != "make_grad_hook"]:
+    for n in [x for x in ["make_grad_hook"] if x in names] + [x for x in names if x != "make_grad_hook"]:
         seg = found[n]
         seg = "\n".join(l for l in seg.splitlines() if not l.strip().startswith("@"))
         import textwrap
@@ -125,6 +125,21 @@ def main():
         cli[f]["args"]["config"] = f
     json.dump(cli, open(os.path.join(HERE, "reference_cli.json"), "w"), indent=1, sort_keys=True)
     print("wrote golden vectors:", {k: len(v) for k, v in out.items()}, len(cli["defaults"]), "flags")
+
+    # CLI of the multi-attribute experiments (exp-3/4/5): defaults + every YAML config ----------
+    multi = {}
+    for exp, d in [("exp-3", "exp-3-debias-gender-race"), ("exp-4", "exp-4-debias-gender-race-age"),
+                   ("exp-5", "exp-5-debias-gender-race-multi-concepts")]:
+        pa = lift(["parse_args"], ref=f"/root/reference/{d}/1-main-debias.py")["parse_args"]
+        e = dict(defaults=vars(pa([])))
+        cdir = f"/root/reference/{d}/configs"
+        for f in sorted(os.listdir(cdir)):
+            if f.endswith(".yaml") and "compute_environment" not in yaml.safe_load(open(os.path.join(cdir, f))):   # skip accelerate launcher configs
+                e[f] = dict(yaml=yaml.safe_load(open(os.path.join(cdir, f))), args=vars(pa(["--config", os.path.join(cdir, f)])))
+                e[f]["args"]["config"] = f
+        multi[exp] = e
+    json.dump(multi, open(os.path.join(HERE, "reference_cli_multi.json"), "w"), indent=1, sort_keys=True)
+    print("wrote multi-attribute CLI goldens:", {k: len(v["defaults"]) for k, v in multi.items()})
 
 
 if __name__ == "__main__":

@@ -271,3 +271,187 @@ def test_multi_attribute_targets_product_vs_oracle(exp):
         assert np.abs(upd.numpy() - uor.numpy()).max() < 0.1
         confident = (uor < 0.35) & (uor >= 0)
         assert torch.equal(tpd[confident], tor[confident])
+
+
+# ------------------------------------------------------------------------------------------ CLI of exp-3/4/5, lr schedule, checkpoints
+def test_cli_multi_attribute_experiments_match_reference(tmp_path):
+    """parse_args of exp-3/4/5 (defaults + every YAML overlay) against the reference's own parse_args output."""
+    import yaml
+    from finetune_fair_diffusion_amd.cli import parse_args
+    gold = json.load(open(os.path.join(HERE, "golden", "reference_cli_multi.json")))
+    assert set(gold) == {"exp-3", "exp-4", "exp-5"}
+    for exp, cases in gold.items():
+        assert vars(parse_args([], experiment=exp)) == cases["defaults"]
+        for f, c in cases.items():
+            if f == "defaults":
+                continue
+            p = tmp_path / f"{exp}-{f}"
+            p.write_text(yaml.safe_dump(c["yaml"]))
+            d = vars(parse_args(["--config", str(p)], experiment=exp))
+            d["config"] = f
+            assert d == c["args"], (exp, f)
+
+
+def test_lr_schedule_matches_lambda_lr():
+    """lr multipliers vs the schedule functions the reference's get_scheduler wraps (same formulas ship in transformers)."""
+    import transformers.optimization as topt
+    from finetune_fair_diffusion_amd.lr_schedule import lr_lambda
+    w, T, base = 3, 20, 5e-5
+
+    def run(make):
+        p = torch.nn.Parameter(torch.zeros(1))
+        opt = torch.optim.SGD([p], lr=base)
+        sch = make(opt)
+        out = []
+        for _ in range(T + 4):
+            out.append(opt.param_groups[0]["lr"])
+            opt.step()
+            sch.step()
+        return out
+    cases = {
+        "constant": lambda o: topt.get_constant_schedule(o),
+        "constant_with_warmup": lambda o: topt.get_constant_schedule_with_warmup(o, w),
+        "linear": lambda o: topt.get_linear_schedule_with_warmup(o, w, T),
+        "cosine": lambda o: topt.get_cosine_schedule_with_warmup(o, w, T),
+        "cosine_with_restarts": lambda o: topt.get_cosine_with_hard_restarts_schedule_with_warmup(o, w, T, num_cycles=3),
+        "polynomial": lambda o: topt.get_polynomial_decay_schedule_with_warmup(o, w, T, power=2.0),
+    }
+    for name, make in cases.items():
+        ref = run(make)
+        mine = [base * lr_lambda(name, s, w, T, 3, 2.0, base) for s in range(T + 4)]
+        assert np.allclose(ref, mine, rtol=1e-9, atol=1e-15), name
+    with pytest.raises(ValueError):
+        lr_lambda("nope", 0)
+
+
+class _FakeModel:
+    def __init__(self, bank):
+        self.lora_bank = bank
+        self.refreshed = 0
+
+    def refresh_lora(self):
+        self.refreshed += 1
+
+
+def _fake_trainer(seed):
+    import types
+    from finetune_fair_diffusion_amd.layers import ParamBank
+    from finetune_fair_diffusion_amd.step import EMAState
+    from finetune_fair_diffusion_amd import weights as W
+    from util_models import TINY_UNET, TINY_CLIP
+    TINY_UNET, TINY_CLIP = W.UNetConfig(**TINY_UNET), W.CLIPTextConfig(**TINY_CLIP)
+    g = torch.Generator().manual_seed(seed)
+    ub = ParamBank(W.unet_lora_param_shapes(TINY_UNET, 4), "cpu")
+    tb = ParamBank(W.clip_lora_param_shapes(TINY_CLIP, 4), "cpu")
+    for b in (ub, tb):
+        for buf in (b.flat, b.exp_avg, b.exp_avg_sq, b.ema):
+            buf.copy_(torch.randn(buf.shape, generator=g))
+    t = types.SimpleNamespace(args=types.SimpleNamespace(train_unet=True, train_text_encoder=True), unet=_FakeModel(ub), te=_FakeModel(tb),
+                              ema=[EMAState(0.996), EMAState(0.996)], opt_step=seed, lr_step=seed + 1,
+                              target_rng=torch.Generator().manual_seed(seed))
+    t.ema[0].optimization_step = 7 + seed
+    return t
+
+
+def test_checkpoint_round_trip_export_and_rolling_cleanup(tmp_path):
+    """Trainer state -> checkpoint_tmp-N -> fresh trainer; the four exported files are the reference's public format
+    (2-export-checkpoint.py:619-642): fp32 CPU dict[str,Tensor] keyed by the diffusers LoRA names."""
+    from finetune_fair_diffusion_amd import checkpoint as ck
+    a, b = _fake_trainer(1), _fake_trainer(2)
+    d = str(tmp_path / "checkpoints")
+    os.makedirs(d)
+    a.target_rng.manual_seed(99)
+    torch.manual_seed(123)
+    path = ck.save_state(a, os.path.join(d, "checkpoint_tmp-20"), 20)
+    expect_next = torch.rand(3)
+    assert sorted(os.listdir(path)) == ["text_encoder_lora.pth", "text_encoder_lora_EMA.pth", "trainer_state.pth", "unet_lora.pth", "unet_lora_EMA.pth"]
+    sd = torch.load(os.path.join(path, "unet_lora.pth"))
+    k0 = "down_blocks.0.attentions.0.transformer_blocks.0.attn1.processor.to_q_lora.down.weight"
+    assert k0 in sd and sd[k0].dtype == torch.float32 and sd[k0].device.type == "cpu" and len(sd) == 256
+    te = torch.load(os.path.join(path, "text_encoder_lora_EMA.pth"))
+    assert "text_model.encoder.layers.0.self_attn.q_proj.lora_linear_layer.down.weight" in te
+    step = ck.load_state(b, path)
+    assert step == 20 and b.opt_step == 1 and b.lr_step == 2 and b.ema[0].optimization_step == 8
+    for x, y in ((a.unet.lora_bank, b.unet.lora_bank), (a.te.lora_bank, b.te.lora_bank)):
+        for n in ("flat", "ema", "exp_avg", "exp_avg_sq"):
+            assert torch.equal(getattr(x, n), getattr(y, n)), n
+    assert torch.equal(torch.rand(3), expect_next)              # RNG stream continues where the checkpoint left it
+    assert b.unet.refreshed == 1 and b.te.refreshed == 1
+    # export = the four LoRA files only
+    out, files = ck.export_checkpoint(path)
+    assert out.endswith("checkpoint_tmp-20_exported") and sorted(files) == sorted(f for v in ck.BANK_FILES.values() for f in v)
+    with pytest.raises(ValueError):
+        ck.export_checkpoint(os.path.join(d, "nope"))
+    # files written by the reference (no trainer_state) load by key; wrong shapes are rejected
+    c = _fake_trainer(3)
+    ck.load_lora_files(ck.trainer_banks(c), out)
+    assert torch.equal(c.unet.lora_bank.flat, a.unet.lora_bank.flat) and torch.equal(c.te.lora_bank.ema, a.te.lora_bank.ema)
+    bad = dict(sd)
+    bad[k0] = torch.zeros(5, 5)
+    torch.save(bad, os.path.join(out, "unet_lora.pth"))
+    with pytest.raises(ValueError):
+        ck.load_lora_files(ck.trainer_banks(c), out)
+    # rolling clean-up (:120-137): before the save at most limit-1 stay, oldest removed first, other names untouched
+    for s in (40, 60, 100):
+        os.makedirs(os.path.join(d, f"checkpoint_tmp-{s}"))
+    os.makedirs(os.path.join(d, "checkpoint-200"))
+    removed = ck.clean_checkpoint(d, "checkpoint_tmp", 2)
+    assert removed == ["checkpoint_tmp-20", "checkpoint_tmp-40", "checkpoint_tmp-60"]
+    assert sorted(os.listdir(d)) == ["checkpoint-200", "checkpoint_tmp-100", "checkpoint_tmp-20_exported"]
+
+
+def test_pretrained_directory_layout_and_legacy_names(tmp_path):
+    """A diffusers-layout directory (safetensors and .bin, legacy VAE attention names, prefix-less CLIP keys) loads into
+    exactly the tensors the modules consume; missing tensors and wrong shapes are loud."""
+    from safetensors.torch import save_file
+    from finetune_fair_diffusion_amd import pretrained as P, weights as W
+    from util_models import TINY_UNET, TINY_VAE, TINY_CLIP
+    TINY_UNET, TINY_VAE, TINY_CLIP = W.UNetConfig(**TINY_UNET), W.VAEConfig(**TINY_VAE), W.CLIPTextConfig(**TINY_CLIP)
+    m = tmp_path / "sd"
+    for sub in ("unet", "vae", "text_encoder"):
+        (m / sub).mkdir(parents=True)
+    u = W.synthetic_state_dict(W.unet_param_shapes(TINY_UNET), seed=1)
+    save_file({k: v.contiguous() for k, v in u.items()}, str(m / "unet" / "diffusion_pytorch_model.safetensors"))
+    v = W.synthetic_state_dict(W.vae_param_shapes(TINY_VAE), seed=2)
+    legacy = {}
+    for k, t in v.items():
+        for new, old in (("to_q", "query"), ("to_k", "key"), ("to_v", "value"), ("to_out.0", "proj_attn")):
+            if f"attentions.0.{new}." in k:
+                k = k.replace(f"attentions.0.{new}.", f"attentions.0.{old}.")
+        legacy[k] = t
+    legacy["encoder.conv_in.weight"] = torch.zeros(3)            # encoder half is ignored
+    torch.save(legacy, str(m / "vae" / "diffusion_pytorch_model.bin"))
+    c = W.synthetic_state_dict(W.clip_param_shapes(TINY_CLIP), seed=3)
+    save_file({k[len("text_model."):]: t.contiguous() for k, t in c.items()}, str(m / "text_encoder" / "model.safetensors"))
+    gu, gv, gc = P.load_unet(str(m), TINY_UNET), P.load_vae(str(m), TINY_VAE), P.load_text_encoder(str(m), TINY_CLIP)
+    for got, ref in ((gu, u), (gv, v), (gc, c)):
+        assert set(got) == set(ref)
+        assert all(torch.equal(got[k], ref[k].float()) for k in ref)
+    clf = W.synthetic_state_dict(W.mobilenet_param_shapes(6), seed=4)
+    torch.save({"state_dict": {"model." + k: t for k, t in clf.items()}}, str(tmp_path / "clf.pt"))
+    gl = P.load_classifier(str(tmp_path / "clf.pt"), 6)
+    assert all(torch.equal(gl[k], clf[k].float()) for k in clf)
+    with pytest.raises(ValueError):
+        P.load_classifier(str(tmp_path / "clf.pt"), 80)          # 6-logit head into an 80-logit model
+    del legacy["post_quant_conv.weight"]
+    torch.save(legacy, str(m / "vae" / "diffusion_pytorch_model.bin"))
+    with pytest.raises(KeyError):
+        P.load_vae(str(m), TINY_VAE)
+    with pytest.raises(FileNotFoundError):
+        P.load_unet(str(tmp_path / "absent"), TINY_UNET)
+
+
+def test_hash_tokenizer_shapes_like_reference_calls():
+    """Prompt: BOS, words, EOS, mask ones.  Uncond: BOS then EOS padding to the same length with mask [1,1,0...] (:1020-1026)."""
+    from finetune_fair_diffusion_amd.train import HashTokenizer, load_prompts
+    import types
+    ids, m, uids, um = HashTokenizer()("a photo of the face of a doctor, a person")
+    L = len(ids)
+    assert L == 13 and ids[0] == 49406 and ids[-1] == 49407 and m.tolist() == [1] * L
+    assert uids.tolist() == [49406] + [49407] * (L - 1) and um.tolist() == [1, 1] + [0] * (L - 2)
+    assert all(320 <= int(i) < 40000 for i in ids[1:-1])
+    assert HashTokenizer()("a photo of the face of a doctor, a person")[0].tolist() == ids.tolist()
+    ps = load_prompts(types.SimpleNamespace(prompt_occupation_path="/nonexistent.json", synthetic=True))
+    assert len(ps) == 12 and "doctor" in ps[0]
+    with pytest.raises(FileNotFoundError):
+        load_prompts(types.SimpleNamespace(prompt_occupation_path="/nonexistent.json", synthetic=False))

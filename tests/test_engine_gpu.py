@@ -9,10 +9,12 @@ classifier's ReLUs) whose state flips for a small fraction of elements between f
 they are compared by direction (cosine > 0.97) and a loose max-norm bound; the per-component tests above pin
 each smooth piece tightly.
 """
+import json
 import math
 import sys
 import os
 
+import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F
@@ -286,3 +288,92 @@ def test_r1_r3_forward_bit_identical_and_shared_mode(dev):
     tr.share_r1_r3 = False
     tr.train_step(tokens, noises, 4)
     assert same(grads[0], grads[2])
+
+
+# ------------------------------------------------------------------------------------------ training driver, checkpoints, consumer
+def _train_argv(out_dir, steps, extra=()):
+    return ["--synthetic", "--train_unet", "--rank", "4", "--max_train_steps", str(steps), "--checkpointing_steps", "2",
+            "--checkpointing_steps_long", "3", "--checkpoints_total_limit", "2", "--num_denoising_steps", "3",
+            "--train_images_per_prompt_GPU", "4", "--train_GPU_batch_size", "3", "--val_GPU_batch_size", "4",
+            "--lr_scheduler", "linear", "--lr_warmup_steps", "1", "--learning_rate", "1e-5", "--output_dir", str(out_dir)] + list(extra)
+
+
+def test_train_loop_checkpoints_and_resume(tmp_path, dev):
+    """The driver loop (1-main-debias.py:1731-2068): JSON log per step, rolling + long-cadence checkpoints in the exported
+    four-file format, and a resumed run lands on the weights of the uninterrupted one (same prompts, noise, S, lr, Adam/EMA state)."""
+    from finetune_fair_diffusion_amd import train, checkpoint as ck
+    from finetune_fair_diffusion_amd.factory import TINY
+    logs = []
+    full, n = train.main(_train_argv(tmp_path / "a", 4), cfgs=TINY, log=logs.append)
+    assert n == 4 and len(logs) == 4
+    recs = [json.loads(x) for x in logs]
+    assert [r["step"] for r in recs] == [1, 2, 3, 4] and all(r["grad_is_finite"] for r in recs)
+    assert recs[0]["lr"] == 0.0 and abs(recs[1]["lr"] - 1e-5) < 1e-14 and abs(recs[3]["lr"] - 1e-5 * (4 - 3) / 3) < 1e-14   # linear, warm-up 1
+    cdir = tmp_path / "a" / "checkpoints"
+    assert sorted(os.listdir(cdir)) == ["checkpoint-3", "checkpoint_tmp-2", "checkpoint_tmp-4"]
+    # interrupted run: 2 steps, then resume from its checkpoint for the remaining 2
+    part, n2 = train.main(_train_argv(tmp_path / "b", 2), cfgs=TINY, log=lambda s: None)
+    assert n2 == 2
+    logs_c = []
+    resumed, n3 = train.main(_train_argv(tmp_path / "c", 4, ["--resume_from_checkpoint", str(tmp_path / "b" / "checkpoints" / "checkpoint_tmp-2")]),
+                             cfgs=TINY, log=logs_c.append)
+    assert n3 == 4 and resumed.opt_step == full.opt_step == 4 and resumed.lr_step == 4
+    # the resumed steps see exactly the inputs of the uninterrupted run: prompt order, S, lr and the CPU noise stream
+    rc = [json.loads(x) for x in logs_c]
+    assert [r["step"] for r in rc] == [3, 4]
+    for r, ref in zip(rc, recs[2:]):
+        for k in ("prompt", "S", "lr", "noise_checksum"):
+            assert r[k] == ref[k], (k, r[k], ref[k])
+        assert abs(r["loss_fair"] - ref["loss_fair"]) < 0.05 * abs(ref["loss_fair"])
+    # loading restores the interrupted trainer bit for bit (weights, EMA, Adam moments, counters)
+    from finetune_fair_diffusion_amd.cli import parse_args
+    from finetune_fair_diffusion_amd.factory import build_trainer
+    args = parse_args(_train_argv(tmp_path / "d", 4), with_extras=True)
+    fresh, _ = build_trainer(args, dev, TINY, seed=args.seed)
+    assert ck.load_state(fresh, str(tmp_path / "b" / "checkpoints" / "checkpoint_tmp-2")) == 2
+    assert (fresh.opt_step, fresh.lr_step, [e.optimization_step for e in fresh.ema]) == (2, 2, [2, 2])
+    for which in ("unet", "te"):
+        a, b = getattr(part, which).lora_bank, getattr(fresh, which).lora_bank
+        for buf in ("flat", "ema", "exp_avg", "exp_avg_sq"):
+            assert torch.equal(getattr(a, buf), getattr(b, buf)), (which, buf)
+    # ... and the two runs end on the same weights up to Adam's 2*lr response to rounding-level gradient differences (fp32
+    # atomics in dK/dV and the crop scatter; this tiny synthetic model with a saturated classifier amplifies them)
+    for which in ("unet", "te"):
+        a, b = getattr(full, which).lora_bank, getattr(resumed, which).lora_bank
+        for buf in ("flat", "ema"):
+            x, y = getattr(a, buf), getattr(b, buf)
+            rel = float((x - y).abs().max() / x.abs().max().clamp_min(1e-12))
+            print(f"[resume {which}.{buf}] rel max diff {rel:.2e}")
+            assert rel < 1e-4, (which, buf, rel)
+    # the LoRA actually moved, and the exported files of the two runs carry the same keys
+    d0 = torch.load(cdir / "checkpoint_tmp-2" / "unet_lora.pth")
+    d1 = torch.load(cdir / "checkpoint_tmp-4" / "unet_lora.pth")
+    assert any(not torch.equal(d0[k], d1[k]) for k in d0) and set(d0) == set(d1)
+    out, files = ck.export_checkpoint(str(cdir / "checkpoint-3"))
+    assert len(files) == 4
+
+
+def test_generate_consumes_exported_lora(tmp_path):
+    """gen-images.py flow (:493-612): exported LoRA files -> images on disk; existing files are skipped; LoRA changes the images."""
+    from finetune_fair_diffusion_amd import generate, train
+    from finetune_fair_diffusion_amd.factory import TINY
+    from PIL import Image
+    tr, _ = train.main(_train_argv(tmp_path / "run", 2), cfgs=TINY, log=lambda s: None)
+    exported = tmp_path / "run" / "checkpoints" / "checkpoint_tmp-2"
+    prompts = tmp_path / "prompts.json"
+    prompts.write_text(json.dumps({"test_prompts": ["a photo of a doctor", "a photo of a chef, a person"]}))
+    base = ["--synthetic", "--prompts_path", str(prompts), "--num_imgs_per_prompt", "3", "--batch_size", "2", "--num_denoising_steps", "4", "--rank", "4"]
+    w0 = generate.main(generate.parse_args(base + ["--save_dir", str(tmp_path / "plain")]), cfgs=TINY)
+    w1 = generate.main(generate.parse_args(base + ["--save_dir", str(tmp_path / "lora"), "--load_unet_lora_from", str(exported / "unet_lora.pth"),
+                                                   "--load_text_encoder_lora_from", str(exported / "text_encoder_lora_EMA.pth")]), cfgs=TINY)
+    assert len(w0) == len(w1) == 6 and os.path.exists(tmp_path / "lora" / "prompt_1" / "img_2.jpg")
+    a = np.asarray(Image.open(tmp_path / "plain" / "prompt_0" / "img_0.jpg")).astype(np.float32)
+    b = np.asarray(Image.open(tmp_path / "lora" / "prompt_0" / "img_0.jpg")).astype(np.float32)
+    assert a.shape == (256, 256, 3) and np.abs(a - b).mean() > 0.0
+    # resume: nothing to do when every file exists; a removed file is regenerated alone
+    assert generate.main(generate.parse_args(base + ["--save_dir", str(tmp_path / "plain")]), cfgs=TINY) == []
+    os.remove(tmp_path / "plain" / "prompt_1" / "img_1.jpg")
+    again = generate.main(generate.parse_args(base + ["--save_dir", str(tmp_path / "plain")]), cfgs=TINY)
+    assert [os.path.basename(p) for p in again] == ["img_1.jpg"]
+    with pytest.raises(NotImplementedError):
+        generate.main(generate.parse_args(base + ["--save_dir", str(tmp_path / "x"), "--load_prefix_embedding_from", "p.pth"]), cfgs=TINY)
