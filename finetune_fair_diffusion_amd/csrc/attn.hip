@@ -93,7 +93,7 @@ __device__ __forceinline__ void zero_col_pad(f16* dst) {
 template <int D>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const f16* __restrict__ Q, const f16* __restrict__ K, const f16* __restrict__ Vt,
                                                        f16* __restrict__ O, float* __restrict__ LSE, int H, int Tq, int Tk, int Tkp,
-                                                       int kv_div, float scale) {
+                                                       int Tkr, int kv_div, float scale) {
     constexpr int DK = (D + 15) / 16 * 16, DV = (D + 31) / 32 * 32, DKP = DK + 8;
     constexpr int NKS = DK / 16, NDV = DV / 32;
     extern __shared__ __attribute__((aligned(16))) f16 smem[];
@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const f16* __restrict__ Q
     float m_run = -INFINITY, l_run = 0.f;
     const float sl2 = scale * LOG2E;
 
-    const f16* Kb = K + (int64_t)bk * Tk * C + h * D;
+    const f16* Kb = K + (int64_t)bk * Tkr * C + h * D;
     const f16* Vtb = Vt + ((int64_t)bk * C + h * D) * Tkp;
 
     TileRegs<D> kreg, vreg;
@@ -238,7 +238,7 @@ template <int D>
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const f16* __restrict__ Q, const f16* __restrict__ K, const f16* __restrict__ V,
                                                           const f16* __restrict__ Kt, const f16* __restrict__ dO,
                                                           const float* __restrict__ LSE, const float* __restrict__ Dd, f16* __restrict__ dQ,
-                                                          int H, int Tq, int Tk, int Tkp, int kv_div, float scale) {
+                                                          int H, int Tq, int Tk, int Tkp, int Tkr, int kv_div, float scale) {
     constexpr int DK = (D + 15) / 16 * 16, DV = (D + 31) / 32 * 32, DKP = DK + 8;
     constexpr int NKS = DK / 16, NDV = DV / 32;
     extern __shared__ __attribute__((aligned(16))) f16 smem[];
@@ -272,8 +272,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const f16* __restrict_
 #pragma unroll
     for (int i = 0; i < NDV; ++i) acc[i] = zero16();
 
-    const f16* Kb = K + (int64_t)bk * Tk * C + h * D;
-    const f16* Vb = V + (int64_t)bk * Tk * C + h * D;
+    const f16* Kb = K + (int64_t)bk * Tkr * C + h * D;
+    const f16* Vb = V + (int64_t)bk * Tkr * C + h * D;
     const f16* Ktb = Kt + ((int64_t)bk * C + h * D) * Tkp;
 
     constexpr bool PF = D <= 80;      // register prefetch where the register file has room
@@ -352,7 +352,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const f16* __restric
                                                             const f16* __restrict__ V, const f16* __restrict__ dO,
                                                             const f16* __restrict__ dOt, const float* __restrict__ LSE,
                                                             const float* __restrict__ Dd, void* __restrict__ dKo, void* __restrict__ dVo,
-                                                            int H, int Tq, int Tk, int kv_div, float scale) {
+                                                            int H, int Tq, int Tk, int Tkr, int kv_div, float scale) {
     constexpr int DK = (D + 15) / 16 * 16, DV = (D + 31) / 32 * 32, DKP = DK + 8;
     constexpr int NKS = DK / 16, NDV = DV / 32;
     extern __shared__ __attribute__((aligned(16))) f16 smem[];
@@ -378,8 +378,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const f16* __restric
         kf[ks] = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
         vf[ks] = kf[ks];
         if (kvalid && col < D) {
-            kf[ks] = *(const f16x8*)(K + ((int64_t)bk * Tk + key) * C + h * D + col);
-            vf[ks] = *(const f16x8*)(V + ((int64_t)bk * Tk + key) * C + h * D + col);
+            kf[ks] = *(const f16x8*)(K + ((int64_t)bk * Tkr + key) * C + h * D + col);
+            vf[ks] = *(const f16x8*)(V + ((int64_t)bk * Tkr + key) * C + h * D + col);
         }
     }
     f32x16 dk[NDV], dv[NDV];
@@ -461,7 +461,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const f16* __restric
             }
     }
     if (kvalid) {
-        const int64_t off = ((int64_t)bk * Tk + key) * C + h * D;
+        const int64_t off = ((int64_t)bk * Tkr + key) * C + h * D;
 #pragma unroll
         for (int i = 0; i < NDV; ++i)
 #pragma unroll
@@ -515,14 +515,14 @@ template <int D> static constexpr size_t dkdv_lds() {
         }                                                                                                        \
     }
 
-extern "C" int fd_attn_fwd(const void* q, const void* k, const void* vt, void* o, float* lse, int B, int H, int Tq, int Tk, int Tkp, int d,
-                           int kv_div, float scale, void* stream) {
-    FD_REQUIRE(B > 0 && H > 0 && Tq > 0 && Tk > 0 && Tkp >= Tk && (Tkp & 7) == 0 && kv_div >= 1, "fd_attn_fwd: bad shape");
+extern "C" int fd_attn_fwd(const void* q, const void* k, const void* vt, void* o, float* lse, int B, int H, int Tq, int Tk, int Tkp, int Tkr,
+                           int d, int kv_div, float scale, void* stream) {
+    FD_REQUIRE(B > 0 && H > 0 && Tq > 0 && Tk > 0 && Tkp >= Tk && (Tkp & 7) == 0 && Tkr >= Tk && kv_div >= 1, "fd_attn_fwd: bad shape");
     dim3 grid((Tq + 127) / 128, H, B);
 #define CALL(DD)                                                                                                                      \
     ALLOW_LDS(attn_fwd_kernel<DD>, fwd_lds<DD>());                                                                                    \
     hipLaunchKernelGGL(attn_fwd_kernel<DD>, grid, dim3(256), fwd_lds<DD>(), (hipStream_t)stream, (const f16*)q, (const f16*)k,        \
-                       (const f16*)vt, (f16*)o, lse, H, Tq, Tk, Tkp, kv_div, scale)
+                       (const f16*)vt, (f16*)o, lse, H, Tq, Tk, Tkp, Tkr, kv_div, scale)
     FD_DISPATCH_D(d, CALL)
 #undef CALL
     return fd_check_launch("fd_attn_fwd");
@@ -538,34 +538,34 @@ extern "C" int fd_attn_bwd_prep(const void* o, const void* d_o, float* D, int B,
 }
 
 extern "C" int fd_attn_bwd_dq(const void* q, const void* k, const void* v, const void* kt, const void* d_o, const float* lse, const float* D,
-                              void* dq, int B, int H, int Tq, int Tk, int Tkp, int d, int kv_div, float scale, void* stream) {
-    FD_REQUIRE(B > 0 && H > 0 && Tq > 0 && Tk > 0 && Tkp >= Tk && (Tkp & 7) == 0 && kv_div >= 1, "fd_attn_bwd_dq: bad shape");
+                              void* dq, int B, int H, int Tq, int Tk, int Tkp, int Tkr, int d, int kv_div, float scale, void* stream) {
+    FD_REQUIRE(B > 0 && H > 0 && Tq > 0 && Tk > 0 && Tkp >= Tk && (Tkp & 7) == 0 && Tkr >= Tk && kv_div >= 1, "fd_attn_bwd_dq: bad shape");
     dim3 grid((Tq + 127) / 128, H, B);
 #define CALL(DD)                                                                                                                      \
     ALLOW_LDS(attn_bwd_dq_kernel<DD>, dq_lds<DD>());                                                                                  \
     hipLaunchKernelGGL(attn_bwd_dq_kernel<DD>, grid, dim3(256), dq_lds<DD>(), (hipStream_t)stream, (const f16*)q, (const f16*)k,      \
-                       (const f16*)v, (const f16*)kt, (const f16*)d_o, lse, D, (f16*)dq, H, Tq, Tk, Tkp, kv_div, scale)
+                       (const f16*)v, (const f16*)kt, (const f16*)d_o, lse, D, (f16*)dq, H, Tq, Tk, Tkp, Tkr, kv_div, scale)
     FD_DISPATCH_D(d, CALL)
 #undef CALL
     return fd_check_launch("fd_attn_bwd_dq");
 }
 
 extern "C" int fd_attn_bwd_dkdv(const void* q, const void* qt, const void* k, const void* v, const void* d_o, const void* d_ot,
-                                const float* lse, const float* D, void* dk, void* dv, int B, int H, int Tq, int Tk, int d, int kv_div,
-                                float scale, void* stream) {
-    FD_REQUIRE(B > 0 && H > 0 && Tq > 0 && Tk > 0 && (Tq & 7) == 0 && kv_div >= 1, "fd_attn_bwd_dkdv: bad shape (Tq %% 8)");
+                                const float* lse, const float* D, void* dk, void* dv, int B, int H, int Tq, int Tk, int Tkr, int d,
+                                int kv_div, float scale, void* stream) {
+    FD_REQUIRE(B > 0 && H > 0 && Tq > 0 && Tk > 0 && (Tq & 7) == 0 && Tkr >= Tk && kv_div >= 1, "fd_attn_bwd_dkdv: bad shape (Tq %% 8)");
     dim3 grid((Tk + 127) / 128, H, B);
 #define CALL(DD)                                                                                                                       \
     if (kv_div > 1) {                                                                                                                  \
         ALLOW_LDS((attn_bwd_dkdv_kernel<DD, true>), dkdv_lds<DD>());                                                                     \
         hipLaunchKernelGGL((attn_bwd_dkdv_kernel<DD, true>), grid, dim3(256), dkdv_lds<DD>(), (hipStream_t)stream, (const f16*)q,      \
                            (const f16*)qt, (const f16*)k, (const f16*)v, (const f16*)d_o, (const f16*)d_ot, lse, D, dk, dv, H, Tq, Tk, \
-                           kv_div, scale);                                                                                             \
+                           Tkr, kv_div, scale);                                                                                             \
     } else {                                                                                                                           \
         ALLOW_LDS((attn_bwd_dkdv_kernel<DD, false>), dkdv_lds<DD>());                                                                    \
         hipLaunchKernelGGL((attn_bwd_dkdv_kernel<DD, false>), grid, dim3(256), dkdv_lds<DD>(), (hipStream_t)stream, (const f16*)q,     \
                            (const f16*)qt, (const f16*)k, (const f16*)v, (const f16*)d_o, (const f16*)d_ot, lse, D, dk, dv, H, Tq, Tk, \
-                           kv_div, scale);                                                                                             \
+                           Tkr, kv_div, scale);                                                                                             \
     }
     FD_DISPATCH_D(d, CALL)
 #undef CALL

@@ -381,3 +381,68 @@ extern "C" int fd_adamw_ema(float* p, const float* g, float* m, float* v, float*
                        bc2s, ema_one_minus_decay);
     return fd_check_launch("fd_adamw_ema");
 }
+
+// ---------------------------------------------------------------- ViT patch embedding input (image regularisers, 1-main-debias.py:1139-1175)
+// chips [N,3,S,S] fp16 NCHW in [-1,1]  ->  patches [N*g*g, Kp] fp16, k = c*P*P + py*P + px (the Conv2d(3,D,P,P) weight order),
+// value ((x+1)/2 - mean_c)/std_c, columns >= 3*P*P zero.
+struct PatchNorm { float mean[3], istd[3]; };
+__global__ void patchify_fwd_kernel(const f16* chips, f16* patches, PatchNorm nm, int S, int P, int Kp, int64_t n) {
+    const int g = S / P, PP = P * P;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int k = (int)(i % Kp);
+        const int64_t row = i / Kp;
+        float v = 0.f;
+        if (k < 3 * PP) {
+            const int c = k / PP, py = (k % PP) / P, px = k % P;
+            const int gx = (int)(row % g), gy = (int)((row / g) % g);
+            const int64_t b = row / (g * g);
+            const float x = (float)chips[((b * 3 + c) * S + gy * P + py) * S + gx * P + px];
+            v = ((x + 1.f) * 0.5f - nm.mean[c]) * nm.istd[c];
+        }
+        patches[i] = (f16)v;
+    }
+}
+// dchips[n,c,y,x] (+)= 0.5/std_c * scale * dpatches[row, k]
+__global__ void patchify_bwd_kernel(const f16* dpatches, float* dchips, PatchNorm nm, int S, int P, int Kp, float scale, int accumulate, int64_t n) {
+    const int g = S / P, PP = P * P;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % S), y = (int)((i / S) % S), c = (int)((i / ((int64_t)S * S)) % 3);
+        const int64_t b = i / ((int64_t)3 * S * S);
+        const int64_t row = (b * g + y / P) * g + x / P;
+        const float v = (float)dpatches[row * Kp + c * PP + (y % P) * P + x % P] * (0.5f * nm.istd[c] * scale);
+        dchips[i] = accumulate ? dchips[i] + v : v;
+    }
+}
+extern "C" int fd_patchify_fwd(const void* chips, void* patches, const float* mean3, const float* std3, int N, int S, int P, int Kp, void* stream) {
+    FD_REQUIRE(N > 0 && P > 0 && S % P == 0 && Kp >= 3 * P * P && (Kp & 7) == 0, "fd_patchify_fwd: S %% P, Kp >= 3*P*P, Kp %% 8 (S=%d P=%d Kp=%d)", S, P, Kp);
+    PatchNorm nm;
+    for (int c = 0; c < 3; ++c) { nm.mean[c] = mean3[c]; nm.istd[c] = 1.f / std3[c]; }
+    const int64_t n = (int64_t)N * (S / P) * (S / P) * Kp;
+    hipLaunchKernelGGL(patchify_fwd_kernel, grid_for(n), dim3(256), 0, (hipStream_t)stream, (const f16*)chips, (f16*)patches, nm, S, P, Kp, n);
+    return fd_check_launch("fd_patchify_fwd");
+}
+extern "C" int fd_patchify_bwd(const void* dpatches, float* dchips, const float* std3, int N, int S, int P, int Kp, float scale, int accumulate,
+                               void* stream) {
+    FD_REQUIRE(N > 0 && P > 0 && S % P == 0 && Kp >= 3 * P * P && (Kp & 7) == 0, "fd_patchify_bwd: S %% P, Kp >= 3*P*P, Kp %% 8");
+    PatchNorm nm;
+    for (int c = 0; c < 3; ++c) { nm.mean[c] = 0.f; nm.istd[c] = 1.f / std3[c]; }
+    const int64_t n = (int64_t)N * 3 * S * S;
+    hipLaunchKernelGGL(patchify_bwd_kernel, grid_for(n), dim3(256), 0, (hipStream_t)stream, (const f16*)dpatches, dchips, nm, S, P, Kp, scale, accumulate, n);
+    return fd_check_launch("fd_patchify_bwd");
+}
+
+// ---------------------------------------------------------------- rectangle scale of an image gradient (apply_grad_hook_face, :1584-1617)
+// dimg [B,3,H,W] fp32: inside rect_b = [x0,y0,x1,y1) multiply by factor_b.  The reference indexes image[:, y0:y1, x0:x1].
+__global__ void rect_scale_kernel(float* dimg, const int32_t* rects, const float* factors, int H, int W, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % W), y = (int)((i / W) % H);
+        const int64_t b = i / ((int64_t)3 * H * W);
+        const int32_t* r = rects + b * 4;
+        if (x >= r[0] && x < r[2] && y >= r[1] && y < r[3]) dimg[i] *= factors[b];
+    }
+}
+extern "C" int fd_rect_scale(float* dimg, const int32_t* rects, const float* factors, int B, int H, int W, void* stream) {
+    const int64_t n = (int64_t)B * 3 * H * W;
+    hipLaunchKernelGGL(rect_scale_kernel, grid_for(n), dim3(256), 0, (hipStream_t)stream, dimg, rects, factors, H, W, n);
+    return fd_check_launch("fd_rect_scale");
+}

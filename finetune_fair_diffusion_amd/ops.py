@@ -130,6 +130,38 @@ def bgemm(a, b, *, alpha=1.0, out=None):
     return out
 
 
+def gemm_batched_into(a, b, out_view, bias, residual, Z, rows):
+    """out_view[z] = a[z*rows:(z+1)*rows] . b^T + bias + residual   for z < Z, where ``out_view`` [Z,rows,N] is a strided view
+    (row stride N, any batch stride) into a larger buffer and ``residual`` [rows,N] is shared by all z (ViT position table)."""
+    K, N = a.shape[1], b.shape[0]
+    assert a.shape[0] == Z * rows and out_view.shape == (Z, rows, N) and out_view.stride(2) == 1 and a.is_contiguous()
+    d = _lib.GemmDesc()
+    d.A, d.lda, d.B, d.ldb = a.data_ptr(), K, b.data_ptr(), b.stride(0)
+    d.C, d.ldc = out_view.data_ptr(), out_view.stride(1)
+    if bias is not None:
+        d.bias = _chk(bias, F32).data_ptr()
+    if residual is not None:
+        d.residual, d.ldr, d.sR = _chk(residual).data_ptr(), residual.stride(0), 0
+    d.alpha, d.M, d.N, d.K, d.batch = 1.0, rows, N, K, Z
+    d.sA, d.sB, d.sC = rows * K, 0, out_view.stride(0)
+    _gemm_call(d, False)
+    return out_view
+
+
+def gemm_batched_from(a_view, b, Z, rows):
+    """C[z*rows:(z+1)*rows] = a_view[z] . b^T with ``a_view`` [Z,rows,K] a strided view (unit column stride)."""
+    K, N = a_view.shape[2], b.shape[0]
+    assert a_view.shape[:2] == (Z, rows) and a_view.stride(2) == 1 and b.shape[1] == K
+    out = torch.empty((Z * rows, N), dtype=F16, device=b.device)
+    d = _lib.GemmDesc()
+    d.A, d.lda, d.B, d.ldb = a_view.data_ptr(), a_view.stride(1), b.data_ptr(), b.stride(0)
+    d.C, d.ldc = out.data_ptr(), N
+    d.alpha, d.M, d.N, d.K, d.batch = 1.0, rows, N, K, Z
+    d.sA, d.sB, d.sC = a_view.stride(0), 0, rows * N
+    _gemm_call(d, False)
+    return out
+
+
 def conv3x3(x, w, B, H, W, *, mode=CONV_NORMAL, bias=None, rowbias=None, residual=None, act="none", out=None):
     """Implicit-GEMM 3x3 conv (pad 1).  x: [B*H*W, Cin] channels-last fp16, w: [Cout, 9*Cin] (ky,kx,ci order).
     Returns ([B*Ho*Wo, Cout], Ho, Wo)."""
@@ -316,27 +348,30 @@ def to_f32(x, scale=1.0):
 
 
 # ----------------------------------------------------------------------------- attention
-def attn_fwd(q, k, vt, B, H, Tq, Tk, d, kv_div=1, scale=None, need_lse=False):
+def attn_fwd(q, k, vt, B, H, Tq, Tk, d, kv_div=1, scale=None, need_lse=False, kv_rows=None):
+    """``kv_rows``: rows per batch item of the k buffer when it is row-padded beyond the Tk keys (ViT token buffers)."""
     Tkp = vt.shape[-1]
+    Tkr = kv_rows or Tk
     o = torch.empty_like(q)
     lse = torch.empty((B, H, Tq), dtype=F32, device=q.device) if need_lse else None
-    _call("fd_attn_fwd", _p(_chk(q)), _p(_chk(k)), _p(_chk(vt)), _p(o), _p(lse), B, H, Tq, Tk, Tkp, d, kv_div,
+    _call("fd_attn_fwd", _p(_chk(q)), _p(_chk(k)), _p(_chk(vt)), _p(o), _p(lse), B, H, Tq, Tk, Tkp, Tkr, d, kv_div,
           scale if scale is not None else d ** -0.5, _stream())
     return (o, lse) if need_lse else o
 
 
-def attn_bwd(q, k, v, o, do, lse, B, H, Tq, Tk, d, kv_div=1, scale=None, kt=None, dk_acc=None, dv_acc=None):
+def attn_bwd(q, k, v, o, do, lse, B, H, Tq, Tk, d, kv_div=1, scale=None, kt=None, dk_acc=None, dv_acc=None, kv_rows=None):
     """Returns (dq, dk, dv).  With kv_div>1 (shared K/V) dk/dv are accumulated into the fp32 buffers dk_acc/dv_acc."""
     scale = scale if scale is not None else d ** -0.5
+    Tkr = kv_rows or Tk
     C = H * d
     Dd = torch.empty((B, H, Tq), dtype=F32, device=q.device)
     _call("fd_attn_bwd_prep", _p(_chk(o)), _p(_chk(do)), _p(Dd), B, H, Tq, d, _stream())
     Bk = B // kv_div
     if kt is None:
-        kt = transpose_btc(k, Bk, Tk, C)
+        kt = transpose_btc(k, Bk, Tkr, C)
     Tkp = kt.shape[-1]
     dq = torch.empty_like(q)
-    _call("fd_attn_bwd_dq", _p(_chk(q)), _p(_chk(k)), _p(_chk(v)), _p(kt), _p(do), _p(lse), _p(Dd), _p(dq), B, H, Tq, Tk, Tkp, d, kv_div,
+    _call("fd_attn_bwd_dq", _p(_chk(q)), _p(_chk(k)), _p(_chk(v)), _p(kt), _p(do), _p(lse), _p(Dd), _p(dq), B, H, Tq, Tk, Tkp, Tkr, d, kv_div,
           scale, _stream())
     qt = transpose_btc(q, B, Tq, C, Tq)
     dot = transpose_btc(do, B, Tq, C, Tq)
@@ -344,8 +379,8 @@ def attn_bwd(q, k, v, o, do, lse, B, H, Tq, Tk, d, kv_div=1, scale=None, kt=None
         dk, dv = dk_acc, dv_acc
         assert dk.dtype == F32 and dv.dtype == F32
     else:
-        dk, dv = torch.empty_like(k), torch.empty_like(v)
-    _call("fd_attn_bwd_dkdv", _p(q), _p(qt), _p(k), _p(v), _p(do), _p(dot), _p(lse), _p(Dd), _p(dk), _p(dv), B, H, Tq, Tk, d, kv_div, scale,
+        dk, dv = (torch.empty_like(k), torch.empty_like(v)) if Tkr == Tk else (torch.zeros_like(k), torch.zeros_like(v))
+    _call("fd_attn_bwd_dkdv", _p(q), _p(qt), _p(k), _p(v), _p(do), _p(dot), _p(lse), _p(Dd), _p(dk), _p(dv), B, H, Tq, Tk, Tkr, d, kv_div, scale,
           _stream())
     return dq, dk, dv
 
@@ -422,6 +457,29 @@ def crop_resize(img, boxes, fill, S):
 def crop_resize_bwd(dchips, boxes, B, H, W, S):
     dimg = torch.zeros((B, 3, H, W), dtype=F32, device=dchips.device)
     _call("fd_crop_resize_bwd", _p(_chk(dchips, F32)), _p(boxes), _p(dimg), B, H, W, S, _stream())
+    return dimg
+
+
+def patchify(chips, mean, std, P, Kp):
+    N, _, S, _ = chips.shape
+    g = S // P
+    out = torch.empty((N * g * g, Kp), dtype=F16, device=chips.device)
+    _call("fd_patchify_fwd", _p(_chk(chips)), _p(out), (ctypes.c_float * 3)(*mean), (ctypes.c_float * 3)(*std), N, S, P, Kp, _stream())
+    return out
+
+
+def patchify_bwd(dpatches, std, N, S, P, scale=1.0, out=None):
+    """dchips [N,3,S,S] fp32 = (or +=, when ``out`` is given) 0.5/std_c * scale * fold(dpatches)."""
+    acc = out is not None
+    if out is None:
+        out = torch.empty((N, 3, S, S), dtype=F32, device=dpatches.device)
+    _call("fd_patchify_bwd", _p(_chk(dpatches)), _p(_chk(out, F32)), (ctypes.c_float * 3)(*std), N, S, P, dpatches.shape[1], scale, int(acc), _stream())
+    return out
+
+
+def rect_scale(dimg, rects, factors):
+    B, _, H, W = dimg.shape
+    _call("fd_rect_scale", _p(_chk(dimg, F32)), _p(rects), _p(_chk(factors, F32)), B, H, W, _stream())
     return dimg
 
 

@@ -266,6 +266,67 @@ def mobilenet_param_shapes(num_classes=80) -> "OrderedDict[str, tuple]":
     return sd
 
 
+# ------------------------------------------------------------------------------------------ image encoders of the regularisers
+@dataclass
+class ViTConfig:
+    """``kind`` "clip": transformers CLIPVisionModelWithProjection (laion/CLIP-ViT-H-14, :948-957);
+    "dino": facebookresearch/dinov2 ``dinov2_vitb14`` (:960-962)."""
+    kind: str = "clip"
+    image_size: int = 224
+    patch_size: int = 14
+    hidden_size: int = 1280
+    num_hidden_layers: int = 32
+    num_attention_heads: int = 16
+    intermediate_size: int = 5120
+    projection_dim: int = 1024
+    layer_norm_eps: float = 1e-5
+    pos_grid: int = 16
+
+
+CLIP_VIT_H14 = ViTConfig()
+DINOV2_VITB14 = ViTConfig(kind="dino", hidden_size=768, num_hidden_layers=12, num_attention_heads=12, intermediate_size=3072,
+                          projection_dim=0, layer_norm_eps=1e-6, pos_grid=37)
+CLIP_IMAGE_MEAN, CLIP_IMAGE_STD = (0.48145466, 0.4578275, 0.40821073), (0.26862954, 0.26130258, 0.27577711)
+DINO_IMAGE_MEAN, DINO_IMAGE_STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
+
+
+def vit_param_shapes(c: ViTConfig) -> "OrderedDict[str, tuple]":
+    sd = OrderedDict()
+    D, I, P = c.hidden_size, c.intermediate_size, c.patch_size
+    if c.kind == "clip":
+        e = "vision_model.embeddings."
+        sd[e + "class_embedding"] = (D,)
+        sd[e + "patch_embedding.weight"] = (D, 3, P, P)
+        sd[e + "position_embedding.weight"] = ((c.image_size // P) ** 2 + 1, D)
+        sd["vision_model.pre_layrnorm.weight"] = (D,); sd["vision_model.pre_layrnorm.bias"] = (D,)
+        for i in range(c.num_hidden_layers):
+            p = f"vision_model.encoder.layers.{i}."
+            for n in ("k_proj", "v_proj", "q_proj", "out_proj"):
+                sd[p + f"self_attn.{n}.weight"] = (D, D); sd[p + f"self_attn.{n}.bias"] = (D,)
+            sd[p + "layer_norm1.weight"] = (D,); sd[p + "layer_norm1.bias"] = (D,)
+            sd[p + "mlp.fc1.weight"] = (I, D); sd[p + "mlp.fc1.bias"] = (I,)
+            sd[p + "mlp.fc2.weight"] = (D, I); sd[p + "mlp.fc2.bias"] = (D,)
+            sd[p + "layer_norm2.weight"] = (D,); sd[p + "layer_norm2.bias"] = (D,)
+        sd["vision_model.post_layernorm.weight"] = (D,); sd["vision_model.post_layernorm.bias"] = (D,)
+        sd["visual_projection.weight"] = (c.projection_dim, D)
+    else:
+        sd["cls_token"] = (1, 1, D)
+        sd["pos_embed"] = (1, 1 + c.pos_grid ** 2, D)
+        sd["patch_embed.proj.weight"] = (D, 3, P, P); sd["patch_embed.proj.bias"] = (D,)
+        for i in range(c.num_hidden_layers):
+            p = f"blocks.{i}."
+            sd[p + "norm1.weight"] = (D,); sd[p + "norm1.bias"] = (D,)
+            sd[p + "attn.qkv.weight"] = (3 * D, D); sd[p + "attn.qkv.bias"] = (3 * D,)
+            sd[p + "attn.proj.weight"] = (D, D); sd[p + "attn.proj.bias"] = (D,)
+            sd[p + "ls1.gamma"] = (D,)
+            sd[p + "norm2.weight"] = (D,); sd[p + "norm2.bias"] = (D,)
+            sd[p + "mlp.fc1.weight"] = (I, D); sd[p + "mlp.fc1.bias"] = (I,)
+            sd[p + "mlp.fc2.weight"] = (D, I); sd[p + "mlp.fc2.bias"] = (D,)
+            sd[p + "ls2.gamma"] = (D,)
+        sd["norm.weight"] = (D,); sd["norm.bias"] = (D,)
+    return sd
+
+
 # ------------------------------------------------------------------------------------------ synthetic init
 def synthetic_state_dict(shapes, seed=0, device="cpu", gain=1.0, dtype=torch.float32):
     """Variance-preserving random weights: W ~ N(0, gain^2/fan_in), biases ~ N(0, 0.02^2),
@@ -284,7 +345,11 @@ def synthetic_state_dict(shapes, seed=0, device="cpu", gain=1.0, dtype=torch.flo
             t = torch.rand(shape, generator=g) * 0.5 + 0.75
         elif len(shape) == 1:
             is_norm = any(k in name for k in ("norm", ".1.weight", ".1.bias", "layer_norm"))
-            if leaf == "weight":
+            if leaf == "class_embedding":
+                t = torch.randn(shape, generator=g) * 0.5
+            elif leaf == "gamma":                                  # DINOv2 LayerScale
+                t = 0.5 + 0.1 * torch.randn(shape, generator=g)
+            elif leaf == "weight":
                 t = 1.0 + 0.1 * torch.randn(shape, generator=g)
             else:
                 t = (0.05 if is_norm else 0.02) * torch.randn(shape, generator=g)
@@ -292,7 +357,7 @@ def synthetic_state_dict(shapes, seed=0, device="cpu", gain=1.0, dtype=torch.flo
             fan_in = 1
             for s in shape[1:]:
                 fan_in *= s
-            if "embedding" in name:
+            if leaf in ("cls_token", "pos_embed") or "position_embedding" in name or "token_embedding" in name:
                 t = torch.randn(shape, generator=g) * 0.5
             elif "lora" in name and ".up." in name:
                 t = torch.zeros(shape)

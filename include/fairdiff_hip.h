@@ -102,20 +102,22 @@ int fd_cast_f32_to_f16(const float* x, void* y, int64_t n, float scale, void* st
 int fd_cast_f16_to_f32(const void* x, float* y, int64_t n, float scale, void* stream);
 
 /* ---- fused attention (diffusers Attention.get_attention_scores + bmm, LoRAAttnProcessor.__call__)
- * q:[B,Tq,H*d]  k:[Bk,Tk,H*d]  vt:[Bk,H*d,Tkp] (V transposed, keys contiguous, Tkp>=Tk, Tkp%8==0)
+ * q:[B,Tq,H*d]  k:[Bk,Tkr,H*d] of which the first Tk rows are keys (Tkr>=Tk: row-padded token buffers of the ViTs)
+ * vt:[Bk,H*d,Tkp] (V transposed, keys contiguous, Tkp>=Tk, Tkp%8==0)
  * sample b uses kv batch b / kv_div (cross-attention K/V are shared by each CFG half).
  * o:[B,Tq,H*d] fp16, lse:[B,H,Tq] fp32 (natural-log sum-exp of the scaled scores).                 */
 int fd_attn_fwd(const void* q, const void* k, const void* vt, void* o, float* lse, int B, int H, int Tq, int Tk,
-                int Tkp, int d, int kv_div, float scale, void* stream);
+                int Tkp, int Tkr, int d, int kv_div, float scale, void* stream);
 /* D[b,h,t] = sum_j dO*O */
 int fd_attn_bwd_prep(const void* o, const void* d_o, float* D, int B, int H, int T, int d, void* stream);
 /* dq from (q, k, v, kt:[Bk,H*d,Tkp], dO, lse, D) */
 int fd_attn_bwd_dq(const void* q, const void* k, const void* v, const void* kt, const void* d_o, const float* lse,
-                   const float* D, void* dq, int B, int H, int Tq, int Tk, int Tkp, int d, int kv_div, float scale, void* stream);
+                   const float* D, void* dq, int B, int H, int Tq, int Tk, int Tkp, int Tkr, int d, int kv_div, float scale,
+                   void* stream);
 /* dk,dv from (q, qt:[B,H*d,Tq], k, v, dO, dOt:[B,H*d,Tq], lse, D). When kv_div>1 the kv batch is shared by
  * kv_div consecutive samples; dk/dv are then fp32 [Bk,Tk,H*d] accumulated with atomics, else fp16. */
 int fd_attn_bwd_dkdv(const void* q, const void* qt, const void* k, const void* v, const void* d_o, const void* d_ot,
-                     const float* lse, const float* D, void* dk, void* dv, int B, int H, int Tq, int Tk, int d,
+                     const float* lse, const float* D, void* dk, void* dv, int B, int H, int Tq, int Tk, int Tkr, int d,
                      int kv_div, float scale, void* stream);
 
 /* ---- masked attention of the CLIP text encoder (transformers CLIPAttention; reference call sites :1011-1014, :1078-1081).
@@ -155,6 +157,15 @@ int fd_conv_small_cin_bwd(const void* dy /* [B,Ho,Wo,Cout] */, const float* w, f
 int fd_crop_resize_fwd(const void* img, const int32_t* boxes, float fill, void* chips, int B, int H, int W, int S, void* stream);
 int fd_crop_resize_bwd(const float* dchips /* [B,3,S,S] */, const int32_t* boxes, float* dimg /* [B,3,H,W] (+=) */,
                        int B, int H, int W, int S, void* stream);
+
+/* ---- image-semantics regularisers (get_clip_feat / get_dino_feat, exp-1 1-main-debias.py:1139-1175; Resize :1860,1905).
+ * chips [N,3,S,S] fp16 NCHW in [-1,1] -> patches [N*(S/P)^2, Kp] fp16 = ((x+1)/2 - mean_c)/std_c in Conv2d(3,D,P,P) weight order
+ * (k = c*P*P + py*P + px), zero-padded to Kp; the patch embedding is then a GEMM.  bwd: dchips fp32 (+)= 0.5/std_c*scale*dpatches */
+int fd_patchify_fwd(const void* chips, void* patches, const float* mean3, const float* std3, int N, int S, int P, int Kp, void* stream);
+int fd_patchify_bwd(const void* dpatches, float* dchips, const float* std3, int N, int S, int P, int Kp, float scale, int accumulate,
+                    void* stream);
+/* apply_grad_hook_face (:1584-1617) in the backward: dimg [B,3,H,W] fp32 *= factors[b] inside rects[b] = [x0,y0,x1,y1) */
+int fd_rect_scale(float* dimg, const int32_t* rects, const float* factors, int B, int H, int W, void* stream);
 
 #ifdef __cplusplus
 }

@@ -377,3 +377,48 @@ def test_generate_consumes_exported_lora(tmp_path):
     assert [os.path.basename(p) for p in again] == ["img_1.jpg"]
     with pytest.raises(NotImplementedError):
         generate.main(generate.parse_args(base + ["--save_dir", str(tmp_path / "x"), "--load_prefix_embedding_from", "p.pth"]), cfgs=TINY)
+
+
+# ------------------------------------------------------------------------------------------ image encoders of the regularisers
+VIT_TINY = dict(
+    clip=dict(kind="clip", image_size=56, patch_size=14, hidden_size=160, num_hidden_layers=3, num_attention_heads=2, intermediate_size=320,
+              projection_dim=48, layer_norm_eps=1e-5, pos_grid=4),
+    dino=dict(kind="dino", image_size=56, patch_size=14, hidden_size=128, num_hidden_layers=3, num_attention_heads=2, intermediate_size=256,
+              projection_dim=0, layer_norm_eps=1e-6, pos_grid=6))
+
+
+@pytest.mark.parametrize("kind", ["clip", "dino"])
+def test_vit_features_and_input_gradient_vs_oracle(dev, kind):
+    """get_clip_feat / get_dino_feat (:1139-1175): embeddings within 2e-2 of max|ref|, cosine-loss input gradient within 5e-2
+    (fp16 activations vs the fp32 oracle); covers the DINOv2 position-table interpolation (6x6 -> 4x4) and LayerScale."""
+    from finetune_fair_diffusion_amd import weights as W
+    from finetune_fair_diffusion_amd.vit import VisionTransformer, feature_loss_and_grad
+    from oracle import nn_vit as OV
+    cfg = W.ViTConfig(**VIT_TINY[kind])
+    sd = W.synthetic_state_dict(W.vit_param_shapes(cfg), seed=11)
+    mean, std = (W.CLIP_IMAGE_MEAN, W.CLIP_IMAGE_STD) if kind == "clip" else (W.DINO_IMAGE_MEAN, W.DINO_IMAGE_STD)
+    om = OV.build(OV.ViTConfig(**VIT_TINY[kind]), sd)
+    pm = VisionTransformer(cfg, sd, dev, mean, std)
+    g = torch.Generator().manual_seed(3)
+    N = 3
+    chips = (torch.rand(N, 3, 56, 56, generator=g) * 2 - 1).half().float()
+    target = F.normalize(torch.randn(N, pm.out_dim, generator=g), dim=-1)
+    w = torch.tensor([1.0, 0.2, 0.5])
+    x = chips.clone().requires_grad_(True)
+    e_ref = OV.image_features(om, x, mean, std, normalize=False)
+    loss_ref = 1 - (F.normalize(e_ref, dim=-1) * target).sum(-1)
+    (loss_ref * w).sum().backward()
+    e = pm.forward(chips.half().to(dev), record=True)
+    check(f"{kind} embedding", e, e_ref, 2e-2)
+    loss, de = feature_loss_and_grad(e, target.to(dev), w.to(dev))
+    check(f"{kind} loss", loss, loss_ref, 2e-2)
+    gscale = 2.0 ** 10
+    dchips = pm.backward(de, gscale)
+    check(f"{kind} d chips", dchips, x.grad, 5e-2)
+    # accumulate-into mode adds on top of an existing gradient buffer
+    pm.forward(chips.half().to(dev), record=True)
+    acc = dchips.clone()
+    pm.backward(de, gscale, out=acc)
+    check(f"{kind} d chips accumulated", acc, 2 * x.grad, 5e-2)
+    # no-record forward (fused GELU epilogue) agrees with the recording one
+    check(f"{kind} embedding (no record)", pm.forward(chips.half().to(dev)), e, 2e-3)
