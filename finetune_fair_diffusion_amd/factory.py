@@ -14,10 +14,14 @@ from .text_encoder import CLIPTextModel
 from .unet import UNet2DConditionModel
 from .vae import AutoencoderKL
 
-SD15 = dict(unet=W.UNetConfig(), vae=W.VAEConfig(), clip=W.CLIPTextConfig())
+SD15 = dict(unet=W.UNetConfig(), vae=W.VAEConfig(), clip=W.CLIPTextConfig(), clip_vision=W.CLIP_VIT_H14, dino=W.DINOV2_VITB14)
 TINY = dict(unet=W.UNetConfig(block_out_channels=(64, 128, 256, 256), attention_head_dim=4, cross_attention_dim=64, sample_size=32),
             vae=W.VAEConfig(block_out_channels=(32, 64, 64, 64)),
-            clip=W.CLIPTextConfig(vocab_size=1000, hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=2))
+            clip=W.CLIPTextConfig(vocab_size=1000, hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=2),
+            clip_vision=W.ViTConfig(kind="clip", image_size=56, hidden_size=160, num_hidden_layers=2, num_attention_heads=2, intermediate_size=320,
+                                    projection_dim=48, pos_grid=4),
+            dino=W.ViTConfig(kind="dino", image_size=56, hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256,
+                             projection_dim=0, layer_norm_eps=1e-6, pos_grid=6))
 
 
 def synthetic_tokens(L=13, vocab=49408, seed=1):
@@ -41,10 +45,12 @@ def default_args(**kw):
 
 
 def build_trainer(args, device, cfgs=SD15, seed=0, rank=0, world_size=1, experiment="exp-1", classifier_gain=1.4, state_dicts=None,
-                  frozen_copies=True):
+                  frozen_copies=True, regularisers=False):
     """Returns (trainer, models dict).  ``state_dicts`` may carry real weights by diffusers key
     (keys 'unet','vae','clip','clf','unet_lora','te_lora'); anything missing is synthetic.
-    ``frozen_copies=False`` skips the original-model replicas of R2 (inference-only consumers such as generate.py)."""
+    ``frozen_copies=False`` skips the original-model replicas of R2 (inference-only consumers such as generate.py).
+    ``regularisers=True`` attaches the CLIP / DINOv2 image encoders of the image-semantics loss term (keys 'clip_vision','dino';
+    ``args.img_size_small`` must equal their input size)."""
     from .fairness import EXPERIMENT_ATTRS
     num_classes = EXPERIMENT_ATTRS[experiment][0]
     sds = dict(state_dicts or {})
@@ -89,7 +95,17 @@ def build_trainer(args, device, cfgs=SD15, seed=0, rank=0, world_size=1, experim
                 dist.broadcast(m.lora_bank.flat, src=0)
                 m.lora_bank.ema.copy_(m.lora_bank.flat)
                 m.refresh_lora()
+    clip_model = dino_model = None
+    if regularisers and getattr(args, "weight_loss_img", 0) != 0:
+        from .vit import VisionTransformer
+        for key, s in (("clip_vision", 9), ("dino", 10)):
+            if key not in sds:
+                sds[key] = gen(W.vit_param_shapes(cfgs[key]), s)
+            if cfgs[key].image_size != args.img_size_small:
+                raise ValueError(f"{key}: encoder input {cfgs[key].image_size} != --img_size_small {args.img_size_small}")
+        clip_model = VisionTransformer(cfgs["clip_vision"], sds.pop("clip_vision"), device, W.CLIP_IMAGE_MEAN, W.CLIP_IMAGE_STD)
+        dino_model = VisionTransformer(cfgs["dino"], sds.pop("dino"), device, W.DINO_IMAGE_MEAN, W.DINO_IMAGE_STD)
     sch = DPMSolverMultistepScheduler()
     tr = FairnessTrainer(args, te, unet, vae, clf, sch, eval_text_encoder=eval_te, eval_unet=eval_unet, experiment=experiment, rank=rank,
-                         world_size=world_size, device=device)
-    return tr, dict(unet=unet, eval_unet=eval_unet, vae=vae, text_encoder=te, eval_text_encoder=eval_te, classifier=clf, scheduler=sch)
+                         world_size=world_size, device=device, clip_model=clip_model, dino_model=dino_model)
+    return tr, dict(clip_vision=clip_model, dino=dino_model, unet=unet, eval_unet=eval_unet, vae=vae, text_encoder=te, eval_text_encoder=eval_te, classifier=clf, scheduler=sch)

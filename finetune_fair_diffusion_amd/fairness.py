@@ -74,7 +74,12 @@ def face_grad_factors(boxes, boxes_ori, targets, preds_ori, factor, H, W):
         if all(v == -1 for v in bb):
             rects.append([0, 0, 0, 0]); facs.append(1.0)
             continue
-        rects.append([max(bb[0], bo[0], 0), max(bb[1], bo[1], 0), min(bb[2], bo[2], H), min(bb[3], bo[3], W)])
+        # the reference slices image[:, y0:y1, x0:x1] with (H,W) swapped in the clamps (:1592-1598); a missing original face
+        # (box_ori = -1) makes y1/x1 negative, which Python slicing counts from the far edge -- reproduced here explicitly
+        x0, y0, x1, y1 = max(bb[0], bo[0], 0), max(bb[1], bo[1], 0), min(bb[2], bo[2], H), min(bb[3], bo[3], W)
+        x1 = max(x1 + W, 0) if x1 < 0 else min(x1, W)
+        y1 = max(y1 + H, 0) if y1 < 0 else min(y1, H)
+        rects.append([x0, y0, x1, y1])
         facs.append(1.0 if (t != -1 and t == p) else factor)
     return torch.tensor(rects, dtype=torch.int32), torch.tensor(facs, dtype=torch.float32)
 

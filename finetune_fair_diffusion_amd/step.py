@@ -15,19 +15,23 @@ exp-1-debias-gender/1-main-debias.py:1746-2029 re-designed for this hardware:
 * gradient sync: one RCCL all-reduce of the flat fp32 LoRA-gradient buffer + fused scale/finite
   check + one AdamW+EMA launch (replaces the 400 per-tensor collectives/launches of :1998-2029).
 
-The loss is the distributional-alignment term (``loss_fair``); the CLIP/DINO/face regularisers are
-SURVEY.md 8f "next" rows.
+The loss is ``loss_fair + weight_loss_img * dynamic_weights * (loss_CLIP + loss_DINO)`` (:1904-1932) when the two image
+encoders are attached (``clip_model`` / ``dino_model``, vit.py); their input gradients join the classifier's at the image
+and go through the VAE once.  The face-realism term (``weight_loss_face``, :1917-1929) is a SURVEY.md 8f "next" row: a
+trainer with image encoders refuses a non-zero ``weight_loss_face`` instead of silently dropping it.
 """
 import math
 
 import torch
 import torch.distributed as dist
+import torch.nn.functional as F
 
 from . import ops
-from .fairness import (EXPERIMENT_ATTRS, SyntheticFaceProvider, fair_loss_and_grad, generate_dynamic_targets,
-                       generate_dynamic_targets_multi, microbatch_weights)
+from .fairness import (EXPERIMENT_ATTRS, SyntheticFaceProvider, face_grad_factors, fair_loss_and_grad, gen_dynamic_weights,
+                       generate_dynamic_targets, generate_dynamic_targets_multi, microbatch_weights)
 from .layers import F16, F32
 from .lr_schedule import lr_lambda
+from .vit import feature_loss_and_grad
 
 
 def _ctx_bytes(obj, seen=None):
@@ -67,8 +71,17 @@ class EMAState:
 
 class FairnessTrainer:
     def __init__(self, args, text_encoder, unet, vae, classifier, scheduler, eval_text_encoder=None, eval_unet=None,
-                 face_provider=None, experiment="exp-1", rank=0, world_size=1, device=None):
+                 face_provider=None, experiment="exp-1", rank=0, world_size=1, device=None, clip_model=None, dino_model=None):
         self.args = args
+        self.clip, self.dino = clip_model, dino_model
+        self.use_img_loss = clip_model is not None and dino_model is not None and getattr(args, "weight_loss_img", 0) != 0
+        if (clip_model is None) != (dino_model is None):
+            raise ValueError("the image-semantics term needs both encoders (CLIP and DINOv2) or neither")
+        if self.use_img_loss and getattr(args, "weight_loss_face", 0) != 0:
+            raise NotImplementedError("weight_loss_face != 0: the face-realism term (SFNet features + nearest-neighbour search, "
+                                      "1-main-debias.py:1917-1929) is not built yet; pass --weight_loss_face 0")
+        if self.use_img_loss and len(EXPERIMENT_ATTRS[experiment][1]) != 1:
+            raise NotImplementedError("image-semantics regularisers are wired for exp-1 (single attribute) only")
         self.te, self.unet, self.vae, self.clf, self.sch = text_encoder, unet, vae, classifier, scheduler
         self.eval_te = eval_text_encoder if eval_text_encoder is not None else text_encoder
         self.eval_unet = eval_unet if eval_unet is not None else unet
@@ -169,6 +182,16 @@ class FairnessTrainer:
             per.append(dict(name=name, preds=preds, probs=probs, logits=la_full))
         return ind, boxes, per
 
+    def resize_small(self, images):
+        """``transforms.Resize(img_size_small)`` (:1860, :1905): bilinear, no antialias == the crop kernel on the full-image box."""
+        N, _, H, W = images.shape
+        box = torch.tensor([[0, 0, W, H]] * N, dtype=torch.int32, device=self.device)
+        return ops.crop_resize(images, box, -1.0, self.args.img_size_small), box
+
+    def image_features(self, small, record=False):
+        """get_clip_feat / get_dino_feat (:1139-1175) raw embeddings (fp32) of both encoders."""
+        return self.clip.forward(small, record=record), self.dino.forward(small, record=record)
+
     def dynamic_targets(self, per, B):
         """Global dynamic targets for this rank's B images from the gathered probabilities of all ranks (:1831-1837;
         exp-3 :2016-2025).  Returns per attribute (targets [B], uncertainty [B])."""
@@ -244,6 +267,9 @@ class FairnessTrainer:
         images_ori = torch.cat([self.decode(self.rollout(self.eval_unet, enc_ori, noises[j:j + vb], S)[0]) for j in range(0, B, vb)])
         ind_o, boxes_o, per_o = self.classify(images_ori)
         out.update(images_ori=images_ori, preds_ori=per_o[0]["preds"], probs_ori=per_o[0]["probs"])
+        if self.use_img_loss:                                                    # :1860-1862
+            e_c, e_d = self.image_features(self.resize_small(images_ori)[0])
+            clip_ori, dino_ori = F.normalize(e_c, dim=-1), F.normalize(e_d, dim=-1)
         # ---- R3: rollout with gradient (:1889-1933), all micro-batches at once with weights 1/n_j
         w, N_backward = microbatch_weights(B, args.train_GPU_batch_size)
         if share:
@@ -265,17 +291,39 @@ class FairnessTrainer:
         loss_fair = loss_by_attr[self.attrs[0][0]]
         out.update(loss_fair=loss_fair, loss_fair_by_attr=loss_by_attr, images_grad=images_g, N_backward=N_backward)
         sel = ind_g.nonzero().view(-1)
-        if len(sel) and float(dlog_full.abs().sum()) > 0:
-            dlog = dlog_full[sel]
-            dchips = self.clf.backward(dlog.to(dev), self.clf_gscale)
-            full = dchips
-            if len(sel) != B:
-                full = torch.zeros((B,) + tuple(dchips.shape[1:]), dtype=F32, device=dev)
-                full[sel.to(dev)] = dchips
-            bx = boxes_g.clone()
-            bx[~ind_g] = 0
-            Himg, Wimg = images_g.shape[2], images_g.shape[3]
-            d_img = ops.crop_resize_bwd(full.contiguous(), bx.to(dev).contiguous(), B, Himg, Wimg, args.size_face)
+        Himg, Wimg = images_g.shape[2], images_g.shape[3]
+        d_img = None
+        if self.use_img_loss:
+            # image-semantics term (:1904-1910, :1931-1932): w_i = (1/n_j) * weight_loss_img * dynamic_weight_i
+            small, fullbox = self.resize_small(images_g)
+            e_c, e_d = self.image_features(small, record=True)
+            dyn = gen_dynamic_weights(ind_g, targets, per_o[0]["preds"], factor=args.factor1)
+            wi = (w * args.weight_loss_img * dyn).to(dev)
+            loss_clip, de_c = feature_loss_and_grad(e_c, clip_ori, wi)
+            loss_dino, de_d = feature_loss_and_grad(e_d, dino_ori, wi)
+            dsmall = self.clip.backward(de_c, _pow2_scale(float(de_c.abs().max()), 1.0))
+            self.dino.backward(de_d, _pow2_scale(float(de_d.abs().max()), 1.0), out=dsmall)
+            d_img = ops.crop_resize_bwd(dsmall, fullbox, B, Himg, Wimg, args.img_size_small)
+            # apply_grad_hook_face (:1904, :1584-1617) acts on this path only: the classifier saw the un-hooked images
+            rects, facs = face_grad_factors(boxes_g, boxes_o, targets, per_o[0]["preds"], args.factor2, Himg, Wimg)
+            ops.rect_scale(d_img, rects.to(dev).contiguous(), facs.to(dev).contiguous())
+            lc, ld = loss_clip.float().cpu(), loss_dino.float().cpu()
+            lsum = loss_fair + args.weight_loss_img * dyn * (lc + ld)
+            out.update(loss_CLIP=lc, loss_DINO=ld, loss=lsum, dynamic_weights=dyn)
+        if (len(sel) and float(dlog_full.abs().sum()) > 0) or d_img is not None:
+            if len(sel) and float(dlog_full.abs().sum()) > 0:
+                dlog = dlog_full[sel]
+                dchips = self.clf.backward(dlog.to(dev), self.clf_gscale)
+                full = dchips
+                if len(sel) != B:
+                    full = torch.zeros((B,) + tuple(dchips.shape[1:]), dtype=F32, device=dev)
+                    full[sel.to(dev)] = dchips
+                bx = boxes_g.clone()
+                bx[~ind_g] = 0
+                d_fair = ops.crop_resize_bwd(full.contiguous(), bx.to(dev).contiguous(), B, Himg, Wimg, args.size_face)
+                d_img = d_fair if d_img is None else d_img.add_(d_fair)
+            else:
+                self.clf._ctx = None
             vscale = _pow2_scale(float(d_img.abs().max()), 64.0)
             dz = self.vae.backward_images(d_img, vscale)
             g = dz * (1.0 / self.vae.config.scaling_factor)          # dL/dx_final  [B,4,h,w] fp32

@@ -16,6 +16,8 @@ import scipy.stats
 import torch
 import torch.nn.functional as F
 
+from .nn_vit import CLIP_IMAGE_MEAN, CLIP_IMAGE_STD, DINO_IMAGE_MEAN, DINO_IMAGE_STD, image_features
+
 
 # --------------------------------------------------------------------------- helpers
 def make_grad_hook(coef):  # :219-220
@@ -291,8 +293,10 @@ class EMAModel:
 
 
 def fairness_step(models, tokens, noises, S, cfg, world=None, attrs=None, targets_by_attr=None):
-    """One training step (:1746-2029) on one rank, synthetic face provider,
-    loss = loss_fair only (CLIP/DINO/face terms are SURVEY 8f "next" rows).
+    """One training step (:1746-2029) on one rank, synthetic face provider.
+    loss_ij = loss_fair + weight_loss_img * dynamic_weights * (loss_CLIP + loss_DINO) (:1904-1932) when ``models`` holds the
+    image encoders ``clip`` / ``dino`` (oracle.nn_vit) and cfg["weight_loss_img"] != 0; the face-realism term
+    (weight_loss_face, :1917-1929) is a SURVEY 8f "next" row and is not part of this oracle.
 
     models: dict(text_encoder, unet, vae, classifier, scheduler, eval_text_encoder, eval_unet)
     cfg: dict(train_GPU_batch_size, val_GPU_batch_size, uncertainty_threshold, factor2, guidance_scale, size_face, slice_fn)
@@ -322,11 +326,17 @@ def fairness_step(models, tokens, noises, S, cfg, world=None, attrs=None, target
                                                            models["eval_unet"], vae, sch, gs) for j in range(0, B, vb)])
         ind_o, boxes_o, chips_o = faces(images_ori)
         preds_o, probs_o, _ = get_face_gender(clf, chips_o, selector=ind_o, slice_fn=slice_fn)
+        w_img = cfg.get("weight_loss_img", 0.0) if ("clip" in models and "dino" in models) else 0.0
+        if w_img:
+            small_o = resize_small(images_ori, cfg.get("img_size_small", 224))              # :1860-1862
+            clip_o = image_features(models["clip"], small_o, CLIP_IMAGE_MEAN, CLIP_IMAGE_STD)
+            dino_o = image_features(models["dino"], small_o, DINO_IMAGE_MEAN, DINO_IMAGE_STD)
     out.update(images=images, images_ori=images_ori, probs=probs, preds=preds, targets=targets, uncertainty=unc,
                preds_ori=preds_o, probs_ori=probs_o, latents_trace=trace)
     tb = cfg["train_GPU_batch_size"]
     N_backward = math.ceil(B / tb)
     loss_fair = torch.ones(B) * (-1)
+    loss_CLIP, loss_DINO, loss_all = torch.ones(B) * (-1), torch.ones(B) * (-1), torch.ones(B) * (-1)
     images_g = []
     for j in range(N_backward):
         idx = list(range(B))[j * tb:(j + 1) * tb]
@@ -339,13 +349,27 @@ def fairness_step(models, tokens, noises, S, cfg, world=None, attrs=None, target
         lf = torch.ones(len(idx)) * (-1)
         w = ((ind_j == True) * (targets[idx] != -1)).nonzero().view([-1])  # noqa: E712
         lf[w] = F.cross_entropy(logits_j[w], targets[idx][w], reduction="none")
-        loss_ij = lf  # + weight_loss_img*dyn*(CLIP+DINO) + weight_loss_face*face  (next rows)
+        loss_ij = lf
+        if w_img:
+            small = resize_small(img, cfg.get("img_size_small", 224))                       # :1905
+            lc = 1 - (image_features(models["clip"], small, CLIP_IMAGE_MEAN, CLIP_IMAGE_STD) * clip_o[idx]).sum(dim=-1)
+            ld = 1 - (image_features(models["dino"], small, DINO_IMAGE_MEAN, DINO_IMAGE_STD) * dino_o[idx]).sum(dim=-1)
+            dyn = gen_dynamic_weights(ind_j, targets[idx], preds_o[idx], factor=cfg.get("factor1", 0.2))
+            loss_ij = lf + w_img * dyn * (lc + ld)                                          # :1932 without the face term
+            loss_CLIP[idx], loss_DINO[idx] = lc.detach(), ld.detach()
         if loss_ij.requires_grad:
             loss_ij.mean().backward()
         loss_fair[idx] = lf.detach()
+        loss_all[idx] = loss_ij.detach()
         images_g.append(img.detach())
-    out.update(loss_fair=loss_fair, N_backward=N_backward, images_grad=torch.cat(images_g))
+    out.update(loss_fair=loss_fair, loss_CLIP=loss_CLIP, loss_DINO=loss_DINO, loss=loss_all, N_backward=N_backward,
+               images_grad=torch.cat(images_g))
     return out
+
+
+def resize_small(images, size):
+    """``transforms.Resize(size)`` on a square float tensor batch (torchvision 0.16: bilinear, antialias default "warn" = off)."""
+    return F.interpolate(images, size=(size, size), mode="bilinear", align_corners=False)
 
 
 def fairness_step_multi(models, tokens, noises, S, cfg, attrs, targets_by_attr):

@@ -84,12 +84,15 @@ def main():
     out["gen_dynamic_weights"] = gdw
     # apply_grad_hook_face: forward identity + gradient mask -----------------------
     agh = []
-    for seed in range(3):
+    for seed in range(4):
         g = torch.Generator().manual_seed(200 + seed)
         n, H = 4, 32
         images = torch.randn(n, 3, H, H, generator=g, requires_grad=True)
         bb = torch.tensor([[4, 6, 20, 24], [-1, -1, -1, -1], [0, 0, 40, 40], [10, 3, 30, 17]])
         bbo = torch.tensor([[8, 2, 28, 22], [3, 3, 9, 9], [5, 5, 25, 25], [-3, -2, 12, 40]])
+        if seed == 3:   # faces that the original model's image does not have: bbox_ori = -1 turns into Python's negative slice ends
+            bb = torch.tensor([[4, 6, 20, 24], [2, 2, 30, 30], [0, 0, 40, 40], [10, 3, 30, 17]])
+            bbo = torch.tensor([[-1, -1, -1, -1], [-1, -1, -1, -1], [5, 5, 25, 25], [-1, -1, -1, -1]])
         targets = torch.tensor([1, 0, -1, 0])
         preds = torch.tensor([1, 0, 1, 1])
         probs = torch.rand(n, 2, generator=g)

@@ -295,7 +295,8 @@ def _train_argv(out_dir, steps, extra=()):
     return ["--synthetic", "--train_unet", "--rank", "4", "--max_train_steps", str(steps), "--checkpointing_steps", "2",
             "--checkpointing_steps_long", "3", "--checkpoints_total_limit", "2", "--num_denoising_steps", "3",
             "--train_images_per_prompt_GPU", "4", "--train_GPU_batch_size", "3", "--val_GPU_batch_size", "4",
-            "--lr_scheduler", "linear", "--lr_warmup_steps", "1", "--learning_rate", "1e-5", "--output_dir", str(out_dir)] + list(extra)
+            "--lr_scheduler", "linear", "--lr_warmup_steps", "1", "--learning_rate", "1e-5", "--output_dir", str(out_dir),
+            "--weight_loss_img", "0", "--weight_loss_face", "0"] + list(extra)
 
 
 def test_train_loop_checkpoints_and_resume(tmp_path, dev):
@@ -422,3 +423,64 @@ def test_vit_features_and_input_gradient_vs_oracle(dev, kind):
     check(f"{kind} d chips accumulated", acc, 2 * x.grad, 5e-2)
     # no-record forward (fused GELU epilogue) agrees with the recording one
     check(f"{kind} embedding (no record)", pm.forward(chips.half().to(dev)), e, 2e-3)
+
+
+def test_full_step_with_image_regularisers(dev):
+    """loss_ij = loss_fair + weight_loss_img * dynamic_weights * (loss_CLIP + loss_DINO) (:1904-1932) with the face-gradient hook on
+    the regulariser path: per-image loss terms and the U-Net LoRA gradient vs the oracle's autograd step (tiny encoders, 56-px input)."""
+    from oracle import fair_step as fs, nn_vit as OV
+    from finetune_fair_diffusion_amd import weights as W
+    from finetune_fair_diffusion_amd.factory import TINY
+    from finetune_fair_diffusion_amd.step import FairnessTrainer
+    from finetune_fair_diffusion_amd.vit import VisionTransformer
+    om = U.oracle_models(train_unet=True, train_te=False, lora_up_std=0.05)
+    pm = U.product_models(om["sds"], dev, train_unet=True, train_te=False)
+    sd_c = W.synthetic_state_dict(W.vit_param_shapes(TINY["clip_vision"]), seed=21)
+    sd_d = W.synthetic_state_dict(W.vit_param_shapes(TINY["dino"]), seed=22)
+    models_o = dict(text_encoder=om["text_encoder"], unet=om["unet"], vae=om["vae"], classifier=om["classifier"], scheduler=om["scheduler"],
+                    eval_text_encoder=om["text_encoder"], eval_unet=om["eval_unet"],
+                    clip=OV.build(OV.ViTConfig(**TINY["clip_vision"].__dict__), sd_c), dino=OV.build(OV.ViTConfig(**TINY["dino"].__dict__), sd_d))
+    args = U.make_args(train_unet=True, train_text_encoder=False, weight_loss_img=8.0, weight_loss_face=0.0, img_size_small=56)
+    tokens = U.tiny_tokens()
+    B, S = 4, 4
+    noises = torch.randn(B, 4, 32, 32, generator=torch.Generator().manual_seed(5991))
+    for p in om["lora_params"]:
+        p.grad = None
+    cfg = dict(train_GPU_batch_size=3, val_GPU_batch_size=8, uncertainty_threshold=0.2, factor1=0.2, factor2=0.2, size_face=64,
+               weight_loss_img=8.0, img_size_small=56)
+    ref = fs.fairness_step(models_o, tokens, noises, S, cfg)
+    ref_total = torch.cat([p.grad.flatten() for p in om["unet_lora_layers"].parameters()]).clone()
+    clip_p = VisionTransformer(TINY["clip_vision"], sd_c, dev, W.CLIP_IMAGE_MEAN, W.CLIP_IMAGE_STD)
+    dino_p = VisionTransformer(TINY["dino"], sd_d, dev, W.DINO_IMAGE_MEAN, W.DINO_IMAGE_STD)
+    tr = FairnessTrainer(args, pm["text_encoder"], pm["unet"], pm["vae"], pm["classifier"], pm["scheduler"], eval_unet=pm["eval_unet"], device=dev,
+                         clip_model=clip_p, dino_model=dino_p)
+    grads = {}
+    tr.sync_and_update = lambda nb, apply=True: (grads.__setitem__(0, tr.banks[0].grad.clone()), True)[1]
+    out = tr.train_step(tokens, noises, S)
+    assert out["targets"].tolist() == ref["targets"].tolist()
+    check("loss_CLIP", out["loss_CLIP"], ref["loss_CLIP"], 3e-2)
+    check("loss_DINO", out["loss_DINO"], ref["loss_DINO"], 3e-2)
+    check("loss (sum of terms, -1 sentinels included)", out["loss"], ref["loss"], 2e-2)
+    names = list(om["unet_lora_layers"].state_dict().keys())
+    got = torch.cat([tr.banks[0].view(n, grads[0]).flatten() for n in names]).cpu().double()
+    cos = F.cosine_similarity(got, ref_total.double(), dim=0)
+    print("cosine(unet grads, fair + image terms) =", float(cos))
+    assert cos > 0.97
+    # the regulariser contribution itself: subtract the fairness-only gradient on both sides
+    for p in om["lora_params"]:
+        p.grad = None
+    fs.fairness_step(models_o, tokens, noises, S, dict(cfg, weight_loss_img=0.0))
+    ref_fair = torch.cat([p.grad.flatten() for p in om["unet_lora_layers"].parameters()]).double()
+    args0 = U.make_args(train_unet=True, train_text_encoder=False, weight_loss_img=0.0, weight_loss_face=0.0, img_size_small=56)
+    tr0 = FairnessTrainer(args0, pm["text_encoder"], pm["unet"], pm["vae"], pm["classifier"], pm["scheduler"], eval_unet=pm["eval_unet"], device=dev)
+    g0 = {}
+    tr0.sync_and_update = lambda nb, apply=True: (g0.__setitem__(0, tr0.banks[0].grad.clone()), True)[1]
+    tr0.train_step(tokens, noises, S)
+    got_fair = torch.cat([tr0.banks[0].view(n, g0[0]).flatten() for n in names]).cpu().double()
+    cos_reg = F.cosine_similarity(got - got_fair, ref_total.double() - ref_fair, dim=0)
+    ratio = float((got - got_fair).norm() / (ref_total.double() - ref_fair).norm())
+    print("cosine(regulariser part) =", float(cos_reg), " norm ratio =", ratio, " |reg|/|fair| =", float((ref_total.double() - ref_fair).norm() / ref_fair.norm()))
+    assert cos_reg > 0.97 and 0.8 < ratio < 1.25
+    with pytest.raises(NotImplementedError):
+        FairnessTrainer(U.make_args(weight_loss_img=8.0, weight_loss_face=1.0, img_size_small=56), pm["text_encoder"], pm["unet"], pm["vae"],
+                        pm["classifier"], pm["scheduler"], eval_unet=pm["eval_unet"], device=dev, clip_model=clip_p, dino_model=dino_p)
