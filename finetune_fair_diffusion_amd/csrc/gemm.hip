@@ -90,50 +90,60 @@ __device__ __forceinline__ void gemm_epilogue(const fd_gemm_desc& p, f32x4 (&acc
 // row segments per store instruction; short-K GEMMs are bound by exactly that store path.  Here each wave parks its
 // WTM x WTN tile in LDS (bias / row-bias / activation already applied) and re-reads it as 16 bytes per lane so that a
 // store instruction covers whole 128-byte row segments; the residual is added on the way out with 16-byte loads.
-template <int TM, int TN>
+template <int TM, int TN, int TMC = TM>
 __device__ __forceinline__ void gemm_epilogue_lds(const fd_gemm_desc& p, f32x4 (&acc)[TM][TN], f16* wave_lds, int mbase, int nbase,
                                                   int lane, int64_t zC, int64_t zR) {
-    constexpr int WTN = TN * 16, WTM = TM * 16, LDW = WTN + 4;   // +4 halfs: 8-byte aligned rows, spreads the ds_write_b64 banks
+    // TMC: 16-row groups staged per pass (the wave-private LDS region holds TMC*16 rows; big tiles need two passes)
+    constexpr int WTN = TN * 16, WTMC = TMC * 16, LDW = WTN + 4;   // +4 halfs: 8-byte aligned rows, spreads the ds_write_b64 banks
+    static_assert(TM % TMC == 0, "chunking");
     const int l15 = lane & 15, lg = lane >> 4;
     const f16* RB = (const f16*)p.rowbias;
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int n = nbase + j * 16 + lg * 4;
-        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-        if (p.bias && n < p.N) bv = *(const f32x4*)(p.bias + n);
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int m = mbase + i * 16 + l15;
-            f16x4 rbv = {0, 0, 0, 0};
-            if (RB && m < p.M && n < p.N) rbv = *(const f16x4*)(RB + (int64_t)(m / p.rows_per_batch) * p.ld_rowbias + n);
-            f16x4 o;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) o[r] = (f16)apply_act(acc[i][j][r] * p.alpha + bv[r] + (float)rbv[r], p.act);
-            *(f16x4*)(wave_lds + (i * 16 + l15) * LDW + j * 16 + lg * 4) = o;
-        }
-    }
-    // wave-private region: no block barrier needed, only this wave's own LDS writes must have landed
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
     const f16* R = p.residual ? (const f16*)p.residual + zR : nullptr;
     constexpr int CPR = WTN / 8;                 // 16-byte chunks per row
     constexpr int RPI = 64 / CPR;                // rows per store instruction
     const int cr = lane / CPR, cc = (lane % CPR) * 8;
 #pragma unroll
-    for (int r0 = 0; r0 < WTM; r0 += RPI) {
-        const int row = r0 + cr;
-        const int m = mbase + row, n = nbase + cc;
-        if (row < WTM && m < p.M && n < p.N) {
-            // LDS rows are 8-byte aligned (LDW*2 bytes is a multiple of 8): two 8-byte reads
-            const f16x4 lo = *(const f16x4*)(wave_lds + row * LDW + cc);
-            const f16x4 hi = *(const f16x4*)(wave_lds + row * LDW + cc + 4);
-            f16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-            if (R) {
-                const f16x8 rv = *(const f16x8*)(R + (int64_t)m * p.ldr + n);
+    for (int c0 = 0; c0 < TM; c0 += TMC) {
 #pragma unroll
-                for (int k = 0; k < 8; ++k) v[k] = (f16)((float)v[k] + (float)rv[k]);
+        for (int j = 0; j < TN; ++j) {
+            const int n = nbase + j * 16 + lg * 4;
+            f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+            if (p.bias && n < p.N) bv = *(const f32x4*)(p.bias + n);
+#pragma unroll
+            for (int ii = 0; ii < TMC; ++ii) {
+                const int i = c0 + ii;
+                const int m = mbase + i * 16 + l15;
+                f16x4 rbv = {0, 0, 0, 0};
+                if (RB && m < p.M && n < p.N) rbv = *(const f16x4*)(RB + (int64_t)(m / p.rows_per_batch) * p.ld_rowbias + n);
+                f16x4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = (f16)apply_act(acc[i][j][r] * p.alpha + bv[r] + (float)rbv[r], p.act);
+                *(f16x4*)(wave_lds + (ii * 16 + l15) * LDW + j * 16 + lg * 4) = o;
             }
-            *(f16x8*)((f16*)p.C + zC + (int64_t)m * p.ldc + n) = v;
+        }
+        // wave-private region: no block barrier needed, only this wave's own LDS writes must have landed
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int r0 = 0; r0 < WTMC; r0 += RPI) {
+            const int row = r0 + cr;
+            const int m = mbase + c0 * 16 + row, n = nbase + cc;
+            if (cr < RPI && row < WTMC && m < p.M && n < p.N) {
+                // LDS rows are 8-byte aligned (LDW*2 bytes is a multiple of 8): two 8-byte reads
+                const f16x4 lo = *(const f16x4*)(wave_lds + row * LDW + cc);
+                const f16x4 hi = *(const f16x4*)(wave_lds + row * LDW + cc + 4);
+                f16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                if (R) {
+                    const f16x8 rv = *(const f16x8*)(R + (int64_t)m * p.ldr + n);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v[k] = (f16)((float)v[k] + (float)rv[k]);
+                }
+                *(f16x8*)((f16*)p.C + zC + (int64_t)m * p.ldc + n) = v;
+            }
+        }
+        if (c0 + TMC < TM) {   // the next pass overwrites the staging rows: this wave's reads must have returned
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
         }
     }
 }
@@ -484,7 +494,18 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_big_kernel(fd_gemm_desc p
         }
         return;
     }
-    gemm_epilogue<TM, TN>(p, acc, m0 + wm * WTM, n0 + wn * WTN, l15, lg, 0, 0);
+    const bool lds_epi = p.out_dtype == FD_OUT_F16 && (p.N & 7) == 0 && (p.ldc & 7) == 0 && (!p.residual || (p.ldr & 7) == 0) &&
+                         (!p.rowbias || (p.ld_rowbias & 3) == 0);
+    if (lds_epi) {
+        // stage the wave tile through the (now idle) operand LDS so that stores are 16 bytes per lane over whole row segments
+        constexpr int LDS_HALFS = 2 * (BM + BN) * 64;
+        constexpr int TMC = (NW * WTM * (WTN + 4) <= LDS_HALFS) ? TM : TM / 2;
+        static_assert(NW * TMC * 16 * (WTN + 4) <= LDS_HALFS, "epilogue staging does not fit");
+        __syncthreads();
+        gemm_epilogue_lds<TM, TN, TMC>(p, acc, smem + wave * (TMC * 16) * (WTN + 4), m0 + wm * WTM, n0 + wn * WTN, lane, 0, 0);
+    } else {
+        gemm_epilogue<TM, TN>(p, acc, m0 + wm * WTM, n0 + wn * WTN, l15, lg, 0, 0);
+    }
 }
 
 // sum the split-K slabs in a fixed order and apply the epilogue
