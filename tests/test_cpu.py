@@ -455,3 +455,53 @@ def test_hash_tokenizer_shapes_like_reference_calls():
     assert len(ps) == 12 and "doctor" in ps[0]
     with pytest.raises(FileNotFoundError):
         load_prompts(types.SimpleNamespace(prompt_occupation_path="/nonexistent.json", synthetic=False))
+
+
+# ------------------------------------------------------------------------------------------ image encoders of the regularisers
+def test_oracle_clip_vision_pinned_against_transformers():
+    """oracle.nn_vit.CLIPVisionModelWithProjection == the installed transformers implementation on the same random weights
+    (get_clip_feat, 1-main-debias.py:1139-1156 uses transformers' model)."""
+    from transformers import CLIPVisionConfig, CLIPVisionModelWithProjection
+    from oracle import nn_vit as V
+    c = V.ViTConfig(image_size=56, patch_size=14, hidden_size=64, num_hidden_layers=2, num_attention_heads=4, intermediate_size=128,
+                    projection_dim=32, pos_grid=4)
+    hc = CLIPVisionConfig(hidden_size=64, intermediate_size=128, projection_dim=32, num_hidden_layers=2, num_attention_heads=4, image_size=56,
+                          patch_size=14, hidden_act="gelu")
+    torch.manual_seed(0)
+    hf = CLIPVisionModelWithProjection(hc).eval()
+    sd = {k: v for k, v in hf.state_dict().items() if "position_ids" not in k}
+    from finetune_fair_diffusion_amd import weights as W
+    shapes = W.vit_param_shapes(W.ViTConfig(**c.__dict__))
+    assert {k: tuple(v.shape) for k, v in sd.items()} == {k: tuple(v) for k, v in shapes.items()}      # key names + shapes are transformers'
+    mine = V.build(c, sd)
+    x = torch.randn(3, 3, 56, 56)
+    with torch.no_grad():
+        a, b = hf(pixel_values=x).image_embeds, mine(x)
+    assert float((a - b).abs().max()) < 1e-5 * float(a.abs().max())
+
+
+def test_vit_inventories_and_feature_loss_gradient():
+    from finetune_fair_diffusion_amd import weights as W
+    from finetune_fair_diffusion_amd.vit import feature_loss_and_grad, _interpolate_pos
+    from oracle import nn_vit as V
+    n = lambda c: sum(int(np.prod(s)) for s in W.vit_param_shapes(c).values())  # noqa: E731
+    assert n(W.CLIP_VIT_H14) == 632_076_800 and n(W.DINOV2_VITB14) == 86_579_712      # ViT-H/14 with projection; dinov2_vitb14 (without mask_token)
+    # oracle modules accept the product inventories (names + shapes), both kinds
+    for cfg in (W.ViTConfig(kind="dino", image_size=56, hidden_size=64, num_hidden_layers=1, num_attention_heads=2, intermediate_size=128,
+                            projection_dim=0, layer_norm_eps=1e-6, pos_grid=6),
+                W.ViTConfig(kind="clip", image_size=56, hidden_size=64, num_hidden_layers=1, num_attention_heads=2, intermediate_size=128,
+                            projection_dim=16, pos_grid=4)):
+        V.build(V.ViTConfig(**cfg.__dict__), W.synthetic_state_dict(W.vit_param_shapes(cfg), seed=1))
+    # position-table interpolation: product host code == oracle
+    pe = torch.randn(1, 1 + 36, 8)
+    assert torch.allclose(_interpolate_pos(pe, 4), V.interpolate_pos_encoding(pe, 4), atol=1e-6)
+    assert torch.equal(_interpolate_pos(pe, 6), pe)
+    # 1 - cos loss and its gradient vs autograd
+    g = torch.Generator().manual_seed(0)
+    e = torch.randn(5, 12, generator=g, requires_grad=True)
+    t = torch.nn.functional.normalize(torch.randn(5, 12, generator=g), dim=-1)
+    w = torch.rand(5, generator=g)
+    loss_ref = 1 - (torch.nn.functional.normalize(e, dim=-1) * t).sum(-1)
+    (loss_ref * w).sum().backward()
+    loss, de = feature_loss_and_grad(e.detach(), t, w)
+    assert torch.allclose(loss, loss_ref.detach(), atol=1e-6) and torch.allclose(de, e.grad, atol=1e-6)
