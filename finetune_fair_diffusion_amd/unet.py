@@ -28,6 +28,17 @@ class _Out:
         self.sample = sample
 
 
+class LoRAAttnProcessor:
+    """Constructor-compatible stand-in for ``diffusers.models.attention_processor.LoRAAttnProcessor`` as the reference builds
+    it (:811-815): carries the sizes only; the tensors live in the U-Net's flat ParamBank once ``set_attn_processor`` ran."""
+
+    def __init__(self, hidden_size, cross_attention_dim=None, rank=4):
+        self.hidden_size, self.cross_attention_dim, self.rank = hidden_size, cross_attention_dim, rank
+
+    def to(self, *a, **k):
+        return self
+
+
 class AttnLoRA:
     """The four LoRALinearLayers of one LoRAAttnProcessor."""
 
@@ -234,7 +245,31 @@ class UNet2DConditionModel:
     def attn_processors(self):
         return {n: (getattr(self._tr_by_name[n][0], f"lora{self._tr_by_name[n][1]}")) for n in unet_attn_names(self.config)}
 
-    def enable_gradient_checkpointing(self):  # always on: the step recomputes per timestep
+    def set_attn_processor(self, processors):
+        """``unet.set_attn_processor(unet_lora_procs)`` (:818, gen-images.py:517): a dict name -> ``LoRAAttnProcessor``
+        (any object with ``hidden_size``, ``cross_attention_dim`` and ``rank``) for all 32 attention layers."""
+        names = unet_attn_names(self.config)
+        if set(processors) != set(names):
+            raise ValueError(f"expected {len(names)} attention processors, got {len(processors)} with different names")
+        ranks = {p.rank for p in processors.values()}
+        if len(ranks) != 1:
+            raise ValueError(f"all LoRA processors must share one rank, got {sorted(ranks)}")
+        shapes = unet_lora_param_shapes(self.config, ranks.pop())
+        for n, p in processors.items():
+            cin = shapes[n + ".to_k_lora.down.weight"][1]
+            hid = shapes[n + ".to_q_lora.down.weight"][1]
+            if p.hidden_size != hid or (p.cross_attention_dim or hid) != cin:
+                raise ValueError(f"{n}: processor sizes ({p.hidden_size}, {p.cross_attention_dim}) do not match the U-Net ({hid}, {cin})")
+        return self.add_lora(next(iter(processors.values())).rank, seed=getattr(next(iter(processors.values())), "seed", 0))
+
+    @property
+    def dtype(self):
+        return F16
+
+    def to(self, *a, **k):
+        return self
+
+    def enable_gradient_checkpointing(self):  # nothing to enable: activations are kept in HBM or recomputed per timestep by the step
         return None
 
     def train(self, mode=True):

@@ -113,6 +113,16 @@ class AutoencoderKL:
             self._ctx = dict(blocks=ctx, x_out=x, st_out=st, pre=y, B=B, H=H, W=W, h=z.shape[2], w=z.shape[3])
         return img
 
+    @property
+    def dtype(self):
+        return F16
+
+    def to(self, *a, **k):
+        return self
+
+    def requires_grad_(self, flag=False):
+        return self
+
     def decode(self, z):
         """diffusers-style: ``vae.decode(latents).sample`` (un-clamped values are not exposed; the
         reference clamps immediately)."""

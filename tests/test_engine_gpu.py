@@ -484,3 +484,36 @@ def test_full_step_with_image_regularisers(dev):
     with pytest.raises(NotImplementedError):
         FairnessTrainer(U.make_args(weight_loss_img=8.0, weight_loss_face=1.0, img_size_small=56), pm["text_encoder"], pm["unet"], pm["vae"],
                         pm["classifier"], pm["scheduler"], eval_unet=pm["eval_unet"], device=dev, clip_model=clip_p, dino_model=dino_p)
+
+
+def test_reference_style_lora_injection(dev):
+    """The reference's injection loop (1-main-debias.py:800-818) runs unchanged against the mirror: attn_processors keys,
+    hidden sizes by name prefix, set_attn_processor, then load_state_dict(strict=False) of an exported file."""
+    from finetune_fair_diffusion_amd import weights as W
+    from finetune_fair_diffusion_amd.unet import LoRAAttnProcessor, UNet2DConditionModel
+    cfg = W.UNetConfig(**U.TINY_UNET)
+    unet = UNet2DConditionModel(cfg, W.synthetic_state_dict(W.unet_param_shapes(cfg), seed=1), dev)
+    procs = {}
+    for name in unet.attn_processors.keys():
+        cross_attention_dim = None if name.endswith("attn1.processor") else unet.config.cross_attention_dim
+        if name.startswith("mid_block"):
+            hidden_size = unet.config.block_out_channels[-1]
+        elif name.startswith("up_blocks"):
+            hidden_size = list(reversed(unet.config.block_out_channels))[int(name[len("up_blocks.")])]
+        elif name.startswith("down_blocks"):
+            hidden_size = unet.config.block_out_channels[int(name[len("down_blocks.")])]
+        procs[name] = LoRAAttnProcessor(hidden_size=hidden_size, cross_attention_dim=cross_attention_dim, rank=4).to(dev)
+    unet.set_attn_processor(procs)
+    assert len(unet.attn_processors) == 32 and unet.lora_bank is not None and len(unet.lora_bank.names) == 256
+    sd = {n: torch.full(unet.lora_bank.shape(n), 0.5) for n in unet.lora_bank.names}
+    unet.load_state_dict(sd, strict=False)
+    assert float(unet.lora_bank.flat.max()) == 0.5
+    bad = dict(procs)
+    bad.pop(next(iter(bad)))
+    with pytest.raises(ValueError):
+        unet.set_attn_processor(bad)
+    wrong = dict(procs)
+    k = next(iter(wrong))
+    wrong[k] = LoRAAttnProcessor(hidden_size=7, cross_attention_dim=None, rank=4)
+    with pytest.raises(ValueError):
+        unet.set_attn_processor(wrong)
