@@ -308,3 +308,65 @@ extern "C" int fd_crop_resize_bwd(const float* dchips, const int32_t* boxes, flo
     hipLaunchKernelGGL(crop_resize_bwd_kernel, grid1d(n), dim3(256), 0, (hipStream_t)stream, dchips, boxes, dimg, H, W, S, n);
     return fd_check_launch("fd_crop_resize_bwd");
 }
+
+// ---------------------------------------------------------------- affine face alignment (image_pipeline, 1-main-debias.py:292-312)
+// kornia.warp_affine(bilinear, zeros padding) applied to (img+1)/2*255 and mapped back: in [-1,1] space that is bilinear sampling
+// with out-of-bounds taps reading -1 (``fill``).  A[n] = 2x3 map from output pixel (x, y, 1) to the sampling position in input
+// pixel units (grid_sample convention already folded in on the host).  img [B,3,H,W] fp16, src_index[n] selects the image of chip n.
+__global__ void warp_affine_fwd_kernel(const f16* img, const int32_t* src_index, const float* A, float fill, f16* chips, int H, int W,
+                                       int S, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int ox = (int)(i % S);
+        int64_t p = i / S;
+        const int oy = (int)(p % S); p /= S;
+        const int c = (int)(p % 3);
+        const int k = (int)(p / 3);
+        const float* a = A + k * 6;
+        const float xs = a[0] * ox + a[1] * oy + a[2], ys = a[3] * ox + a[4] * oy + a[5];
+        const float xf = floorf(xs), yf = floorf(ys);
+        const int x0 = (int)xf, y0 = (int)yf;
+        const float lx = xs - xf, ly = ys - yf;
+        const f16* ip = img + ((int64_t)src_index[k] * 3 + c) * H * W;
+        auto at = [&](int yy, int xx) -> float { return (yy >= 0 && yy < H && xx >= 0 && xx < W) ? (float)ip[(int64_t)yy * W + xx] : fill; };
+        const float v = (1.f - ly) * ((1.f - lx) * at(y0, x0) + lx * at(y0, x0 + 1)) + ly * ((1.f - lx) * at(y0 + 1, x0) + lx * at(y0 + 1, x0 + 1));
+        chips[i] = (f16)v;
+    }
+}
+__global__ void warp_affine_bwd_kernel(const float* dchips, const int32_t* src_index, const float* A, float* dimg, int H, int W, int S,
+                                       int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int ox = (int)(i % S);
+        int64_t p = i / S;
+        const int oy = (int)(p % S); p /= S;
+        const int c = (int)(p % 3);
+        const int k = (int)(p / 3);
+        const float* a = A + k * 6;
+        const float xs = a[0] * ox + a[1] * oy + a[2], ys = a[3] * ox + a[4] * oy + a[5];
+        const float xf = floorf(xs), yf = floorf(ys);
+        const int x0 = (int)xf, y0 = (int)yf;
+        const float lx = xs - xf, ly = ys - yf;
+        float* ip = dimg + ((int64_t)src_index[k] * 3 + c) * H * W;
+        const float g = dchips[i];
+        auto put = [&](int yy, int xx, float wgt) {
+            if (yy >= 0 && yy < H && xx >= 0 && xx < W) atomicAdd(ip + (int64_t)yy * W + xx, g * wgt);
+        };
+        put(y0, x0, (1.f - ly) * (1.f - lx));
+        put(y0, x0 + 1, (1.f - ly) * lx);
+        put(y0 + 1, x0, ly * (1.f - lx));
+        put(y0 + 1, x0 + 1, ly * lx);
+    }
+}
+extern "C" int fd_warp_affine_fwd(const void* img, const int32_t* src_index, const float* A, float fill, void* chips, int n_chips, int H, int W,
+                                  int S, void* stream) {
+    const int64_t n = (int64_t)n_chips * 3 * S * S;
+    if (n == 0) return FD_OK;
+    hipLaunchKernelGGL(warp_affine_fwd_kernel, grid1d(n), dim3(256), 0, (hipStream_t)stream, (const f16*)img, src_index, A, fill, (f16*)chips, H, W, S, n);
+    return fd_check_launch("fd_warp_affine_fwd");
+}
+extern "C" int fd_warp_affine_bwd(const float* dchips, const int32_t* src_index, const float* A, float* dimg, int n_chips, int H, int W, int S,
+                                  void* stream) {
+    const int64_t n = (int64_t)n_chips * 3 * S * S;
+    if (n == 0) return FD_OK;
+    hipLaunchKernelGGL(warp_affine_bwd_kernel, grid1d(n), dim3(256), 0, (hipStream_t)stream, dchips, src_index, A, dimg, H, W, S, n);
+    return fd_check_launch("fd_warp_affine_bwd");
+}

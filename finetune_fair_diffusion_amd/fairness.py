@@ -25,15 +25,70 @@ def expand_bbox(bbox, expand_coef, target_ratio):
             int(round(bbox[2] + more_w * 0.5)), int(round(bbox[3] + more_h * 0.5))]
 
 
+# canonical 5-point template of the 112x112 aligned chip (:297-303): eyes, nose, mouth corners
+ALIGNED_FACE_LANDMARKS = np.array([[38.2946, 51.6963], [73.5318, 51.5014], [56.0252, 71.7366], [41.5493, 92.3655], [70.7299, 92.2041]])
+
+
 class SyntheticFaceProvider:
     """Deterministic stand-in for the detector side-car: every image has one face whose raw detector
     box is the centred half-size square; the reference's ``expand_bbox(bbox, 0.5, 1)`` then applies
-    (:1335).  A real provider returns (indicators [N] bool, boxes [N,4] int, -1 where no face)."""
+    (:1335).  A real provider returns (indicators [N] bool, boxes [N,4] int, -1 where no face) and, for the
+    face-realism term, ``landmarks(images)`` -> [N,5,2] float (x,y) pixel positions (-1 where no face)."""
 
     def __call__(self, images):
         N, _, H, W = images.shape
         box = expand_bbox([0.25 * W, 0.25 * H, 0.75 * W, 0.75 * H], 0.5, 1)
         return torch.ones(N, dtype=torch.bool), torch.tensor([box] * N, dtype=torch.int32)
+
+    def landmarks(self, images):
+        """The canonical template scaled into the raw detector box."""
+        N, _, H, W = images.shape
+        pts = ALIGNED_FACE_LANDMARKS / 112.0 * np.array([0.5 * W, 0.5 * H]) + np.array([0.25 * W, 0.25 * H])
+        return torch.tensor(pts, dtype=torch.float32)[None].repeat(N, 1, 1)
+
+
+def umeyama_similarity(src, dst):
+    """Least-squares similarity transform (Umeyama 1991) with scale, mapping ``src`` -> ``dst`` points [n,2]; what
+    ``skimage.transform.SimilarityTransform().estimate(src, dst)`` stores in ``.params`` (:305-306).  Returns the 3x3 matrix."""
+    src, dst = np.asarray(src, dtype=np.float64), np.asarray(dst, dtype=np.float64)
+    n, dim = src.shape
+    ms, md = src.mean(axis=0), dst.mean(axis=0)
+    s0, d0 = src - ms, dst - md
+    cov = d0.T @ s0 / n
+    sign = np.ones(dim)
+    if np.linalg.det(cov) < 0:
+        sign[-1] = -1
+    U, S, Vt = np.linalg.svd(cov)
+    rank = np.linalg.matrix_rank(cov)
+    T = np.eye(dim + 1)
+    if rank == 0:
+        return np.full_like(T, np.nan)
+    if rank == dim - 1 and np.linalg.det(U) * np.linalg.det(Vt) <= 0:
+        flip = sign.copy()
+        flip[-1] = -1
+        T[:dim, :dim] = U @ np.diag(flip) @ Vt
+    elif rank == dim - 1:
+        T[:dim, :dim] = U @ Vt
+    else:
+        T[:dim, :dim] = U @ np.diag(sign) @ Vt
+    scale = (S @ sign) / s0.var(axis=0).sum()
+    T[:dim, dim] = md - scale * (T[:dim, :dim] @ ms)
+    T[:dim, :dim] *= scale
+    return T
+
+
+def alignment_sampling_matrix(landmarks, H, W, crop=112):
+    """image_pipeline (:292-312) as one 2x3 matrix per face: output pixel (x, y, 1) of the ``crop`` x ``crop`` chip -> sampling
+    position in input pixels.  Folds together the similarity transform image -> template, kornia 0.7 ``warp_affine``'s
+    normalisation of that pixel homography with (size-1), ``affine_grid`` and ``grid_sample`` at ``align_corners=False``:
+        base grid  x_n = (2x+1)/crop - 1;  kornia dst pixel  x_d = (x_n+1)(crop-1)/2;  src pixel p = M^-1 x_d;
+        normalised g = 2p/(W-1) - 1;  sampled position  ((g+1) W - 1)/2 = p W/(W-1) - 1/2."""
+    M = umeyama_similarity(np.asarray(landmarks, dtype=np.float64), ALIGNED_FACE_LANDMARKS * (crop / 112.0))
+    Minv = np.linalg.inv(M)
+    a = (crop - 1.0) / crop
+    to_dst = np.array([[a, 0.0, 0.5 * a], [0.0, a, 0.5 * a], [0.0, 0.0, 1.0]])                 # output pixel index -> kornia dst pixel
+    to_samp = np.array([[W / (W - 1.0), 0.0, -0.5], [0.0, H / (H - 1.0), -0.5], [0.0, 0.0, 1.0]])  # src pixel -> grid_sample position
+    return (to_samp @ Minv @ to_dst)[:2].reshape(6)
 
 
 @torch.no_grad()

@@ -477,6 +477,22 @@ def patchify_bwd(dpatches, std, N, S, P, scale=1.0, out=None):
     return out
 
 
+def warp_affine(img, src_index, A, S, fill=-1.0):
+    """chips [n,3,S,S] fp16 sampled from img [B,3,H,W] fp16 through the per-chip 2x3 maps A [n,6] (output pixel -> input position)."""
+    n = A.shape[0]
+    _, _, H, W = img.shape
+    chips = torch.empty((n, 3, S, S), dtype=F16, device=img.device)
+    _call("fd_warp_affine_fwd", _p(_chk(img)), _p(src_index), _p(_chk(A, F32)), fill, _p(chips), n, H, W, S, _stream())
+    return chips
+
+
+def warp_affine_bwd(dchips, src_index, A, dimg, S):
+    """dimg [B,3,H,W] fp32 += scatter of dchips [n,3,S,S] fp32."""
+    _, _, H, W = dimg.shape
+    _call("fd_warp_affine_bwd", _p(_chk(dchips, F32)), _p(src_index), _p(_chk(A, F32)), _p(_chk(dimg, F32)), A.shape[0], H, W, S, _stream())
+    return dimg
+
+
 def rect_scale(dimg, rects, factors):
     B, _, H, W = dimg.shape
     _call("fd_rect_scale", _p(_chk(dimg, F32)), _p(rects), _p(_chk(factors, F32)), B, H, W, _stream())

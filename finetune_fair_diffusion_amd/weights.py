@@ -327,6 +327,26 @@ def vit_param_shapes(c: ViTConfig) -> "OrderedDict[str, tuple]":
     return sd
 
 
+# ------------------------------------------------------------------------------------------ face-feature network (face-realism term)
+SFNET20_LAYERS = (1, 2, 4, 1)
+SFNET20_CHANNELS = (64, 128, 256, 512)
+
+
+def sfnet20_param_shapes(channels=SFNET20_CHANNELS, out_channel=512, in_size=112) -> "OrderedDict[str, tuple]":
+    """opensphere ``sfnet20`` without norm layers (opensphere/model/backbone/sfnet.py:123-202, 252-261): per stage a stride-2 ConvBlock
+    (``layerK.0.conv1``) and n BasicBlocks (``layerK.j.conv1/conv2``), then ``fc`` on the NCHW-flattened 7x7 map."""
+    sd = OrderedDict()
+    cin = 3
+    for i, (c, n) in enumerate(zip(channels, SFNET20_LAYERS)):
+        sd[f"layer{i + 1}.0.conv1.weight"] = (c, cin, 3, 3); sd[f"layer{i + 1}.0.conv1.bias"] = (c,)
+        for j in range(1, n + 1):
+            for k in ("conv1", "conv2"):
+                sd[f"layer{i + 1}.{j}.{k}.weight"] = (c, c, 3, 3); sd[f"layer{i + 1}.{j}.{k}.bias"] = (c,)
+        cin = c
+    sd["fc.weight"] = (out_channel, channels[3] * (in_size // 16) ** 2); sd["fc.bias"] = (out_channel,)
+    return sd
+
+
 # ------------------------------------------------------------------------------------------ synthetic init
 def synthetic_state_dict(shapes, seed=0, device="cpu", gain=1.0, dtype=torch.float32):
     """Variance-preserving random weights: W ~ N(0, gain^2/fan_in), biases ~ N(0, 0.02^2),

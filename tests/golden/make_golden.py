@@ -144,6 +144,28 @@ def main():
     json.dump(multi, open(os.path.join(HERE, "reference_cli_multi.json"), "w"), indent=1, sort_keys=True)
     print("wrote multi-attribute CLI goldens:", {k: len(v["defaults"]) for k, v in multi.items()})
 
+    sfnet_golden()
+
+
+def sfnet_golden():
+    """opensphere's own ``sfnet20`` (vendored under /root/reference/opensphere, pure torch) on the build's seeded synthetic weights and
+    a seeded input: pins oracle/nn_sfnet.py::SFNet20 (same state-dict keys) to the reference's module."""
+    sys.path.insert(0, "/root/reference")
+    sys.path.insert(0, "/root/reference/opensphere")
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from opensphere.model.backbone.sfnet import sfnet20
+    from finetune_fair_diffusion_amd import weights as W
+    sd = W.synthetic_state_dict(W.sfnet20_param_shapes(), seed=31)
+    net = sfnet20().eval()
+    net.load_state_dict(sd, strict=True)
+    x = torch.rand(2, 3, 112, 112, generator=torch.Generator().manual_seed(77)) * 2 - 1
+    with torch.no_grad():
+        y = net(x)
+        y2 = net(torch.flip(x, [3]))
+    json.dump(dict(weights_seed=31, input_seed=77, n_params=sum(p.numel() for p in net.parameters()), keys=list(net.state_dict().keys()),
+                   out=y.tolist(), out_flipped=y2.tolist()), open(os.path.join(HERE, "reference_sfnet20.json"), "w"))
+    print("wrote sfnet20 golden:", tuple(y.shape), float(y.abs().max()))
+
 
 if __name__ == "__main__":
     main()

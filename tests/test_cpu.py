@@ -505,3 +505,65 @@ def test_vit_inventories_and_feature_loss_gradient():
     (loss_ref * w).sum().backward()
     loss, de = feature_loss_and_grad(e.detach(), t, w)
     assert torch.allclose(loss, loss_ref.detach(), atol=1e-6) and torch.allclose(de, e.grad, atol=1e-6)
+
+
+# ------------------------------------------------------------------------------------------ face-realism term pieces
+def test_oracle_sfnet20_pinned_against_opensphere_golden():
+    """oracle.nn_sfnet.SFNet20 reproduces the outputs of the reference's own opensphere sfnet20 (tests/golden/reference_sfnet20.json,
+    generated by importing /root/reference/opensphere) on the same seeded weights and input; key names are the reference's."""
+    from finetune_fair_diffusion_amd import weights as W
+    from oracle import nn_sfnet as OS
+    gold = json.load(open(os.path.join(HERE, "golden", "reference_sfnet20.json")))
+    sd = W.synthetic_state_dict(W.sfnet20_param_shapes(), seed=gold["weights_seed"])
+    assert list(sd.keys()) == gold["keys"] or set(sd.keys()) == set(gold["keys"])
+    assert sum(v.numel() for v in sd.values()) == gold["n_params"] == 24_500_992
+    net = OS.SFNet20().eval()
+    net.load_state_dict(sd, strict=True)
+    x = torch.rand(2, 3, 112, 112, generator=torch.Generator().manual_seed(gold["input_seed"])) * 2 - 1
+    with torch.no_grad():
+        y, y2 = net(x), net(torch.flip(x, [3]))
+        f = OS.get_face_feats(net, x, normalize=False)
+    ref, ref2 = torch.tensor(gold["out"]), torch.tensor(gold["out_flipped"])
+    assert float((y - ref).abs().max()) < 1e-4 * float(ref.abs().max())
+    assert float((y2 - ref2).abs().max()) < 1e-4 * float(ref2.abs().max())
+    assert torch.allclose(f, ref + ref2, atol=1e-3)
+
+
+def test_face_alignment_host_math():
+    """Umeyama similarity: exact recovery of a known transform, product == oracle restatement; the folded 2x3 sampling matrix equals
+    the oracle's kornia-style normalise / affine_grid / grid_sample chain (bilinear taps evaluated on the CPU)."""
+    from finetune_fair_diffusion_amd.fairness import ALIGNED_FACE_LANDMARKS, SyntheticFaceProvider, alignment_sampling_matrix, umeyama_similarity
+    from oracle import nn_sfnet as OS
+    th, sc, t = 0.3, 1.7, np.array([5.0, -3.0])
+    R = np.array([[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]])
+    src = np.random.RandomState(0).rand(5, 2) * 100
+    T = umeyama_similarity(src, (sc * (R @ src.T)).T + t)
+    assert np.abs(T[:2, :2] - sc * R).max() < 1e-12 and np.abs(T[:2, 2] - t).max() < 1e-10
+    assert np.array_equal(ALIGNED_FACE_LANDMARKS, OS.SRC_LANDMARKS)
+    H = W = 64
+    crop = 28
+    rng = np.random.RandomState(1)
+    lm = OS.SRC_LANDMARKS / 112 * 30 + np.array([17.0, 12.0]) + rng.randn(5, 2)
+    assert np.allclose(umeyama_similarity(lm, OS.SRC_LANDMARKS), OS.umeyama(lm, OS.SRC_LANDMARKS))
+    A = alignment_sampling_matrix(lm, H, W, crop).reshape(2, 3)
+    img = torch.rand(3, H, W, generator=torch.Generator().manual_seed(0)) * 2 - 1
+    ref = OS.image_pipeline(img, lm, crop).numpy()
+    ys, xs = np.meshgrid(np.arange(crop), np.arange(crop), indexing="ij")
+    px, py = A[0, 0] * xs + A[0, 1] * ys + A[0, 2], A[1, 0] * xs + A[1, 1] * ys + A[1, 2]
+    x0, y0 = np.floor(px).astype(int), np.floor(py).astype(int)
+    lx, ly = px - x0, py - y0
+
+    def at(c, yy, xx):
+        ok = (yy >= 0) & (yy < H) & (xx >= 0) & (xx < W)
+        v = np.full(yy.shape, -1.0)
+        v[ok] = img[c].numpy()[yy[ok], xx[ok]]
+        return v
+    out = np.stack([(1 - ly) * ((1 - lx) * at(c, y0, x0) + lx * at(c, y0, x0 + 1)) + ly * ((1 - lx) * at(c, y0 + 1, x0) + lx * at(c, y0 + 1, x0 + 1))
+                    for c in range(3)])
+    assert np.abs(out - ref).max() < 1e-4
+    # the synthetic provider's landmarks sit inside its raw detector box and map back to the template under the estimated transform
+    lms = SyntheticFaceProvider().landmarks(torch.zeros(2, 3, 512, 512))
+    assert lms.shape == (2, 5, 2) and float(lms.min()) > 128 and float(lms.max()) < 384
+    M = umeyama_similarity(lms[0].numpy(), ALIGNED_FACE_LANDMARKS)
+    back = (M[:2, :2] @ lms[0].numpy().T).T + M[:2, 2]
+    assert np.abs(back - ALIGNED_FACE_LANDMARKS).max() < 1e-3

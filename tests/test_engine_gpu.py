@@ -517,3 +517,61 @@ def test_reference_style_lora_injection(dev):
     wrong[k] = LoRAAttnProcessor(hidden_size=7, cross_attention_dim=None, rank=4)
     with pytest.raises(ValueError):
         unet.set_attn_processor(wrong)
+
+
+# ------------------------------------------------------------------------------------------ face-realism term pieces
+def test_face_alignment_warp_vs_oracle(dev):
+    """image_pipeline (:292-312): similarity transform from 5 landmarks + kornia-style warp, forward and image gradient."""
+    from finetune_fair_diffusion_amd import ops
+    from finetune_fair_diffusion_amd.fairness import alignment_sampling_matrix
+    from oracle import nn_sfnet as OS
+    g = torch.Generator().manual_seed(5)
+    B, H, W, crop = 3, 96, 96, 112
+    imgs = (torch.rand(B, 3, H, W, generator=g) * 2 - 1).half().float()
+    rng = np.random.RandomState(2)
+    lms = [OS.SRC_LANDMARKS / 112 * 40 + np.array([20.0 + 8 * i, 25.0 - 5 * i]) + rng.randn(5, 2) for i in range(B)]
+    lms[2] = OS.SRC_LANDMARKS / 112 * 130 + np.array([-20.0, -15.0])      # face larger than the image: zero-padded (-1) border
+    x = imgs.clone().requires_grad_(True)
+    ref = torch.stack([OS.image_pipeline(x[i], lms[i], crop) for i in range(B)])
+    gw = torch.randn(ref.shape, generator=g)
+    (ref * gw).sum().backward()
+    A = torch.tensor(np.stack([alignment_sampling_matrix(lms[i], H, W, crop) for i in range(B)]), dtype=torch.float32, device=dev)
+    idx = torch.arange(B, dtype=torch.int32, device=dev)
+    chips = ops.warp_affine(imgs.half().to(dev), idx, A, crop)
+    check("aligned chips", chips, ref, 2e-3)
+    assert float((ref[2] == -1).float().mean()) > 0.05
+    dimg = torch.zeros(B, 3, H, W, dtype=torch.float32, device=dev)
+    ops.warp_affine_bwd(gw.to(dev).contiguous(), idx, A, dimg, crop)
+    check("d images (warp)", dimg, x.grad, 1e-4)
+
+
+def test_sfnet20_features_and_input_gradient_vs_oracle(dev):
+    """get_face_feats (:1176-1190): net(x) + net(flip(x)), L2-normalised; 1 - cos loss gradient w.r.t. the chips."""
+    from finetune_fair_diffusion_amd import weights as W
+    from finetune_fair_diffusion_amd.sfnet import SFNet20, face_features, face_features_backward
+    from finetune_fair_diffusion_amd.vit import feature_loss_and_grad
+    from oracle import nn_sfnet as OS
+    sd = W.synthetic_state_dict(W.sfnet20_param_shapes(), seed=31)
+    om = OS.SFNet20().eval()
+    om.load_state_dict(sd)
+    pm = SFNet20(sd, dev)
+    g = torch.Generator().manual_seed(9)
+    N = 3
+    chips = (torch.rand(N, 3, 112, 112, generator=g) * 2 - 1).half().float()
+    target = F.normalize(torch.randn(N, 512, generator=g), dim=-1)
+    w = torch.tensor([1.0, 0.3, 0.6])
+    x = chips.clone().requires_grad_(True)
+    f_ref = OS.get_face_feats(om, x, normalize=False)
+    loss_ref = 1 - (F.normalize(f_ref, dim=-1) * target).sum(-1)
+    (loss_ref * w).sum().backward()
+    f, ctxs = face_features(pm, chips.half().to(dev), record=True)
+    check("sfnet20 features", f, f_ref, 2e-2)
+    loss, df = feature_loss_and_grad(f, target.to(dev), w.to(dev))
+    check("loss_face", loss, loss_ref, 2e-2)
+    dchips = face_features_backward(pm, ctxs, df, 2.0 ** 12)
+    # 21 ReLU masks in series: a few mask bits differ between fp16 and fp32 activations, so point-wise agreement is looser than
+    # for the smooth networks; direction and norm are tight
+    cos = F.cosine_similarity(dchips.flatten().cpu().double(), x.grad.flatten().double(), dim=0)
+    print("cosine(d chips) =", float(cos), " norm ratio =", float(dchips.norm().cpu() / x.grad.norm()))
+    check("d chips (sfnet20)", dchips, x.grad, 1.5e-1)
+    assert cos > 0.995 and 0.97 < float(dchips.norm().cpu() / x.grad.norm()) < 1.03
