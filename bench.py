@@ -58,7 +58,7 @@ def main():
     ap.add_argument("--tiny", action="store_true", help="tiny model config (plumbing check only; not a valid bench line)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU plumbing checks)")
     ap.add_argument("--share_gpu0", action="store_true", help="plumbing check: every rank uses cuda:0")
-    ap.add_argument("--no_regularisers", action="store_true", help="drop the CLIP/DINOv2 image-semantics terms (loss_fair only)")
+    ap.add_argument("--no_regularisers", action="store_true", help="drop the CLIP/DINOv2 image-semantics and SFNet face-realism terms (loss_fair only)")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_roofline", action="store_true")
     a = ap.parse_args()
@@ -84,7 +84,7 @@ def main():
                                 train_GPU_batch_size=3, val_GPU_batch_size=8, mixed_precision="fp16",
                                 size_face=64 if a.tiny else 224, img_size_small=56 if a.tiny else 224,
                                 weight_loss_img=0.0 if a.no_regularisers else 8.0,   # debias-unet.yaml:4
-                                weight_loss_face=0.0)                                # face-realism term: not built (SURVEY 8 f1 remainder)
+                                weight_loss_face=0.0 if a.no_regularisers else 1.0)  # debias-unet.yaml:5
     cfgs = factory.TINY if a.tiny else factory.SD15
     tr, models = factory.build_trainer(args, dev, cfgs=cfgs, seed=0, rank=rank, world_size=world, regularisers=not a.no_regularisers)
     L = 13
@@ -125,9 +125,10 @@ def main():
                    "global_batch": world * a.batch, "steps_per_s": a.steps / dt, "parallelism": f"dp{world}",
                    "algorithmic_flop_per_image": f_img(a.S), "step_mfma_frac": value / world * f_img(a.S) / MFMA_PEAK_F16,
                    "loss_fair_mean": float(out["loss_fair"][out["loss_fair"] != -1].mean()) if (out["loss_fair"] != -1).any() else None,
-                   "loss_terms": "loss_fair" if a.no_regularisers else "loss_fair + 8*dyn*(loss_CLIP[ViT-H/14] + loss_DINO[ViT-B/14]); face-realism term not built",
+                   "loss_terms": "loss_fair" if a.no_regularisers else "loss_fair + 8*dyn*(loss_CLIP[ViT-H/14] + loss_DINO[ViT-B/14]) + 1*loss_face[SFNet-20]",
                    "loss_CLIP_mean": float(out["loss_CLIP"].mean()) if "loss_CLIP" in out else None,
                    "loss_DINO_mean": float(out["loss_DINO"].mean()) if "loss_DINO" in out else None,
+                   "loss_face_mean": float(out["loss_face"][out["loss_face"] != -1].mean()) if "loss_face" in out and (out["loss_face"] != -1).any() else None,
                    "grad_is_finite": bool(out["grad_is_finite"]),
                    "peak_hbm_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
                    "r3_activation_gb_per_timestep": round(tr.last_ctx_bytes / 2 ** 30, 2),

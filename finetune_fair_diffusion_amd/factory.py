@@ -50,7 +50,8 @@ def build_trainer(args, device, cfgs=SD15, seed=0, rank=0, world_size=1, experim
     (keys 'unet','vae','clip','clf','unet_lora','te_lora'); anything missing is synthetic.
     ``frozen_copies=False`` skips the original-model replicas of R2 (inference-only consumers such as generate.py).
     ``regularisers=True`` attaches the CLIP / DINOv2 image encoders of the image-semantics loss term (keys 'clip_vision','dino';
-    ``args.img_size_small`` must equal their input size)."""
+    ``args.img_size_small`` must equal their input size) when ``weight_loss_img`` != 0, and the SFNet-20 face-feature network plus
+    its feature database (keys 'face_net','face_db') when ``weight_loss_face`` != 0."""
     from .fairness import EXPERIMENT_ATTRS
     num_classes = EXPERIMENT_ATTRS[experiment][0]
     sds = dict(state_dicts or {})
@@ -105,7 +106,16 @@ def build_trainer(args, device, cfgs=SD15, seed=0, rank=0, world_size=1, experim
                 raise ValueError(f"{key}: encoder input {cfgs[key].image_size} != --img_size_small {args.img_size_small}")
         clip_model = VisionTransformer(cfgs["clip_vision"], sds.pop("clip_vision"), device, W.CLIP_IMAGE_MEAN, W.CLIP_IMAGE_STD)
         dino_model = VisionTransformer(cfgs["dino"], sds.pop("dino"), device, W.DINO_IMAGE_MEAN, W.DINO_IMAGE_STD)
+    face_net = face_db = None
+    if regularisers and getattr(args, "weight_loss_face", 0) != 0:
+        from .sfnet import SFNet20
+        if "face_net" not in sds:
+            sds["face_net"] = gen(W.sfnet20_param_shapes(in_size=args.size_aligned_face), 11)
+        if "face_db" not in sds:   # FaceFeatsModel's face_feats.pkl (:80-92): here 4096 random unit vectors
+            sds["face_db"] = torch.nn.functional.normalize(torch.randn(4096, 512, generator=torch.Generator().manual_seed(seed + 12)), dim=-1)
+        face_net = SFNet20(sds.pop("face_net"), device, in_size=args.size_aligned_face)
+        face_db = sds.pop("face_db")
     sch = DPMSolverMultistepScheduler()
     tr = FairnessTrainer(args, te, unet, vae, clf, sch, eval_text_encoder=eval_te, eval_unet=eval_unet, experiment=experiment, rank=rank,
-                         world_size=world_size, device=device, clip_model=clip_model, dino_model=dino_model)
-    return tr, dict(clip_vision=clip_model, dino=dino_model, unet=unet, eval_unet=eval_unet, vae=vae, text_encoder=te, eval_text_encoder=eval_te, classifier=clf, scheduler=sch)
+                         world_size=world_size, device=device, clip_model=clip_model, dino_model=dino_model, face_net=face_net, face_db=face_db)
+    return tr, dict(clip_vision=clip_model, dino=dino_model, face_net=face_net, unet=unet, eval_unet=eval_unet, vae=vae, text_encoder=te, eval_text_encoder=eval_te, classifier=clf, scheduler=sch)

@@ -16,9 +16,10 @@ exp-1-debias-gender/1-main-debias.py:1746-2029 re-designed for this hardware:
   check + one AdamW+EMA launch (replaces the 400 per-tensor collectives/launches of :1998-2029).
 
 The loss is ``loss_fair + weight_loss_img * dynamic_weights * (loss_CLIP + loss_DINO)`` (:1904-1932) when the two image
-encoders are attached (``clip_model`` / ``dino_model``, vit.py); their input gradients join the classifier's at the image
-and go through the VAE once.  The face-realism term (``weight_loss_face``, :1917-1929) is a SURVEY.md 8f "next" row: a
-trainer with image encoders refuses a non-zero ``weight_loss_face`` instead of silently dropping it.
+encoders are attached (``clip_model`` / ``dino_model``, vit.py), plus ``weight_loss_face * loss_face`` (:1917-1932) when the
+face-feature network and its feature database are attached (``face_net`` sfnet.py, ``face_db``); all input gradients join the
+classifier's at the image and go through the VAE once.  A non-zero ``weight_loss_face`` without a face network is refused
+rather than silently dropped.
 """
 import math
 
@@ -71,17 +72,24 @@ class EMAState:
 
 class FairnessTrainer:
     def __init__(self, args, text_encoder, unet, vae, classifier, scheduler, eval_text_encoder=None, eval_unet=None,
-                 face_provider=None, experiment="exp-1", rank=0, world_size=1, device=None, clip_model=None, dino_model=None):
+                 face_provider=None, experiment="exp-1", rank=0, world_size=1, device=None, clip_model=None, dino_model=None,
+                 face_net=None, face_db=None):
         self.args = args
         self.clip, self.dino = clip_model, dino_model
         self.use_img_loss = clip_model is not None and dino_model is not None and getattr(args, "weight_loss_img", 0) != 0
         if (clip_model is None) != (dino_model is None):
             raise ValueError("the image-semantics term needs both encoders (CLIP and DINOv2) or neither")
-        if self.use_img_loss and getattr(args, "weight_loss_face", 0) != 0:
-            raise NotImplementedError("weight_loss_face != 0: the face-realism term (SFNet features + nearest-neighbour search, "
-                                      "1-main-debias.py:1917-1929) is not built yet; pass --weight_loss_face 0")
-        if self.use_img_loss and len(EXPERIMENT_ATTRS[experiment][1]) != 1:
-            raise NotImplementedError("image-semantics regularisers are wired for exp-1 (single attribute) only")
+        self.face_net = face_net
+        self.face_db = None if face_db is None else F.normalize(face_db.to(unet.device if device is None else device, F32), dim=-1)  # :88
+        self.face_db16 = None if face_db is None else self.face_db.to(F16).contiguous()
+        self.use_face_loss = face_net is not None and face_db is not None and getattr(args, "weight_loss_face", 0) != 0
+        if (face_net is None) != (face_db is None):
+            raise ValueError("the face-realism term needs both the face-feature network and its feature database, or neither")
+        if self.use_img_loss and not self.use_face_loss and getattr(args, "weight_loss_face", 0) != 0:
+            raise ValueError("weight_loss_face != 0 but no face-feature network / database is attached "
+                             "(build_trainer(..., regularisers=True) attaches them; or pass --weight_loss_face 0)")
+        if (self.use_img_loss or self.use_face_loss) and len(EXPERIMENT_ATTRS[experiment][1]) != 1:
+            raise NotImplementedError("the regulariser terms are wired for exp-1 (single attribute) only")
         self.te, self.unet, self.vae, self.clf, self.sch = text_encoder, unet, vae, classifier, scheduler
         self.eval_te = eval_text_encoder if eval_text_encoder is not None else text_encoder
         self.eval_unet = eval_unet if eval_unet is not None else unet
@@ -192,6 +200,32 @@ class FairnessTrainer:
         """get_clip_feat / get_dino_feat (:1139-1175) raw embeddings (fp32) of both encoders."""
         return self.clip.forward(small, record=record), self.dino.forward(small, record=record)
 
+    def aligned_faces(self, images, ind):
+        """aligned_face_chips of get_face (:1337-1338, image_pipeline :292-312) for the images with a face.
+        Returns (chips [n,3,112,112] fp16, src_index [n] int32, A [n,6] fp32) -- the last two drive the backward scatter."""
+        from .fairness import alignment_sampling_matrix
+        import numpy as np
+        N, _, H, W = images.shape
+        crop = self.args.size_aligned_face
+        lms = self.faces.landmarks(images)
+        sel = ind.nonzero().view(-1).tolist()
+        A = np.stack([alignment_sampling_matrix(lms[i].numpy(), H, W, crop) for i in sel]) if sel else np.zeros((0, 6))
+        A = torch.tensor(A, dtype=F32, device=self.device).contiguous()
+        idx = torch.tensor(sel, dtype=torch.int32, device=self.device)
+        return ops.warp_affine(images, idx, A, crop), idx, A
+
+    def nearest_face_feats(self, query):
+        """FaceFeatsModel.semantic_search (:98-117): database row with the largest dot product.  fp16 MFMA scores shortlist 8
+        candidates per query; the winner is chosen among them in fp32."""
+        M = self.face_db.shape[0]
+        q16 = torch.zeros(((query.shape[0] + 7) // 8 * 8, query.shape[1]), dtype=F16, device=self.device)
+        q16[:query.shape[0]] = query.to(F16)
+        scores = ops.gemm(self.face_db16, q16, out_dtype=F32)[:, :query.shape[0]].t()         # [n, M]
+        cand = scores.topk(min(8, M), dim=-1).indices                                           # [n, 8]
+        exact = (self.face_db[cand] * query[:, None, :]).sum(dim=-1)
+        best = cand.gather(1, exact.argmax(dim=-1, keepdim=True))[:, 0]
+        return self.face_db[best]
+
     def dynamic_targets(self, per, B):
         """Global dynamic targets for this rank's B images from the gathered probabilities of all ranks (:1831-1837;
         exp-3 :2016-2025).  Returns per attribute (targets [B], uncertainty [B])."""
@@ -270,6 +304,12 @@ class FairnessTrainer:
         if self.use_img_loss:                                                    # :1860-1862
             e_c, e_d = self.image_features(self.resize_small(images_ori)[0])
             clip_ori, dino_ori = F.normalize(e_c, dim=-1), F.normalize(e_d, dim=-1)
+        if self.use_face_loss:                                                   # :1870
+            from .sfnet import face_features
+            ch_o, idx_o, _ = self.aligned_faces(images_ori, ind_o)
+            face_ori = torch.zeros((B, 512), dtype=F32, device=dev)
+            if len(idx_o):
+                face_ori[idx_o.long()] = F.normalize(face_features(self.face_net, ch_o)[0], dim=-1)
         # ---- R3: rollout with gradient (:1889-1933), all micro-batches at once with weights 1/n_j
         w, N_backward = microbatch_weights(B, args.train_GPU_batch_size)
         if share:
@@ -310,6 +350,31 @@ class FairnessTrainer:
             lc, ld = loss_clip.float().cpu(), loss_dino.float().cpu()
             lsum = loss_fair + args.weight_loss_img * dyn * (lc + ld)
             out.update(loss_CLIP=lc, loss_DINO=ld, loss=lsum, dynamic_weights=dyn)
+        if self.use_face_loss:
+            # face-realism term (:1917-1932): target = the original image's own face features when the target class equals the
+            # original prediction with confidence >= face_gender_confidence_level, else the nearest database face
+            from .sfnet import face_features, face_features_backward
+            probs_o = per_o[0]["probs"]
+            has = ind_g & (targets != -1)
+            from_ori = has & (targets == per_o[0]["preds"]) & (probs_o.max(dim=-1).values >= args.face_gender_confidence_level)
+            loss_face = torch.full((B,), -1.0)
+            rows = has.nonzero().view(-1)
+            if len(rows):
+                chips_f, idx_f, A_f = self.aligned_faces(images_g, has)
+                feats, fctx = face_features(self.face_net, chips_f, record=True)
+                fn = F.normalize(feats, dim=-1)
+                tgt = self.nearest_face_feats(fn)
+                use_ori = from_ori[rows].to(dev)
+                tgt = torch.where(use_ori[:, None], face_ori[rows.to(dev)], tgt)
+                wf = (w[rows] * args.weight_loss_face).to(dev)
+                lf_rows, df = feature_loss_and_grad(feats, tgt, wf)
+                loss_face[rows] = lf_rows.float().cpu()
+                dch = face_features_backward(self.face_net, fctx, df, _pow2_scale(float(df.abs().max()), 1.0))
+                if d_img is None:
+                    d_img = torch.zeros((B, 3, Himg, Wimg), dtype=F32, device=dev)
+                ops.warp_affine_bwd(dch.contiguous(), idx_f, A_f, d_img, args.size_aligned_face)   # un-hooked images (:1901)
+            out.update(loss_face=loss_face)
+            out["loss"] = out.get("loss", loss_fair) + args.weight_loss_face * loss_face
         if (len(sel) and float(dlog_full.abs().sum()) > 0) or d_img is not None:
             if len(sel) and float(dlog_full.abs().sum()) > 0:
                 dlog = dlog_full[sel]

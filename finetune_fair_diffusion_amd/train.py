@@ -100,7 +100,7 @@ def main(argv=None, experiment="exp-1", cfgs=None, log=None):
         from .pretrained import load_pretrained
         state_dicts = load_pretrained(args, cfgs)
     trainer, models = build_trainer(args, device, cfgs, seed=args.seed, rank=rank, world_size=world, experiment=experiment,
-                                    state_dicts=state_dicts, regularisers=args.weight_loss_img != 0)
+                                    state_dicts=state_dicts, regularisers=(args.weight_loss_img != 0 or args.weight_loss_face != 0))
     tok_dir = os.path.join(args.pretrained_model_name_or_path, "tokenizer")
     tokenizer = CLIPTokenizerAdapter(tok_dir) if os.path.isdir(tok_dir) else HashTokenizer(cfgs["clip"].vocab_size)
     if not os.path.isdir(tok_dir) and not args.synthetic:
@@ -150,6 +150,7 @@ def main(argv=None, experiment="exp-1", cfgs=None, log=None):
                            loss_fair=float(lf[lf != -1].mean()) if bool((lf != -1).any()) else None,
                            loss_CLIP=float(out["loss_CLIP"].mean()) if "loss_CLIP" in out else None,
                            loss_DINO=float(out["loss_DINO"].mean()) if "loss_DINO" in out else None,
+                           loss_face=(float(out["loss_face"][out["loss_face"] != -1].mean()) if (out["loss_face"] != -1).any() else None) if "loss_face" in out else None,
                            p_class1_mean=float(out["probs"][:, 1][out["probs"][:, 1] != -1].mean()) if bool((out["probs"] != -1).any()) else None,
                            seconds=round(time.time() - t0, 3))
                 (log or print)(json.dumps(rec))

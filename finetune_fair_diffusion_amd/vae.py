@@ -113,10 +113,6 @@ class AutoencoderKL:
             self._ctx = dict(blocks=ctx, x_out=x, st_out=st, pre=y, B=B, H=H, W=W, h=z.shape[2], w=z.shape[3])
         return img
 
-    @property
-    def dtype(self):
-        return F16
-
     def to(self, *a, **k):
         return self
 

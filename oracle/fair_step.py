@@ -16,6 +16,7 @@ import scipy.stats
 import torch
 import torch.nn.functional as F
 
+from .nn_sfnet import SRC_LANDMARKS, get_face_feats, image_pipeline, semantic_search
 from .nn_vit import CLIP_IMAGE_MEAN, CLIP_IMAGE_STD, DINO_IMAGE_MEAN, DINO_IMAGE_STD, image_features
 
 
@@ -68,6 +69,16 @@ class SyntheticFaceProvider:
         boxes = torch.tensor([bbox] * N, dtype=torch.long)
         chips = torch.stack([crop_face(images[i], bbox, [self.size_face, self.size_face], fill_value) for i in range(N)])
         return ind, boxes, chips
+
+    def landmarks(self, images):
+        """The 5-point template of the aligned chip scaled into the raw detector box."""
+        N, _, H, W = images.shape
+        pts = SRC_LANDMARKS / 112.0 * np.array([0.5 * W, 0.5 * H]) + np.array([0.25 * W, 0.25 * H])
+        return [pts.copy() for _ in range(N)]
+
+    def aligned(self, images, crop=112):
+        """aligned_face_chips of get_face (:1337-1338): image_pipeline on every image (differentiable w.r.t. the image)."""
+        return torch.stack([image_pipeline(images[i], lm, crop) for i, lm in enumerate(self.landmarks(images))])
 
 
 def get_face_gender(classifier, face_chips, selector=None, fill_value=-1, slice_fn=None):  # :1355-1401
@@ -295,8 +306,9 @@ class EMAModel:
 def fairness_step(models, tokens, noises, S, cfg, world=None, attrs=None, targets_by_attr=None):
     """One training step (:1746-2029) on one rank, synthetic face provider.
     loss_ij = loss_fair + weight_loss_img * dynamic_weights * (loss_CLIP + loss_DINO) (:1904-1932) when ``models`` holds the
-    image encoders ``clip`` / ``dino`` (oracle.nn_vit) and cfg["weight_loss_img"] != 0; the face-realism term
-    (weight_loss_face, :1917-1929) is a SURVEY 8f "next" row and is not part of this oracle.
+    image encoders ``clip`` / ``dino`` (oracle.nn_vit) and cfg["weight_loss_img"] != 0, plus
+    ``weight_loss_face * loss_face`` (:1917-1932) when it holds ``face_net`` (oracle.nn_sfnet.SFNet20) and ``face_db`` (normalised
+    [M,512] database of FaceFeatsModel, :80-92) and cfg["weight_loss_face"] != 0.
 
     models: dict(text_encoder, unet, vae, classifier, scheduler, eval_text_encoder, eval_unet)
     cfg: dict(train_GPU_batch_size, val_GPU_batch_size, uncertainty_threshold, factor2, guidance_scale, size_face, slice_fn)
@@ -331,18 +343,23 @@ def fairness_step(models, tokens, noises, S, cfg, world=None, attrs=None, target
             small_o = resize_small(images_ori, cfg.get("img_size_small", 224))              # :1860-1862
             clip_o = image_features(models["clip"], small_o, CLIP_IMAGE_MEAN, CLIP_IMAGE_STD)
             dino_o = image_features(models["dino"], small_o, DINO_IMAGE_MEAN, DINO_IMAGE_STD)
+        w_face = cfg.get("weight_loss_face", 0.0) if ("face_net" in models and "face_db" in models) else 0.0
+        crop = cfg.get("size_aligned_face", 112)
+        if w_face:
+            face_feats_o = get_face_feats(models["face_net"], faces.aligned(images_ori, crop))            # :1870
     out.update(images=images, images_ori=images_ori, probs=probs, preds=preds, targets=targets, uncertainty=unc,
                preds_ori=preds_o, probs_ori=probs_o, latents_trace=trace)
     tb = cfg["train_GPU_batch_size"]
     N_backward = math.ceil(B / tb)
     loss_fair = torch.ones(B) * (-1)
-    loss_CLIP, loss_DINO, loss_all = torch.ones(B) * (-1), torch.ones(B) * (-1), torch.ones(B) * (-1)
+    loss_CLIP, loss_DINO, loss_all, loss_face = torch.ones(B) * (-1), torch.ones(B) * (-1), torch.ones(B) * (-1), torch.ones(B) * (-1)
     images_g = []
     for j in range(N_backward):
         idx = list(range(B))[j * tb:(j + 1) * tb]
         img = generate_image_w_gradient(tokens, noises[idx], S, te, unet, vae, sch, gs)
         ind_j, boxes_j, chips_j = faces(img)
         preds_j, probs_j, logits_j = get_face_gender(clf, chips_j, selector=ind_j, slice_fn=slice_fn)
+        img_raw = img
         img = apply_grad_hook_face(img, boxes_j, boxes_o[idx], targets[idx], preds_o[idx], factor=cfg["factor2"])
         # NB (:1904-1915): the hooked images feed only the CLIP/DINO terms in the reference; the
         # fairness loss uses logits computed from the un-hooked chips, so the hook does not touch it.
@@ -357,12 +374,27 @@ def fairness_step(models, tokens, noises, S, cfg, world=None, attrs=None, target
             dyn = gen_dynamic_weights(ind_j, targets[idx], preds_o[idx], factor=cfg.get("factor1", 0.2))
             loss_ij = lf + w_img * dyn * (lc + ld)                                          # :1932 without the face term
             loss_CLIP[idx], loss_DINO[idx] = lc.detach(), ld.detach()
+        if w_face:                                                                           # :1917-1929, :1932
+            aligned_j = faces.aligned(img_raw, crop)        # get_face runs before the hook (:1901): un-hooked images
+            t_j, p_o, pr_o = targets[idx], preds_o[idx], probs_o[idx]
+            lface = torch.ones(len(idx)) * (-1)
+            from_ori = ((ind_j == True) * (t_j != -1) * (t_j == p_o) *  # noqa: E712
+                        (pr_o.max(dim=-1).values >= cfg.get("face_gender_confidence_level", 0.9))).nonzero().view([-1]).tolist()
+            if len(from_ori) > 0:
+                f1 = get_face_feats(models["face_net"], aligned_j[from_ori])
+                lface[from_ori] = (1 - (f1 * face_feats_o[idx][from_ori]).sum(dim=-1)).to(lface.dtype)
+            from_search = sorted(set(((ind_j == True) * (t_j != -1)).nonzero().view([-1]).tolist()) - set(from_ori))  # noqa: E712
+            if len(from_search) > 0:
+                f2 = get_face_feats(models["face_net"], aligned_j[from_search])
+                lface[from_search] = (1 - (f2 * semantic_search(models["face_db"], f2)).sum(dim=-1)).to(lface.dtype)
+            loss_ij = loss_ij + w_face * lface
+            loss_face[idx] = lface.detach()
         if loss_ij.requires_grad:
             loss_ij.mean().backward()
         loss_fair[idx] = lf.detach()
         loss_all[idx] = loss_ij.detach()
         images_g.append(img.detach())
-    out.update(loss_fair=loss_fair, loss_CLIP=loss_CLIP, loss_DINO=loss_DINO, loss=loss_all, N_backward=N_backward,
+    out.update(loss_fair=loss_fair, loss_CLIP=loss_CLIP, loss_DINO=loss_DINO, loss_face=loss_face, loss=loss_all, N_backward=N_backward,
                images_grad=torch.cat(images_g))
     return out
 

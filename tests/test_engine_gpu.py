@@ -481,7 +481,7 @@ def test_full_step_with_image_regularisers(dev):
     ratio = float((got - got_fair).norm() / (ref_total.double() - ref_fair).norm())
     print("cosine(regulariser part) =", float(cos_reg), " norm ratio =", ratio, " |reg|/|fair| =", float((ref_total.double() - ref_fair).norm() / ref_fair.norm()))
     assert cos_reg > 0.97 and 0.8 < ratio < 1.25
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(ValueError):   # a face weight without a face network is refused, not silently dropped
         FairnessTrainer(U.make_args(weight_loss_img=8.0, weight_loss_face=1.0, img_size_small=56), pm["text_encoder"], pm["unet"], pm["vae"],
                         pm["classifier"], pm["scheduler"], eval_unet=pm["eval_unet"], device=dev, clip_model=clip_p, dino_model=dino_p)
 
@@ -575,3 +575,66 @@ def test_sfnet20_features_and_input_gradient_vs_oracle(dev):
     print("cosine(d chips) =", float(cos), " norm ratio =", float(dchips.norm().cpu() / x.grad.norm()))
     check("d chips (sfnet20)", dchips, x.grad, 1.5e-1)
     assert cos > 0.995 and 0.97 < float(dchips.norm().cpu() / x.grad.norm()) < 1.03
+
+
+def test_full_step_with_face_realism_term(dev):
+    """loss_ij += weight_loss_face * loss_face (:1917-1932): aligned chips -> SFNet-20 (+mirror) -> cosine to the original image's
+    face features (confident, unchanged class) or to the nearest database face; per-image loss and the term's share of the U-Net
+    LoRA gradient vs the oracle's autograd step."""
+    from oracle import fair_step as fs, nn_sfnet as OS
+    from finetune_fair_diffusion_amd import weights as W
+    from finetune_fair_diffusion_amd.sfnet import SFNet20
+    from finetune_fair_diffusion_amd.step import FairnessTrainer
+    om = U.oracle_models(train_unet=True, train_te=False, lora_up_std=0.05)
+    pm = U.product_models(om["sds"], dev, train_unet=True, train_te=False)
+    sd_f = W.synthetic_state_dict(W.sfnet20_param_shapes(), seed=31)
+    db = F.normalize(torch.randn(257, 512, generator=torch.Generator().manual_seed(4)), dim=-1)
+    onet = OS.SFNet20().eval().requires_grad_(False)
+    onet.load_state_dict(sd_f)
+    models_o = dict(text_encoder=om["text_encoder"], unet=om["unet"], vae=om["vae"], classifier=om["classifier"], scheduler=om["scheduler"],
+                    eval_text_encoder=om["text_encoder"], eval_unet=om["eval_unet"], face_net=onet, face_db=db)
+    tokens = U.tiny_tokens()
+    B, S = 4, 4
+    noises = torch.randn(B, 4, 32, 32, generator=torch.Generator().manual_seed(5991))
+    names = list(om["unet_lora_layers"].state_dict().keys())
+
+    def oracle_run(w_face, conf):
+        for p in om["lora_params"]:
+            p.grad = None
+        r = fs.fairness_step(models_o, tokens, noises, S, dict(train_GPU_batch_size=3, val_GPU_batch_size=8, uncertainty_threshold=0.6, factor1=0.2,
+                                                               factor2=0.2, size_face=64, weight_loss_face=w_face, face_gender_confidence_level=conf))
+        return r, torch.cat([p.grad.flatten() for p in om["unet_lora_layers"].parameters()]).double().clone()
+
+    def product_run(w_face, conf):
+        args = U.make_args(train_unet=True, train_text_encoder=False, weight_loss_img=0.0, weight_loss_face=w_face, size_aligned_face=112,
+                           face_gender_confidence_level=conf, uncertainty_threshold=0.6)
+        tr = FairnessTrainer(args, pm["text_encoder"], pm["unet"], pm["vae"], pm["classifier"], pm["scheduler"], eval_unet=pm["eval_unet"], device=dev,
+                             face_net=SFNet20(sd_f, dev) if w_face else None, face_db=db if w_face else None)
+        g = {}
+        tr.sync_and_update = lambda nb, apply=True: (g.__setitem__(0, tr.banks[0].grad.clone()), True)[1]
+        o = tr.train_step(tokens, noises, S)
+        return o, torch.cat([tr.banks[0].view(n, g[0]).flatten() for n in names]).cpu().double()
+
+    ref0, rg0 = oracle_run(0.0, 0.9)
+    out0, pg0 = product_run(0.0, 0.9)
+    seen = set()
+    for conf in (0.0, 2.0):       # uncertainty threshold 0.6 keeps all four targets.  conf 0: every image whose target equals the original
+        ref, rg = oracle_run(1.0, conf)   # prediction is pulled to its own original face, the rest search the database; conf 2: all search
+        out, pg = product_run(1.0, conf)
+        same = (ref["targets"] == ref["preds_ori"]) & (ref["targets"] != -1)
+        print("targets", ref["targets"].tolist(), "preds_ori", ref["preds_ori"].tolist())
+        assert same.any() and (~same).any()
+        seen.add(tuple(round(v, 3) for v in ref["loss_face"].tolist()))
+        assert out["targets"].tolist() == ref["targets"].tolist()
+        print("loss_face product", out["loss_face"].tolist(), "oracle", ref["loss_face"].tolist())
+        assert ((out["loss_face"] == -1) == (ref["loss_face"] == -1)).all() and (ref["loss_face"] != -1).any()
+        check(f"loss_face (conf {conf})", out["loss_face"], ref["loss_face"], 2e-2)
+        check(f"loss (conf {conf})", out["loss"], ref["loss"], 2e-2)
+        cos = F.cosine_similarity(pg - pg0, rg - rg0, dim=0)
+        ratio = float((pg - pg0).norm() / (rg - rg0).norm())
+        print(f"conf {conf}: cosine(face-term gradient) = {float(cos):.4f}, norm ratio = {ratio:.3f}, |face|/|fair| = {float((rg - rg0).norm() / rg0.norm()):.3f}")
+        assert cos > 0.97 and 0.8 < ratio < 1.25
+    assert len(seen) == 2        # the two target sources really differ
+    with pytest.raises(ValueError):
+        FairnessTrainer(U.make_args(weight_loss_face=1.0), pm["text_encoder"], pm["unet"], pm["vae"], pm["classifier"], pm["scheduler"],
+                        eval_unet=pm["eval_unet"], device=dev, face_net=SFNet20(sd_f, dev))

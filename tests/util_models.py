@@ -22,7 +22,8 @@ def tiny_tokens(L=7, vocab=1000):
 def make_args(**kw):
     d = dict(train_unet=True, train_text_encoder=False, rank=4, guidance_scale=7.5, train_GPU_batch_size=3, val_GPU_batch_size=8,
              uncertainty_threshold=0.2, factor1=0.2, factor2=0.2, size_face=64, learning_rate=5e-5, adam_beta1=0.9, adam_beta2=0.999,
-             adam_weight_decay=1e-2, adam_epsilon=1e-8, EMA_decay=0.996)
+             adam_weight_decay=1e-2, adam_epsilon=1e-8, EMA_decay=0.996, weight_loss_img=0.0, weight_loss_face=0.0, img_size_small=224,
+             size_aligned_face=112, face_gender_confidence_level=0.9)
     d.update(kw)
     return types.SimpleNamespace(**d)
 
