@@ -139,6 +139,31 @@ def face_grad_factors(boxes, boxes_ori, targets, preds_ori, factor, H, W):
     return torch.tensor(rects, dtype=torch.int32), torch.tensor(facs, dtype=torch.float32)
 
 
+def _mismatch_factor(targets_i, preds_ori_i, factors):
+    """1 when every attribute's target equals the original prediction, else the smallest factor among the mismatching attributes
+    (a missing target, -1, never equals a prediction) -- exp-3 :1764-1771 / :1793-1800, exp-4 :1844-1854 / :1882-1892."""
+    bad = [f for t, p, f in zip(targets_i, preds_ori_i, factors) if t != p]
+    return 1.0 if not bad else float(min(bad))
+
+
+def gen_dynamic_weights_multi(face_indicators, targets_list, preds_ori_list, factors):
+    """exp-3 :1786-1803, exp-4 :1870-1895: images without a face get min(factors) (exp-1's single-attribute version gives them 1)."""
+    w = []
+    for i, ind in enumerate(face_indicators.tolist()):
+        w.append(float(min(factors)) if not ind else _mismatch_factor([t[i].item() for t in targets_list], [p[i].item() for p in preds_ori_list], factors))
+    return torch.tensor(w, dtype=torch.float32)
+
+
+def face_grad_factors_multi(boxes, boxes_ori, targets_list, preds_ori_list, factors, H, W):
+    """Multi-attribute ``apply_grad_hook_face`` (exp-3 :1751-1783, exp-4 :1823-1867): same rectangle as exp-1, factor by _mismatch_factor."""
+    rects, _ = face_grad_factors(boxes, boxes_ori, targets_list[0], preds_ori_list[0], 1.0, H, W)
+    facs = []
+    for i, bb in enumerate(boxes.tolist()):
+        facs.append(1.0 if all(v == -1 for v in bb) else
+                    _mismatch_factor([t[i].item() for t in targets_list], [p[i].item() for p in preds_ori_list], factors))
+    return rects, torch.tensor(facs, dtype=torch.float32)
+
+
 def microbatch_weights(B, train_GPU_batch_size):
     """The reference back-propagates ``loss_ij.mean()`` per micro-batch j (:1889-1933) and later divides
     the gradient by N_backward (:2005): image i of a chunk of n_j images carries weight 1/n_j.
@@ -257,6 +282,14 @@ def generate_dynamic_targets_multi(probs_list, class_cdfs, num_samples_per_devic
         out_u[a][idx] = 1 - marg.max(dim=-1).values
     return list(zip(out_t, out_u))
 
+
+# per experiment: (factor1 flags, factor2 flags, confidence-level flag) of the regulariser terms, in attribute order
+EXPERIMENT_REG_FLAGS = {
+    "exp-1": (["factor1"], ["factor2"], "face_gender_confidence_level"),
+    "exp-3": (["factor1_gender", "factor1_race"], ["factor2_gender", "factor2_race"], "face_gender_race_confidence_level"),
+    "exp-4": (["factor1_gender", "factor1_race", "factor1_age"], ["factor2_gender", "factor2_race", "factor2_age"], "face_gender_race_age_confidence_level"),
+    "exp-5": (["factor1_gender", "factor1_race"], ["factor2_gender", "factor2_race"], "face_gender_race_confidence_level"),
+}
 
 EXPERIMENT_ATTRS = {
     # name: (classifier logits, [(attribute, first logit column, width)], class CDF edges, exp-4 age asymmetry)

@@ -28,7 +28,8 @@ import torch.distributed as dist
 import torch.nn.functional as F
 
 from . import ops
-from .fairness import (EXPERIMENT_ATTRS, SyntheticFaceProvider, face_grad_factors, fair_loss_and_grad, gen_dynamic_weights,
+from .fairness import (EXPERIMENT_ATTRS, EXPERIMENT_REG_FLAGS, SyntheticFaceProvider, face_grad_factors, face_grad_factors_multi,
+                       fair_loss_and_grad, gen_dynamic_weights, gen_dynamic_weights_multi,
                        generate_dynamic_targets, generate_dynamic_targets_multi, microbatch_weights)
 from .layers import F16, F32
 from .lr_schedule import lr_lambda
@@ -88,8 +89,10 @@ class FairnessTrainer:
         if self.use_img_loss and not self.use_face_loss and getattr(args, "weight_loss_face", 0) != 0:
             raise ValueError("weight_loss_face != 0 but no face-feature network / database is attached "
                              "(build_trainer(..., regularisers=True) attaches them; or pass --weight_loss_face 0)")
-        if (self.use_img_loss or self.use_face_loss) and len(EXPERIMENT_ATTRS[experiment][1]) != 1:
-            raise NotImplementedError("the regulariser terms are wired for exp-1 (single attribute) only")
+        f1, f2, conf = EXPERIMENT_REG_FLAGS[experiment]
+        if self.use_img_loss or self.use_face_loss:
+            self.factors1, self.factors2 = [getattr(args, k) for k in f1], [getattr(args, k) for k in f2]
+            self.face_conf = getattr(args, conf)
         self.te, self.unet, self.vae, self.clf, self.sch = text_encoder, unet, vae, classifier, scheduler
         self.eval_te = eval_text_encoder if eval_text_encoder is not None else text_encoder
         self.eval_unet = eval_unet if eval_unet is not None else unet
@@ -337,7 +340,11 @@ class FairnessTrainer:
             # image-semantics term (:1904-1910, :1931-1932): w_i = (1/n_j) * weight_loss_img * dynamic_weight_i
             small, fullbox = self.resize_small(images_g)
             e_c, e_d = self.image_features(small, record=True)
-            dyn = gen_dynamic_weights(ind_g, targets, per_o[0]["preds"], factor=args.factor1)
+            tl, pl = [t for t, _ in tgt], [a["preds"] for a in per_o]
+            if len(tl) == 1:
+                dyn = gen_dynamic_weights(ind_g, targets, per_o[0]["preds"], factor=self.factors1[0])
+            else:
+                dyn = gen_dynamic_weights_multi(ind_g, tl, pl, self.factors1)
             wi = (w * args.weight_loss_img * dyn).to(dev)
             loss_clip, de_c = feature_loss_and_grad(e_c, clip_ori, wi)
             loss_dino, de_d = feature_loss_and_grad(e_d, dino_ori, wi)
@@ -345,18 +352,23 @@ class FairnessTrainer:
             self.dino.backward(de_d, _pow2_scale(float(de_d.abs().max()), 1.0), out=dsmall)
             d_img = ops.crop_resize_bwd(dsmall, fullbox, B, Himg, Wimg, args.img_size_small)
             # apply_grad_hook_face (:1904, :1584-1617) acts on this path only: the classifier saw the un-hooked images
-            rects, facs = face_grad_factors(boxes_g, boxes_o, targets, per_o[0]["preds"], args.factor2, Himg, Wimg)
+            if len(tl) == 1:
+                rects, facs = face_grad_factors(boxes_g, boxes_o, targets, per_o[0]["preds"], self.factors2[0], Himg, Wimg)
+            else:
+                rects, facs = face_grad_factors_multi(boxes_g, boxes_o, tl, pl, self.factors2, Himg, Wimg)
             ops.rect_scale(d_img, rects.to(dev).contiguous(), facs.to(dev).contiguous())
             lc, ld = loss_clip.float().cpu(), loss_dino.float().cpu()
-            lsum = loss_fair + args.weight_loss_img * dyn * (lc + ld)
+            lsum = sum(loss_by_attr.values()) + args.weight_loss_img * dyn * (lc + ld)
             out.update(loss_CLIP=lc, loss_DINO=ld, loss=lsum, dynamic_weights=dyn)
         if self.use_face_loss:
             # face-realism term (:1917-1932): target = the original image's own face features when the target class equals the
             # original prediction with confidence >= face_gender_confidence_level, else the nearest database face
             from .sfnet import face_features, face_features_backward
-            probs_o = per_o[0]["probs"]
-            has = ind_g & (targets != -1)
-            from_ori = has & (targets == per_o[0]["preds"]) & (probs_o.max(dim=-1).values >= args.face_gender_confidence_level)
+            # exp-1 searches only for images with a target (:1926); the multi-attribute scripts search for every face (exp-3 :2135)
+            from_ori = ind_g.clone()
+            for (t_a, _), a in zip(tgt, per_o):
+                from_ori &= (t_a != -1) & (t_a == a["preds"]) & (a["probs"].max(dim=-1).values >= self.face_conf)
+            has = (ind_g & (targets != -1)) if len(tgt) == 1 else ind_g.clone()
             loss_face = torch.full((B,), -1.0)
             rows = has.nonzero().view(-1)
             if len(rows):
@@ -374,7 +386,7 @@ class FairnessTrainer:
                     d_img = torch.zeros((B, 3, Himg, Wimg), dtype=F32, device=dev)
                 ops.warp_affine_bwd(dch.contiguous(), idx_f, A_f, d_img, args.size_aligned_face)   # un-hooked images (:1901)
             out.update(loss_face=loss_face)
-            out["loss"] = out.get("loss", loss_fair) + args.weight_loss_face * loss_face
+            out["loss"] = out.get("loss", sum(loss_by_attr.values())) + args.weight_loss_face * loss_face
         if (len(sel) and float(dlog_full.abs().sum()) > 0) or d_img is not None:
             if len(sel) and float(dlog_full.abs().sum()) > 0:
                 dlog = dlog_full[sel]

@@ -404,18 +404,76 @@ def resize_small(images, size):
     return F.interpolate(images, size=(size, size), mode="bilinear", align_corners=False)
 
 
+def _mismatch_factor(ts, ps, factors):
+    bad = [f for t, p, f in zip(ts, ps, factors) if t != p]
+    return 1 if not bad else min(bad)
+
+
+def gen_dynamic_weights_multi(face_indicators, targets_list, preds_ori_list, factors):  # exp-3 :1786-1803, exp-4 :1870-1895
+    w = []
+    for i, ind in enumerate(face_indicators):
+        w.append(min(factors) if not bool(ind) else _mismatch_factor([t[i] for t in targets_list], [p[i] for p in preds_ori_list], factors))
+    return torch.tensor(w, dtype=torch.float32)
+
+
+def apply_grad_hook_face_multi(images, face_bboxs, face_bboxs_ori, targets_list, preds_ori_list, factors):  # exp-3 :1751-1783, exp-4 :1823-1867
+    out = []
+    for i, (image, bb, bbo) in enumerate(zip(images, face_bboxs, face_bboxs_ori)):
+        if (bb == -1).all():
+            out.append(image[None])
+            continue
+        img_w, img_h = image.shape[1:]
+        l, r = max(bb[0], bbo[0], 0), min(bb[2], bbo[2], img_w)
+        b, t = max(bb[1], bbo[1], 0), min(bb[3], bbo[3], img_h)
+        face = image[:, b:t, l:r].clone()
+        face.register_hook(make_grad_hook(_mismatch_factor([x[i] for x in targets_list], [x[i] for x in preds_ori_list], factors)))
+        add = torch.zeros_like(image)
+        add[:, b:t, l:r] = face
+        mask = torch.zeros_like(image)
+        mask[:, b:t, l:r] = 1
+        out.append((mask * add + (1 - mask) * image)[None])
+    return torch.cat(out)
+
+
 def fairness_step_multi(models, tokens, noises, S, cfg, attrs, targets_by_attr):
     """Multi-attribute variant of the R3 part (exp-3 `:2079-2155`): loss_ij = sum_a CE_a with -1 sentinels; the dynamic
-    targets are passed in (they come from a Monte-Carlo OT procedure, tested separately).  attrs: [(name, col0, width)]."""
+    targets are passed in (they come from a Monte-Carlo OT procedure, tested separately).  attrs: [(name, col0, width)].
+    With ``clip``/``dino`` and/or ``face_net``/``face_db`` in ``models`` (and ``eval_unet``/``eval_text_encoder`` for R2) the regulariser
+    terms of exp-3 `:2106-2147` are added: cfg factors1 / factors2 (per attribute), weight_loss_img, weight_loss_face, face_conf."""
     te, unet, vae, clf, sch = (models[k] for k in ("text_encoder", "unet", "vae", "classifier", "scheduler"))
     faces = SyntheticFaceProvider(cfg.get("size_face", 224))
     gs, B, tb = cfg.get("guidance_scale", 7.5), noises.shape[0], cfg["train_GPU_batch_size"]
     N_backward = math.ceil(B / tb)
     losses = {a[0]: torch.ones(B) * (-1) for a in attrs}
+    w_img = cfg.get("weight_loss_img", 0.0) if ("clip" in models and "dino" in models) else 0.0
+    w_face = cfg.get("weight_loss_face", 0.0) if ("face_net" in models and "face_db" in models) else 0.0
+    crop = cfg.get("size_aligned_face", 112)
+    extra = {k: torch.ones(B) * (-1) for k in ("loss_CLIP", "loss_DINO", "loss_face", "loss")}
+    if w_img or w_face:
+        with torch.no_grad():
+            vb = cfg.get("val_GPU_batch_size", B)
+            images_ori = torch.cat([generate_image_no_gradient(tokens, noises[j:j + vb], S, models["eval_text_encoder"], models["eval_unet"],
+                                                               vae, sch, gs) for j in range(0, B, vb)])
+            ind_o, boxes_o, chips_o = faces(images_ori)
+            lo = clf(chips_o[ind_o])
+            preds_o, probs_o = [], []
+            for name, c0, k in attrs:
+                pr = torch.ones(B, k) * (-1)
+                pd = torch.ones(B, dtype=torch.long) * (-1)
+                p = torch.softmax(lo[:, c0:c0 + k], dim=-1)
+                pr[ind_o], pd[ind_o] = p, p.max(dim=-1).indices
+                preds_o.append(pd)
+                probs_o.append(pr)
+            if w_img:
+                small_o = resize_small(images_ori, cfg.get("img_size_small", 224))
+                clip_o = image_features(models["clip"], small_o, CLIP_IMAGE_MEAN, CLIP_IMAGE_STD)
+                dino_o = image_features(models["dino"], small_o, DINO_IMAGE_MEAN, DINO_IMAGE_STD)
+            if w_face:
+                face_feats_o = get_face_feats(models["face_net"], faces.aligned(images_ori, crop))
     for j in range(N_backward):
         idx = list(range(B))[j * tb:(j + 1) * tb]
         img = generate_image_w_gradient(tokens, noises[idx], S, te, unet, vae, sch, gs)
-        ind_j, _, chips_j = faces(img)
+        ind_j, boxes_j, chips_j = faces(img)
         logits = clf(chips_j[ind_j])
         loss_ij = 0
         for name, c0, k in attrs:
@@ -427,6 +485,33 @@ def fairness_step_multi(models, tokens, noises, S, cfg, attrs, targets_by_attr):
             lf[w] = F.cross_entropy(la[w], t[w], reduction="none")
             losses[name][idx] = lf.detach()
             loss_ij = loss_ij + lf
+        tl = [targets_by_attr[a[0]][idx] for a in attrs]
+        if w_img:
+            pl = [p[idx] for p in preds_o]
+            hooked = apply_grad_hook_face_multi(img, boxes_j, boxes_o[idx], tl, pl, cfg["factors2"])
+            small = resize_small(hooked, cfg.get("img_size_small", 224))
+            lc = 1 - (image_features(models["clip"], small, CLIP_IMAGE_MEAN, CLIP_IMAGE_STD) * clip_o[idx]).sum(dim=-1)
+            ld = 1 - (image_features(models["dino"], small, DINO_IMAGE_MEAN, DINO_IMAGE_STD) * dino_o[idx]).sum(dim=-1)
+            dyn = gen_dynamic_weights_multi(ind_j, tl, pl, cfg["factors1"])
+            loss_ij = loss_ij + w_img * dyn * (lc + ld)
+            extra["loss_CLIP"][idx], extra["loss_DINO"][idx] = lc.detach(), ld.detach()
+        if w_face:
+            aligned_j = faces.aligned(img, crop)
+            sel = (ind_j == True)  # noqa: E712
+            for t, p, pr in zip(tl, [p[idx] for p in preds_o], [p[idx] for p in probs_o]):
+                sel = sel * (t != -1) * (t == p) * (pr.max(dim=-1).values >= cfg.get("face_conf", 0.8))
+            from_ori = sel.nonzero().view([-1]).tolist()
+            lface = torch.ones(len(idx)) * (-1)
+            if len(from_ori) > 0:
+                f1 = get_face_feats(models["face_net"], aligned_j[from_ori])
+                lface[from_ori] = 1 - (f1 * face_feats_o[idx][from_ori]).sum(dim=-1)
+            from_search = sorted(set((ind_j == True).nonzero().view([-1]).tolist()) - set(from_ori))  # noqa: E712  (exp-3 :2135: every face)
+            if len(from_search) > 0:
+                f2 = get_face_feats(models["face_net"], aligned_j[from_search])
+                lface[from_search] = 1 - (f2 * semantic_search(models["face_db"], f2)).sum(dim=-1)
+            loss_ij = loss_ij + w_face * lface
+            extra["loss_face"][idx] = lface.detach()
         if torch.is_tensor(loss_ij) and loss_ij.requires_grad:
             loss_ij.mean().backward()
-    return dict(losses=losses, N_backward=N_backward)
+        extra["loss"][idx] = loss_ij.detach() if torch.is_tensor(loss_ij) else extra["loss"][idx]
+    return dict(losses=losses, N_backward=N_backward, **extra)

@@ -116,6 +116,7 @@ def main():
         preds, probs, logits = ns["get_face_gender"](chips, selector=sel, fill_value=-1)
         gfg.append(dict(W=W.tolist(), chips=chips.tolist(), selector=sel.tolist(), preds=preds.tolist(), probs=probs.tolist(), logits=logits.tolist()))
     out["get_face_gender"] = gfg
+    multi_attribute_goldens(out)
     json.dump(out, open(os.path.join(HERE, "reference_pure_functions.json"), "w"))
 
     # CLI: defaults + YAML overlays of every exp-1 config ---------------------------
@@ -145,6 +146,49 @@ def main():
     print("wrote multi-attribute CLI goldens:", {k: len(v["defaults"]) for k, v in multi.items()})
 
     sfnet_golden()
+
+
+def multi_attribute_goldens(out):
+    """exp-3 / exp-4 versions of gen_dynamic_weights and apply_grad_hook_face (2 and 3 attributes), lifted from their own scripts."""
+    for exp, d, na in [("exp3", "exp-3-debias-gender-race", 2), ("exp4", "exp-4-debias-gender-race-age", 3)]:
+        ns = lift(["make_grad_hook", "gen_dynamic_weights", "apply_grad_hook_face"], ref=f"/root/reference/{d}/1-main-debias.py")
+        ns["itertools"] = itertools
+        factors1, factors2 = [0.2, 0.6, 0.5][:na], [0.25, 0.3, 0.1][:na]
+        names = ["gender", "race", "age"][:na]
+        widths = [2, 4, 2][:na]
+        gdw, agh = [], []
+        for seed in range(4):
+            g = torch.Generator().manual_seed(500 + seed)
+            n = 6
+            ind = torch.rand(n, generator=g) > 0.25
+            T = [torch.randint(-1, w, (n,), generator=g) for w in widths]
+            P = [torch.randint(0, w, (n,), generator=g) for w in widths]
+            for k in range(na):      # make matches likely
+                m = torch.rand(n, generator=g) < 0.5
+                T[k][m] = P[k][m]
+            probs = [torch.rand(n, w, generator=g) for w in widths]
+            args, kw = [ind], {}
+            for k in range(na):
+                args += [T[k], P[k], probs[k]]
+                kw[f"factor_{names[k]}"] = factors1[k]
+            w = ns["gen_dynamic_weights"](*args, **kw)
+            gdw.append(dict(face_indicators=ind.tolist(), targets=[t.tolist() for t in T], preds_ori=[p.tolist() for p in P], factors=factors1,
+                            weights=[round(float(v), 6) for v in w]))
+            H = 24
+            images = torch.randn(n, 3, H, H, generator=g, requires_grad=True)
+            bb = torch.tensor([[4, 6, 20, 22], [-1, -1, -1, -1], [0, 0, 30, 30], [10, 3, 20, 17], [2, 2, 12, 12], [5, 5, 19, 23]])
+            bbo = torch.tensor([[8, 2, 28, 20], [3, 3, 9, 9], [5, 5, 25, 25], [-3, -2, 12, 40], [-1, -1, -1, -1], [6, 4, 18, 20]])
+            args, kw = [images, bb, bbo], {}
+            for k in range(na):
+                args += [T[k], P[k], probs[k]]
+                kw[f"factor_{names[k]}"] = factors2[k]
+            y = ns["apply_grad_hook_face"](*args, **kw)
+            gw = torch.randn(y.shape, generator=g)
+            (y * gw).sum().backward()
+            agh.append(dict(seed=500 + seed, bbox=bb.tolist(), bbox_ori=bbo.tolist(), targets=[t.tolist() for t in T], preds_ori=[p.tolist() for p in P],
+                            factors=factors2, grad_ratio_ch0=(images.grad / gw)[:, 0].round(decimals=4).tolist()))
+        out[f"gen_dynamic_weights_{exp}"] = gdw
+        out[f"apply_grad_hook_face_{exp}"] = agh
 
 
 def sfnet_golden():

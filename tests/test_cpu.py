@@ -567,3 +567,21 @@ def test_face_alignment_host_math():
     M = umeyama_similarity(lms[0].numpy(), ALIGNED_FACE_LANDMARKS)
     back = (M[:2, :2] @ lms[0].numpy().T).T + M[:2, 2]
     assert np.abs(back - ALIGNED_FACE_LANDMARKS).max() < 1e-3
+
+
+def test_multi_attribute_regulariser_rules_golden():
+    """exp-3 / exp-4 gen_dynamic_weights and apply_grad_hook_face (reference outputs) vs the product's attribute-count-generic forms."""
+    from finetune_fair_diffusion_amd.fairness import face_grad_factors_multi, gen_dynamic_weights_multi
+    for exp in ("exp3", "exp4"):
+        for c in GOLD[f"gen_dynamic_weights_{exp}"]:
+            w = gen_dynamic_weights_multi(torch.tensor(c["face_indicators"]), [torch.tensor(t) for t in c["targets"]],
+                                          [torch.tensor(p) for p in c["preds_ori"]], c["factors"])
+            assert np.allclose(w.numpy(), c["weights"], atol=1e-6), (exp, w, c["weights"])
+        for c in GOLD[f"apply_grad_hook_face_{exp}"]:
+            H = len(c["grad_ratio_ch0"][0])
+            rects, facs = face_grad_factors_multi(torch.tensor(c["bbox"]), torch.tensor(c["bbox_ori"]), [torch.tensor(t) for t in c["targets"]],
+                                                  [torch.tensor(p) for p in c["preds_ori"]], c["factors"], H, H)
+            mask = torch.ones(len(c["bbox"]), H, H)
+            for i, (r, f) in enumerate(zip(rects.tolist(), facs.tolist())):
+                mask[i, r[1]:r[3], r[0]:r[2]] = f
+            assert torch.allclose(mask, torch.tensor(c["grad_ratio_ch0"]), atol=1e-4), exp

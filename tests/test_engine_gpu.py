@@ -638,3 +638,53 @@ def test_full_step_with_face_realism_term(dev):
     with pytest.raises(ValueError):
         FairnessTrainer(U.make_args(weight_loss_face=1.0), pm["text_encoder"], pm["unet"], pm["vae"], pm["classifier"], pm["scheduler"],
                         eval_unet=pm["eval_unet"], device=dev, face_net=SFNet20(sd_f, dev))
+
+
+def test_full_step_exp3_with_all_regularisers(dev):
+    """exp-3 (gender x race): loss_ij = CE_gender + CE_race + w_img*dyn*(CLIP+DINO) + w_face*face (exp-3 :2106-2147) with the
+    per-attribute factor rules (min over mismatching attributes; every face searches the database): per-image terms and the total
+    U-Net LoRA gradient vs the oracle, using the product's OT targets."""
+    from oracle import fair_step as fs, nn_sfnet as OS, nn_vit as OV
+    from finetune_fair_diffusion_amd import weights as W
+    from finetune_fair_diffusion_amd.fairness import EXPERIMENT_ATTRS
+    from finetune_fair_diffusion_amd.factory import TINY
+    from finetune_fair_diffusion_amd.sfnet import SFNet20
+    from finetune_fair_diffusion_amd.step import FairnessTrainer
+    from finetune_fair_diffusion_amd.vit import VisionTransformer
+    om = U.oracle_models(train_unet=True, train_te=False, lora_up_std=0.05, num_classes=6)
+    pm = U.product_models(om["sds"], dev, train_unet=True, train_te=False, num_classes=6)
+    sd_c = W.synthetic_state_dict(W.vit_param_shapes(TINY["clip_vision"]), seed=21)
+    sd_d = W.synthetic_state_dict(W.vit_param_shapes(TINY["dino"]), seed=22)
+    sd_f = W.synthetic_state_dict(W.sfnet20_param_shapes(), seed=31)
+    db = F.normalize(torch.randn(129, 512, generator=torch.Generator().manual_seed(4)), dim=-1)
+    onet = OS.SFNet20().eval().requires_grad_(False)
+    onet.load_state_dict(sd_f)
+    models_o = dict(text_encoder=om["text_encoder"], unet=om["unet"], vae=om["vae"], classifier=om["classifier"], scheduler=om["scheduler"],
+                    eval_text_encoder=om["text_encoder"], eval_unet=om["eval_unet"], face_net=onet, face_db=db,
+                    clip=OV.build(OV.ViTConfig(**TINY["clip_vision"].__dict__), sd_c), dino=OV.build(OV.ViTConfig(**TINY["dino"].__dict__), sd_d))
+    args = U.make_args(train_unet=True, train_text_encoder=False, uncertainty_threshold=0.6, weight_loss_img=8.0, weight_loss_face=0.1, img_size_small=56,
+                       factor1_gender=0.2, factor1_race=0.6, factor2_gender=0.2, factor2_race=0.3, face_gender_race_confidence_level=0.0)
+    tokens = U.tiny_tokens()
+    B, S = 4, 3
+    noises = torch.randn(B, 4, 32, 32, generator=torch.Generator().manual_seed(7))
+    tr = FairnessTrainer(args, pm["text_encoder"], pm["unet"], pm["vae"], pm["classifier"], pm["scheduler"], eval_unet=pm["eval_unet"], experiment="exp-3",
+                         device=dev, clip_model=VisionTransformer(TINY["clip_vision"], sd_c, dev, W.CLIP_IMAGE_MEAN, W.CLIP_IMAGE_STD),
+                         dino_model=VisionTransformer(TINY["dino"], sd_d, dev, W.DINO_IMAGE_MEAN, W.DINO_IMAGE_STD), face_net=SFNet20(sd_f, dev), face_db=db)
+    grads = {}
+    tr.sync_and_update = lambda nb, apply=True: (grads.__setitem__(0, tr.banks[0].grad.clone()), True)[1]
+    out = tr.train_step(tokens, noises, S)
+    tg = out["targets_by_attr"]
+    for p in om["lora_params"]:
+        p.grad = None
+    ref = fs.fairness_step_multi(models_o, tokens, noises, S, dict(train_GPU_batch_size=3, val_GPU_batch_size=8, size_face=64, weight_loss_img=8.0,
+                                                                    weight_loss_face=0.1, img_size_small=56, factors1=[0.2, 0.6], factors2=[0.2, 0.3],
+                                                                    face_conf=0.0), EXPERIMENT_ATTRS["exp-3"][1], tg)
+    for k in ("loss_CLIP", "loss_DINO", "loss_face", "loss"):
+        check(f"exp-3 {k}", out[k], ref[k], 3e-2)
+    assert (ref["loss_face"] != -1).all()         # multi-attribute rule: every face gets a face target
+    names = list(om["unet_lora_layers"].state_dict().keys())
+    refg = torch.cat([p.grad.flatten() for p in om["unet_lora_layers"].parameters()]).double()
+    got = torch.cat([tr.banks[0].view(n, grads[0]).flatten() for n in names]).cpu().double()
+    cos = F.cosine_similarity(got, refg, dim=0)
+    print("cosine(exp-3 unet grads, all terms) =", float(cos), " norm ratio =", float(got.norm() / refg.norm()))
+    assert cos > 0.97
