@@ -1,6 +1,6 @@
 """Training driver: the loop of exp-1-debias-gender/1-main-debias.py ``main`` (:647-2070) around FairnessTrainer.
 
-    python -m finetune_fair_diffusion_amd.train --config exp-1-debias-gender/_yaml/debias-unet.yaml [--synthetic]
+    python -m finetune_fair_diffusion_amd.train [--experiment exp-1|exp-3|exp-4|exp-5] --config <yaml> [--synthetic]
     python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 -m finetune_fair_diffusion_amd.train ...
 
 Same flags, YAML overlay, seeding (``set_seed(seed, device_specific=True)`` :693, prompt order from
@@ -60,6 +60,7 @@ class CLIPTokenizerAdapter:
 
 
 def load_prompts(args):
+    """Occupation prompts (:905-908); exp-5 mixes in three more files at 6x / 20x / 4x (exp-5 :934-947)."""
     if os.path.exists(args.prompt_occupation_path):
         with open(args.prompt_occupation_path, "r") as f:
             data = json.load(f)
@@ -67,7 +68,17 @@ def load_prompts(args):
         data = SYNTHETIC_PROMPTS
     else:
         raise FileNotFoundError(f"{args.prompt_occupation_path} (pass --synthetic to run without the reference's data.zip)")
-    return [p.format(occupation=o) for p in data["prompt_templates_train"] for o in data["occupations_train_set"]]
+    prompts = [p.format(occupation=o) for p in data["prompt_templates_train"] for o in data["occupations_train_set"]]
+    extra = [("prompt_occupation_w_style_and_context_path", 6), ("prompt_personal_descroptor_path", 20), ("prompt_sports_path", 4)]
+    if all(hasattr(args, k) for k, _ in extra):
+        for k, rep in extra:
+            path = getattr(args, k)
+            if os.path.exists(path):
+                with open(path, "r") as f:
+                    prompts += json.load(f)["train_prompts"] * rep
+            elif not getattr(args, "synthetic", False):
+                raise FileNotFoundError(f"{path} (pass --synthetic to run without the reference's data.zip)")
+    return prompts
 
 
 def set_seed(seed, device_specific, rank):
@@ -81,8 +92,16 @@ def set_seed(seed, device_specific, rank):
         torch.cuda.manual_seed_all(seed)
 
 
-def main(argv=None, experiment="exp-1", cfgs=None, log=None):
-    args = parse_args(argv if argv is not None else sys.argv[1:], with_extras=True, experiment=experiment)
+def main(argv=None, experiment=None, cfgs=None, log=None):
+    argv = list(argv if argv is not None else sys.argv[1:])
+    if experiment is None:       # build addition: one driver for the reference's per-experiment scripts
+        import argparse
+        pre = argparse.ArgumentParser(add_help=False)
+        pre.add_argument("--experiment", default="exp-1", choices=["exp-1", "exp-3", "exp-4", "exp-5"])
+        ns, argv = pre.parse_known_args(argv)
+        experiment = ns.experiment
+    args = parse_args(argv, with_extras=True, experiment=experiment)
+    args.experiment = experiment
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))

@@ -585,3 +585,22 @@ def test_multi_attribute_regulariser_rules_golden():
             for i, (r, f) in enumerate(zip(rects.tolist(), facs.tolist())):
                 mask[i, r[1]:r[3], r[0]:r[2]] = f
             assert torch.allclose(mask, torch.tensor(c["grad_ratio_ch0"]), atol=1e-4), exp
+
+
+def test_exp5_prompt_mix(tmp_path):
+    """exp-5 :934-947: occupation prompts + 6x / 20x / 4x of the three extra prompt files."""
+    import types
+    from finetune_fair_diffusion_amd.train import load_prompts
+    occ = tmp_path / "occ.json"
+    occ.write_text(json.dumps({"prompt_templates_train": ["a {occupation}", "the {occupation}"], "occupations_train_set": ["x", "y", "z"]}))
+    files = {}
+    for k, n in (("prompt_occupation_w_style_and_context_path", 2), ("prompt_personal_descroptor_path", 1), ("prompt_sports_path", 3)):
+        f = tmp_path / (k + ".json")
+        f.write_text(json.dumps({"train_prompts": [f"{k}-{i}" for i in range(n)]}))
+        files[k] = str(f)
+    ps = load_prompts(types.SimpleNamespace(prompt_occupation_path=str(occ), synthetic=False, **files))
+    assert len(ps) == 6 + 2 * 6 + 1 * 20 + 3 * 4 and ps[:2] == ["a x", "a y"] and ps[6] == "prompt_occupation_w_style_and_context_path-0"
+    assert len(load_prompts(types.SimpleNamespace(prompt_occupation_path=str(occ), synthetic=False))) == 6
+    files["prompt_sports_path"] = str(tmp_path / "missing.json")
+    with pytest.raises(FileNotFoundError):
+        load_prompts(types.SimpleNamespace(prompt_occupation_path=str(occ), synthetic=False, **files))

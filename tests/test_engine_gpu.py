@@ -688,3 +688,23 @@ def test_full_step_exp3_with_all_regularisers(dev):
     cos = F.cosine_similarity(got, refg, dim=0)
     print("cosine(exp-3 unet grads, all terms) =", float(cos), " norm ratio =", float(got.norm() / refg.norm()))
     assert cos > 0.97
+
+
+@pytest.mark.parametrize("experiment", ["exp-1", "exp-4"])
+def test_train_driver_runs_full_loss(tmp_path, experiment):
+    """The driver with every loss term on (synthetic weights, tiny configs): exp-1 and the three-attribute exp-4 (8-logit head, OT targets,
+    per-attribute factors) step, log all loss terms and stay finite."""
+    from finetune_fair_diffusion_amd import train
+    from finetune_fair_diffusion_amd.factory import TINY
+    logs = []
+    argv = ["--experiment", experiment, "--synthetic", "--train_unet", "--rank", "4", "--max_train_steps", "2", "--checkpointing_steps", "100",
+            "--checkpointing_steps_long", "100", "--num_denoising_steps", "3", "--train_images_per_prompt_GPU", "4", "--train_GPU_batch_size", "3",
+            "--val_GPU_batch_size", "4", "--img_size_small", "56", "--weight_loss_img", "8", "--weight_loss_face", "0.5", "--uncertainty_threshold", "0.6",
+            "--output_dir", str(tmp_path)]
+    tr, n = train.main(argv, cfgs=TINY, log=logs.append)
+    recs = [json.loads(x) for x in logs]
+    assert n == 2 and tr.experiment == experiment and tr.use_img_loss and tr.use_face_loss
+    for r in recs:
+        assert r["grad_is_finite"] and r["loss_CLIP"] is not None and r["loss_DINO"] is not None and r["loss_face"] is not None
+        assert 0 <= r["loss_CLIP"] < 2 and 0 <= r["loss_face"] < 2
+    assert tr.clf.num_classes == (80 if experiment == "exp-1" else 8)
