@@ -29,22 +29,21 @@ def f_img(S):
     return 8 * S * F_UNET + 4 * F_VAE
 
 
-def pmc_traffic(kernel, flop_per_launch):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes (FETCH_SIZE / WRITE_SIZE cannot be read
-    from inside a process; they are collected with rocprofv3 --pmc in separate runs, profiles/r01_pmc_traffic_*.json, with the
-    gfx950 corrections of MI355X_MICROARCH.md applied).  The kernel's three shapes differ only in Cin, and both bytes and FLOPs
-    are affine in Cin, so the per-launch figure for this run's launch mix is interpolated at its mean FLOPs per launch."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic_conv256x320.json")
+def pmc_traffic(kernel, algorithmic_bytes_per_launch):
+    """HBM-side bytes per launch of the dominant kernel from the committed PMC passes (FETCH_SIZE / WRITE_SIZE cannot be read from
+    inside a process; they are collected with rocprofv3 --pmc in separate runs on the kernel's own shapes, profiles/r01_pmc_traffic.json,
+    with the gfx950 corrections of MI355X_MICROARCH.md applied).  This run's per-launch figure = its mean ALGORITHMIC bytes per launch
+    (exact, from every launch's M, N, K) x the measured traffic / algorithmic ratio of that kernel variant."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
     if not os.path.exists(path):
         return None, "no PMC summary committed"
-    d = json.load(open(path))
-    if d["kernel"] != kernel:
-        return None, f"PMC summary is for {d['kernel']}"
-    sh = sorted(d["shapes"], key=lambda x: x["flop"])
-    (f0, b0), (f1, b1) = (sh[0]["flop"], sh[0]["hbm_bytes"]), (sh[-1]["flop"], sh[-1]["hbm_bytes"])
-    return b0 + (flop_per_launch - f0) * (b1 - b0) / (f1 - f0), "bytes/launch, rocprofv3 PMC (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), " \
-        "interpolated to this run's mean FLOP/launch; algorithmic bytes are %.0f%% of it" % (
-            100 * sum(x["algorithmic_bytes"] for x in sh) / sum(x["hbm_bytes"] for x in sh))
+    d = json.load(open(path))["kernels"].get(kernel)
+    if d is None:
+        return None, "no PMC summary for " + kernel
+    ratio = sum(x["hbm_bytes"] for x in d["shapes"]) / sum(x["algorithmic_bytes"] for x in d["shapes"])
+    return algorithmic_bytes_per_launch * ratio, "bytes/launch = mean algorithmic bytes/launch of this run (%.1f MB) x %.2f, the rocprofv3 PMC ratio " \
+        "(FETCH_SIZE x2 gfx950 correction + WRITE_SIZE) / algorithmic bytes on this kernel's shapes; Infinity-Cache hits are included" % (
+            algorithmic_bytes_per_launch / 1e6, ratio)
 
 
 def main():
@@ -144,11 +143,12 @@ def main():
         top = max(summ.items(), key=lambda kv: kv[1]["ms"])
         name, s = top
         achieved = s["flops"] / (s["ms"] * 1e-3) / 1e12
-        traffic, traffic_note = pmc_traffic(name, s["flops"] / s["launches"])
+        traffic, traffic_note = pmc_traffic(name, s["bytes"] / s["launches"])
         line["roofline"] = {"bound": "mfma", "kernel": name, "achieved": achieved, "peak": MFMA_PEAK_F16 / 1e12, "unit": "TFLOP/s",
                             "frac": achieved / (MFMA_PEAK_F16 / 1e12), "traffic": traffic, "traffic_note": traffic_note,
                             "launches": s["launches"],
                             "avg_launch_us": 1e3 * s["ms"] / s["launches"], "algorithmic_flop_per_launch": s["flops"] / s["launches"],
+                            "algorithmic_bytes_per_launch": s["bytes"] / s["launches"],
                             "family": {k: {"launches": v["launches"], "ms": round(v["ms"], 2), "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1)}
                                        for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"])}}
     if world == 1 and not a.no_roofline:

@@ -50,16 +50,16 @@ class OpTimer:
     (torch's current stream); used by bench.py's roofline pass, never inside the timed region."""
 
     def __init__(self):
-        self.records = []  # (variant, flops, start_event, end_event)
+        self.records = []  # (variant, flops, algorithmic bytes, start_event, end_event)
 
     def summary(self):
         torch.cuda.synchronize()
         agg = {}
-        for variant, flops, a, b in self.records:
+        for variant, flops, nbytes, a, b in self.records:
             ms = a.elapsed_time(b)
-            e = agg.setdefault(variant, [0, 0.0, 0.0])
-            e[0] += 1; e[1] += flops; e[2] += ms
-        return {k: dict(launches=v[0], flops=v[1], ms=v[2]) for k, v in agg.items()}
+            e = agg.setdefault(variant, [0, 0.0, 0.0, 0.0])
+            e[0] += 1; e[1] += flops; e[2] += ms; e[3] += nbytes
+        return {k: dict(launches=v[0], flops=v[1], ms=v[2], bytes=v[3]) for k, v in agg.items()}
 
 
 TIMER = None
@@ -77,9 +77,12 @@ def _gemm_call(d, conv):
     _call("fd_gemm", ctypes.byref(d), _stream())
     b.record()
     flops = 2.0 * d.M * d.N * (d.K + d.K2) * max(d.batch, 1)
+    # algorithmic bytes: every operand element read once, the output written once (3x3 gather: the Cin-wide input rows, not 9x)
+    a_elems = (d.Bn * d.H * d.W * d.Cin) if conv else d.M * d.K
+    nbytes = 2.0 * max(d.batch, 1) * (a_elems + d.M * d.K2 + d.N * (d.K + d.K2) + d.M * d.N)
     split, tile = tile // 1000000, tile % 1000000
     kname = "gemm_big_kernel" if tile in (256320, 128320, 128160, 256128) else "gemm_glds_kernel"
-    TIMER.records.append((f"{kname}<{tile // 1000},{tile % 1000},{'conv3x3' if conv else 'dense'}{',splitK' if split > 1 else ''}>", flops, a, b))
+    TIMER.records.append((f"{kname}<{tile // 1000},{tile % 1000},{'conv3x3' if conv else 'dense'}{',splitK' if split > 1 else ''}>", flops, nbytes, a, b))
 
 
 def _chk(t, dtype=F16):

@@ -41,7 +41,10 @@ def test_gemm_plain(ops, dev, M, N, K):
 
 
 @pytest.mark.parametrize("M,N,K,tile", [(51300, 320, 1280, 256320), (20600, 320, 1288, 128320), (20500, 640, 1032, 128320), (1300, 2560, 1024, 128160),
-                                          (51300, 128, 1096, 256128), (65536, 320, 320, 128064), (1024, 1280, 11520, 8128320), (1000, 320, 5120, 8128160), (4096, 1280, 11520, 2128320)])
+                                          (51300, 128, 1096, 256128), (65536, 320, 320, 256320), (65536, 320, 256, 128064), (1024, 1280, 11520, 8128320), (1000, 320, 5120, 8128160),
+                                          (4096, 1280, 11520, 2128320),
+                                          # banded tile order: B slab per 320-wide n-tile 1.3 MB -> bands of 2 n-tiles; 7 n-tiles -> bands 2,2,2,1
+                                          (3000, 2240, 2048, 128320), (8200, 2240, 2048, 256320)])
 def test_gemm_big_tiles(ops, dev, M, N, K, tile):
     """The 8-wave BK=64 tile variants (incl. M tails and K tails inside a 64-wide k-tile), with the LoRA slab + epilogue."""
     a, b = rnd(M, K, dev=dev, seed=1), rnd(N, K, dev=dev, scale=0.1, seed=2)
