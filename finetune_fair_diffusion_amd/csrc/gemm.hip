@@ -638,6 +638,9 @@ extern "C" int fd_gemm_tile(const fd_gemm_desc* dp) {
             if (c) return c;
         }
         if (d.N % 160 == 0 && m128 * (d.N / 160) >= 160) return 128160;
+        // VAE decoder widths (256 / 512 channels at 256^2 / 512^2 pixels): 256x256 halves the A re-reads of the 256x128 tile
+        static const bool no256 = getenv("FD_GEMM_NO256256") != nullptr;
+        if (!no256 && d.N % 256 == 0 && m256 * (d.N / 256) >= 200) return 256256;
         if (d.N % 128 == 0 && m256 * (d.N / 128) >= 200) return 256128;
         // small-M, long-K (8x8 level): split K so that all 256 CUs get a block
         if (can_split && d.N % 160 == 0) {
@@ -680,6 +683,7 @@ extern "C" int fd_gemm(const fd_gemm_desc* dp, void* stream) {
         case 256320: return (w16 && !d.conv) ? launch_big<256, 320, 4, 4>(d, s) : launch_big<256, 320, 2, 4>(d, s);
         case 128320: return w16 ? launch_big<128, 320, 4, 4>(d, s) : launch_big<128, 320, 2, 4>(d, s);
         case 128160: return launch_big<128, 160, 4, 2>(d, s);
+        case 256256: return launch_big<256, 256, 2, 4>(d, s);
         case 256128: return launch_big<256, 128, 4, 2>(d, s);
         case 128128: return launch<128, 128>(d, s);
         case 128064: return launch<128, 64>(d, s);
