@@ -641,6 +641,8 @@ extern "C" int fd_gemm_tile(const fd_gemm_desc* dp) {
         // VAE decoder widths (256 / 512 channels at 256^2 / 512^2 pixels): 256x256 halves the A re-reads of the 256x128 tile
         static const bool no256 = getenv("FD_GEMM_NO256256") != nullptr;
         if (!no256 && d.N % 256 == 0 && m256 * (d.N / 256) >= 200) return 256256;
+        static const bool no512 = getenv("FD_GEMM_NO512128") != nullptr;
+        if (!no512 && d.N == 128 && ((d.M + 511) / 512) >= 400) return 512128;   // 128-channel layers at 512^2: the tallest tile that fits the LDS
         if (d.N % 128 == 0 && m256 * (d.N / 128) >= 200) return 256128;
         // small-M, long-K (8x8 level): split K so that all 256 CUs get a block
         if (can_split && d.N % 160 == 0) {
@@ -677,13 +679,15 @@ extern "C" int fd_gemm(const fd_gemm_desc* dp, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     static const bool w16 = getenv("FD_GEMM_W8") == nullptr;   // 16-wave variants by default (A/B switch for measurement)
     const int sel = fd_gemm_tile(&d);
-    if (sel >= 1000000)
+    if (sel >= 1000000) {
         return (sel % 1000000 == 128320) ? launch_big<128, 320, 4, 4>(d, s, sel / 1000000) : launch_big<128, 160, 4, 2>(d, s, sel / 1000000);
+    }
     switch (sel) {
         case 256320: return (w16 && !d.conv) ? launch_big<256, 320, 4, 4>(d, s) : launch_big<256, 320, 2, 4>(d, s);
         case 128320: return w16 ? launch_big<128, 320, 4, 4>(d, s) : launch_big<128, 320, 2, 4>(d, s);
         case 128160: return launch_big<128, 160, 4, 2>(d, s);
         case 256256: return launch_big<256, 256, 2, 4>(d, s);
+        case 512128: return launch_big<512, 128, 8, 2>(d, s);
         case 256128: return launch_big<256, 128, 4, 2>(d, s);
         case 128128: return launch<128, 128>(d, s);
         case 128064: return launch<128, 64>(d, s);

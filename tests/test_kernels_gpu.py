@@ -45,7 +45,7 @@ def test_gemm_plain(ops, dev, M, N, K):
                                           (4096, 1280, 11520, 2128320),
                                           # banded tile order: B slab per 320-wide n-tile 1.3 MB -> bands of 2 n-tiles; 7 n-tiles -> bands 2,2,2,1
                                           (3000, 2240, 2048, 128320), (8200, 2240, 2048, 256320),
-                                          (51300, 512, 1096, 256256), (26000, 256, 520, 256128)])
+                                          (51300, 512, 1096, 256256), (26000, 256, 520, 256128), (205000, 128, 1160, 512128)])
 def test_gemm_big_tiles(ops, dev, M, N, K, tile):
     """The 8-wave BK=64 tile variants (incl. M tails and K tails inside a 64-wide k-tile), with the LoRA slab + epilogue."""
     a, b = rnd(M, K, dev=dev, seed=1), rnd(N, K, dev=dev, scale=0.1, seed=2)
@@ -62,7 +62,7 @@ def test_gemm_big_tiles(ops, dev, M, N, K, tile):
     check(f"gemm big {M}x{N}x{K}", c, a.float() @ b.float().t() + a2.float() @ b2.float().t() + bias + res.float(), 2e-3)
 
 
-@pytest.mark.parametrize("B,H,Cin,Cout", [(16, 64, 320, 320), (14, 64, 64, 128), (13, 32, 128, 640), (3, 136, 128, 256), (2, 168, 64, 512)])
+@pytest.mark.parametrize("B,H,Cin,Cout", [(16, 64, 320, 320), (14, 64, 64, 128), (13, 32, 128, 640), (3, 136, 128, 256), (2, 168, 64, 512), (1, 456, 64, 128)])
 def test_conv3x3_big_tiles(ops, dev, B, H, Cin, Cout):
     x = rnd(B, Cin, H, H, dev=dev, seed=1)
     w = rnd(Cout, Cin, 3, 3, dev=dev, scale=0.05, seed=2)
