@@ -127,6 +127,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const f16* __restrict__ Q
     TileRegs<D> kreg, vreg;
     zero_row_pad<D, DKP>(Ks);
     zero_col_pad<D, DV>(Vts);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // Q fragments landed: no VM event may pend on them inside the loop
     load_rows<D>(kreg, Kb, C, 0, Tk);
     load_cols<D>(vreg, Vtb, Tkp, 0, Tkp);
     for (int k0 = 0; k0 < Tk; k0 += 64) {
@@ -134,11 +135,6 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const f16* __restrict__ Q
         store_rows<D, DKP>(kreg, Ks);
         store_cols<D>(vreg, Vts);
         __syncthreads();
-        if (k0 + 64 < Tk) {            // next tile's loads fly under this tile's MFMAs
-            load_rows<D>(kreg, Kb, C, k0 + 64, Tk);
-            load_cols<D>(vreg, Vtb, Tkp, k0 + 64, Tkp);
-        }
-
         f32x16 s[2];
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
@@ -149,9 +145,16 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const f16* __restrict__ Q
                 s[kt] = mfma32(kf, qf[ks], s[kt]);
             }
         }
+        // next tile's loads are issued behind the QK^T MFMAs and fly under the softmax and the PV MFMAs (issued in front of them the
+        // compiler parks an s_waitcnt vmcnt(0) before the first MFMA and the whole load latency is exposed every tile)
+        if (k0 + 64 < Tk) {
+            load_rows<D>(kreg, Kb, C, k0 + 64, Tk);
+            load_cols<D>(vreg, Vtb, Tkp, k0 + 64, Tkp);
+        }
         // online softmax on the raw scores: p = exp2(s*sl2 - m*sl2) is one FMA + one v_exp per element; the
         // key mask only exists in the last (partial) tile, a wave-uniform branch
         if (k0 + 64 > Tk) {
+            asm volatile("" ::: "memory");   // keeps this a real (wave-uniform) branch: if-converted it costs ~90 VALU on every tile
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -297,11 +300,6 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const f16* __restrict_
         store_rows<D, DKP>(vreg, Vs);
         store_cols<D>(ktreg, Kts);
         __syncthreads();
-        if (PF && k0 + 64 < Tk) {
-            load_rows<D>(kreg, Kb, C, k0 + 64, Tk);
-            load_rows<D>(vreg, Vb, C, k0 + 64, Tk);
-            load_cols<D>(ktreg, Ktb, Tkp, k0 + 64, Tkp);
-        }
         f16x8 dsf[4];
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
@@ -312,6 +310,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const f16* __restrict_
                 const f16x8 vf = *(const f16x8*)(Vs + (kt * 32 + ql) * DKP + ks * 16 + g * 8);
                 s = mfma32(kf, qf[ks], s);
                 dp = mfma32(vf, gf[ks], dp);
+            }
+            // next tile's loads go out behind the first MFMA group (in front of it the compiler waits for them at once, see forward)
+            if (kt == 0 && PF && k0 + 64 < Tk) {
+                load_rows<D>(kreg, Kb, C, k0 + 64, Tk);
+                load_rows<D>(vreg, Vb, C, k0 + 64, Tk);
+                load_cols<D>(ktreg, Ktb, Tkp, k0 + 64, Tkp);
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -424,12 +428,6 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const f16* __restric
             dd_s[threadIdx.x] = tq < Tq ? Db[tq] : 0.f;
         }
         __syncthreads();
-        if (PF && q0 + 64 < Tq) {
-            load_rows<D>(qreg, Qb, C, q0 + 64, Tq);
-            load_rows<D>(greg, Gb, C, q0 + 64, Tq);
-            load_cols<D>(qtreg, Qtb, Tq, q0 + 64, Tq);
-            load_cols<D>(gtreg, Gtb, Tq, q0 + 64, Tq);
-        }
         f16x8 pf[4], dsf[4];
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) {
@@ -440,6 +438,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const f16* __restric
                 const f16x8 ga = *(const f16x8*)(Gs + (qt * 32 + kl) * DKP + ks * 16 + g * 8);
                 s = mfma32(qa, kf[ks], s);
                 dp = mfma32(ga, vf[ks], dp);
+            }
+            if (qt == 0 && PF && q0 + 64 < Tq) {       // prefetch behind the first MFMA group (see forward)
+                load_rows<D>(qreg, Qb, C, q0 + 64, Tq);
+                load_rows<D>(greg, Gb, C, q0 + 64, Tq);
+                load_cols<D>(qtreg, Qtb, Tq, q0 + 64, Tq);
+                load_cols<D>(gtreg, Gtb, Tq, q0 + 64, Tq);
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
