@@ -377,6 +377,18 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_big_kernel(fd_gemm_desc p
             const int ox = r - oy * p.Wo;
             crow_b[i] = b;
             crow_yx[i] = valid ? ((oy << 16) | ox) : (int)0x80008000u;   // (-32768, -32768)
+            if (p.conv_mode == FD_CONV_NORMAL) {
+                // stride-1 convs (all ResBlock convs): per row the element offset of the centre pixel and a 9-bit tap-validity mask,
+                // so that a k-step costs one add + one select per row instead of the coordinate arithmetic below
+                int mask = 0;
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const int iy = oy + t / 3 - 1, ix = ox + t % 3 - 1;
+                    if (valid && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) mask |= 1 << t;
+                }
+                crow_b[i] = (int)(((int64_t)(b * p.H + oy) * p.W + ox) * p.lda) + kchunk;   // < 2^31 elements (checked by the launcher)
+                crow_yx[i] = mask;
+            }
         }
     }
     auto issue = [&](int kt, int buf, int part) {
@@ -387,6 +399,18 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_big_kernel(fd_gemm_desc p
             const int tap = kt - cc * 9;
             const int c0 = cc << 6;
             const int ky = tap / 3, kx = tap - ky * 3;
+            if (p.conv_mode == FD_CONV_NORMAL) {
+                const int toff = ((ky - 1) * p.W + (kx - 1)) * (int)p.lda + c0;
+#pragma unroll
+                for (int i = 0; i < AI; ++i) {
+                    const int g = wave + i * NW;
+                    if (g < NA && (part & 1)) {
+                        const bool ok = (crow_yx[i] >> tap) & 1;
+                        const f16* src = ok ? A + (int64_t)(crow_b[i] + toff) : fd_zero_page;
+                        glds16(src, As + (buf * BM + g * 8) * 64);
+                    }
+                }
+            } else
 #pragma unroll
             for (int i = 0; i < AI; ++i) {
                 const int g = wave + i * NW;
@@ -674,6 +698,7 @@ extern "C" int fd_gemm(const fd_gemm_desc* dp, void* stream) {
         FD_REQUIRE((d.Cin & 31) == 0 && d.K == 9 * d.Cin, "fd_gemm(conv): Cin must be a multiple of 32 and K == 9*Cin");
         FD_REQUIRE(d.M == d.Bn * d.Ho * d.Wo, "fd_gemm(conv): M != B*Ho*Wo");
         FD_REQUIRE(d.batch <= 1, "fd_gemm(conv): not batched");
+        FD_REQUIRE((int64_t)d.Bn * d.H * d.W * d.lda < (1LL << 31), "fd_gemm(conv): input larger than 2^31 elements");
     }
     if (d.rowbias) FD_REQUIRE(d.rows_per_batch > 0, "fd_gemm: rows_per_batch");
     hipStream_t s = (hipStream_t)stream;
