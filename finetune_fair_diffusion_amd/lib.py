@@ -9,7 +9,7 @@ import os
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfairdiff_hip.so")
+LIB_PATH = os.environ.get("FAIRDIFF_LIB") or os.path.join(_HERE, "libfairdiff_hip.so")   # override: A/B builds of the same ABI
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "fairdiff_hip.h")
 
 
