@@ -149,6 +149,8 @@ def main():
                             "launches": s["launches"],
                             "avg_launch_us": 1e3 * s["ms"] / s["launches"], "algorithmic_flop_per_launch": s["flops"] / s["launches"],
                             "algorithmic_bytes_per_launch": s["bytes"] / s["launches"],
+                            # the same launches against the other roof: short-K shapes (K = 320) of this family are closer to HBM than to MFMA
+                            "algorithmic_GBps": s["bytes"] / (s["ms"] * 1e-3) / 1e9, "hbm_frac_of_8TBps": s["bytes"] / (s["ms"] * 1e-3) / 8e12,
                             "family": {k: {"launches": v["launches"], "ms": round(v["ms"], 2), "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1)}
                                        for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"])}}
     if world == 1 and not a.no_roofline:
