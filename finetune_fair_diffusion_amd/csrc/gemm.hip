@@ -171,6 +171,50 @@ __device__ __forceinline__ void gemm_epilogue_lds(const fd_gemm_desc& p, f32x4 (
     }
 }
 
+// GEGLU fused into the FF1 projection (no-record forwards): B rows are interleaved (value_c, gate_c), so a lane's four consecutive
+// accumulator columns are (v0, g0, v1, g1).  Both halves are rounded to fp16 first, exactly like the unfused projection followed by
+// fd_geglu_fwd, so the fused and the unfused path give bit-identical results.  Output tile width is half the GEMM tile width.
+template <int TM, int TN, int TMC>
+__device__ __forceinline__ void gemm_epilogue_geglu_lds(const fd_gemm_desc& p, f32x4 (&acc)[TM][TN], f16* wave_lds, int mbase, int nbase, int lane) {
+    constexpr int WTO = TN * 8, WTMC = TMC * 16, LDW = WTO + 4;
+    constexpr int CPR = WTO / 8, RPI = 64 / CPR;
+    const int l15 = lane & 15, lg = lane >> 4;
+    const int cr = lane / CPR, cc = (lane % CPR) * 8;
+    const int No = p.N >> 1;
+#pragma unroll
+    for (int c0 = 0; c0 < TM; c0 += TMC) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = nbase + j * 16 + lg * 4;
+            f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+            if (p.bias && n < p.N) bv = *(const f32x4*)(p.bias + n);
+#pragma unroll
+            for (int ii = 0; ii < TMC; ++ii) {
+                const f32x4 v = acc[c0 + ii][j] + bv;
+                const f16 v0 = (f16)v[0], g0 = (f16)v[1], v1 = (f16)v[2], g1 = (f16)v[3];
+                f16x2 o = {(f16)((float)v0 * gelu_erf_f((float)g0)), (f16)((float)v1 * gelu_erf_f((float)g1))};
+                *(f16x2*)(wave_lds + (ii * 16 + l15) * LDW + j * 8 + lg * 2) = o;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int r0 = 0; r0 < WTMC; r0 += RPI) {
+            const int row = r0 + cr;
+            const int m = mbase + c0 * 16 + row, n = (nbase >> 1) + cc;
+            if (cr < RPI && row < WTMC && m < p.M && n < No) {
+                const f16x4 lo = *(const f16x4*)(wave_lds + row * LDW + cc);
+                const f16x4 hi = *(const f16x4*)(wave_lds + row * LDW + cc + 4);
+                *(f16x8*)((f16*)p.C + (int64_t)m * p.ldc + n) = (f16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            }
+        }
+        if (c0 + TMC < TM) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
 template <int BM, int BN, bool CONV>
 __global__ __launch_bounds__(256) void gemm_glds_kernel(fd_gemm_desc p, int ntm, int ntn) {
     constexpr int TM = BM / 32, TN = BN / 32;
@@ -305,7 +349,10 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(fd_gemm_desc p, int ntm,
 
     const bool lds_epi = p.out_dtype == FD_OUT_F16 && (p.N & 7) == 0 && (p.ldc & 7) == 0 && (!p.residual || (p.ldr & 7) == 0) &&
                          (!p.rowbias || (p.ld_rowbias & 3) == 0);
-    if (lds_epi) {
+    if (p.act == FD_ACT_GEGLU) {      // fd_gemm checked the preconditions (fp16 out, aligned, unbatched)
+        __syncthreads();
+        gemm_epilogue_geglu_lds<TM, TN, TM>(p, acc, smem + wave * (BM / 2) * (BN / 2 + 4), m0 + wm * (BM / 2), n0 + wn * (BN / 2), lane);
+    } else if (lds_epi) {
         __syncthreads();   // every wave is done reading the operand stages before they are reused as epilogue staging
         gemm_epilogue_lds<TM, TN>(p, acc, smem + wave * (BM / 2) * (BN / 2 + 4), m0 + wm * (BM / 2), n0 + wn * (BN / 2), lane,
                                   (int64_t)z * p.sC, (int64_t)z * p.sR);
@@ -560,6 +607,11 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_big_kernel(fd_gemm_desc p
                          (!p.rowbias || (p.ld_rowbias & 3) == 0);
     if (p.batch == -3) {   // measurement only (FD_GEMM_DBG=3): no epilogue at all
         if (acc[0][0][0] == 12345.678f) ((f16*)p.C)[0] = (f16)1.f;
+    } else if (p.act == FD_ACT_GEGLU) {
+        constexpr int LDS_HALFS = 2 * (BM + BN) * 64;
+        constexpr int TMC = (NW * WTM * (WTN + 4) <= LDS_HALFS) ? TM : TM / 2;
+        __syncthreads();
+        gemm_epilogue_geglu_lds<TM, TN, TMC>(p, acc, smem + wave * (TMC * 16) * (WTN + 4), m0 + wm * WTM, n0 + wn * WTN, lane);
     } else if (lds_epi) {
         // stage the wave tile through the (now idle) operand LDS so that stores are 16 bytes per lane over whole row segments
         constexpr int LDS_HALFS = 2 * (BM + BN) * 64;
@@ -648,7 +700,7 @@ extern "C" int fd_gemm_tile(const fd_gemm_desc* dp) {
             if (m256 * (d.N / 320) >= 200) return 256320;
             if (m128 * (d.N / 320) >= 160) return 128320;
         }
-        const bool can_split = d.workspace && (d.N & 3) == 0 && (d.ldc & 3) == 0;
+        const bool can_split = d.workspace && (d.N & 3) == 0 && (d.ldc & 3) == 0 && d.act != FD_ACT_GEGLU;
         const long nk = (d.K + 63) / 64 + (d.K2 + 63) / 64;
         auto split_for = [&](long blocks, int tilecode) -> int {   // split K so ~256 blocks exist, >= 8 k-tiles each
             long split = blocks > 0 ? 256 / blocks : 1;
@@ -701,6 +753,10 @@ extern "C" int fd_gemm(const fd_gemm_desc* dp, void* stream) {
         FD_REQUIRE((int64_t)d.Bn * d.H * d.W * d.lda < (1LL << 31), "fd_gemm(conv): input larger than 2^31 elements");
     }
     if (d.rowbias) FD_REQUIRE(d.rows_per_batch > 0, "fd_gemm: rows_per_batch");
+    if (d.act == FD_ACT_GEGLU)
+        FD_REQUIRE(!d.conv && d.batch <= 1 && d.out_dtype == FD_OUT_F16 && !d.residual && !d.rowbias && d.alpha == 1.f && (d.N & 15) == 0 &&
+                       (d.ldc & 7) == 0 && d.K2 == 0,
+                   "fd_gemm(GEGLU): needs a plain fp16 GEMM with N %% 16 == 0 and ldc %% 8 == 0");
     hipStream_t s = (hipStream_t)stream;
     static const bool w16 = getenv("FD_GEMM_W8") == nullptr;   // 16-wave variants by default (A/B switch for measurement)
     const int sel = fd_gemm_tile(&d);

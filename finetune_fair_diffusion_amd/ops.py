@@ -9,7 +9,7 @@ import torch
 
 from . import lib as _lib
 
-ACT = dict(none=0, silu=1, quick_gelu=2, gelu=3, relu=4, hardswish=5, hardsigmoid=6)
+ACT = dict(none=0, silu=1, quick_gelu=2, gelu=3, relu=4, hardswish=5, hardsigmoid=6, geglu=7)
 CONV_NORMAL, CONV_STRIDE2, CONV_UP2, CONV_TRANS2 = 0, 1, 2, 3
 F16, F32 = torch.float16, torch.float32
 
@@ -93,12 +93,13 @@ def _chk(t, dtype=F16):
 # ----------------------------------------------------------------------------- GEMM / conv
 def gemm(a, b, *, a2=None, b2=None, bias=None, rowbias=None, rows_per_batch=0, residual=None, act="none", alpha=1.0,
          out=None, out_dtype=F16, n=None):
-    """C[M,N] = act(alpha*(a.b^T + a2.b2^T) + bias + rowbias) + residual.  a:[M,K] (row stride free), b:[N,K]."""
+    """C[M,N] = act(alpha*(a.b^T + a2.b2^T) + bias + rowbias) + residual.  a:[M,K] (row stride free), b:[N,K].
+    act="geglu": b / bias rows interleaved (value_c, gate_c) -> C[M, N/2] = value * gelu(gate) (see ``interleave_geglu``)."""
     M, K = a.shape
     N = b.shape[0] if n is None else n
     assert b.shape[1] == K and a.stride(1) == 1 and b.stride(1) == 1
     if out is None:
-        out = torch.empty((M, N), dtype=out_dtype, device=a.device)
+        out = torch.empty((M, N // 2 if act == "geglu" else N), dtype=out_dtype, device=a.device)
     d = _lib.GemmDesc()
     d.A, d.lda, d.B, d.ldb = a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0)
     if a2 is not None:
@@ -116,6 +117,14 @@ def gemm(a, b, *, a2=None, b2=None, bias=None, rowbias=None, rows_per_batch=0, r
     d.act, d.out_dtype, d.batch = ACT[act], 1 if out.dtype == F32 else 0, 1
     _gemm_call(d, False)
     return out
+
+
+def interleave_geglu(w, bias):
+    """diffusers GEGLU projects to [value | gate] halves; the fused epilogue wants (value_c, gate_c) adjacent."""
+    F = w.shape[0] // 2
+    wi = torch.stack([w[:F], w[F:]], dim=1).reshape(2 * F, w.shape[1]).contiguous()
+    bi = torch.stack([bias[:F], bias[F:]], dim=1).reshape(2 * F).contiguous() if bias is not None else None
+    return wi, bi
 
 
 def bgemm(a, b, *, alpha=1.0, out=None):

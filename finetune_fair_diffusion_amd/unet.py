@@ -69,6 +69,7 @@ class TransformerBlock:
         self.q1, self.k1, self.v1, self.o1 = (Linear(sd, b + "attn1." + n, dev) for n in ("to_q", "to_k", "to_v", "to_out.0"))
         self.q2, self.k2, self.v2, self.o2 = (Linear(sd, b + "attn2." + n, dev) for n in ("to_q", "to_k", "to_v", "to_out.0"))
         self.ff1, self.ff2 = Linear(sd, b + "ff.net.0.proj", dev), Linear(sd, b + "ff.net.2", dev)
+        self.ff1_wi, self.ff1_bi = ops.interleave_geglu(self.ff1.w, self.ff1.bias)   # no-record forwards: GEGLU fused into the projection
         self.lora1 = self.lora2 = None  # AttnLoRA for attn1 / attn2
         self.name1, self.name2 = b + "attn1.processor", b + "attn2.processor"
         self.cross = None  # per-rollout cross-attention K/V cache
@@ -129,8 +130,11 @@ class TransformerBlock:
         o2, lse2 = ops.attn_fwd(q2, cr["K"], cr["Vt"], B, h, HW, cr["L"], d, kv_div, need_lse=True)
         h2, to2 = lora_linear_fwd(o2, self.o2, l2.out if l2 else None, residual=h1)
         n3, ln3 = ops.layernorm(h2, self.ln3.gamma, self.ln3.beta, 1e-5, save_stats=True)
-        proj = ops.gemm(n3, self.ff1.w, bias=self.ff1.bias)
-        gg = ops.geglu(proj)
+        if rec:
+            proj = ops.gemm(n3, self.ff1.w, bias=self.ff1.bias)
+            gg = ops.geglu(proj)
+        else:   # bit-identical to the two-kernel path (both halves are rounded to fp16 before the gate), half the output traffic
+            gg = ops.gemm(n3, self.ff1_wi, bias=self.ff1_bi, act="geglu")
         h3 = ops.gemm(gg, self.ff2.w, bias=self.ff2.bias, residual=h2)
         out = ops.gemm(h3, self.proj_out.w, bias=self.proj_out.bias, residual=x)
         if rec:

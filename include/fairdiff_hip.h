@@ -25,7 +25,10 @@ extern "C" {
 #define FD_ERR_LAUNCH (-2)
 
 enum { FD_ACT_NONE = 0, FD_ACT_SILU = 1, FD_ACT_QUICK_GELU = 2, FD_ACT_GELU = 3, FD_ACT_RELU = 4,
-       FD_ACT_HARDSWISH = 5, FD_ACT_HARDSIGMOID = 6 };
+       FD_ACT_HARDSWISH = 5, FD_ACT_HARDSIGMOID = 6,
+       /* fd_gemm only: B rows (and bias) interleaved (value_c, gate_c); C [M, N/2] = value * gelu_erf(gate), both rounded to fp16 first
+          (== fd_geglu_fwd on the unfused projection, diffusers GEGLU) */
+       FD_ACT_GEGLU = 7 };
 enum { FD_OUT_F16 = 0, FD_OUT_F32 = 1 };
 enum { FD_CONV_NORMAL = 0, FD_CONV_STRIDE2 = 1, FD_CONV_UP2 = 2, FD_CONV_TRANS2 = 3 };
 

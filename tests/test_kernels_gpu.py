@@ -375,3 +375,18 @@ def test_small_convs_and_classifier_pieces(ops, dev):
     dimg = rnd(B, 3, 16, dev=dev, dtype=torch.float32, seed=21)
     pm = pre[:, :3].float().reshape(B, 16, 3).permute(0, 2, 1)
     check("clamp bwd", ops.clamp_bwd(pre, dimg, B, 16, 3), dimg * ((pm >= -1) & (pm <= 1)), 1e-6)
+
+
+@pytest.mark.parametrize("M,F,K", [(300, 64, 64), (4100, 1280, 320), (65536, 1280, 320), (1024, 5120, 1280)])
+def test_gemm_fused_geglu_bit_identical(ops, dev, M, F, K):
+    """FF1 with the GEGLU gate fused into the epilogue == projection GEMM followed by fd_geglu_fwd, bit for bit
+    (both halves are rounded to fp16 before the gate in either path)."""
+    a = rnd(M, K, dev=dev, seed=1)
+    w = rnd(2 * F, K, dev=dev, scale=0.1, seed=2)
+    bias = rnd(2 * F, dev=dev, dtype=torch.float32, seed=3)
+    ref = ops.geglu(ops.gemm(a, w, bias=bias))
+    wi, bi = ops.interleave_geglu(w, bias)
+    got = ops.gemm(a, wi, bias=bi, act="geglu")
+    assert got.shape == (M, F) and torch.equal(got, ref)
+    x = a.float() @ w.float().t() + bias
+    check(f"geglu {M}x{F}x{K}", got, x[:, :F] * torch.nn.functional.gelu(x[:, F:]), 5e-3)
