@@ -43,6 +43,27 @@ __global__ void geglu_bwd_kernel(const f16* proj, const f16* dy, f16* dproj, int
         *(f16x8*)(dproj + m * 2 * F + F + f) = dg;
     }
 }
+__global__ void geglu_bwd_il_kernel(const f16* proj, const f16* dy, f16* dproj, int64_t n4) {
+    // 4 (value, gate) pairs per thread: 16 B of proj, 8 B of dy in, 16 B of dproj out
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const f16x8 pr = *(const f16x8*)(proj + i * 8);
+        const f16x4 d = *(const f16x4*)(dy + i * 4);
+        f16x8 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float a = (float)pr[2 * j], g = (float)pr[2 * j + 1], dj = (float)d[j];
+            o[2 * j] = (f16)(dj * gelu_erf_f(g));
+            o[2 * j + 1] = (f16)(dj * a * gelu_erf_grad_f(g));
+        }
+        *(f16x8*)(dproj + i * 8) = o;
+    }
+}
+extern "C" int fd_geglu_bwd_interleaved(const void* proj, const void* dy, void* dproj, int M, int F, void* stream) {
+    FD_REQUIRE((F & 3) == 0, "fd_geglu_bwd_interleaved: F %% 4");
+    const int64_t n4 = (int64_t)M * (F / 4);
+    hipLaunchKernelGGL(geglu_bwd_il_kernel, grid_for(n4), dim3(256), 0, (hipStream_t)stream, (const f16*)proj, (const f16*)dy, (f16*)dproj, n4);
+    return fd_check_launch("fd_geglu_bwd_interleaved");
+}
 extern "C" int fd_geglu_fwd(const void* proj, void* y, int M, int F, void* stream) {
     FD_REQUIRE((F & 7) == 0, "fd_geglu_fwd: F %% 8");
     hipLaunchKernelGGL(geglu_fwd_kernel, grid_for((int64_t)M * (F / 8)), dim3(256), 0, (hipStream_t)stream, (const f16*)proj, (f16*)y, (int64_t)M, F);

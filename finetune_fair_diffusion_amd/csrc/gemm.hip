@@ -181,8 +181,38 @@ __device__ __forceinline__ void gemm_epilogue_geglu_lds(const fd_gemm_desc& p, f
     const int l15 = lane & 15, lg = lane >> 4;
     const int cr = lane / CPR, cc = (lane % CPR) * 8;
     const int No = p.N >> 1;
+    f16* AUX = (f16*)p.residual;     // recording forwards: the pre-gate projection (interleaved columns) is kept for the backward
 #pragma unroll
     for (int c0 = 0; c0 < TM; c0 += TMC) {
+        if (AUX) {
+            constexpr int LDWP = TN * 16 + 4, CPRP = TN * 2, RPIP = 64 / CPRP;
+            const int crp = lane / CPRP, ccp = (lane % CPRP) * 8;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = nbase + j * 16 + lg * 4;
+                f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+                if (p.bias && n < p.N) bv = *(const f32x4*)(p.bias + n);
+#pragma unroll
+                for (int ii = 0; ii < TMC; ++ii) {
+                    const f32x4 v = acc[c0 + ii][j] + bv;
+                    *(f16x4*)(wave_lds + (ii * 16 + l15) * LDWP + j * 16 + lg * 4) = (f16x4){(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int r0 = 0; r0 < WTMC; r0 += RPIP) {
+                const int row = r0 + crp;
+                const int m = mbase + c0 * 16 + row, n = nbase + ccp;
+                if (crp < RPIP && row < WTMC && m < p.M && n < p.N) {
+                    const f16x4 lo = *(const f16x4*)(wave_lds + row * LDWP + ccp);
+                    const f16x4 hi = *(const f16x4*)(wave_lds + row * LDWP + ccp + 4);
+                    *(f16x8*)(AUX + (int64_t)m * p.ldr + n) = (f16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+        }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int n = nbase + j * 16 + lg * 4;
@@ -754,9 +784,10 @@ extern "C" int fd_gemm(const fd_gemm_desc* dp, void* stream) {
     }
     if (d.rowbias) FD_REQUIRE(d.rows_per_batch > 0, "fd_gemm: rows_per_batch");
     if (d.act == FD_ACT_GEGLU)
-        FD_REQUIRE(!d.conv && d.batch <= 1 && d.out_dtype == FD_OUT_F16 && !d.residual && !d.rowbias && d.alpha == 1.f && (d.N & 15) == 0 &&
-                       (d.ldc & 7) == 0 && d.K2 == 0,
-                   "fd_gemm(GEGLU): needs a plain fp16 GEMM with N %% 16 == 0 and ldc %% 8 == 0");
+        // in this mode ``residual`` is an optional second OUTPUT [M, N] (ldr): the pre-gate projection, interleaved like B
+        FD_REQUIRE(!d.conv && d.batch <= 1 && d.out_dtype == FD_OUT_F16 && !d.rowbias && d.alpha == 1.f && (d.N & 15) == 0 &&
+                       (d.ldc & 7) == 0 && d.K2 == 0 && (!d.residual || (d.ldr & 7) == 0),
+                   "fd_gemm(GEGLU): needs a plain fp16 GEMM with N %% 16 == 0 and ldc, ldr %% 8 == 0");
     hipStream_t s = (hipStream_t)stream;
     static const bool w16 = getenv("FD_GEMM_W8") == nullptr;   // 16-wave variants by default (A/B switch for measurement)
     const int sel = fd_gemm_tile(&d);

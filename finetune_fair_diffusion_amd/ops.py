@@ -92,7 +92,7 @@ def _chk(t, dtype=F16):
 
 # ----------------------------------------------------------------------------- GEMM / conv
 def gemm(a, b, *, a2=None, b2=None, bias=None, rowbias=None, rows_per_batch=0, residual=None, act="none", alpha=1.0,
-         out=None, out_dtype=F16, n=None):
+         out=None, out_dtype=F16, n=None, aux=None):
     """C[M,N] = act(alpha*(a.b^T + a2.b2^T) + bias + rowbias) + residual.  a:[M,K] (row stride free), b:[N,K].
     act="geglu": b / bias rows interleaved (value_c, gate_c) -> C[M, N/2] = value * gelu(gate) (see ``interleave_geglu``)."""
     M, K = a.shape
@@ -113,6 +113,9 @@ def gemm(a, b, *, a2=None, b2=None, bias=None, rowbias=None, rows_per_batch=0, r
     if residual is not None:
         assert residual.dtype == F16 and residual.stride(1) == 1
         d.residual, d.ldr = residual.data_ptr(), residual.stride(0)
+    if aux is not None:     # act="geglu": second output, the pre-gate projection [M, N] in interleaved column order
+        assert act == "geglu" and residual is None and aux.shape == (M, N) and aux.dtype == F16 and aux.is_contiguous()
+        d.residual, d.ldr = aux.data_ptr(), N
     d.alpha, d.M, d.N, d.K = alpha, M, N, K
     d.act, d.out_dtype, d.batch = ACT[act], 1 if out.dtype == F32 else 0, 1
     _gemm_call(d, False)
@@ -265,6 +268,13 @@ def groupnorm_bwd(x1, x2, dy, B, HW, groups, stats, gamma, beta, silu, add1=None
     _call("fd_groupnorm_bwd", _p(x1), C1, _p(x2), C2, _p(_chk(dy)), B, HW, groups, _p(stats), _p(gamma), _p(beta), int(silu), _p(sc),
           _p(add1), _p(add2), _p(dx1), _p(dx2), _stream())
     return dx1, dx2
+
+
+def geglu_bwd_interleaved(proj_il, dy):
+    M, F2 = proj_il.shape
+    d = torch.empty_like(proj_il)
+    _call("fd_geglu_bwd_interleaved", _p(_chk(proj_il)), _p(_chk(dy)), _p(d), M, F2 // 2, _stream())
+    return d
 
 
 def layernorm(x, gamma, beta, eps=1e-5, save_stats=False):

@@ -68,8 +68,11 @@ class TransformerBlock:
         self.ln1, self.ln2, self.ln3 = Norm(sd, b + "norm1", dev), Norm(sd, b + "norm2", dev), Norm(sd, b + "norm3", dev)
         self.q1, self.k1, self.v1, self.o1 = (Linear(sd, b + "attn1." + n, dev) for n in ("to_q", "to_k", "to_v", "to_out.0"))
         self.q2, self.k2, self.v2, self.o2 = (Linear(sd, b + "attn2." + n, dev) for n in ("to_q", "to_k", "to_v", "to_out.0"))
-        self.ff1, self.ff2 = Linear(sd, b + "ff.net.0.proj", dev), Linear(sd, b + "ff.net.2", dev)
-        self.ff1_wi, self.ff1_bi = ops.interleave_geglu(self.ff1.w, self.ff1.bias)   # no-record forwards: GEGLU fused into the projection
+        ff1, self.ff2 = Linear(sd, b + "ff.net.0.proj", dev), Linear(sd, b + "ff.net.2", dev)
+        # GEGLU is fused into the FF1 projection: weights with (value_c, gate_c) rows adjacent; recording forwards also keep the
+        # pre-gate projection (same interleaved order) for the backward
+        self.ff1_wi, self.ff1_bi = ops.interleave_geglu(ff1.w, ff1.bias)
+        self._ff1_wiT = None
         self.lora1 = self.lora2 = None  # AttnLoRA for attn1 / attn2
         self.name1, self.name2 = b + "attn1.processor", b + "attn2.processor"
         self.cross = None  # per-rollout cross-attention K/V cache
@@ -130,11 +133,9 @@ class TransformerBlock:
         o2, lse2 = ops.attn_fwd(q2, cr["K"], cr["Vt"], B, h, HW, cr["L"], d, kv_div, need_lse=True)
         h2, to2 = lora_linear_fwd(o2, self.o2, l2.out if l2 else None, residual=h1)
         n3, ln3 = ops.layernorm(h2, self.ln3.gamma, self.ln3.beta, 1e-5, save_stats=True)
-        if rec:
-            proj = ops.gemm(n3, self.ff1.w, bias=self.ff1.bias)
-            gg = ops.geglu(proj)
-        else:   # bit-identical to the two-kernel path (both halves are rounded to fp16 before the gate), half the output traffic
-            gg = ops.gemm(n3, self.ff1_wi, bias=self.ff1_bi, act="geglu")
+        # bit-identical to projection + fd_geglu_fwd (both halves are rounded to fp16 before the gate)
+        proj = torch.empty((n3.shape[0], self.ff1_wi.shape[0]), dtype=F16, device=n3.device) if rec else None
+        gg = ops.gemm(n3, self.ff1_wi, bias=self.ff1_bi, act="geglu", aux=proj)
         h3 = ops.gemm(gg, self.ff2.w, bias=self.ff2.bias, residual=h2)
         out = ops.gemm(h3, self.proj_out.w, bias=self.proj_out.bias, residual=x)
         if rec:
@@ -148,8 +149,10 @@ class TransformerBlock:
         l1, l2 = self.lora1, self.lora2
         dh3 = ops.gemm(d_out, self.proj_out.wT)
         dgg = ops.gemm(dh3, self.ff2.wT)
-        dproj = ops.geglu_bwd(c["proj"], dgg)
-        dn3 = ops.gemm(dproj, self.ff1.wT)
+        dproj = ops.geglu_bwd_interleaved(c["proj"], dgg)
+        if self._ff1_wiT is None:
+            self._ff1_wiT = self.ff1_wi.t().contiguous()
+        dn3 = ops.gemm(dproj, self._ff1_wiT)
         dh2 = ops.layernorm_bwd(c["h2"], dn3, self.ln3.gamma, c["ln3"], add=dh3)
         # attn2 (cross)
         do2 = lora_linear_bwd(dh2, c["o2"], c["to2"], self.o2, l2.out if l2 else None, gscale)

@@ -27,7 +27,8 @@ extern "C" {
 enum { FD_ACT_NONE = 0, FD_ACT_SILU = 1, FD_ACT_QUICK_GELU = 2, FD_ACT_GELU = 3, FD_ACT_RELU = 4,
        FD_ACT_HARDSWISH = 5, FD_ACT_HARDSIGMOID = 6,
        /* fd_gemm only: B rows (and bias) interleaved (value_c, gate_c); C [M, N/2] = value * gelu_erf(gate), both rounded to fp16 first
-          (== fd_geglu_fwd on the unfused projection, diffusers GEGLU) */
+          (== fd_geglu_fwd on the unfused projection, diffusers GEGLU); ``residual`` is then an optional second
+          OUTPUT [M, N] (ldr) receiving the pre-gate projection in the same interleaved column order (for fd_geglu_bwd_interleaved) */
        FD_ACT_GEGLU = 7 };
 enum { FD_OUT_F16 = 0, FD_OUT_F32 = 1 };
 enum { FD_CONV_NORMAL = 0, FD_CONV_STRIDE2 = 1, FD_CONV_UP2 = 2, FD_CONV_TRANS2 = 3 };
@@ -92,6 +93,8 @@ int fd_layernorm_bwd(const void* x, const void* dy, const float* gamma, const fl
 /* ---- elementwise */
 int fd_geglu_fwd(const void* proj /* [M,2F] */, void* y /* [M,F] */, int M, int F, void* stream);
 int fd_geglu_bwd(const void* proj, const void* dy, void* dproj, int M, int F, void* stream);
+/* same with (value_c, gate_c) adjacent in proj / dproj [M, 2F] (the layout the fused FD_ACT_GEGLU projection keeps) */
+int fd_geglu_bwd_interleaved(const void* proj, const void* dy, void* dproj, int M, int F, void* stream);
 int fd_act_fwd(const void* x, void* y, int64_t n, int act, void* stream);
 int fd_act_bwd(const void* z, const void* dy, void* dx, int64_t n, int act, void* stream);
 int fd_add(const void* a, const void* b, void* y, int64_t n, float sa, float sb, void* stream);      /* y = sa*a + sb*b (fp16) */

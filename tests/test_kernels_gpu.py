@@ -390,3 +390,22 @@ def test_gemm_fused_geglu_bit_identical(ops, dev, M, F, K):
     assert got.shape == (M, F) and torch.equal(got, ref)
     x = a.float() @ w.float().t() + bias
     check(f"geglu {M}x{F}x{K}", got, x[:, :F] * torch.nn.functional.gelu(x[:, F:]), 5e-3)
+
+
+def test_gemm_fused_geglu_with_pregate_output_and_interleaved_backward(ops, dev):
+    """Recording forwards: the fused FF1 also keeps the pre-gate projection (interleaved columns); its backward kernel equals
+    fd_geglu_bwd on the de-interleaved tensors."""
+    M, F, K = 4100, 1280, 320
+    a = rnd(M, K, dev=dev, seed=1)
+    w = rnd(2 * F, K, dev=dev, scale=0.1, seed=2)
+    bias = rnd(2 * F, dev=dev, dtype=torch.float32, seed=3)
+    proj = ops.gemm(a, w, bias=bias)
+    wi, bi = ops.interleave_geglu(w, bias)
+    aux = torch.empty(M, 2 * F, dtype=torch.float16, device=dev)
+    gg = ops.gemm(a, wi, bias=bi, act="geglu", aux=aux)
+    assert torch.equal(gg, ops.geglu(proj))
+    assert torch.equal(aux[:, 0::2], proj[:, :F]) and torch.equal(aux[:, 1::2], proj[:, F:])
+    dy = rnd(M, F, dev=dev, seed=4)
+    d_il = ops.geglu_bwd_interleaved(aux, dy)
+    d_ref = ops.geglu_bwd(proj, dy)
+    assert torch.equal(d_il[:, 0::2], d_ref[:, :F]) and torch.equal(d_il[:, 1::2], d_ref[:, F:])
