@@ -197,7 +197,7 @@ def cpu_baseline(S):
         dt = (time.perf_counter() - t0) / n
     flops_per_s = 2 * F_UNET / dt
     return {"value": flops_per_s / f_img(S), "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": f"oracle fp32 U-Net forward, SD-v1.5 size, CFG pair (batch 2): {dt:.2f} s per call = {flops_per_s / 1e12:.3f} TFLOP/s on {cores} threads; "
+            "sample": f"oracle fp32 U-Net forward, SD-v1.5 size, CFG pair (batch 2), {n} calls in {dt * n:.1f} s: {dt:.2f} s per call = {flops_per_s / 1e12:.3f} TFLOP/s on {cores} threads; "
                       f"extrapolated with {f_img(S) / 1e12:.1f} algorithmic TFLOP per trained image"}
 
 
