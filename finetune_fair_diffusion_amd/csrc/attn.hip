@@ -240,8 +240,9 @@ __global__ void attn_bwd_prep_kernel(const f16* O, const f16* dO, float* Dd, int
 template <int D>
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const f16* __restrict__ Q, const f16* __restrict__ K, const f16* __restrict__ V,
                                                           const f16* __restrict__ Kt, const f16* __restrict__ dO,
-                                                          const float* __restrict__ LSE, const float* __restrict__ Dd, f16* __restrict__ dQ,
-                                                          int H, int Tq, int Tk, int Tkp, int Tkr, int kv_div, float scale) {
+                                                          const float* __restrict__ LSE, float* __restrict__ Dd, f16* __restrict__ dQ,
+                                                          const f16* __restrict__ O, int H, int Tq, int Tk, int Tkp, int Tkr, int kv_div,
+                                                          float scale) {
     constexpr int DK = (D + 15) / 16 * 16, DV = (D + 31) / 32 * 32, DKP = DK + 8;
     constexpr int NKS = DK / 16, NDV = DV / 32;
     extern __shared__ __attribute__((aligned(16))) f16 smem[];
@@ -269,7 +270,23 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const f16* __restrict_
         }
     }
     const float lse2 = tvalid ? LSE[((int64_t)b * H + h) * Tq + t] * LOG2E : INFINITY;
-    const float dd = tvalid ? Dd[((int64_t)b * H + h) * Tq + t] : 0.f;
+    float dd;
+    if (O) {   // D = rowsum(dO * O) computed here (each lane holds half of its query's columns) and published for the dK/dV kernel
+        float part = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            const int col = ks * 16 + g * 8;
+            if (tvalid && col < D) {
+                const f16x8 ov = *(const f16x8*)(O + ((int64_t)b * Tq + t) * C + h * D + col);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) part += (float)ov[j] * (float)gf[ks][j];
+            }
+        }
+        dd = part + __shfl_xor(part, 32, 64);
+        if (tvalid && g == 0) Dd[((int64_t)b * H + h) * Tq + t] = dd;
+    } else {
+        dd = tvalid ? Dd[((int64_t)b * H + h) * Tq + t] : 0.f;
+    }
     const float sl2 = scale * LOG2E;
     f32x16 acc[NDV];
 #pragma unroll
@@ -541,14 +558,15 @@ extern "C" int fd_attn_bwd_prep(const void* o, const void* d_o, float* D, int B,
     return fd_check_launch("fd_attn_bwd_prep");
 }
 
-extern "C" int fd_attn_bwd_dq(const void* q, const void* k, const void* v, const void* kt, const void* d_o, const float* lse, const float* D,
-                              void* dq, int B, int H, int Tq, int Tk, int Tkp, int Tkr, int d, int kv_div, float scale, void* stream) {
+extern "C" int fd_attn_bwd_dq(const void* q, const void* k, const void* v, const void* kt, const void* d_o, const float* lse, float* D,
+                              const void* o, void* dq, int B, int H, int Tq, int Tk, int Tkp, int Tkr, int d, int kv_div, float scale,
+                              void* stream) {
     FD_REQUIRE(B > 0 && H > 0 && Tq > 0 && Tk > 0 && Tkp >= Tk && (Tkp & 7) == 0 && Tkr >= Tk && kv_div >= 1, "fd_attn_bwd_dq: bad shape");
     dim3 grid((Tq + 127) / 128, H, B);
 #define CALL(DD)                                                                                                                      \
     ALLOW_LDS(attn_bwd_dq_kernel<DD>, dq_lds<DD>());                                                                                  \
     hipLaunchKernelGGL(attn_bwd_dq_kernel<DD>, grid, dim3(256), dq_lds<DD>(), (hipStream_t)stream, (const f16*)q, (const f16*)k,      \
-                       (const f16*)v, (const f16*)kt, (const f16*)d_o, lse, D, (f16*)dq, H, Tq, Tk, Tkp, Tkr, kv_div, scale)
+                       (const f16*)v, (const f16*)kt, (const f16*)d_o, lse, D, (f16*)dq, (const f16*)o, H, Tq, Tk, Tkp, Tkr, kv_div, scale)
     FD_DISPATCH_D(d, CALL)
 #undef CALL
     return fd_check_launch("fd_attn_bwd_dq");

@@ -386,15 +386,14 @@ def attn_bwd(q, k, v, o, do, lse, B, H, Tq, Tk, d, kv_div=1, scale=None, kt=None
     scale = scale if scale is not None else d ** -0.5
     Tkr = kv_rows or Tk
     C = H * d
-    Dd = torch.empty((B, H, Tq), dtype=F32, device=q.device)
-    _call("fd_attn_bwd_prep", _p(_chk(o)), _p(_chk(do)), _p(Dd), B, H, Tq, d, _stream())
+    Dd = torch.empty((B, H, Tq), dtype=F32, device=q.device)     # D = rowsum(dO*O): produced inside the dq kernel, read by dk/dv
     Bk = B // kv_div
     if kt is None:
         kt = transpose_btc(k, Bk, Tkr, C)
     Tkp = kt.shape[-1]
     dq = torch.empty_like(q)
-    _call("fd_attn_bwd_dq", _p(_chk(q)), _p(_chk(k)), _p(_chk(v)), _p(kt), _p(do), _p(lse), _p(Dd), _p(dq), B, H, Tq, Tk, Tkp, Tkr, d, kv_div,
-          scale, _stream())
+    _call("fd_attn_bwd_dq", _p(_chk(q)), _p(_chk(k)), _p(_chk(v)), _p(kt), _p(_chk(do)), _p(lse), _p(Dd), _p(_chk(o)), _p(dq), B, H, Tq, Tk, Tkp, Tkr, d,
+          kv_div, scale, _stream())
     qt = transpose_btc(q, B, Tq, C, Tq)
     dot = transpose_btc(do, B, Tq, C, Tq)
     if kv_div > 1:

@@ -116,9 +116,10 @@ int fd_attn_fwd(const void* q, const void* k, const void* vt, void* o, float* ls
                 int Tkp, int Tkr, int d, int kv_div, float scale, void* stream);
 /* D[b,h,t] = sum_j dO*O */
 int fd_attn_bwd_prep(const void* o, const void* d_o, float* D, int B, int H, int T, int d, void* stream);
-/* dq from (q, k, v, kt:[Bk,H*d,Tkp], dO, lse, D) */
+/* dq from (q, k, v, kt:[Bk,H*d,Tkp], dO, lse, D).  With o != NULL the kernel computes D = rowsum(dO*O) itself and WRITES it to D
+ * for fd_attn_bwd_dkdv (fd_attn_bwd_prep is then not needed); with o == NULL it reads D. */
 int fd_attn_bwd_dq(const void* q, const void* k, const void* v, const void* kt, const void* d_o, const float* lse,
-                   const float* D, void* dq, int B, int H, int Tq, int Tk, int Tkp, int Tkr, int d, int kv_div, float scale,
+                   float* D, const void* o, void* dq, int B, int H, int Tq, int Tk, int Tkp, int Tkr, int d, int kv_div, float scale,
                    void* stream);
 /* dk,dv from (q, qt:[B,H*d,Tq], k, v, dO, dOt:[B,H*d,Tq], lse, D). When kv_div>1 the kv batch is shared by
  * kv_div consecutive samples; dk/dv are then fp32 [Bk,Tk,H*d] accumulated with atomics, else fp16. */
