@@ -391,6 +391,67 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(fd_gemm_desc p, int ntm,
     }
 }
 
+
+// ---- pinned fragment schedule for the 8/16-wave main loop.
+// Written as plain loads + MFMAs, the compiler (at the register cap of these kernels) sinks every streamed-fragment ds_read to
+// directly in front of its consumers and waits lgkmcnt(0): read -> full LDS latency -> TN MFMAs, with only the second wave of the
+// SIMD to cover it (measured: MFMA loop alone at ~55 % of the 1.6 PFLOP/s the same loop reaches with the reads ahead of use,
+// scratch/mb_mfma_peak.hip).  Here the ds_read_b128 are inline asm with hand-counted s_waitcnt lgkmcnt(n): the resident operand's
+// fragments are read once per k-step, the streamed operand runs PD fragments ahead through a ring of PD+1 registers, and a
+// sched_barrier after each fragment's MFMAs keeps that order.  LDS reads return in order, so "n = reads issued after the one
+// needed" is exact (and only ever conservative if the compiler adds LGKM operations of its own).
+#include <type_traits>
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+template <int OFF>
+__device__ __forceinline__ void ds_read16(f16x8& d, uint32_t addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_lgkm() {
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ void tie(f16x8& v) { asm volatile("" : "+v"(v)); }
+
+// one k = 32 step of a wave tile: acc[i][j] += A_i . B_j^T over fragments at a_addr + i*2048 / b_addr + j*2048 (LDS byte addresses)
+template <int TM, int TN, int PD>
+__device__ __forceinline__ void mma_k32(f32x4 (&acc)[TM][TN], uint32_t a_addr, uint32_t b_addr) {
+    constexpr bool BRES = TN <= TM;   // the operand with fewer fragments stays resident for the step
+    constexpr int NR = BRES ? TN : TM, NS = BRES ? TM : TN, R = PD + 1;
+    const uint32_t r_addr = BRES ? b_addr : a_addr, s_addr = BRES ? a_addr : b_addr;
+    f16x8 res[NR], ring[R];
+    static_for<0, NR>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        ds_read16<i * 2048>(res[i], r_addr);
+    });
+    static_for<0, (PD < NS ? PD : NS)>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        ds_read16<i * 2048>(ring[i % R], s_addr);
+    });
+    static_for<0, NS>([&](auto ic) {
+        constexpr int s = decltype(ic)::value;
+        if constexpr (s + PD < NS) ds_read16<(s + PD) * 2048>(ring[(s + PD) % R], s_addr);
+        constexpr int after = (NS - 1 - s) < PD ? (NS - 1 - s) : PD;
+        wait_lgkm<after>();
+        if constexpr (s == 0) {
+#pragma unroll
+            for (int r = 0; r < NR; ++r) tie(res[r]);
+        }
+        tie(ring[s % R]);
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            if constexpr (BRES) acc[s][r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(res[r], ring[s % R], acc[s][r], 0, 0, 0);
+            else acc[r][s] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ring[s % R], res[r], acc[r][s], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    });
+}
+
 // ======================================================================================= 8/16-wave, BK = 64
 // The per-CU global->LDS path saturates near 15-20 B/clk (measured: the 128x128 and 128x64 tiles above both sit
 // at ~15 B/clk/CU at very different TFLOP/s), so arithmetic intensity -- tile size -- is the lever.  This kernel
@@ -562,6 +623,11 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_big_kernel(fd_gemm_desc p
     // fragment read: row l15 of a 16-row tile, k-chunk (ks*4 + lg) lives in slot chunk ^ (row & 7)
     const int frow = l15 * 64;
     const int fsw = l15 & 7;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)smem;
+    // same-box A/B of the whole training step: the 8-wave variants gain 5-7 % in situ (256x320 and 256x256 gathers); the 16-wave ones
+    // (4 waves per SIMD already cover the LDS latency) do not move, and 512x128 spills 60 registers under the pinned order: they
+    // keep the compiler-scheduled fragment loop
+    constexpr bool PINNED = NW == 8;
 
     // split-K: blockIdx.y owns the k-tiles [kbeg, kend) and writes raw fp32 partials to the workspace
     const int nsplit = gridDim.y;
@@ -574,46 +640,56 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_big_kernel(fd_gemm_desc p
         // (issuing the B half between the two k-steps was measured: it pushes the 16-wave variant into scratch, 8x slower)
         if (kt + 1 < kend && p.batch != -1) issue(kt + 1, buf ^ 1, 3);
         if (p.batch == -2) continue;
-        const f16* Ab = As + (buf * BM + wm * WTM) * 64 + frow;
-        const f16* Bb = Bs + (buf * BN + wn * WTN) * 64 + frow;
+        if constexpr (PINNED) {
+            const uint32_t a_base = lds0 + (uint32_t)((buf * BM + wm * WTM) * 64 + frow) * 2;
+            const uint32_t b_base = lds0 + (uint32_t)((2 * BM + buf * BN + wn * WTN) * 64 + frow) * 2;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int slot = ((ks * 4 + lg) ^ fsw) * 8;
-            // keep the smaller operand set resident and stream the other one with a 2-deep register prefetch, the
-            // ds_read of fragment i+2 pinned in front of the MFMAs of fragment i (LDS latency hidden under 2x TN MFMAs)
-            if (TN <= TM) {
-                f16x8 bf[TN];
+            for (int ks = 0; ks < 2; ++ks) {
+                const uint32_t slot = (uint32_t)(((ks * 4 + lg) ^ fsw) * 16);
+                mma_k32<TM, TN, 2>(acc, a_base + slot, b_base + slot);
+            }
+        } else {
+            const f16* Ab = As + (buf * BM + wm * WTM) * 64 + frow;
+            const f16* Bb = Bs + (buf * BN + wn * WTN) * 64 + frow;
 #pragma unroll
-                for (int j = 0; j < TN; ++j) bf[j] = *(const f16x8*)(Bb + j * 16 * 64 + slot);
-                f16x8 a0 = *(const f16x8*)(Ab + slot);
-                f16x8 a1 = *(const f16x8*)(Ab + (TM > 1 ? 1 : 0) * 16 * 64 + slot);
+            for (int ks = 0; ks < 2; ++ks) {
+                const int slot = ((ks * 4 + lg) ^ fsw) * 8;
+                // keep the smaller operand set resident and stream the other one with a 2-deep register prefetch, the
+                // ds_read of fragment i+2 pinned in front of the MFMAs of fragment i (LDS latency hidden under 2x TN MFMAs)
+                if (TN <= TM) {
+                    f16x8 bf[TN];
 #pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    f16x8 a2 = a1;
-                    if (i + 2 < TM) a2 = *(const f16x8*)(Ab + (i + 2) * 16 * 64 + slot);
+                    for (int j = 0; j < TN; ++j) bf[j] = *(const f16x8*)(Bb + j * 16 * 64 + slot);
+                    f16x8 a0 = *(const f16x8*)(Ab + slot);
+                    f16x8 a1 = *(const f16x8*)(Ab + (TM > 1 ? 1 : 0) * 16 * 64 + slot);
 #pragma unroll
-                    for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], a0, acc[i][j], 0, 0, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x008, TN, 0);
-                    a0 = a1;
-                    a1 = a2;
-                }
-            } else {
-                f16x8 af[TM];
+                    for (int i = 0; i < TM; ++i) {
+                        f16x8 a2 = a1;
+                        if (i + 2 < TM) a2 = *(const f16x8*)(Ab + (i + 2) * 16 * 64 + slot);
 #pragma unroll
-                for (int i = 0; i < TM; ++i) af[i] = *(const f16x8*)(Ab + i * 16 * 64 + slot);
-                f16x8 b0 = *(const f16x8*)(Bb + slot);
-                f16x8 b1 = *(const f16x8*)(Bb + (TN > 1 ? 1 : 0) * 16 * 64 + slot);
+                        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], a0, acc[i][j], 0, 0, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, TN, 0);
+                        a0 = a1;
+                        a1 = a2;
+                    }
+                } else {
+                    f16x8 af[TM];
 #pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    f16x8 b2 = b1;
-                    if (j + 2 < TN) b2 = *(const f16x8*)(Bb + (j + 2) * 16 * 64 + slot);
+                    for (int i = 0; i < TM; ++i) af[i] = *(const f16x8*)(Ab + i * 16 * 64 + slot);
+                    f16x8 b0 = *(const f16x8*)(Bb + slot);
+                    f16x8 b1 = *(const f16x8*)(Bb + (TN > 1 ? 1 : 0) * 16 * 64 + slot);
 #pragma unroll
-                    for (int i = 0; i < TM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b0, af[i], acc[i][j], 0, 0, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x008, TM, 0);
-                    b0 = b1;
-                    b1 = b2;
+                    for (int j = 0; j < TN; ++j) {
+                        f16x8 b2 = b1;
+                        if (j + 2 < TN) b2 = *(const f16x8*)(Bb + (j + 2) * 16 * 64 + slot);
+#pragma unroll
+                        for (int i = 0; i < TM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b0, af[i], acc[i][j], 0, 0, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, TM, 0);
+                        b0 = b1;
+                        b1 = b2;
+                    }
                 }
             }
         }
