@@ -782,6 +782,115 @@ static int launch_big(const fd_gemm_desc& d, hipStream_t s, int nsplit = 1) {
     return fd_check_launch("fd_gemm(big)");
 }
 
+
+// ======================================================================================= skinny N (LoRA down-projections)
+// C[M, N <= 64] = A[M,K] . B[N,K]^T with nothing else in the epilogue: t = x.down^T of every LoRALinearLayer (N = rank padded to
+// 8, or 3 stacked ranks for q/k/v) and dt = g.up of its backward.  4149 launches per training step took 3.7 % of it on the 64x64
+// tile at 43 TFLOP/s; the problem is a pure stream over A.  Here a wave owns 16 rows: it loads its A fragments straight from
+// global memory in MFMA layout (16 B per lane, 64 B contiguous per row and k-step), B (a few KB, L1-resident) likewise; no LDS,
+// no barrier in the main loop.  KS waves of a workgroup split K in slabs of 320 and are summed through LDS in a fixed order.
+template <int NT, int KS, int RT>
+__global__ __launch_bounds__(KS * 64) void gemm_skinny_kernel(fd_gemm_desc p) {
+    __shared__ float red[KS > 1 ? (KS - 1) * RT * NT * 256 : 1];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l15 = lane & 15, lg = lane >> 4;
+    const f16* A[RT];
+    bool mok[RT];
+#pragma unroll
+    for (int r = 0; r < RT; ++r) {
+        const int m = (blockIdx.x * RT + r) * 16 + l15;
+        mok[r] = m < p.M;
+        A[r] = (const f16*)p.A + (int64_t)(mok[r] ? m : 0) * p.lda + lg * 8;
+    }
+    const f16* B = (const f16*)p.B + lg * 8;
+    f32x4 acc[RT][NT];
+#pragma unroll
+    for (int r = 0; r < RT; ++r)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[r][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int nks = p.K >> 5;                                  // k-steps of 32
+    const int per = (nks + KS - 1) / KS;                       // k-steps per wave
+    const int kbeg = wave * per, kend = min(nks, kbeg + per);
+    constexpr int CH = 10 / RT;                                // k-steps in flight per wave (40 VGPRs of A)
+    for (int k0 = kbeg; k0 < kend; k0 += CH) {
+        f16x8 af[RT][CH];
+#pragma unroll
+        for (int c = 0; c < CH; ++c)
+#pragma unroll
+            for (int r = 0; r < RT; ++r) {
+                af[r][c] = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
+                if (k0 + c < kend && mok[r]) af[r][c] = *(const f16x8*)(A[r] + (int64_t)(k0 + c) * 32);
+            }
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            if (k0 + c < kend) {
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    const int n = j * 16 + l15;
+                    f16x8 bf = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
+                    if (n < p.N) bf = *(const f16x8*)(B + (int64_t)n * p.ldb + (int64_t)(k0 + c) * 32);   // one B fragment feeds RT row tiles
+#pragma unroll
+                    for (int r = 0; r < RT; ++r) acc[r][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf, af[r][c], acc[r][j], 0, 0, 0);
+                }
+            }
+        }
+    }
+    if (KS > 1) {
+        if (wave > 0) {
+#pragma unroll
+            for (int r = 0; r < RT; ++r)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) *(f32x4*)(red + ((((wave - 1) * RT + r) * NT + j) * 64 + lane) * 4) = acc[r][j];
+        }
+        __syncthreads();
+        if (wave > 0) return;
+#pragma unroll
+        for (int w = 1; w < KS; ++w)
+#pragma unroll
+            for (int r = 0; r < RT; ++r)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[r][j] += *(const f32x4*)(red + ((((w - 1) * RT + r) * NT + j) * 64 + lane) * 4);
+    }
+#pragma unroll
+    for (int r = 0; r < RT; ++r) {
+        if (!mok[r]) continue;
+        f16* C = (f16*)p.C + (int64_t)((blockIdx.x * RT + r) * 16 + l15) * p.ldc;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int n = j * 16 + lg * 4;                    // lane holds C[m][n..n+3] (swapped-operand MFMA layout)
+            if (n < p.N) *(f16x4*)(C + n) = (f16x4){(f16)acc[r][j][0], (f16)acc[r][j][1], (f16)acc[r][j][2], (f16)acc[r][j][3]};
+        }
+    }
+}
+
+static bool skinny_ok(const fd_gemm_desc& d) {
+    static const bool off = getenv("FD_GEMM_NOSKINNY") != nullptr;   // A/B switch for measurement
+    // rocprofv3 kernel times, hot caches (scratch/prof_skinny.sh), this kernel vs the 64x64 / 128x64 tiles: M=4096 K=1280: 5.2 vs 14.6 us,
+    // M=16384 K=640: 6.8 vs 8.6, M=65536 K=320: 10.4 vs 10.3 at N=8 (both at the A stream's bandwidth) but 12.8 vs 10.7 at N=24, where
+    // the B fragments re-read through L1 by every wave outweigh the A stream: wide-M problems with more than one column tile stay on the LDS tiles
+    if (d.N > 16 && d.M >= 32768) return false;
+    return !off && !d.conv && d.batch <= 1 && d.K2 == 0 && d.N <= 64 && (d.N & 3) == 0 && (d.K & 31) == 0 && d.M >= 1024 && !d.bias && !d.rowbias &&
+           !d.residual && d.act == FD_ACT_NONE && d.alpha == 1.f && d.out_dtype == FD_OUT_F16 && (d.ldc & 3) == 0;
+}
+
+template <int NT, int RT>
+static int launch_skinny_rt(const fd_gemm_desc& d, hipStream_t s) {
+    const int blocks = (d.M + 16 * RT - 1) / (16 * RT);
+    const int ks = d.K >= 1280 ? 4 : d.K >= 640 ? 2 : 1;     // slabs of >= 320 per wave
+    if (ks == 4) hipLaunchKernelGGL((gemm_skinny_kernel<NT, 4, RT>), dim3(blocks), dim3(256), 0, s, d);
+    else if (ks == 2) hipLaunchKernelGGL((gemm_skinny_kernel<NT, 2, RT>), dim3(blocks), dim3(128), 0, s, d);
+    else hipLaunchKernelGGL((gemm_skinny_kernel<NT, 1, RT>), dim3(blocks), dim3(64), 0, s, d);
+    return fd_check_launch("fd_gemm(skinny)");
+}
+
+template <int NT>
+static int launch_skinny(const fd_gemm_desc& d, hipStream_t s) {
+    // measurement switch: two row tiles per wave share each B fragment (13.4 us on the N=24 case above: still behind the LDS tile)
+    static const int rt = getenv("FD_GEMM_SKINNY_RT") ? atoi(getenv("FD_GEMM_SKINNY_RT")) : 0;
+    const bool two = rt == 2;
+    return two ? launch_skinny_rt<NT, 2>(d, s) : launch_skinny_rt<NT, 1>(d, s);
+}
+
 template <int BM, int BN>
 static int launch(const fd_gemm_desc& d, hipStream_t s) {
     const int ntm = (d.M + BM - 1) / BM, ntn = (d.N + BN - 1) / BN;
@@ -797,6 +906,7 @@ extern "C" int fd_gemm_tile(const fd_gemm_desc* dp) {
     const long nb = d.batch > 1 ? d.batch : 1;
     static const bool nobig = getenv("FD_GEMM_NOBIG") != nullptr;
     static const int force = getenv("FD_GEMM_FORCE") ? atoi(getenv("FD_GEMM_FORCE")) : 0;   // measurement only: force a big-tile code for dense
+    if (skinny_ok(d)) return 16000 + (d.N + 15) / 16 * 16;      // 16 rows per wave x N padded to 16: the LoRA down-projections
     if (force && nb == 1 && !d.conv) return force;
     // big-tile (BK=64, 8-wave) variants: unbatched, K-tiles of 64 must not straddle a conv tap
     static const int bigk = getenv("FD_GEMM_BIGK") ? atoi(getenv("FD_GEMM_BIGK")) : 320;
@@ -871,6 +981,10 @@ extern "C" int fd_gemm(const fd_gemm_desc* dp, void* stream) {
         return (sel % 1000000 == 128320) ? launch_big<128, 320, 4, 4>(d, s, sel / 1000000) : launch_big<128, 160, 4, 2>(d, s, sel / 1000000);
     }
     switch (sel) {
+        case 16016: return launch_skinny<1>(d, s);
+        case 16032: return launch_skinny<2>(d, s);
+        case 16048: return launch_skinny<3>(d, s);
+        case 16064: return launch_skinny<4>(d, s);
         case 256320: return (w16 && !d.conv) ? launch_big<256, 320, 4, 4>(d, s) : launch_big<256, 320, 2, 4>(d, s);
         case 128320: return w16 ? launch_big<128, 320, 4, 4>(d, s) : launch_big<128, 320, 2, 4>(d, s);
         case 128160: return launch_big<128, 160, 4, 2>(d, s);

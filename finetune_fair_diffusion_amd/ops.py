@@ -81,7 +81,7 @@ def _gemm_call(d, conv):
     a_elems = (d.Bn * d.H * d.W * d.Cin) if conv else d.M * d.K
     nbytes = 2.0 * max(d.batch, 1) * (a_elems + d.M * d.K2 + d.N * (d.K + d.K2) + d.M * d.N)
     split, tile = tile // 1000000, tile % 1000000
-    kname = "gemm_big_kernel" if tile in (256320, 128320, 128160, 256128, 256256, 512128) else "gemm_glds_kernel"
+    kname = "gemm_big_kernel" if tile in (256320, 128320, 128160, 256128, 256256, 512128) else "gemm_skinny_kernel" if tile // 1000 == 16 else "gemm_glds_kernel"
     TIMER.records.append((f"{kname}<{tile // 1000},{tile % 1000},{'conv3x3' if conv else 'dense'}{',splitK' if split > 1 else ''}>", flops, nbytes, a, b))
 
 

@@ -62,6 +62,23 @@ def test_gemm_big_tiles(ops, dev, M, N, K, tile):
     check(f"gemm big {M}x{N}x{K}", c, a.float() @ b.float().t() + a2.float() @ b2.float().t() + bias + res.float(), 2e-3)
 
 
+@pytest.mark.parametrize("M,N,K", [(65536, 8, 320), (24576, 24, 320), (16384, 8, 640), (4100, 24, 1280), (1030, 56, 1280), (20000, 8, 768), (4096, 64, 320), (3000, 40, 96)])
+def test_gemm_skinny(ops, dev, M, N, K):
+    """LoRA down-projection shapes (N = padded rank or three stacked ranks): one wave per 16 rows, K split over the waves of a block.
+    A is a column slice of a wider matrix (row stride > K), as the stacked q/k/v down-projection outputs are consumed."""
+    import ctypes
+    from finetune_fair_diffusion_amd import lib
+    wide = rnd(M, K + 64, dev=dev, seed=1)
+    a = wide[:, 32:32 + K]
+    b = rnd(N, K, dev=dev, scale=0.1, seed=2)
+    d = lib.GemmDesc(); d.M, d.N, d.K, d.batch, d.ldc, d.alpha = M, N, K, 1, N, 1.0
+    assert lib.get().fd_gemm_tile(ctypes.byref(d)) == 16000 + (N + 15) // 16 * 16
+    out = torch.full((M, N + 8), 7.0, dtype=torch.float16, device=dev)
+    c = ops.gemm(a, b, out=out[:, :N])
+    check(f"gemm skinny {M}x{N}x{K}", c, a.float() @ b.float().t(), 2e-3)
+    assert bool((out[:, N:] == 7.0).all())          # nothing written beyond N
+
+
 @pytest.mark.parametrize("B,H,Cin,Cout", [(16, 64, 320, 320), (14, 64, 64, 128), (13, 32, 128, 640), (3, 136, 128, 256), (2, 168, 64, 512), (1, 456, 64, 128)])
 def test_conv3x3_big_tiles(ops, dev, B, H, Cin, Cout):
     x = rnd(B, Cin, H, H, dev=dev, seed=1)
