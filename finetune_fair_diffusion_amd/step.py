@@ -22,6 +22,7 @@ classifier's at the image and go through the VAE once.  A non-zero ``weight_loss
 rather than silently dropped.
 """
 import math
+import os
 
 import torch
 import torch.distributed as dist
@@ -34,6 +35,10 @@ from .fairness import (EXPERIMENT_ATTRS, EXPERIMENT_REG_FLAGS, SyntheticFaceProv
 from .layers import F16, F32
 from .lr_schedule import lr_lambda
 from .vit import feature_loss_and_grad
+
+# The two halves of a CFG batch share everything up to the first cross-attention (unet.forward_step(pair=True)); FD_NO_CFG_PAIR=1
+# evaluates the duplicated batch instead (A/B measurement only; eps is bit-identical either way).
+_CFG_PAIR = os.environ.get("FD_NO_CFG_PAIR") is None
 
 
 def _ctx_bytes(obj, seen=None):
@@ -148,9 +153,9 @@ class FairnessTrainer:
         for i in range(S):
             if keep_inputs:
                 inputs.append(lat.clone())
-            x = ops.to_f16(lat).repeat(2, 1, 1, 1)
             rec = keep_activations and (i == 0 or budget > 0)
-            eps = unet.forward_step(x, i, record=rec)
+            x = ops.to_f16(lat)
+            eps = unet.forward_step(x if _CFG_PAIR else x.repeat(2, 1, 1, 1), i, record=rec, pair=_CFG_PAIR)   # cat([latents] * 2) (:1043)
             if rec:
                 ctxs[i] = unet._ctx
                 unet._ctx = None
@@ -413,8 +418,8 @@ class FairnessTrainer:
                     if i in ctxs:
                         self.unet._ctx = ctxs.pop(i)        # activations kept from the forward rollout
                     else:                                   # gradient-checkpointed recompute of this timestep
-                        x = ops.to_f16(inputs[i]).repeat(2, 1, 1, 1)
-                        self.unet.forward_step(x, i, record=True)
+                        x = ops.to_f16(inputs[i])
+                        self.unet.forward_step(x if _CFG_PAIR else x.repeat(2, 1, 1, 1), i, record=True, pair=_CFG_PAIR)
                     d = g * float(coefs[i] * gscale)
                     self.unet.backward_step(torch.cat([d * (1.0 - gs), d * gs]), gscale)
                 denc = self.unet.finish_prompt_backward(gscale, need_denc=train_te)

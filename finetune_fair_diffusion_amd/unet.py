@@ -106,8 +106,11 @@ class TransformerBlock:
         return denc
 
     # -- forward -------------------------------------------------------------------------------
-    def forward(self, x, B, H, W, ctx=None):
-        HW, M, C, h, d = H * W, B * H * W, self.C, self.heads, self.d
+    def forward(self, x, B, H, W, ctx=None, pair=False):
+        """x [B*HW, C].  ``pair``: x holds the N = B latents of a CFG pair whose two halves differ only in the prompt, and this is the
+        first cross-attention of the U-Net: everything up to the cross-attention query (norm, proj_in, self-attention, attn2.to_q) is
+        identical for the uncond and the cond half, is computed once on N samples and duplicated; returns the 2N-sample output."""
+        HW, C, h, d = H * W, self.C, self.heads, self.d
         rec = ctx is not None
         g, st = ops.groupnorm(x, None, B, HW, self.groups, 1e-6, self.norm.gamma, self.norm.beta, False)
         h0 = ops.gemm(g, self.proj_in.w, bias=self.proj_in.bias)
@@ -128,25 +131,30 @@ class TransformerBlock:
         n2, ln2 = ops.layernorm(h1, self.ln2.gamma, self.ln2.beta, 1e-5, save_stats=True)
         l2 = self.lora2
         q2, tq2 = lora_linear_fwd(n2, self.q2, l2.q if l2 else None)
+        B2 = 2 * B if pair else B
+        q2f, h1f, xf = (torch.cat([q2, q2]), torch.cat([h1, h1]), torch.cat([x, x])) if pair else (q2, h1, x)
         cr = self.cross
-        kv_div = B // cr["Bk"]
-        o2, lse2 = ops.attn_fwd(q2, cr["K"], cr["Vt"], B, h, HW, cr["L"], d, kv_div, need_lse=True)
-        h2, to2 = lora_linear_fwd(o2, self.o2, l2.out if l2 else None, residual=h1)
+        kv_div = B2 // cr["Bk"]
+        o2, lse2 = ops.attn_fwd(q2f, cr["K"], cr["Vt"], B2, h, HW, cr["L"], d, kv_div, need_lse=True)
+        h2, to2 = lora_linear_fwd(o2, self.o2, l2.out if l2 else None, residual=h1f)
         n3, ln3 = ops.layernorm(h2, self.ln3.gamma, self.ln3.beta, 1e-5, save_stats=True)
         # bit-identical to projection + fd_geglu_fwd (both halves are rounded to fp16 before the gate)
         proj = torch.empty((n3.shape[0], self.ff1_wi.shape[0]), dtype=F16, device=n3.device) if rec else None
         gg = ops.gemm(n3, self.ff1_wi, bias=self.ff1_bi, act="geglu", aux=proj)
         h3 = ops.gemm(gg, self.ff2.w, bias=self.ff2.bias, residual=h2)
-        out = ops.gemm(h3, self.proj_out.w, bias=self.proj_out.bias, residual=x)
+        out = ops.gemm(h3, self.proj_out.w, bias=self.proj_out.bias, residual=xf)
         if rec:
             ctx.append(dict(x=x, st=st, h0=h0, ln1=ln1, n1=n1, t1=t1, q=q, k=k, v=v, o=o, lse=lse, to1=to1, h1=h1, ln2=ln2, n2=n2,
-                            tq2=tq2, q2=q2, o2=o2, lse2=lse2, to2=to2, h2=h2, ln3=ln3, proj=proj))
+                            tq2=tq2, q2=q2f, o2=o2, lse2=lse2, to2=to2, h2=h2, ln3=ln3, proj=proj, pair=pair))
         return out
 
     # -- backward ------------------------------------------------------------------------------
-    def backward(self, d_out, B, H, W, c, gscale):
+    def backward(self, d_out, B, H, W, c, gscale, need_dx=True):
+        """d_out [B*HW, C] (B counts both halves of a paired forward).  ``need_dx=False``: nothing trainable upstream (first attention
+        of the U-Net), the gradient w.r.t. the block input is not formed."""
         HW, C, h, d = H * W, self.C, self.heads, self.d
         l1, l2 = self.lora1, self.lora2
+        pair = c.get("pair", False)
         dh3 = ops.gemm(d_out, self.proj_out.wT)
         dgg = ops.gemm(dh3, self.ff2.wT)
         dproj = ops.geglu_bwd_interleaved(c["proj"], dgg)
@@ -165,6 +173,14 @@ class TransformerBlock:
             dq2, dk2, dv2 = ops.attn_bwd(c["q2"], cr["K"], cr["V"], c["o2"], do2, c["lse2"], B, h, HW, cr["L"], d, 1, kt=cr["Kt"])
             cr["dK"] += dk2.float()
             cr["dV"] += dv2.float()
+        if pair:
+            # the shared prefix received the gradient of both halves
+            B = B // 2
+            M = B * HW
+            dq2 = ops.add(dq2[:M], dq2[M:])
+            dh2 = ops.add(dh2[:M], dh2[M:])
+            if need_dx:
+                d_out = ops.add(d_out[:M], d_out[M:])
         dn2 = lora_linear_bwd(dq2, c["n2"], c["tq2"], self.q2, l2.q if l2 else None, gscale)
         dh1 = ops.layernorm_bwd(c["h1"], dn2, self.ln2.gamma, c["ln2"], add=dh2)
         # attn1 (self)
@@ -173,9 +189,11 @@ class TransformerBlock:
         t1 = c["t1"]
         rp = l1.q.rp if l1 else 0
         sl = (lambda i: t1[:, i * rp:(i + 1) * rp]) if l1 else (lambda i: None)
-        dn1 = lora_linear_bwd(dq, c["n1"], sl(0), self.q1, l1.q if l1 else None, gscale)
-        dn1 = lora_linear_bwd(dk, c["n1"], sl(1), self.k1, l1.k if l1 else None, gscale, residual=dn1)
-        dn1 = lora_linear_bwd(dv, c["n1"], sl(2), self.v1, l1.v if l1 else None, gscale, residual=dn1)
+        dn1 = lora_linear_bwd(dq, c["n1"], sl(0), self.q1, l1.q if l1 else None, gscale, need_dx=need_dx)
+        dn1 = lora_linear_bwd(dk, c["n1"], sl(1), self.k1, l1.k if l1 else None, gscale, residual=dn1, need_dx=need_dx)
+        dn1 = lora_linear_bwd(dv, c["n1"], sl(2), self.v1, l1.v if l1 else None, gscale, residual=dn1, need_dx=need_dx)
+        if not need_dx:
+            return None
         dh0 = ops.layernorm_bwd(c["h0"], dn1, self.ln1.gamma, c["ln1"], add=dh1)
         dg = ops.gemm(dh0, self.proj_in.wT)
         dx, _ = ops.groupnorm_bwd(c["x"], None, dg, B, HW, self.groups, c["st"], self.norm.gamma, self.norm.beta, False, add1=d_out)
@@ -342,11 +360,15 @@ class UNet2DConditionModel:
         return denc
 
     # ------------------------------------------------------------------ forward / backward
-    def forward_step(self, sample, step_index, record=False):
+    def forward_step(self, sample, step_index, record=False, pair=False):
         """sample: [B,4,H,W] NCHW (fp32 or fp16; cast to wd as the reference does :1043).
-        Returns eps [B,4,H*W] fp32 (values are fp16-rounded, then upcast like :1051)."""
+        Returns eps [B,4,H*W] fp32 (values are fp16-rounded, then upcast like :1051).
+        ``pair``: sample holds the N latents of a CFG rollout step, standing for the batch ``cat([sample, sample])`` (:1043) whose halves
+        meet different prompt embeddings only at the first cross-attention; conv_in, the first ResnetBlock and that transformer's
+        self-attention are evaluated once on N samples (bit-identical to evaluating them twice).  Returns eps for the 2N batch."""
         cfg = self.config
         B, Cin, H, W = sample.shape
+        pair = pair and self.down[0]["attn"] is not None
         boc = cfg.block_out_channels
         trow = self.temb_table[step_index:step_index + 1]
         ctx = [] if record else None
@@ -357,12 +379,14 @@ class UNet2DConditionModel:
 
         x16 = sample if sample.dtype == F16 else ops.to_f16(sample.contiguous())
         x, _, _ = ops.conv_small_cin(x16.contiguous(), self.conv_in_w, self.conv_in_b, B, H, W, Cin, boc[0], 3, 1, nchw=True)
-        skips = [(x, H, W)]
+        skips = [(torch.cat([x, x]) if pair else x, H, W)]
         for blk in self.down:
             for j, r in enumerate(blk["res"]):
                 x = r.forward(x, None, B, H, W, temb(r), ctx)
                 if blk["attn"] is not None:
-                    x = blk["attn"][j].forward(x, B, H, W, ctx)
+                    x = blk["attn"][j].forward(x, B, H, W, ctx, pair=pair)
+                    if pair:
+                        pair, B = False, 2 * B
                 skips.append((x, H, W))
             if blk["down"] is not None:
                 x, H, W = ops.conv3x3(x, blk["down"].wk, B, H, W, mode=ops.CONV_STRIDE2, bias=blk["down"].bias)
@@ -424,9 +448,9 @@ class UNet2DConditionModel:
                 dx, H, W = ops.conv3x3(dx, blk["down"].wd, B, H, W, mode=ops.CONV_TRANS2)
             for j in range(len(blk["res"]) - 1, -1, -1):
                 dx = ops.add(dx, dskips[k]); k -= 1
-                if blk["attn"] is not None:
-                    dx = blk["attn"][j].backward(dx, B, H, W, blocks.pop(), gscale)
                 last = (bi == first_attn and j == 0)
+                if blk["attn"] is not None:
+                    dx = blk["attn"][j].backward(dx, B, H, W, blocks.pop(), gscale, need_dx=not last)
                 if last:
                     done = True  # nothing trainable upstream of the first attention: stop here
                     break

@@ -111,6 +111,32 @@ def test_unet_forward_and_backward(pair, dev):
     check("unet __call__ (per-sample kv)", out, eps_o, 2e-2)
 
 
+def test_unet_cfg_pair_prefix_sharing(pair, dev):
+    """forward_step(pair=True) on the N latents of a CFG step == forward_step on cat([latents]*2) (:1043): the prefix up to the first
+    cross-attention query is evaluated once.  eps must be bit-identical; the LoRA gradients agree up to the fp16 rounding of the summed
+    half-gradients that enter the shared prefix."""
+    om, pm = pair
+    N = 3
+    tokens, enc_o = _enc(om, pm, dev, N)
+    xh = torch.randn(N, 4, 32, 32, generator=torch.Generator().manual_seed(11)).to(dev)
+    unet_p = pm["unet"]
+    unet_p.prepare_timesteps([401])
+    unet_p.prepare_prompt(torch.stack([enc_o[0], enc_o[N]]).to(dev).half(), record=True)
+    g = torch.randn(2 * N, 4, 32, 32, generator=torch.Generator().manual_seed(12)).to(dev)
+    bank, gs, grads = unet_p.lora_bank, 64.0, []
+    for use_pair in (False, True):
+        x = xh if use_pair else torch.cat([xh, xh])
+        eps = unet_p.forward_step(x, 0, record=True, pair=use_pair)
+        bank.grad.zero_()
+        unet_p.backward_step(g * gs, gs)
+        grads.append((eps.clone(), bank.grad.clone()))
+    unet_p.finish_prompt_backward(gs, need_denc=False)
+    assert grads[0][0].shape == grads[1][0].shape and torch.equal(grads[0][0], grads[1][0])
+    check("lora grads, shared prefix vs duplicated batch", grads[1][1], grads[0][1], 1e-2)
+    cos = torch.nn.functional.cosine_similarity(grads[1][1].flatten(), grads[0][1].flatten(), dim=0)
+    assert float(cos) > 0.9999, float(cos)
+
+
 def test_vae_decode_fwd_bwd(pair, dev):
     om, pm = pair
     z = torch.randn(2, 4, 32, 32, generator=torch.Generator().manual_seed(4))
