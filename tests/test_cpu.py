@@ -441,6 +441,42 @@ def test_pretrained_directory_layout_and_legacy_names(tmp_path):
         P.load_unet(str(tmp_path / "absent"), TINY_UNET)
 
 
+def test_regulariser_asset_loaders(tmp_path, monkeypatch):
+    """opensphere backbone saved from nn.DataParallel ('module.' prefix), face_feats.pkl triple, a CLIP directory that also holds
+    the text tower, a DINOv2 hub checkpoint with its unused mask_token; missing locations for the hub-fetched encoders are loud."""
+    import pickle, types
+    from safetensors.torch import save_file
+    from finetune_fair_diffusion_amd import pretrained as P, weights as W
+    fn = W.synthetic_state_dict(W.sfnet20_param_shapes(in_size=112), seed=5)
+    torch.save({"module." + k: v for k, v in fn.items()}, str(tmp_path / "backbone.pth"))
+    got = P.load_face_net(str(tmp_path / "backbone.pth"), 112)
+    assert set(got) == set(fn) and all(torch.equal(got[k], fn[k].float()) for k in fn)
+    feats = torch.randn(50, 512, generator=torch.Generator().manual_seed(1)) * 3
+    with open(tmp_path / "face_feats.pkl", "wb") as f:
+        pickle.dump((feats, torch.zeros(50), torch.zeros(50, 2)), f)
+    db = P.load_face_db(str(tmp_path / "face_feats.pkl"))
+    assert db.shape == (50, 512) and torch.allclose(db.norm(dim=-1), torch.ones(50), atol=1e-6)
+    assert torch.allclose(db, torch.nn.functional.normalize(feats, dim=-1))
+    ccfg = W.ViTConfig(kind="clip", image_size=28, patch_size=14, hidden_size=32, num_hidden_layers=2, num_attention_heads=2, intermediate_size=64, projection_dim=16)
+    dcfg = W.ViTConfig(kind="dino", image_size=28, patch_size=14, hidden_size=24, num_hidden_layers=2, num_attention_heads=2, intermediate_size=48, projection_dim=0,
+                       layer_norm_eps=1e-6, pos_grid=3)
+    cv, dn = W.synthetic_state_dict(W.vit_param_shapes(ccfg), seed=6), W.synthetic_state_dict(W.vit_param_shapes(dcfg), seed=7)
+    (tmp_path / "clip").mkdir()
+    save_file({**{k: v.contiguous() for k, v in cv.items()}, "text_model.embeddings.token_embedding.weight": torch.zeros(4, 4)}, str(tmp_path / "clip" / "model.safetensors"))
+    torch.save({**dn, "mask_token": torch.zeros(1, 24)}, str(tmp_path / "dinov2_vitb14_pretrain.pth"))
+    gc, gd = P.load_clip_vision(str(tmp_path / "clip"), ccfg), P.load_dino(str(tmp_path / "dinov2_vitb14_pretrain.pth"), dcfg)
+    assert set(gc) == set(cv) and set(gd) == set(dn)
+    args = types.SimpleNamespace(weight_loss_img=8.0, weight_loss_face=1.0, opensphere_model_path=str(tmp_path / "backbone.pth"),
+                                 face_feats_path=str(tmp_path / "face_feats.pkl"), size_aligned_face=112)
+    monkeypatch.delenv("FD_CLIP_VISION_DIR", raising=False)
+    with pytest.raises(FileNotFoundError):
+        P.load_regularisers(args, dict(clip_vision=ccfg, dino=dcfg))
+    monkeypatch.setenv("FD_CLIP_VISION_DIR", str(tmp_path / "clip"))
+    monkeypatch.setenv("FD_DINO_WEIGHTS", str(tmp_path / "dinov2_vitb14_pretrain.pth"))
+    out = P.load_regularisers(args, dict(clip_vision=ccfg, dino=dcfg))
+    assert set(out) == {"clip_vision", "dino", "face_net", "face_db"}
+
+
 def test_hash_tokenizer_shapes_like_reference_calls():
     """Prompt: BOS, words, EOS, mask ones.  Uncond: BOS then EOS padding to the same length with mask [1,1,0...] (:1020-1026)."""
     from finetune_fair_diffusion_amd.train import HashTokenizer, load_prompts
