@@ -477,7 +477,17 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_big_kernel(fd_gemm_desc p
     // tile order: an XCD walks a contiguous range of tile ids.  Row-major ids (n fastest) re-stream the whole B operand for every
     // row of tiles once B outgrows the 4 MB L2 (measured on 4096x10240x1280: 431 MB fetched for 121 MB of operands); banding the
     // n-tiles in groups of ``gn`` whose B slab fits the L2 (m fastest inside a band) reads B about once and A once per band.
-    const int tile = xcd_remap(blockIdx.x, ntm * ntn);
+    int tile = xcd_remap(blockIdx.x, gridDim.x);
+    // FD_CONV_UP2P: the four output phases (py, px) of conv3x3(nearest-up2(x)) are four 2x2-tap problems over the low-res input with
+    // their own pre-summed weights; they share one launch, phase-major in the tile index, weights and output
+    int phase = 0;
+    if (CONV && p.conv_mode == FD_CONV_UP2P) {
+        phase = tile / (ntm * ntn);
+        tile -= phase * (ntm * ntn);
+        p.B = (const f16*)p.B + (int64_t)phase * p.N * p.ldb;
+        p.C = (f16*)p.C + (int64_t)phase * p.M * p.ldc;
+    }
+    const int ph_y = phase >> 1, ph_x = phase & 1;
     int mt, nt;
     if (gn >= ntn) {
         mt = tile / ntn;
@@ -533,8 +543,9 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_big_kernel(fd_gemm_desc p
         if (CONV) {
             // k order = (64-channel chunk, tap): the 9 taps of one chunk re-read the same 128-byte lines shifted by a
             // pixel, so the tile's working set per chunk (~48 KB) stays in L1/L2 instead of cycling all Cin channels
-            const int cc = kt / 9;
-            const int tap = kt - cc * 9;
+            const int ntap = p.conv_mode == FD_CONV_UP2P ? 4 : p.conv_mode == FD_CONV_UP2P_BWD ? 16 : 9;
+            const int cc = kt / ntap;
+            const int tap = kt - cc * ntap;
             const int c0 = cc << 6;
             const int ky = tap / 3, kx = tap - ky * 3;
             if (p.conv_mode == FD_CONV_NORMAL) {
@@ -565,6 +576,14 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_big_kernel(fd_gemm_desc p
                         iy += ky - 1; ix += kx - 1;
                         ok = ok && iy >= 0 && iy < 2 * p.H && ix >= 0 && ix < 2 * p.W;
                         iy >>= 1; ix >>= 1;
+                    } else if (p.conv_mode == FD_CONV_UP2P) {          // tap = dy*2+dx over the low-res input, shifted by the phase
+                        iy += (tap >> 1) + ph_y - 1; ix += (tap & 1) + ph_x - 1;
+                        ok = ok && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+                    } else if (p.conv_mode == FD_CONV_UP2P_BWD) {      // tap = ((py*2+px)*2+dy)*2+dx; source = high-res gradient [Bn,H,W], H = 2*Ho
+                        const int qy = (tap >> 3) & 1, qx = (tap >> 2) & 1;
+                        const int u = iy - ((tap >> 1) & 1) - qy + 1, v = ix - (tap & 1) - qx + 1;
+                        ok = ok && u >= 0 && u < p.Ho && v >= 0 && v < p.Wo;
+                        iy = 2 * u + qy; ix = 2 * v + qx;
                     } else {
                         iy += ky - 1; ix += kx - 1;
                         ok = ok && iy >= 0 && ix >= 0 && !(iy & 1) && !(ix & 1);
@@ -769,10 +788,11 @@ static int launch_big(const fd_gemm_desc& d, hipStream_t s, int nsplit = 1) {
     }
     // n-tiles per band: the band's B slab (gn * BN rows of K halfs, per split) should fit an XCD's L2 next to the streaming A tiles
     static const long l2_budget = getenv("FD_GEMM_L2_KB") ? atol(getenv("FD_GEMM_L2_KB")) * 1024 : 3 * 1024 * 1024;
-    const long ktot = (d.conv ? 9L * d.Cin : (long)d.K + d.K2) / nsplit;
+    const long ktot = ((long)d.K + d.K2) / nsplit;
+    const int nph = (d.conv && d.conv_mode == FD_CONV_UP2P) ? 4 : 1;
     long gnl = l2_budget / ((long)BN * ktot * 2);
     const int gn = (int)(gnl < 1 ? 1 : (gnl > ntn ? ntn : gnl));
-    if (d.conv) hipLaunchKernelGGL((gemm_big_kernel<BM, BN, WGM, WGN, true>), dim3(ntm * ntn, nsplit), dim3(WGM * WGN * 64), lds, s, d, ntm, ntn, gn);
+    if (d.conv) hipLaunchKernelGGL((gemm_big_kernel<BM, BN, WGM, WGN, true>), dim3(ntm * ntn * nph, nsplit), dim3(WGM * WGN * 64), lds, s, d, ntm, ntn, gn);
     else hipLaunchKernelGGL((gemm_big_kernel<BM, BN, WGM, WGN, false>), dim3(ntm * ntn, nsplit), dim3(WGM * WGN * 64), lds, s, d, ntm, ntn, gn);
     if (nsplit > 1) {
         int64_t blocks = ((int64_t)d.M * d.N / 4 + 255) / 256;
@@ -911,12 +931,13 @@ extern "C" int fd_gemm_tile(const fd_gemm_desc* dp) {
     // big-tile (BK=64, 8-wave) variants: unbatched, K-tiles of 64 must not straddle a conv tap
     static const int bigk = getenv("FD_GEMM_BIGK") ? atoi(getenv("FD_GEMM_BIGK")) : 320;
     if (!nobig && nb == 1 && (d.conv ? (d.Cin & 63) == 0 : (d.K + d.K2) >= bigk)) {
-        const long m256 = (d.M + 255) / 256, m128 = (d.M + 127) / 128;
+        const long phs = (d.conv && d.conv_mode == FD_CONV_UP2P) ? 4 : 1;    // four phases share the launch
+        const long m256 = phs * ((d.M + 255) / 256), m128 = phs * ((d.M + 127) / 128);
         if (d.N % 320 == 0) {
             if (m256 * (d.N / 320) >= 200) return 256320;
             if (m128 * (d.N / 320) >= 160) return 128320;
         }
-        const bool can_split = d.workspace && (d.N & 3) == 0 && (d.ldc & 3) == 0 && d.act != FD_ACT_GEGLU;
+        const bool can_split = d.workspace && (d.N & 3) == 0 && (d.ldc & 3) == 0 && d.act != FD_ACT_GEGLU && phs == 1;
         const long nk = (d.K + 63) / 64 + (d.K2 + 63) / 64;
         auto split_for = [&](long blocks, int tilecode) -> int {   // split K so ~256 blocks exist, >= 8 k-tiles each
             long split = blocks > 0 ? 256 / blocks : 1;
@@ -963,7 +984,9 @@ extern "C" int fd_gemm(const fd_gemm_desc* dp, void* stream) {
         FD_REQUIRE(d.batch <= 1, "fd_gemm: second slab is not batched");
     } else d.K2 = 0;
     if (d.conv) {
-        FD_REQUIRE((d.Cin & 31) == 0 && d.K == 9 * d.Cin, "fd_gemm(conv): Cin must be a multiple of 32 and K == 9*Cin");
+        const int ntap = d.conv_mode == FD_CONV_UP2P ? 4 : d.conv_mode == FD_CONV_UP2P_BWD ? 16 : 9;
+        FD_REQUIRE((d.Cin & 31) == 0 && d.K == ntap * d.Cin, "fd_gemm(conv): Cin must be a multiple of 32 and K == taps*Cin");
+        if (d.conv_mode == FD_CONV_UP2P) FD_REQUIRE(!d.residual && !d.rowbias, "fd_gemm(conv up2 phases): bias-only epilogue");
         FD_REQUIRE(d.M == d.Bn * d.Ho * d.Wo, "fd_gemm(conv): M != B*Ho*Wo");
         FD_REQUIRE(d.batch <= 1, "fd_gemm(conv): not batched");
         FD_REQUIRE((int64_t)d.Bn * d.H * d.W * d.lda < (1LL << 31), "fd_gemm(conv): input larger than 2^31 elements");
@@ -977,6 +1000,11 @@ extern "C" int fd_gemm(const fd_gemm_desc* dp, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     static const bool w16 = getenv("FD_GEMM_W8") == nullptr;   // 16-wave variants by default (A/B switch for measurement)
     const int sel = fd_gemm_tile(&d);
+    if (d.conv && d.conv_mode >= FD_CONV_UP2P) {
+        const int t = sel % 1000000;
+        FD_REQUIRE(t == 256320 || t == 128320 || t == 128160 || t == 256256 || t == 512128 || t == 256128,
+                   "fd_gemm(conv up2 phases): shape not taken by the big-tile kernels (Cin %% 64, enough tiles); use FD_CONV_UP2");
+    }
     if (sel >= 1000000) {
         return (sel % 1000000 == 128320) ? launch_big<128, 320, 4, 4>(d, s, sel / 1000000) : launch_big<128, 160, 4, 2>(d, s, sel / 1000000);
     }

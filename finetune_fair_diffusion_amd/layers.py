@@ -48,6 +48,28 @@ class Conv3x3:
             self._wd = self._w.flip(2, 3).permute(1, 2, 3, 0).reshape(self.cin, 9 * self.cout).contiguous()
         return self._wd
 
+    def _phase_weights(self):
+        """conv3x3(nearest_up2(x)) at output pixel (2y+py, 2x+px) only sees the 2x2 low-res pixels (y+dy+py-1, x+dx+px-1): per phase the
+        3x3 kernel folds into a 2x2 one, Wp[py,px,dy,dx] = sum_{ky,kx} R[py,dy,ky] R[px,dx,kx] w[ky,kx] (summed in fp32, then fp16)."""
+        R = torch.tensor([[[1., 0., 0.], [0., 1., 1.]], [[1., 1., 0.], [0., 0., 1.]]], device=self._w.device)   # [p, d, k]
+        return torch.einsum("pdk,qel,nckl->pqdenc", R, R, self._w.float())                                      # [py,px,dy,dx,N,C]
+
+    @property
+    def wk_up2p(self):
+        """[4*Cout, 4*Cin]: phase-major (py*2+px) forward operand, k = (dy*2+dx)*Cin + c  (FD_CONV_UP2P)."""
+        if getattr(self, "_wk_up2p", None) is None:
+            wp = self._phase_weights()
+            self._wk_up2p = wp.permute(0, 1, 4, 2, 3, 5).reshape(4 * self.cout, 4 * self.cin).to(F16).contiguous()
+        return self._wk_up2p
+
+    @property
+    def wd_up2p(self):
+        """[Cin, 16*Cout]: input-gradient operand, k = (((py*2+px)*2+dy)*2+dx)*Cout + n  (FD_CONV_UP2P_BWD)."""
+        if getattr(self, "_wd_up2p", None) is None:
+            wp = self._phase_weights()
+            self._wd_up2p = wp.permute(5, 0, 1, 2, 3, 4).reshape(self.cin, 16 * self.cout).to(F16).contiguous()
+        return self._wd_up2p
+
 
 class Norm:
     def __init__(self, sd, name, dev):

@@ -3,6 +3,7 @@ pointers + the current HIP stream out.  torch is plumbing here (device memory, s
 every op fails loudly if the HIP library is missing or a kernel reports an error.
 """
 import ctypes
+import os
 import math
 
 import torch
@@ -76,10 +77,11 @@ def _gemm_call(d, conv):
     a.record()
     _call("fd_gemm", ctypes.byref(d), _stream())
     b.record()
-    flops = 2.0 * d.M * d.N * (d.K + d.K2) * max(d.batch, 1)
+    nph = 4 if (conv and d.conv_mode == 4) else 1          # FD_CONV_UP2P: four phase problems per launch
+    flops = 2.0 * nph * d.M * d.N * (d.K + d.K2) * max(d.batch, 1)
     # algorithmic bytes: every operand element read once, the output written once (3x3 gather: the Cin-wide input rows, not 9x)
     a_elems = (d.Bn * d.H * d.W * d.Cin) if conv else d.M * d.K
-    nbytes = 2.0 * max(d.batch, 1) * (a_elems + d.M * d.K2 + d.N * (d.K + d.K2) + d.M * d.N)
+    nbytes = 2.0 * max(d.batch, 1) * (a_elems + d.M * d.K2 + nph * d.N * (d.K + d.K2) + nph * d.M * d.N)
     split, tile = tile // 1000000, tile % 1000000
     kname = "gemm_big_kernel" if tile in (256320, 128320, 128160, 256128, 256256, 512128) else "gemm_skinny_kernel" if tile // 1000 == 16 else "gemm_glds_kernel"
     TIMER.records.append((f"{kname}<{tile // 1000},{tile % 1000},{'conv3x3' if conv else 'dense'}{',splitK' if split > 1 else ''}>", flops, nbytes, a, b))
@@ -207,6 +209,55 @@ def conv3x3(x, w, B, H, W, *, mode=CONV_NORMAL, bias=None, rowbias=None, residua
     d.conv, d.conv_mode, d.Bn, d.H, d.W, d.Cin, d.Ho, d.Wo = 1, mode, B, H, W, Cin, Ho, Wo
     _gemm_call(d, True)
     return out, Ho, Wo
+
+
+CONV_UP2P, CONV_UP2P_BWD = 4, 5
+_BIG_TILES = (256320, 128320, 128160, 256128, 256256, 512128)
+_NO_UP2P = os.environ.get("FD_NO_UP2P") is not None      # A/B switch: nearest-up2 convs as 3x3 gathers at the high resolution
+
+
+def _up2p_desc(x, w, out, B, H, W, Cin, Cout, bwd, bias=None):
+    d = _lib.GemmDesc()
+    if bwd:   # x = dOut [B*2H*2W, Cin] (high-res), out [B*H*W, Cout]
+        d.K, d.conv_mode, d.H, d.W = 16 * Cin, CONV_UP2P_BWD, 2 * H, 2 * W
+    else:     # x [B*H*W, Cin], out [4, B*H*W, Cout]
+        d.K, d.conv_mode, d.H, d.W = 4 * Cin, CONV_UP2P, H, W
+    d.A, d.lda, d.B, d.ldb, d.C, d.ldc = x.data_ptr(), Cin, w.data_ptr(), d.K, out.data_ptr(), Cout
+    if bias is not None:
+        d.bias = _chk(bias, F32).data_ptr()
+    d.alpha, d.M, d.N, d.act, d.batch, d.out_dtype = 1.0, B * H * W, Cout, ACT["none"], 1, 0
+    d.conv, d.Bn, d.Cin, d.Ho, d.Wo = 1, B, Cin, H, W
+    ws = gemm_workspace()
+    d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * 4
+    return d
+
+
+def conv_up2(x, conv, B, H, W):
+    """Upsample2D: conv3x3(nearest-up2(x)) + bias.  x [B*H*W, Cin] -> ([B*2H*2W, Cout], 2H, 2W).  Evaluated as four 2x2-tap phase problems
+    over the low-res input (4/9 of the multiply-adds) when the big-tile kernels take the shape, else as a 3x3 gather at the high resolution."""
+    Cin, Cout = conv.cin, conv.cout
+    if not _NO_UP2P and Cin % 64 == 0 and Cout % 8 == 0:
+        ph = torch.empty((4 * B * H * W, Cout), dtype=F16, device=x.device)
+        d = _up2p_desc(_chk(x), conv.wk_up2p, ph, B, H, W, Cin, Cout, False, conv.bias)
+        if _lib.get().fd_gemm_tile(ctypes.byref(d)) in _BIG_TILES:
+            _gemm_call(d, True)
+            out = torch.empty((4 * B * H * W, Cout), dtype=F16, device=x.device)
+            _call("fd_phase_shuffle", _p(ph), _p(out), B, H, W, Cout, _stream())
+            return out, 2 * H, 2 * W
+    return conv3x3(x, conv.wk, B, H, W, mode=CONV_UP2, bias=conv.bias)
+
+
+def conv_up2_bwd(dy, conv, B, H, W):
+    """Input gradient of ``conv_up2``: dy [B*2H*2W, Cout] -> [B*H*W, Cin] (H, W = low resolution)."""
+    Cin, Cout = conv.cin, conv.cout
+    if not _NO_UP2P and Cout % 64 == 0 and Cin % 8 == 0:
+        out = torch.empty((B * H * W, Cin), dtype=F16, device=dy.device)
+        d = _up2p_desc(_chk(dy), conv.wd_up2p, out, B, H, W, Cout, Cin, True)
+        if _lib.get().fd_gemm_tile(ctypes.byref(d)) % 1000000 in _BIG_TILES:
+            _gemm_call(d, True)
+            return out
+    dxu, _, _ = conv3x3(dy, conv.wd, B, 2 * H, 2 * W)          # grad at the upsampled resolution
+    return downsum2x2(dxu, B, H, W, Cin)                        # nearest-upsample backward
 
 
 def conv_small_cin(x, w, bias, B, H, W, Cin, Cout, k, stride=1, nchw=True, act="none"):

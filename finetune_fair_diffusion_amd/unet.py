@@ -401,7 +401,7 @@ class UNet2DConditionModel:
                 if blk["attn"] is not None:
                     x = blk["attn"][j].forward(x, B, H, W, ctx)
             if blk["up"] is not None:
-                x, H, W = ops.conv3x3(x, blk["up"].wk, B, H, W, mode=ops.CONV_UP2, bias=blk["up"].bias)
+                x, H, W = ops.conv_up2(x, blk["up"], B, H, W)
         g, st = ops.groupnorm(x, None, B, H * W, cfg.norm_num_groups, 1e-5, self.norm_out.gamma, self.norm_out.beta, True)
         y, _, _ = ops.conv3x3(g, self.conv_out.wk, B, H, W, bias=self.conv_out.bias)
         eps = ops.nhwc_to_nchw(y, B, H * W, cfg.out_channels, out_dtype=F32)
@@ -423,9 +423,8 @@ class UNet2DConditionModel:
         for bi in range(len(self.up) - 1, -1, -1):
             blk = self.up[bi]
             if blk["up"] is not None:
-                dxu, _, _ = ops.conv3x3(dx, blk["up"].wd, B, H, W)            # grad at the upsampled resolution
                 H, W = H // 2, W // 2
-                dx = ops.downsum2x2(dxu, B, H, W, dxu.shape[1])              # nearest-upsample backward
+                dx = ops.conv_up2_bwd(dx, blk["up"], B, H, W)
             for j in range(len(blk["res"]) - 1, -1, -1):
                 if blk["attn"] is not None:
                     dx = blk["attn"][j].backward(dx, B, H, W, blocks.pop(), gscale)

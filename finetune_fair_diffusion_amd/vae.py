@@ -105,7 +105,7 @@ class AutoencoderKL:
             for r in blk["res"]:
                 x = r.forward(x, None, B, H, W, None, ctx)
             if blk["up"] is not None:
-                x, H, W = ops.conv3x3(x, blk["up"].wk, B, H, W, mode=ops.CONV_UP2, bias=blk["up"].bias)
+                x, H, W = ops.conv_up2(x, blk["up"], B, H, W)
         g, st = ops.groupnorm(x, None, B, H * W, cfg.norm_num_groups, 1e-6, self.norm_out.gamma, self.norm_out.beta, True)
         y, _, _ = ops.conv3x3(g, self.conv_out.wk, B, H, W, bias=self.conv_out.bias)
         img = ops.nhwc_to_nchw(y, B, H * W, cfg.out_channels, out_dtype=F16, lo=-1.0, hi=1.0).view(B, cfg.out_channels, H, W)
@@ -135,9 +135,8 @@ class AutoencoderKL:
         dx, _ = ops.groupnorm_bwd(c["x_out"], None, dg, B, H * W, cfg.norm_num_groups, c["st_out"], self.norm_out.gamma, self.norm_out.beta, True)
         for blk in reversed(self.ups):
             if blk["up"] is not None:
-                dxu, _, _ = ops.conv3x3(dx, blk["up"].wd, B, H, W)
                 H, W = H // 2, W // 2
-                dx = ops.downsum2x2(dxu, B, H, W, dxu.shape[1])
+                dx = ops.conv_up2_bwd(dx, blk["up"], B, H, W)
             for r in reversed(blk["res"]):
                 dx, _ = r.backward(dx, B, H, W, blocks.pop())
         dx, _ = self.mid_res[1].backward(dx, B, H, W, blocks.pop())

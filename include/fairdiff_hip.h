@@ -31,7 +31,14 @@ enum { FD_ACT_NONE = 0, FD_ACT_SILU = 1, FD_ACT_QUICK_GELU = 2, FD_ACT_GELU = 3,
           OUTPUT [M, N] (ldr) receiving the pre-gate projection in the same interleaved column order (for fd_geglu_bwd_interleaved) */
        FD_ACT_GEGLU = 7 };
 enum { FD_OUT_F16 = 0, FD_OUT_F32 = 1 };
-enum { FD_CONV_NORMAL = 0, FD_CONV_STRIDE2 = 1, FD_CONV_UP2 = 2, FD_CONV_TRANS2 = 3 };
+enum { FD_CONV_NORMAL = 0, FD_CONV_STRIDE2 = 1, FD_CONV_UP2 = 2, FD_CONV_TRANS2 = 3,
+       /* conv3x3(nearest-up2(x)) (Upsample2D, diffusers resnet.py) as four 2x2-tap phase problems over the low-res input: A = x [Bn,H,W,Cin],
+        * M = Bn*H*W per phase, K = 4*Cin (k = (dy*2+dx)*Cin + c), B = [4][N][K] pre-summed phase weights, C = [4][M][N] phase-major
+        * (phase = py*2+px is output pixel (2y+py, 2x+px)); 4/9 of the multiply-adds.  Big-tile kernels only.                          */
+       FD_CONV_UP2P = 4,
+       /* its input gradient: A = dOut [Bn,H,W,Cin] at the HIGH resolution (H = 2*Ho), M = Bn*Ho*Wo, K = 16*Cin
+        * (k = (((py*2+px)*2+dy)*2+dx)*Cin + c), B = [N][K].                                                                              */
+       FD_CONV_UP2P_BWD = 5 };
 
 const char* fd_last_error(void);
 int fd_version(void);
@@ -100,6 +107,8 @@ int fd_act_bwd(const void* z, const void* dy, void* dx, int64_t n, int act, void
 int fd_add(const void* a, const void* b, void* y, int64_t n, float sa, float sb, void* stream);      /* y = sa*a + sb*b (fp16) */
 int fd_copy_cols(const void* src, int64_t lds, void* dst, int64_t ldd, int64_t M, int cols, void* stream); /* strided 2-D copy, fp16 */
 int fd_transpose_btc(const void* x /* [B,T,C] */, void* y /* [B,C,Tp] */, int B, int T, int C, int Tp, void* stream);
+/* phase-major [4][B,H,W,C] (FD_CONV_UP2P output) -> channels-last [B,2H,2W,C] */
+int fd_phase_shuffle(const void* src, void* dst, int B, int H, int W, int C, void* stream);
 int fd_downsum2x2(const void* x /* [B,2H,2W,C] */, void* y /* [B,H,W,C] */, int B, int H, int W, int C, void* stream);
 /* y = softmax(scale*x + mask); mask fp32 [.., mask_t, cols], mask row = (row / mask_ht) * mask_t + row % mask_t, or NULL */
 int fd_softmax_rows(const void* x, void* y, int64_t rows, int cols, float scale, const float* mask, int mask_t, int mask_ht, void* stream);

@@ -62,6 +62,32 @@ def test_gemm_big_tiles(ops, dev, M, N, K, tile):
     check(f"gemm big {M}x{N}x{K}", c, a.float() @ b.float().t() + a2.float() @ b2.float().t() + bias + res.float(), 2e-3)
 
 
+@pytest.mark.parametrize("B,H,Cin,Cout", [(16, 32, 640, 640), (5, 16, 1280, 1280), (3, 40, 128, 512), (2, 64, 256, 256), (16, 8, 1280, 1280)])
+def test_conv_up2_phase_decomposition(ops, dev, B, H, Cin, Cout):
+    """Upsample2D = conv3x3(nearest-up2(x)) as four 2x2-tap phase problems (FD_CONV_UP2P) and its input gradient (FD_CONV_UP2P_BWD),
+    against torch fp32 and against the 3x3 gather at the high resolution (FD_CONV_UP2) that it replaces."""
+    import torch.nn.functional as F
+    from finetune_fair_diffusion_amd.layers import Conv3x3
+    x = rnd(B, Cin, H, H, dev=dev, seed=1)
+    w = rnd(Cout, Cin, 3, 3, dev=dev, scale=0.03, seed=2)
+    bias = rnd(Cout, dev=dev, dtype=torch.float32, seed=3)
+    conv = Conv3x3({"c.weight": w, "c.bias": bias}, "c", dev)
+    xl = x.permute(0, 2, 3, 1).reshape(B * H * H, Cin).contiguous()
+    xr = x.float().requires_grad_(True)
+    ref = F.conv2d(F.interpolate(xr, scale_factor=2, mode="nearest"), w.float(), bias, padding=1)
+    y, Ho, Wo = ops.conv_up2(xl, conv, B, H, H)
+    assert (Ho, Wo) == (2 * H, 2 * H)
+    got = y.view(B, Ho, Wo, Cout).permute(0, 3, 1, 2)
+    check(f"conv_up2 phases {Cin}->{Cout}@{H}", got, ref, 4e-3)
+    old, _, _ = ops.conv3x3(xl, conv.wk, B, H, H, mode=ops.CONV_UP2, bias=conv.bias)
+    check("conv_up2 phases vs 3x3 gather", y, old.float(), 4e-3)
+    g = rnd(B, Cout, Ho, Wo, dev=dev, seed=4)
+    ref.backward(g.float())
+    gl = g.permute(0, 2, 3, 1).reshape(B * Ho * Wo, Cout).contiguous()
+    dx = ops.conv_up2_bwd(gl, conv, B, H, H)
+    check(f"conv_up2 phases dgrad {Cin}->{Cout}@{H}", dx.view(B, H, H, Cin).permute(0, 3, 1, 2), xr.grad, 4e-3)
+
+
 @pytest.mark.parametrize("M,N,K", [(65536, 8, 320), (24576, 24, 320), (16384, 8, 640), (4100, 24, 1280), (1030, 56, 1280), (20000, 8, 768), (4096, 64, 320), (3000, 40, 96)])
 def test_gemm_skinny(ops, dev, M, N, K):
     """LoRA down-projection shapes (N = padded rank or three stacked ranks): one wave per 16 rows, K split over the waves of a block.
