@@ -458,7 +458,10 @@ __device__ __forceinline__ void mma_k32(f32x4 (&acc)[TM][TN], uint32_t a_addr, u
 // uses 8 waves (512 threads), a BM x BN x 64 tile (N tiles of 320/160 match the U-Net's channel counts, which are
 // all multiples of 320), full 128-byte rows per operand row (one L2 line per row per k-tile), direct-to-LDS
 // loads, the conflict-free XOR slot permutation chunk = slot ^ (row & 7), and two LDS stages.
-template <int BM, int BN, int WGM, int WGN, bool CONV>
+// CONV: 0 = dense operands, 1 = the 3x3 gathers (stride 1 / stride 2 / nearest-up2 / transposed stride 2), 2 = the Upsample2D phase pair
+// (FD_CONV_UP2P, FD_CONV_UP2P_BWD) -- its own instantiation: compiled into variant 1 the extra gather arithmetic cost the 8-wave 256x320
+// and the 512x128 gathers 34 and 52 spilled registers
+template <int BM, int BN, int WGM, int WGN, int CONV>
 __global__ __launch_bounds__(WGM * WGN * 64) void gemm_big_kernel(fd_gemm_desc p, int ntm, int ntn, int gn) {
     constexpr int NW = WGM * WGN;                   // 8 or 16 waves
     static_assert(NW == 8 || NW == 16, "8 or 16 waves");
@@ -481,7 +484,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_big_kernel(fd_gemm_desc p
     // FD_CONV_UP2P: the four output phases (py, px) of conv3x3(nearest-up2(x)) are four 2x2-tap problems over the low-res input with
     // their own pre-summed weights; they share one launch, phase-major in the tile index, weights and output
     int phase = 0;
-    if (CONV && p.conv_mode == FD_CONV_UP2P) {
+    if (CONV == 2 && p.conv_mode == FD_CONV_UP2P) {
         phase = tile / (ntm * ntn);
         tile -= phase * (ntm * ntn);
         p.B = (const f16*)p.B + (int64_t)phase * p.N * p.ldb;
@@ -525,7 +528,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_big_kernel(fd_gemm_desc p
             const int ox = r - oy * p.Wo;
             crow_b[i] = b;
             crow_yx[i] = valid ? ((oy << 16) | ox) : (int)0x80008000u;   // (-32768, -32768)
-            if (p.conv_mode == FD_CONV_NORMAL) {
+            if (CONV == 1 && p.conv_mode == FD_CONV_NORMAL) {
                 // stride-1 convs (all ResBlock convs): per row the element offset of the centre pixel and a 9-bit tap-validity mask,
                 // so that a k-step costs one add + one select per row instead of the coordinate arithmetic below
                 int mask = 0;
@@ -543,12 +546,12 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_big_kernel(fd_gemm_desc p
         if (CONV) {
             // k order = (64-channel chunk, tap): the 9 taps of one chunk re-read the same 128-byte lines shifted by a
             // pixel, so the tile's working set per chunk (~48 KB) stays in L1/L2 instead of cycling all Cin channels
-            const int ntap = p.conv_mode == FD_CONV_UP2P ? 4 : p.conv_mode == FD_CONV_UP2P_BWD ? 16 : 9;
+            const int ntap = CONV == 2 ? (p.conv_mode == FD_CONV_UP2P ? 4 : 16) : 9;
             const int cc = kt / ntap;
             const int tap = kt - cc * ntap;
             const int c0 = cc << 6;
             const int ky = tap / 3, kx = tap - ky * 3;
-            if (p.conv_mode == FD_CONV_NORMAL) {
+            if (CONV == 1 && p.conv_mode == FD_CONV_NORMAL) {
                 const int toff = ((ky - 1) * p.W + (kx - 1)) * (int)p.lda + c0;
 #pragma unroll
                 for (int i = 0; i < AI; ++i) {
@@ -566,7 +569,17 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_big_kernel(fd_gemm_desc p
                 if (g < NA && (part & 1)) {
                     int iy = crow_yx[i] >> 16, ix = (int)(short)(crow_yx[i] & 0xffff);
                     bool ok = true;
-                    if (p.conv_mode == FD_CONV_NORMAL) {
+                    if (CONV == 2) {
+                        if (p.conv_mode == FD_CONV_UP2P) {                 // tap = dy*2+dx over the low-res input, shifted by the phase
+                            iy += (tap >> 1) + ph_y - 1; ix += (tap & 1) + ph_x - 1;
+                            ok = ok && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+                        } else {                                           // tap = ((py*2+px)*2+dy)*2+dx; source = high-res gradient [Bn,H,W], H = 2*Ho
+                            const int qy = (tap >> 3) & 1, qx = (tap >> 2) & 1;
+                            const int u = iy - ((tap >> 1) & 1) - qy + 1, v = ix - (tap & 1) - qx + 1;
+                            ok = ok && u >= 0 && u < p.Ho && v >= 0 && v < p.Wo;
+                            iy = 2 * u + qy; ix = 2 * v + qx;
+                        }
+                    } else if (p.conv_mode == FD_CONV_NORMAL) {
                         iy += ky - 1; ix += kx - 1;
                         ok = ok && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
                     } else if (p.conv_mode == FD_CONV_STRIDE2) {
@@ -576,14 +589,6 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_big_kernel(fd_gemm_desc p
                         iy += ky - 1; ix += kx - 1;
                         ok = ok && iy >= 0 && iy < 2 * p.H && ix >= 0 && ix < 2 * p.W;
                         iy >>= 1; ix >>= 1;
-                    } else if (p.conv_mode == FD_CONV_UP2P) {          // tap = dy*2+dx over the low-res input, shifted by the phase
-                        iy += (tap >> 1) + ph_y - 1; ix += (tap & 1) + ph_x - 1;
-                        ok = ok && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-                    } else if (p.conv_mode == FD_CONV_UP2P_BWD) {      // tap = ((py*2+px)*2+dy)*2+dx; source = high-res gradient [Bn,H,W], H = 2*Ho
-                        const int qy = (tap >> 3) & 1, qx = (tap >> 2) & 1;
-                        const int u = iy - ((tap >> 1) & 1) - qy + 1, v = ix - (tap & 1) - qx + 1;
-                        ok = ok && u >= 0 && u < p.Ho && v >= 0 && v < p.Wo;
-                        iy = 2 * u + qy; ix = 2 * v + qx;
                     } else {
                         iy += ky - 1; ix += kx - 1;
                         ok = ok && iy >= 0 && ix >= 0 && !(iy & 1) && !(ix & 1);
@@ -782,8 +787,9 @@ static int launch_big(const fd_gemm_desc& d, hipStream_t s, int nsplit = 1) {
     constexpr size_t lds = (size_t)2 * (BM + BN) * 64 * sizeof(f16);
     static bool once = false;
     if (!once) {
-        (void)hipFuncSetAttribute((const void*)gemm_big_kernel<BM, BN, WGM, WGN, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute((const void*)gemm_big_kernel<BM, BN, WGM, WGN, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)gemm_big_kernel<BM, BN, WGM, WGN, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)gemm_big_kernel<BM, BN, WGM, WGN, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)gemm_big_kernel<BM, BN, WGM, WGN, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         once = true;
     }
     // n-tiles per band: the band's B slab (gn * BN rows of K halfs, per split) should fit an XCD's L2 next to the streaming A tiles
@@ -792,8 +798,10 @@ static int launch_big(const fd_gemm_desc& d, hipStream_t s, int nsplit = 1) {
     const int nph = (d.conv && d.conv_mode == FD_CONV_UP2P) ? 4 : 1;
     long gnl = l2_budget / ((long)BN * ktot * 2);
     const int gn = (int)(gnl < 1 ? 1 : (gnl > ntn ? ntn : gnl));
-    if (d.conv) hipLaunchKernelGGL((gemm_big_kernel<BM, BN, WGM, WGN, true>), dim3(ntm * ntn * nph, nsplit), dim3(WGM * WGN * 64), lds, s, d, ntm, ntn, gn);
-    else hipLaunchKernelGGL((gemm_big_kernel<BM, BN, WGM, WGN, false>), dim3(ntm * ntn, nsplit), dim3(WGM * WGN * 64), lds, s, d, ntm, ntn, gn);
+    if (d.conv && d.conv_mode >= FD_CONV_UP2P)
+        hipLaunchKernelGGL((gemm_big_kernel<BM, BN, WGM, WGN, 2>), dim3(ntm * ntn * nph, nsplit), dim3(WGM * WGN * 64), lds, s, d, ntm, ntn, gn);
+    else if (d.conv) hipLaunchKernelGGL((gemm_big_kernel<BM, BN, WGM, WGN, 1>), dim3(ntm * ntn, nsplit), dim3(WGM * WGN * 64), lds, s, d, ntm, ntn, gn);
+    else hipLaunchKernelGGL((gemm_big_kernel<BM, BN, WGM, WGN, 0>), dim3(ntm * ntn, nsplit), dim3(WGM * WGN * 64), lds, s, d, ntm, ntn, gn);
     if (nsplit > 1) {
         int64_t blocks = ((int64_t)d.M * d.N / 4 + 255) / 256;
         if (blocks > 2048) blocks = 2048;
