@@ -96,9 +96,10 @@ def main():
         return tr.train_step(tokens, noises.to(dev), a.S)
 
     def fence():
+        torch.cuda.synchronize()      # this rank's work is done before it enters the barrier ...
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+            torch.cuda.synchronize()  # ... and the barrier's own collective has completed before the clock is read
 
     for _ in range(a.warmup):
         one_step()
