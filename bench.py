@@ -85,7 +85,8 @@ def main():
                                 weight_loss_img=0.0 if a.no_regularisers else 8.0,   # debias-unet.yaml:4
                                 weight_loss_face=0.0 if a.no_regularisers else 1.0)  # debias-unet.yaml:5
     cfgs = factory.TINY if a.tiny else factory.SD15
-    tr, models = factory.build_trainer(args, dev, cfgs=cfgs, seed=0, rank=rank, world_size=world, regularisers=not a.no_regularisers)
+    tr, models = factory.build_trainer(args, dev, cfgs=cfgs, seed=0, rank=rank, world_size=world, regularisers=not a.no_regularisers,
+                                       lora_up_std=0.01)   # up != 0 as after one warm-up optimiser step
     L = 13
     tokens = factory.synthetic_tokens(L, cfgs["clip"].vocab_size)
     hw = cfgs["unet"].sample_size

@@ -9,7 +9,8 @@ consumes exactly those four files.
 Here a checkpoint directory *is* the exported format plus one extra file:
 
     checkpoint-{step}/unet_lora.pth, unet_lora_EMA.pth, text_encoder_lora.pth, text_encoder_lora_EMA.pth
-    checkpoint-{step}/trainer_state.pth   Adam moments (flat fp32 per bank), optimiser / EMA / lr step counters, RNG states
+    checkpoint-{step}/trainer_state.pth   Adam moments (flat fp32 per bank), optimiser / EMA / lr step counters, world size (rank 0 writes it)
+    checkpoint-{step}/rng_rank{r}.pth     python / numpy / torch / OT-target RNG streams of rank r (every rank writes its own)
 
 so the reference's export step becomes a file copy (``export_checkpoint``), and files exported by the reference load
 back into the banks by key (``load_lora_files``).  Raw ``accelerate.save_state`` directories are not read.
@@ -25,7 +26,10 @@ BANK_FILES = {"unet": ("unet_lora.pth", "unet_lora_EMA.pth"), "text_encoder": ("
 
 
 def clean_checkpoint(ckpts_save_dir, name, checkpoints_total_limit):
-    """:120-137 -- before saving, keep at most ``limit - 1`` directories called ``{name}-{step}`` (oldest removed first)."""
+    """:120-137 -- before saving, keep at most ``limit - 1`` directories called ``{name}-{step}`` (oldest removed first).
+    Deviation (harmless, deliberate): the reference matches ``d.startswith(name)``, so a call with name='checkpoint' would also count
+    the rolling ``checkpoint_tmp-*`` directories (it only ever calls it with 'checkpoint_tmp', :2053); here the match is
+    ``name + '-'`` followed by digits, so the two cadences can never delete each other's directories and ``*_exported`` copies stay."""
     ck = [d for d in os.listdir(ckpts_save_dir) if d.startswith(name + "-") and d.split("-")[1].isdigit()]   # "<ckpt>_exported" dirs stay
     ck = sorted(ck, key=lambda x: int(x.split("-")[1]))
     removed = []
@@ -77,24 +81,37 @@ def load_lora_files(banks, path, strict=True):
                     bank.view(n, bank.ema).copy_(sde[n].to(bank.flat.device, torch.float32))
 
 
+def _rng_state(trainer):
+    return dict(python=random.getstate(), numpy=np.random.get_state(), torch=torch.get_rng_state(), targets=trainer.target_rng.get_state())
+
+
 def save_state(trainer, save_path, global_step, extra=None):
     """What ``accelerator.save_state`` preserves for this loop: parameters, AdamW moments, scheduler position,
-    the registered EMA models and the RNG streams (:1654-1659, :2058)."""
+    the registered EMA models and the RNG streams (:1654-1659, :2058).  Called by EVERY rank: rank 0 writes the shared state,
+    each rank writes its own ``rng_rank{r}.pth`` -- the per-rank streams (CPU noise :1746-1749 seeded ``seed + rank`` :693, OT draws
+    1234 + rank) must stay distinct after a resume, as they do in the reference, where a rank that finds no ``random_states_{r}.pkl``
+    keeps its own device-specific stream."""
+    rank, world = getattr(trainer, "rank", 0), getattr(trainer, "world", 1)
     banks = trainer_banks(trainer)
-    save_lora_files(banks, save_path)
-    st = dict(global_step=int(global_step), opt_step=int(trainer.opt_step), lr_step=int(getattr(trainer, "lr_step", 0)),
-              ema_steps=[e.optimization_step for e in trainer.ema], bank_order=list(banks.keys()),
-              exp_avg={k: b.exp_avg.detach().cpu() for k, b in banks.items()},
-              exp_avg_sq={k: b.exp_avg_sq.detach().cpu() for k, b in banks.items()},
-              rng=dict(python=random.getstate(), numpy=np.random.get_state(), torch=torch.get_rng_state(),
-                       targets=trainer.target_rng.get_state()),
-              extra=extra or {})
-    torch.save(st, os.path.join(save_path, "trainer_state.pth"))
+    if rank == 0:
+        save_lora_files(banks, save_path)
+        st = dict(global_step=int(global_step), opt_step=int(trainer.opt_step), lr_step=int(getattr(trainer, "lr_step", 0)),
+                  ema_steps=[e.optimization_step for e in trainer.ema], bank_order=list(banks.keys()),
+                  exp_avg={k: b.exp_avg.detach().cpu() for k, b in banks.items()},
+                  exp_avg_sq={k: b.exp_avg_sq.detach().cpu() for k, b in banks.items()},
+                  world_size=world, extra=extra or {})
+        torch.save(st, os.path.join(save_path, "trainer_state.pth"))
+    else:
+        os.makedirs(save_path, exist_ok=True)
+    torch.save(_rng_state(trainer), os.path.join(save_path, f"rng_rank{rank}.pth"))
     return save_path
 
 
-def load_state(trainer, path):
-    """Inverse of save_state; returns the global step (the reference parses it from the directory name, :1708)."""
+def load_state(trainer, path, seed=None):
+    """Inverse of save_state; returns the global step (the reference parses it from the directory name, :1708).  Every rank restores
+    the shared state and ONLY ITS OWN RNG file; when the checkpoint was written by a different world size (or the file is absent)
+    the rank keeps / re-derives its device-specific streams (``seed + rank``, OT 1234 + rank) instead of cloning rank 0's."""
+    rank, world = getattr(trainer, "rank", 0), getattr(trainer, "world", 1)
     banks = trainer_banks(trainer)
     load_lora_files(banks, path)
     st = torch.load(os.path.join(path, "trainer_state.pth"), map_location="cpu", weights_only=False)
@@ -107,10 +124,22 @@ def load_state(trainer, path):
     trainer.lr_step = st["lr_step"]
     for e, n in zip(trainer.ema, st["ema_steps"]):
         e.optimization_step = n
-    random.setstate(st["rng"]["python"])
-    np.random.set_state(st["rng"]["numpy"])
-    torch.set_rng_state(st["rng"]["torch"])
-    trainer.target_rng.set_state(st["rng"]["targets"])
+    rng_file = os.path.join(path, f"rng_rank{rank}.pth")
+    rng = None
+    if st.get("world_size", 1) == world and os.path.exists(rng_file):
+        rng = torch.load(rng_file, map_location="cpu", weights_only=False)
+    elif "rng" in st and world == 1:          # round-1 single-process checkpoints kept the streams inside trainer_state.pth
+        rng = st["rng"]
+    if rng is not None:
+        random.setstate(rng["python"])
+        np.random.set_state(rng["numpy"])
+        torch.set_rng_state(rng["torch"])
+        trainer.target_rng.set_state(rng["targets"])
+    elif seed is not None:                     # different world size: fresh device-specific streams, offset by the step so they are new
+        random.seed(seed + rank + 7919 * st["global_step"])
+        np.random.seed((seed + rank + 7919 * st["global_step"]) % (2 ** 32))
+        torch.manual_seed(seed + rank + 7919 * st["global_step"])
+        trainer.target_rng.manual_seed(1234 + rank + 7919 * st["global_step"])
     if getattr(trainer.args, "train_unet", False):
         trainer.unet.refresh_lora()
     if getattr(trainer.args, "train_text_encoder", False):

@@ -8,6 +8,7 @@ cannot be set from YAML and booleans follow Python's ``bool(value)`` -- plus the
   --synthetic            synthetic weights / token ids / face provider (no network, no data.zip)
   --face_provider        detector seam: "synthetic" (default)
   --num_classifier_logits  80 (exp-1) / 6 (exp-3,5) / 8 (exp-4)
+  --lora_up_std          std of the LoRA ``up`` init; 0 (default) = zeros like the reference, non-zero only for synthetic experiments
 
 The multi-attribute experiments change a few flags and defaults (exp-3-debias-gender-race/1-main-debias.py:343-660,
 exp-4-debias-gender-race-age/...:343-672, exp-5-...:343-690): ``factor{1,2}`` split per attribute,
@@ -115,7 +116,7 @@ def build_parser(experiment="exp-1"):
     return p
 
 
-EXTRA_DEFAULTS = dict(num_denoising_steps=0, synthetic=False, face_provider="synthetic", num_classifier_logits=80)
+EXTRA_DEFAULTS = dict(num_denoising_steps=0, synthetic=False, face_provider="synthetic", num_classifier_logits=80, lora_up_std=0.0)
 
 
 def parse_args(input_args=None, with_extras=False, experiment="exp-1"):
@@ -125,6 +126,7 @@ def parse_args(input_args=None, with_extras=False, experiment="exp-1"):
         p.add_argument("--synthetic", action="store_true", default=False)
         p.add_argument("--face_provider", type=str, default="synthetic")
         p.add_argument("--num_classifier_logits", type=int, default=80)
+        p.add_argument("--lora_up_std", type=float, default=0.0)
     args = p.parse_args(input_args) if input_args is not None else p.parse_args()
     if args.config:
         with open(args.config, "r") as f:

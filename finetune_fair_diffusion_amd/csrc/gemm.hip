@@ -8,6 +8,20 @@
 //   gemm_big_kernel   8 or 16 waves, BK = 64, tiles 256x320 / 128x320 / 128x160 / 256x128, optional split-K
 #include "common.h"
 #include <stdlib.h>
+#include <mutex>
+
+// Measurement hooks (FD_GEMM_DBG sentinels inside the kernels, tile-policy A/B switches read from the environment) exist only in
+// builds made with -DFD_BENCH_HOOKS (``make BENCH_HOOKS=1``): in the product library a stray environment variable can neither
+// change tile selection nor skip work.
+#ifdef FD_BENCH_HOOKS
+#define FD_DBG_IS(p, v) ((p).batch == -(v))
+#define FD_DBG_GE(p, v) ((p).batch <= -(v))
+static inline const char* bench_env(const char* name) { return getenv(name); }
+#else
+#define FD_DBG_IS(p, v) false
+#define FD_DBG_GE(p, v) false
+static inline const char* bench_env(const char*) { return nullptr; }
+#endif
 
 struct ConvRow {
     int b, oy, ox;
@@ -104,7 +118,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const fd_gemm_desc& p, f32x4 (
     const int cr = lane / CPR, cc = (lane % CPR) * 8;
     // the epilogue mode is uniform over the launch: branch once, outside the per-element loops (a per-element runtime switch on
     // p.act plus the always-on alpha / row-bias arithmetic made short-K GEMMs VALU-bound here: 149 -> 100 us of epilogue on FF1)
-    const bool plain = (p.act == FD_ACT_NONE) && !RB && p.alpha == 1.f && p.batch != -5;
+    const bool plain = (p.act == FD_ACT_NONE) && !RB && p.alpha == 1.f && !FD_DBG_IS(p, 5);
 #pragma unroll
     for (int c0 = 0; c0 < TM; c0 += TMC) {
         if (plain) {
@@ -139,7 +153,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const fd_gemm_desc& p, f32x4 (
 #pragma unroll
                         for (int r = 0; r < 4; ++r) o[r] = (f16)apply_act(acc[i][j][r] * p.alpha + bv[r] + (float)rbv[r], p.act);
                     }
-                    if (p.batch == -5) o = (f16x4){(f16)acc[i][j][0], (f16)acc[i][j][1], (f16)acc[i][j][2], (f16)acc[i][j][3]};   // FD_GEMM_DBG=5
+                    if (FD_DBG_IS(p, 5)) o = (f16x4){(f16)acc[i][j][0], (f16)acc[i][j][1], (f16)acc[i][j][2], (f16)acc[i][j][3]};   // FD_GEMM_DBG=5
                     *(f16x4*)(wave_lds + (ii * 16 + l15) * LDW + j * 16 + lg * 4) = o;
                 }
             }
@@ -453,9 +467,9 @@ __device__ __forceinline__ void mma_k32(f32x4 (&acc)[TM][TN], uint32_t a_addr, u
 }
 
 // ======================================================================================= 8/16-wave, BK = 64
-// The per-CU global->LDS path saturates near 15-20 B/clk (measured: the 128x128 and 128x64 tiles above both sit
-// at ~15 B/clk/CU at very different TFLOP/s), so arithmetic intensity -- tile size -- is the lever.  This kernel
-// uses 8 waves (512 threads), a BM x BN x 64 tile (N tiles of 320/160 match the U-Net's channel counts, which are
+// Staged bytes per FLOP bound the main loop (the L2 -> LDS path itself sustains 50-60 B/clk/CU, scratch/mb_l2_lds.hip; what is
+// shared is the LDS array between the direct-to-LDS writes and the fragment reads), so arithmetic intensity -- tile size -- is the
+// lever.  This kernel uses 8 or 16 waves (512 threads), a BM x BN x 64 tile (N tiles of 320/160 match the U-Net's channel counts, which are
 // all multiples of 320), full 128-byte rows per operand row (one L2 line per row per k-tile), direct-to-LDS
 // loads, the conflict-free XOR slot permutation chunk = slot ^ (row & 7), and two LDS stages.
 // CONV: 0 = dense operands, 1 = the 3x3 gathers (stride 1 / stride 2 / nearest-up2 / transposed stride 2), 2 = the Upsample2D phase pair
@@ -657,13 +671,13 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_big_kernel(fd_gemm_desc p
     const int nsplit = gridDim.y;
     const int kbeg = (int)((int64_t)nk * blockIdx.y / nsplit), kend = (int)((int64_t)nk * (blockIdx.y + 1) / nsplit);
     issue(kbeg, 0, 3);
-    for (int kt = kbeg; kt < (p.batch <= -4 ? kbeg : kend); ++kt) {   // FD_GEMM_DBG=4/5: epilogue only
+    for (int kt = kbeg; kt < (FD_DBG_GE(p, 4) ? kbeg : kend); ++kt) {   // FD_GEMM_DBG=4/5: epilogue only
         const int buf = (kt - kbeg) & 1;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         // (issuing the B half between the two k-steps was measured: it pushes the 16-wave variant into scratch, 8x slower)
-        if (kt + 1 < kend && p.batch != -1) issue(kt + 1, buf ^ 1, 3);
-        if (p.batch == -2) continue;
+        if (kt + 1 < kend && !FD_DBG_IS(p, 1)) issue(kt + 1, buf ^ 1, 3);
+        if (FD_DBG_IS(p, 2)) continue;
         if constexpr (PINNED) {
             const uint32_t a_base = lds0 + (uint32_t)((buf * BM + wm * WTM) * 64 + frow) * 2;
             const uint32_t b_base = lds0 + (uint32_t)((2 * BM + buf * BN + wn * WTN) * 64 + frow) * 2;
@@ -735,7 +749,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_big_kernel(fd_gemm_desc p
     }
     const bool lds_epi = p.out_dtype == FD_OUT_F16 && (p.N & 7) == 0 && (p.ldc & 7) == 0 && (!p.residual || (p.ldr & 7) == 0) &&
                          (!p.rowbias || (p.ld_rowbias & 3) == 0);
-    if (p.batch == -3) {   // measurement only (FD_GEMM_DBG=3): no epilogue at all
+    if (FD_DBG_IS(p, 3)) {   // measurement only (FD_GEMM_DBG=3): no epilogue at all
         if (acc[0][0][0] == 12345.678f) ((f16*)p.C)[0] = (f16)1.f;
     } else if (p.act == FD_ACT_GEGLU) {
         constexpr int LDS_HALFS = 2 * (BM + BN) * 64;
@@ -785,15 +799,14 @@ template <int BM, int BN, int WGM, int WGN>
 static int launch_big(const fd_gemm_desc& d, hipStream_t s, int nsplit = 1) {
     const int ntm = (d.M + BM - 1) / BM, ntn = (d.N + BN - 1) / BN;
     constexpr size_t lds = (size_t)2 * (BM + BN) * 64 * sizeof(f16);
-    static bool once = false;
-    if (!once) {
+    static std::once_flag once;
+    std::call_once(once, [] {
         (void)hipFuncSetAttribute((const void*)gemm_big_kernel<BM, BN, WGM, WGN, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipFuncSetAttribute((const void*)gemm_big_kernel<BM, BN, WGM, WGN, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipFuncSetAttribute((const void*)gemm_big_kernel<BM, BN, WGM, WGN, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        once = true;
-    }
+    });
     // n-tiles per band: the band's B slab (gn * BN rows of K halfs, per split) should fit an XCD's L2 next to the streaming A tiles
-    static const long l2_budget = getenv("FD_GEMM_L2_KB") ? atol(getenv("FD_GEMM_L2_KB")) * 1024 : 3 * 1024 * 1024;
+    static const long l2_budget = bench_env("FD_GEMM_L2_KB") ? atol(bench_env("FD_GEMM_L2_KB")) * 1024 : 3 * 1024 * 1024;
     const long ktot = ((long)d.K + d.K2) / nsplit;
     const int nph = (d.conv && d.conv_mode == FD_CONV_UP2P) ? 4 : 1;
     long gnl = l2_budget / ((long)BN * ktot * 2);
@@ -892,7 +905,7 @@ __global__ __launch_bounds__(KS * 64) void gemm_skinny_kernel(fd_gemm_desc p) {
 }
 
 static bool skinny_ok(const fd_gemm_desc& d) {
-    static const bool off = getenv("FD_GEMM_NOSKINNY") != nullptr;   // A/B switch for measurement
+    static const bool off = bench_env("FD_GEMM_NOSKINNY") != nullptr;   // A/B switch for measurement
     // rocprofv3 kernel times, hot caches (scratch/prof_skinny.sh), this kernel vs the 64x64 / 128x64 tiles: M=4096 K=1280: 5.2 vs 14.6 us,
     // M=16384 K=640: 6.8 vs 8.6, M=65536 K=320: 10.4 vs 10.3 at N=8 (both at the A stream's bandwidth) but 12.8 vs 10.7 at N=24, where
     // the B fragments re-read through L1 by every wave outweigh the A stream: wide-M problems with more than one column tile stay on the LDS tiles
@@ -914,7 +927,7 @@ static int launch_skinny_rt(const fd_gemm_desc& d, hipStream_t s) {
 template <int NT>
 static int launch_skinny(const fd_gemm_desc& d, hipStream_t s) {
     // measurement switch: two row tiles per wave share each B fragment (13.4 us on the N=24 case above: still behind the LDS tile)
-    static const int rt = getenv("FD_GEMM_SKINNY_RT") ? atoi(getenv("FD_GEMM_SKINNY_RT")) : 0;
+    static const int rt = bench_env("FD_GEMM_SKINNY_RT") ? atoi(bench_env("FD_GEMM_SKINNY_RT")) : 0;
     const bool two = rt == 2;
     return two ? launch_skinny_rt<NT, 2>(d, s) : launch_skinny_rt<NT, 1>(d, s);
 }
@@ -932,12 +945,12 @@ static int launch(const fd_gemm_desc& d, hipStream_t s) {
 extern "C" int fd_gemm_tile(const fd_gemm_desc* dp) {
     const fd_gemm_desc& d = *dp;
     const long nb = d.batch > 1 ? d.batch : 1;
-    static const bool nobig = getenv("FD_GEMM_NOBIG") != nullptr;
-    static const int force = getenv("FD_GEMM_FORCE") ? atoi(getenv("FD_GEMM_FORCE")) : 0;   // measurement only: force a big-tile code for dense
+    static const bool nobig = bench_env("FD_GEMM_NOBIG") != nullptr;
+    static const int force = bench_env("FD_GEMM_FORCE") ? atoi(bench_env("FD_GEMM_FORCE")) : 0;   // measurement only: force a big-tile code for dense
     if (skinny_ok(d)) return 16000 + (d.N + 15) / 16 * 16;      // 16 rows per wave x N padded to 16: the LoRA down-projections
     if (force && nb == 1 && !d.conv) return force;
     // big-tile (BK=64, 8-wave) variants: unbatched, K-tiles of 64 must not straddle a conv tap
-    static const int bigk = getenv("FD_GEMM_BIGK") ? atoi(getenv("FD_GEMM_BIGK")) : 320;
+    static const int bigk = bench_env("FD_GEMM_BIGK") ? atoi(bench_env("FD_GEMM_BIGK")) : 320;
     if (!nobig && nb == 1 && (d.conv ? (d.Cin & 63) == 0 : (d.K + d.K2) >= bigk)) {
         const long phs = (d.conv && d.conv_mode == FD_CONV_UP2P) ? 4 : 1;    // four phases share the launch
         const long m256 = phs * ((d.M + 255) / 256), m128 = phs * ((d.M + 127) / 128);
@@ -960,9 +973,9 @@ extern "C" int fd_gemm_tile(const fd_gemm_desc* dp) {
         }
         if (d.N % 160 == 0 && m128 * (d.N / 160) >= 160) return 128160;
         // VAE decoder widths (256 / 512 channels at 256^2 / 512^2 pixels): 256x256 halves the A re-reads of the 256x128 tile
-        static const bool no256 = getenv("FD_GEMM_NO256256") != nullptr;
+        static const bool no256 = bench_env("FD_GEMM_NO256256") != nullptr;
         if (!no256 && d.N % 256 == 0 && m256 * (d.N / 256) >= 200) return 256256;
-        static const bool no512 = getenv("FD_GEMM_NO512128") != nullptr;
+        static const bool no512 = bench_env("FD_GEMM_NO512128") != nullptr;
         if (!no512 && d.N == 128 && ((d.M + 511) / 512) >= 400) return 512128;   // 128-channel layers at 512^2: the tallest tile that fits the LDS
         if (d.N % 128 == 0 && m256 * (d.N / 128) >= 200) return 256128;
         // small-M, long-K (8x8 level): split K so that all 256 CUs get a block
@@ -981,8 +994,10 @@ extern "C" int fd_gemm_tile(const fd_gemm_desc* dp) {
 
 extern "C" int fd_gemm(const fd_gemm_desc* dp, void* stream) {
     fd_gemm_desc d = *dp;
-    static const char* dbg = getenv("FD_GEMM_DBG");   // measurement only: 1 = no loads after the first tile, 2 = no MFMAs
+#ifdef FD_BENCH_HOOKS
+    static const char* dbg = bench_env("FD_GEMM_DBG");   // measurement only: 1 = no loads after the first tile, 2 = no MFMAs
     if (dbg && d.batch <= 1) d.batch = -atoi(dbg);
+#endif
     FD_REQUIRE(d.A && d.B && d.C, "fd_gemm: null operand");
     FD_REQUIRE(d.M > 0 && d.N > 0 && d.K > 0, "fd_gemm: bad shape M=%d N=%d K=%d", d.M, d.N, d.K);
     FD_REQUIRE((d.K & 7) == 0 && (d.lda & 7) == 0 && (d.ldb & 7) == 0, "fd_gemm: K, lda, ldb must be multiples of 8");
@@ -1006,7 +1021,7 @@ extern "C" int fd_gemm(const fd_gemm_desc* dp, void* stream) {
                        (d.ldc & 7) == 0 && d.K2 == 0 && (!d.residual || (d.ldr & 7) == 0),
                    "fd_gemm(GEGLU): needs a plain fp16 GEMM with N %% 16 == 0 and ldc, ldr %% 8 == 0");
     hipStream_t s = (hipStream_t)stream;
-    static const bool w16 = getenv("FD_GEMM_W8") == nullptr;   // 16-wave variants by default (A/B switch for measurement)
+    static const bool w16 = bench_env("FD_GEMM_W8") == nullptr;   // 16-wave variants by default (A/B switch for measurement)
     const int sel = fd_gemm_tile(&d);
     if (d.conv && d.conv_mode >= FD_CONV_UP2P) {
         const int t = sel % 1000000;

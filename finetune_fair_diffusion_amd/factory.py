@@ -45,13 +45,16 @@ def default_args(**kw):
 
 
 def build_trainer(args, device, cfgs=SD15, seed=0, rank=0, world_size=1, experiment="exp-1", classifier_gain=1.4, state_dicts=None,
-                  frozen_copies=True, regularisers=False):
+                  frozen_copies=True, regularisers=False, lora_up_std=0.0):
     """Returns (trainer, models dict).  ``state_dicts`` may carry real weights by diffusers key
     (keys 'unet','vae','clip','clf','unet_lora','te_lora'); anything missing is synthetic.
     ``frozen_copies=False`` skips the original-model replicas of R2 (inference-only consumers such as generate.py).
     ``regularisers=True`` attaches the CLIP / DINOv2 image encoders of the image-semantics loss term (keys 'clip_vision','dino';
     ``args.img_size_small`` must equal their input size) when ``weight_loss_img`` != 0, and the SFNet-20 face-feature network plus
-    its feature database (keys 'face_net','face_db') when ``weight_loss_face`` != 0."""
+    its feature database (keys 'face_net','face_db') when ``weight_loss_face`` != 0.
+    ``lora_up_std``: fresh LoRA ``up`` matrices are ZERO, exactly like diffusers' ``LoRALinearLayer`` / ``_modify_text_encoder``
+    (:798-818, :829-883), so the finetuned model equals the frozen original at step 0 and R1 == R2.  Only synthetic bench / smoke /
+    test runs pass a non-zero std (the "one warm-up optimiser step" of SURVEY 8d) so that dL/d(down) is non-zero on the first step."""
     from .fairness import EXPERIMENT_ATTRS
     num_classes = EXPERIMENT_ATTRS[experiment][0]
     sds = dict(state_dicts or {})
@@ -73,20 +76,20 @@ def build_trainer(args, device, cfgs=SD15, seed=0, rank=0, world_size=1, experim
     clf = MobileNetV3Large(sds["clf"], device, num_classes)
     if args.train_unet:
         bank = unet.add_lora(args.rank, sds.get("unet_lora"), seed=seed + 5)
-        if "unet_lora" not in sds:   # one warm-up so the up matrices are non-zero
+        if "unet_lora" not in sds and lora_up_std:   # synthetic warm-up so the up matrices are non-zero
             g = torch.Generator().manual_seed(seed + 7)
             for n in bank.names:
                 if ".up." in n:
-                    bank.view(n).copy_((torch.randn(bank.shape(n), generator=g) * 0.01).to(device))
+                    bank.view(n).copy_((torch.randn(bank.shape(n), generator=g) * lora_up_std).to(device))
             bank.ema.copy_(bank.flat)
             unet.refresh_lora()
     if args.train_text_encoder:
         bank = te.add_lora(args.rank, sds.get("te_lora"), seed=seed + 6)
-        if "te_lora" not in sds:
+        if "te_lora" not in sds and lora_up_std:
             g = torch.Generator().manual_seed(seed + 8)
             for n in bank.names:
                 if ".up." in n:
-                    bank.view(n).copy_((torch.randn(bank.shape(n), generator=g) * 0.01).to(device))
+                    bank.view(n).copy_((torch.randn(bank.shape(n), generator=g) * lora_up_std).to(device))
             bank.ema.copy_(bank.flat)
             te.refresh_lora()
     if world_size > 1:  # identical LoRA init on every rank (:820-821, :848-854): one flat broadcast per bank

@@ -119,7 +119,8 @@ def main(argv=None, experiment=None, cfgs=None, log=None):
         from .pretrained import load_pretrained
         state_dicts = load_pretrained(args, cfgs)
     trainer, models = build_trainer(args, device, cfgs, seed=args.seed, rank=rank, world_size=world, experiment=experiment,
-                                    state_dicts=state_dicts, regularisers=(args.weight_loss_img != 0 or args.weight_loss_face != 0))
+                                    state_dicts=state_dicts, regularisers=(args.weight_loss_img != 0 or args.weight_loss_face != 0),
+                                    lora_up_std=getattr(args, "lora_up_std", 0.0))
     tok_dir = os.path.join(args.pretrained_model_name_or_path, "tokenizer")
     tokenizer = CLIPTokenizerAdapter(tok_dir) if os.path.isdir(tok_dir) else HashTokenizer(cfgs["clip"].vocab_size)
     if not os.path.isdir(tok_dir) and not args.synthetic:
@@ -145,7 +146,7 @@ def main(argv=None, experiment=None, cfgs=None, log=None):
                 print(f"Checkpoint '{args.resume_from_checkpoint}' does not exist. Starting a new training run.")
             args.resume_from_checkpoint = None
         else:
-            global_step = ckpt.load_state(trainer, args.resume_from_checkpoint)
+            global_step = ckpt.load_state(trainer, args.resume_from_checkpoint, seed=args.seed)
             first_epoch, resume_step = global_step // steps_per_epoch, global_step % steps_per_epoch
     lat = cfgs["unet"].sample_size
     B = args.train_images_per_prompt_GPU
@@ -173,12 +174,15 @@ def main(argv=None, experiment=None, cfgs=None, log=None):
                            p_class1_mean=float(out["probs"][:, 1][out["probs"][:, 1] != -1].mean()) if bool((out["probs"] != -1).any()) else None,
                            seconds=round(time.time() - t0, 3))
                 (log or print)(json.dumps(rec))
-                if global_step % args.checkpointing_steps == 0:
-                    if args.checkpoints_total_limit is not None:
-                        ckpt.clean_checkpoint(ckpts_dir, "checkpoint_tmp", args.checkpoints_total_limit)
-                    ckpt.save_state(trainer, os.path.join(ckpts_dir, f"checkpoint_tmp-{global_step}"), global_step)
-                if global_step % args.checkpointing_steps_long == 0:
-                    ckpt.save_state(trainer, os.path.join(ckpts_dir, f"checkpoint-{global_step}"), global_step)
+            # checkpoints (:2050-2068): rank 0 cleans up and writes the shared state, every rank adds its own RNG streams
+            if global_step % args.checkpointing_steps == 0:
+                if rank == 0 and args.checkpoints_total_limit is not None:
+                    ckpt.clean_checkpoint(ckpts_dir, "checkpoint_tmp", args.checkpoints_total_limit)
+                if world > 1:
+                    dist.barrier()
+                ckpt.save_state(trainer, os.path.join(ckpts_dir, f"checkpoint_tmp-{global_step}"), global_step)
+            if global_step % args.checkpointing_steps_long == 0:
+                ckpt.save_state(trainer, os.path.join(ckpts_dir, f"checkpoint-{global_step}"), global_step)
     if world > 1:
         dist.barrier()
     return trainer, global_step

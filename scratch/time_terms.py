@@ -5,7 +5,7 @@ dev = torch.device("cuda", 0)
 def run(wi, wf):
     args = factory.default_args(train_unet=True, train_text_encoder=False, rank=4, train_images_per_prompt_GPU=8, train_GPU_batch_size=3,
                                 val_GPU_batch_size=8, size_face=224, img_size_small=224, weight_loss_img=wi, weight_loss_face=wf)
-    tr, _ = factory.build_trainer(args, dev, seed=0, regularisers=True)
+    tr, _ = factory.build_trainer(args, dev, seed=0, regularisers=True, lora_up_std=0.01)
     tokens = factory.synthetic_tokens(13, 49408)
     torch.manual_seed(5991)
     ts = []

@@ -110,3 +110,49 @@ def test_two_ranks_equal_one_rank_with_double_batch():
     assert np.abs(out[0]["grad"] - ref).max() <= 3e-2 * np.abs(ref).max()
     cos = float(np.dot(out[0]["grad"], ref) / (np.linalg.norm(out[0]["grad"]) * np.linalg.norm(ref)))
     assert cos > 0.999
+
+
+def _resume_worker(rank, world, port, tmp, out):
+    """Each rank seeds its own streams (set_seed(seed, device_specific=True) :693), saves a checkpoint, advances, reloads."""
+    _init(rank, world, port)
+    import random
+    import types
+    from finetune_fair_diffusion_amd import checkpoint as ck
+    from finetune_fair_diffusion_amd.train import set_seed
+    set_seed(5991, True, rank)
+    tr = types.SimpleNamespace(args=types.SimpleNamespace(train_unet=False, train_text_encoder=False), rank=rank, world=world, ema=[],
+                               opt_step=3, lr_step=3, target_rng=torch.Generator().manual_seed(1234 + rank))
+    torch.randn(7)                                                   # some consumption before the checkpoint
+    path = os.path.join(tmp, "checkpoint_tmp-3")
+    ck.save_state(tr, path, 3)
+    dist.barrier()
+    expect = dict(noise=float(torch.randn(2, 4, 8, 8).double().sum()), py=random.random(), np=float(np.random.rand()),
+                  ot=float(torch.rand(1, generator=tr.target_rng)))
+    torch.randn(100); random.random(); np.random.rand(); torch.rand(5, generator=tr.target_rng)   # diverge
+    assert ck.load_state(tr, path, seed=5991) == 3
+    got = dict(noise=float(torch.randn(2, 4, 8, 8).double().sum()), py=random.random(), np=float(np.random.rand()),
+               ot=float(torch.rand(1, generator=tr.target_rng)))
+    # a checkpoint written by a different world size: no cloning of rank 0's streams, fresh device-specific ones
+    st = torch.load(os.path.join(path, "trainer_state.pth"), weights_only=False)
+    dist.barrier()
+    if rank == 0:
+        st["world_size"] = 4
+        torch.save(st, os.path.join(path, "trainer_state.pth"))
+    dist.barrier()
+    ck.load_state(tr, path, seed=5991)
+    other = float(torch.randn(2, 4, 8, 8).double().sum())
+    out[rank] = dict(expect=expect, got=got, other_world=other)
+    dist.destroy_process_group()
+
+
+def test_resume_keeps_per_rank_rng_streams_gloo_world2(tmp_path):
+    """rank 0's RNG state must not be restored on every rank -- after a resume each rank continues ITS OWN noise / OT
+    streams (the reference: only rank 0 finds random_states_0.pkl, the other ranks keep their device-specific seeds)."""
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_resume_worker, args=(2, 29613, str(tmp_path), out), nprocs=2, join=True)
+    for r in (0, 1):
+        assert out[r]["got"] == out[r]["expect"], (r, out[r])
+    assert out[0]["got"]["noise"] != out[1]["got"]["noise"] and out[0]["got"]["ot"] != out[1]["got"]["ot"]
+    assert out[0]["other_world"] != out[1]["other_world"]
+    assert sorted(os.listdir(tmp_path / "checkpoint_tmp-3")) == ["rng_rank0.pth", "rng_rank1.pth", "trainer_state.pth"]
