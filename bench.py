@@ -59,6 +59,7 @@ def main():
     ap.add_argument("--share_gpu0", action="store_true", help="plumbing check: every rank uses cuda:0")
     ap.add_argument("--no_regularisers", action="store_true", help="drop the CLIP/DINOv2 image-semantics and SFNet face-realism terms (loss_fair only)")
     ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--cpu_baseline_full", action="store_true", help="cfg1-size oracle step (B=2, S=4), warm-up + median of 3 (~15 min)")
     ap.add_argument("--no_roofline", action="store_true")
     a = ap.parse_args()
 
@@ -136,41 +137,56 @@ def main():
                    "r3_timesteps_kept_in_hbm": min(a.S, 1 + max(tr.last_ctx_budget, 0)) if tr.keep_activations else 0},
     }
 
+    # executed vs algorithmic work: with R3 consuming R1's recorded forward the step EXECUTES 6*S*F_unet + 3*F_vae per image (R1 fwd, R2
+    # fwd, one backward) while the reference's algorithm counts 8*S*F_unet + 4*F_vae; both fractions are reported
+    shared = bool(tr.share_r1_r3 and args.val_GPU_batch_size >= a.batch)
+    f_exec = (6 if shared else 8) * a.S * F_UNET + (3 if shared else 4) * F_VAE
+    line["config"].update(r3_consumes_r1_forward=shared, executed_flop_per_image=f_exec,
+                          step_mfma_frac_executed=value / world * f_exec / MFMA_PEAK_F16)
+
     if rank == 0 and not a.no_roofline:
-        # roofline pass: one more identical step with per-launch HIP events on the GEMM/conv kernel family
+        # roofline pass: one more identical step with per-launch HIP events on the GEMM/conv kernel family (keyed by the rocprof kernel
+        # name) and the per-phase HIP events of the trainer
         ops.TIMER = ops.OpTimer()
+        tr.timers = True
         one_step()
         summ = ops.TIMER.summary()
         ops.TIMER = None
+        phases = tr.phase_ms()
+        tr.timers = None
+        line["config"]["phase_ms"] = {k: round(v, 1) for k, v in phases.items()}
         top = max(summ.items(), key=lambda kv: kv[1]["ms"])
         name, s = top
         achieved = s["flops"] / (s["ms"] * 1e-3) / 1e12
         traffic, traffic_note = pmc_traffic(name, s["bytes"] / s["launches"])
         line["roofline"] = {"bound": "mfma", "kernel": name, "achieved": achieved, "peak": MFMA_PEAK_F16 / 1e12, "unit": "TFLOP/s",
                             "frac": achieved / (MFMA_PEAK_F16 / 1e12), "traffic": traffic, "traffic_note": traffic_note,
-                            "launches": s["launches"],
+                            "launches": s["launches"], "splitk_launches": s["splitk_launches"],
                             "avg_launch_us": 1e3 * s["ms"] / s["launches"], "algorithmic_flop_per_launch": s["flops"] / s["launches"],
                             "algorithmic_bytes_per_launch": s["bytes"] / s["launches"],
                             # the same launches against the other roof: short-K shapes (K = 320) of this family are closer to HBM than to MFMA
                             "algorithmic_GBps": s["bytes"] / (s["ms"] * 1e-3) / 1e9, "hbm_frac_of_8TBps": s["bytes"] / (s["ms"] * 1e-3) / 8e12,
+                            "note": "kernel = rocprofv3 kernel name (fd_gemm_kernel_name); split-K launches of the instantiation are included and "
+                                    "their HIP events bracket the splitk_reduce_kernel too",
                             "family": {k: {"launches": v["launches"], "ms": round(v["ms"], 2), "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1)}
                                        for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"])}}
-    if world == 1 and not a.no_roofline:
-        # informational only (NOT the headline value): the same step when R3 consumes R1's recorded forward instead of
-        # recomputing the bit-identical rollout; measured after the timed region
-        tr.share_r1_r3 = True
+    if world == 1 and not a.no_roofline and shared:
+        # A/B, informational: the reference's own schedule (R1 and R3 each run their forward rollout; FD_NO_SHARE=1), after the timed region
+        tr.share_r1_r3 = False
         one_step()
         fence()
         t1 = time.perf_counter()
         one_step()
         fence()
-        line["config"]["images_per_s_if_r3_shares_r1_forward"] = a.batch / (time.perf_counter() - t1)
-        tr.share_r1_r3 = False
+        line["config"]["images_per_s_reference_schedule_r1_and_r3_both_forward"] = a.batch / (time.perf_counter() - t1)
+        tr.share_r1_r3 = True
     if world > 1:
         dist.barrier()
 
     if rank == 0 and world == 1 and not a.no_cpu_baseline and not a.tiny:
-        line["cpu_baseline"] = cpu_baseline(a.S)
+        del tr, models
+        torch.cuda.empty_cache()
+        line["cpu_baseline"] = cpu_baseline(a.S, full=a.cpu_baseline_full)
 
     if rank == 0:
         print(json.dumps(line))
@@ -178,29 +194,64 @@ def main():
         dist.destroy_process_group()
 
 
-def cpu_baseline(S):
-    """The oracle (fp32 PyTorch restatement of the reference's diffusers path) timed on this box's host
-    cores on a bounded sample: one CFG pair (batch 2) of the SD-v1.5 U-Net forward -- the op that is
-    >95 % of the step's FLOPs -- extrapolated to images/s with the algorithmic FLOPs per image."""
+def cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(S, full=False):
+    """SURVEY 8d / BASELINE.md 3: the oracle (fp32 PyTorch restatement of the reference's diffusers path, stock torch ops) timed on this
+    box's host cores on a COMPLETE fairness step at SD-v1.5 size -- BASELINE configs[0]: exp-1, LoRA rank 4 on the text encoder only --
+    i.e. R1 + R2 no-grad rollouts, R3 rollout with autograd, VAE, classifier, loss, backward.
+      default   bounded sample: B=1, S=1, one warm-up U-Net call + ONE timed step (tens of seconds; keeps the default bench within minutes)
+      --cpu_baseline_full   the full protocol: cfg1 size B=2, S=4, one warm-up step, median of 3 timed steps (~15 min); its result is
+                committed under profiles/ and quoted in DESIGN.md
+    ``value`` = images/s of the timed sample itself; the extrapolation to configs[1] (B=8, S=20) by algorithmic FLOPs is labelled as such."""
+    import statistics
     import torch
-    from oracle import nn_unet
-    cores = min(os.cpu_count() or 1, 32)  # beyond ~32 threads the fp32 convs of a batch-2 call stop scaling
-    torch.set_num_threads(cores)
-    torch.manual_seed(0)
-    with torch.no_grad():
-        unet = nn_unet.UNet2DConditionModel(nn_unet.UNetConfig())
-        x = torch.randn(2, 4, 64, 64)
-        enc = torch.randn(2, 13, 768)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import util_models as U
+    from oracle import fair_step as fs
+    ncpu = os.cpu_count() or 1
+    threads = min(ncpu, 64)
+    torch.set_num_threads(threads)
+    B, Sc, reps = (2, 4, 3) if full else (1, 1, 1)
+    om = U.oracle_models(rank=4, train_unet=False, train_te=True, lora_up_std=0.01, size="sd15", eval_copies=True)
+    models = dict(text_encoder=om["text_encoder"], unet=om["unet"], vae=om["vae"], classifier=om["classifier"], scheduler=om["scheduler"],
+                  eval_text_encoder=om["eval_text_encoder"], eval_unet=om["unet"])
+    from finetune_fair_diffusion_amd import factory
+    tokens = factory.synthetic_tokens(13, 49408)
+    cfg = dict(train_GPU_batch_size=4, val_GPU_batch_size=8, uncertainty_threshold=0.2, factor2=0.2, size_face=224)
+    noises = torch.randn(B, 4, 64, 64, generator=torch.Generator().manual_seed(5991))
+
+    def step():
+        for p in om["lora_params"]:
+            p.grad = None
         t0 = time.perf_counter()
-        n = 0
-        while n < 1 or (time.perf_counter() - t0 < 15.0 and n < 8):
-            unet(x, torch.tensor(500), enc)
-            n += 1
-        dt = (time.perf_counter() - t0) / n
-    flops_per_s = 2 * F_UNET / dt
-    return {"value": flops_per_s / f_img(S), "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": f"oracle fp32 U-Net forward, SD-v1.5 size, CFG pair (batch 2), {n} calls in {dt * n:.1f} s: {dt:.2f} s per call = {flops_per_s / 1e12:.3f} TFLOP/s on {cores} threads; "
-                      f"extrapolated with {f_img(S) / 1e12:.1f} algorithmic TFLOP per trained image"}
+        fs.fairness_step(models, tokens, noises, Sc, cfg)
+        return time.perf_counter() - t0
+
+    if full:
+        step()                                                     # warm-up step (thread pools, oneDNN primitive caches)
+    else:
+        with torch.no_grad():                                      # warm-up: one CFG-pair U-Net call
+            om["unet"](torch.randn(2, 4, 64, 64), torch.tensor(500), encoder_hidden_states=torch.randn(2, 13, 768))
+    times = [step() for _ in range(reps)]
+    dt = statistics.median(times)
+    flop = B * f_img(Sc)
+    return {"value": B / dt, "unit": "images/s", "cores": threads, "kind": "port", "host_cpu_count": ncpu, "cpu_model": cpu_model(),
+            "seconds_per_step": dt, "all_step_seconds": [round(t, 2) for t in times],
+            "sample": f"oracle fp32 full fairness step (R1+R2+R3 fwd/bwd, VAE, classifier, loss; exp-1, TE-LoRA r=4, SD-v1.5 512x512) at B={B}, S={Sc}: "
+                      f"{'median of 3 after one warm-up step' if full else 'one timed step after a U-Net warm-up call (bounded sample; --cpu_baseline_full runs cfg1 B=2,S=4, median of 3)'}; "
+                      f"{threads} torch threads on {ncpu} logical CPUs ({cpu_model()})",
+            "achieved_tflops": flop / dt / 1e12,
+            "extrapolated_to_configs1_images_per_s": (flop / dt) / f_img(S),
+            "extrapolation_note": f"EXTRAPOLATION, not a measurement: sample FLOP/s ({flop / dt / 1e12:.3f} TFLOP/s) / {f_img(S) / 1e12:.1f} algorithmic TFLOP per trained image at S={S}"}
 
 
 if __name__ == "__main__":

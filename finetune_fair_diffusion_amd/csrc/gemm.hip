@@ -8,6 +8,7 @@
 //   gemm_big_kernel   8 or 16 waves, BK = 64, tiles 256x320 / 128x320 / 128x160 / 256x128, optional split-K
 #include "common.h"
 #include <stdlib.h>
+#include <stdio.h>
 #include <mutex>
 
 // Measurement hooks (FD_GEMM_DBG sentinels inside the kernels, tile-policy A/B switches read from the environment) exist only in
@@ -990,6 +991,34 @@ extern "C" int fd_gemm_tile(const fd_gemm_desc* dp) {
     const long t12864 = (long)((d.M + 127) / 128) * ((d.N + 63) / 64) * nb;
     if (t12864 >= 512) return 128064;
     return 64064;
+}
+
+// Name of the kernel fd_gemm launches for this problem, spelled as rocprofv3 --kernel-trace prints it (template arguments included), so
+// that bench.py's live HIP-event roofline and the committed profiles/ summaries key the same thing.  Split-K launches add a
+// ``splitk_reduce_kernel`` that the bench's events bracket together with the GEMM.
+extern "C" int fd_gemm_kernel_name(const fd_gemm_desc* dp, char* buf, int n) {
+    fd_gemm_desc d = *dp;
+    if (d.K2 <= 0 || !d.A2) d.K2 = 0;
+    const int sel = fd_gemm_tile(&d);
+    const int t = sel % 1000000;
+    const bool w16 = bench_env("FD_GEMM_W8") == nullptr;
+    const int cv = d.conv ? (d.conv_mode >= FD_CONV_UP2P ? 2 : 1) : 0;
+    int bm = t / 1000, bn = t % 1000, wgm = 0, wgn = 0;
+    const char* fam = "gemm_big_kernel";
+    if (sel >= 1000000) { wgm = 4; wgn = t == 128320 ? 4 : 2; }
+    else switch (t) {
+        case 256320: wgm = (w16 && !d.conv) ? 4 : 2; wgn = 4; break;
+        case 128320: wgm = w16 ? 4 : 2; wgn = 4; break;
+        case 128160: wgm = 4; wgn = 2; break;
+        case 256256: wgm = 2; wgn = 4; break;
+        case 512128: wgm = 8; wgn = 2; break;
+        case 256128: wgm = 4; wgn = 2; break;
+        default: fam = bm == 16 ? "gemm_skinny_kernel" : "gemm_glds_kernel"; break;
+    }
+    if (wgm) snprintf(buf, n, "%s<%d, %d, %d, %d, %d>", fam, bm, bn, wgm, wgn, cv);
+    else if (bm == 16) snprintf(buf, n, "%s<%d, %d, 1>", fam, bn / 16, d.K >= 1280 ? 4 : d.K >= 640 ? 2 : 1);
+    else snprintf(buf, n, "%s<%d, %d, %s>", fam, bm, bn, d.conv ? "true" : "false");
+    return sel / 1000000;   // split-K factor (0 or 1 = none)
 }
 
 extern "C" int fd_gemm(const fd_gemm_desc* dp, void* stream) {

@@ -51,16 +51,16 @@ class OpTimer:
     (torch's current stream); used by bench.py's roofline pass, never inside the timed region."""
 
     def __init__(self):
-        self.records = []  # (variant, flops, algorithmic bytes, start_event, end_event)
+        self.records = []  # (rocprof kernel name, flops, algorithmic bytes, start_event, end_event, is_split_k)
 
     def summary(self):
         torch.cuda.synchronize()
         agg = {}
-        for variant, flops, nbytes, a, b in self.records:
+        for variant, flops, nbytes, a, b, split in self.records:
             ms = a.elapsed_time(b)
-            e = agg.setdefault(variant, [0, 0.0, 0.0, 0.0])
-            e[0] += 1; e[1] += flops; e[2] += ms; e[3] += nbytes
-        return {k: dict(launches=v[0], flops=v[1], ms=v[2], bytes=v[3]) for k, v in agg.items()}
+            e = agg.setdefault(variant, [0, 0.0, 0.0, 0.0, 0])
+            e[0] += 1; e[1] += flops; e[2] += ms; e[3] += nbytes; e[4] += int(split)
+        return {k: dict(launches=v[0], flops=v[1], ms=v[2], bytes=v[3], splitk_launches=v[4]) for k, v in agg.items()}
 
 
 TIMER = None
@@ -72,7 +72,8 @@ def _gemm_call(d, conv):
     if TIMER is None:
         _call("fd_gemm", ctypes.byref(d), _stream())
         return
-    tile = _lib.get().fd_gemm_tile(ctypes.byref(d))
+    buf = ctypes.create_string_buffer(128)
+    split = _lib.get().fd_gemm_kernel_name(ctypes.byref(d), buf, 128)
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
     _call("fd_gemm", ctypes.byref(d), _stream())
@@ -82,9 +83,9 @@ def _gemm_call(d, conv):
     # algorithmic bytes: every operand element read once, the output written once (3x3 gather: the Cin-wide input rows, not 9x)
     a_elems = (d.Bn * d.H * d.W * d.Cin) if conv else d.M * d.K
     nbytes = 2.0 * max(d.batch, 1) * (a_elems + d.M * d.K2 + nph * d.N * (d.K + d.K2) + nph * d.M * d.N)
-    split, tile = tile // 1000000, tile % 1000000
-    kname = "gemm_big_kernel" if tile in (256320, 128320, 128160, 256128, 256256, 512128) else "gemm_skinny_kernel" if tile // 1000 == 16 else "gemm_glds_kernel"
-    TIMER.records.append((f"{kname}<{tile // 1000},{tile % 1000},{'conv3x3' if conv else 'dense'}{',splitK' if split > 1 else ''}>", flops, nbytes, a, b))
+    # keyed by the rocprof kernel name: split-K and plain launches of one instantiation are ONE entry (the events bracket the
+    # splitk_reduce_kernel of a split launch together with its GEMM)
+    TIMER.records.append((buf.value.decode(), flops, nbytes, a, b, split > 1))
 
 
 def _chk(t, dtype=F16):

@@ -39,6 +39,7 @@ from .vit import feature_loss_and_grad
 # The two halves of a CFG batch share everything up to the first cross-attention (unet.forward_step(pair=True)); FD_NO_CFG_PAIR=1
 # evaluates the duplicated batch instead (A/B measurement only; eps is bit-identical either way).
 _CFG_PAIR = os.environ.get("FD_NO_CFG_PAIR") is None
+_ROCTX = os.environ.get("FD_ROCTX") is not None
 
 
 def _ctx_bytes(obj, seen=None):
@@ -126,9 +127,34 @@ class FairnessTrainer:
         # R1 and the forward half of R3 evaluate the same function on the same inputs (same prompt, noise, S and LoRA
         # weights; only the grad bookkeeping differs in the reference).  With deterministic, batch-invariant kernels the
         # two are bit-identical (asserted in tests), so R3 can consume R1's recorded rollout/decode/classifier forward.
-        # OFF by default: the headline step executes R1 and R3 separately, exactly like the reference.
-        self.share_r1_r3 = False
+        # ON by default whenever R1 runs as one chunk (val_GPU_batch_size >= B) and a separate frozen U-Net serves R2; FD_NO_SHARE=1
+        # executes R1 and R3 separately, exactly like the reference (A/B measurement; same images, same gradient to rounding).
+        self.share_r1_r3 = os.environ.get("FD_NO_SHARE") is None
+        # per-phase wall-clock of the last step (HIP events on the launch stream; read with phase_ms()); None = off
         self.timers = None
+        self._marks = []
+
+    # ------------------------------------------------------------------ per-phase timing (R1 / R2 / R3-fwd / R3-bwd / sync)
+    def _mark(self, name):
+        """Phase boundary: a HIP event on the launch stream (no host sync) and, with FD_ROCTX=1, a roctx range for rocprofv3 --marker-trace."""
+        if self.timers is None:
+            return
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        self._marks.append((name, ev))
+        if _ROCTX:
+            if len(self._marks) > 1:
+                torch.cuda.nvtx.range_pop()
+            if name != "end":
+                torch.cuda.nvtx.range_push(name)
+
+    def phase_ms(self):
+        """{phase: ms} of the last train_step (time from each mark to the next one), after a device sync."""
+        torch.cuda.synchronize()
+        out = {}
+        for (n0, e0), (_, e1) in zip(self._marks[:-1], self._marks[1:]):
+            out[n0] = out.get(n0, 0.0) + e0.elapsed_time(e1)
+        return out
 
     # ------------------------------------------------------------------ pieces
     def encode_pair(self, te, tokens, record=False):
@@ -284,20 +310,26 @@ class FairnessTrainer:
         for bank in self.banks:
             bank.grad.zero_()
         vb = args.val_GPU_batch_size
+        self._marks = []
+        self._mark("R1_rollout")
         # ---- R1: images from the model being finetuned (:1786-1795)
         train_te = getattr(args, "train_text_encoder", False) and self.te.lora_bank is not None
         train_unet = getattr(args, "train_unet", False) and self.unet.lora_bank is not None
-        share = self.share_r1_r3 and vb >= B
+        share = self.share_r1_r3 and vb >= B and self.eval_unet is not self.unet and (train_unet or train_te)
         shared = None
         if share:
             enc = self.encode_pair(self.te, tokens, record=train_te)
             x_final, inputs, ctxs = self.rollout(self.unet, enc, noises, S, keep_inputs=True, record_prompt=True,
                                                  keep_activations=self.keep_activations)
+            self._mark("R1_vae")
             images = self.decode(x_final, record=True)
             shared = (enc, inputs, ctxs)
         else:
             enc = self.encode_pair(self.te, tokens)
-            images = torch.cat([self.decode(self.rollout(self.unet, enc, noises[j:j + vb], S)[0]) for j in range(0, B, vb)])
+            lats = [self.rollout(self.unet, enc, noises[j:j + vb], S)[0] for j in range(0, B, vb)]
+            self._mark("R1_vae")
+            images = torch.cat([self.decode(x) for x in lats])
+        self._mark("classify_targets")
         ind, boxes, per = self.classify(images, record=share)
         # ---- dynamic targets from the global batch (:1805-1837)
         tgt = self.dynamic_targets(per, B)
@@ -305,8 +337,12 @@ class FairnessTrainer:
         out.update(images=images, probs=per[0]["probs"], preds=per[0]["preds"], targets=targets, uncertainty=tgt[0][1],
                    targets_by_attr={a["name"]: t for a, (t, _) in zip(per, tgt)})
         # ---- R2: images from the frozen original models (:1844-1858)
+        self._mark("R2_rollout")
         enc_ori = self.encode_pair(self.eval_te, tokens) if self.eval_te is not self.te else enc
-        images_ori = torch.cat([self.decode(self.rollout(self.eval_unet, enc_ori, noises[j:j + vb], S)[0]) for j in range(0, B, vb)])
+        lats = [self.rollout(self.eval_unet, enc_ori, noises[j:j + vb], S)[0] for j in range(0, B, vb)]
+        self._mark("R2_vae")
+        images_ori = torch.cat([self.decode(x) for x in lats])
+        self._mark("R2_classify_regularisers")
         ind_o, boxes_o, per_o = self.classify(images_ori)
         out.update(images_ori=images_ori, preds_ori=per_o[0]["preds"], probs_ori=per_o[0]["probs"])
         if self.use_img_loss:                                                    # :1860-1862
@@ -322,14 +358,15 @@ class FairnessTrainer:
         w, N_backward = microbatch_weights(B, args.train_GPU_batch_size)
         if share:
             (enc_g, inputs, ctxs), images_g, ind_g, boxes_g, per_g = shared, images, ind, boxes, per
-            if self.eval_unet is self.unet:   # R2 re-used the same U-Net object: restore the recorded prompt state
-                raise RuntimeError("share_r1_r3 needs a separate frozen U-Net for R2")
         else:
+            self._mark("R3_fwd_rollout")
             enc_g = self.encode_pair(self.te, tokens, record=train_te)
             x_final, inputs, ctxs = self.rollout(self.unet, enc_g, noises, S, keep_inputs=True, record_prompt=True,
                                                  keep_activations=self.keep_activations)
+            self._mark("R3_fwd_vae")
             images_g = self.decode(x_final, record=True)
             ind_g, boxes_g, per_g = self.classify(images_g, record=True)
+        self._mark("R3_loss_and_image_grad")
         dlog_full = torch.zeros((B, self.clf.num_classes), dtype=F32)
         loss_by_attr = {}
         for (name, c0, k), a, (t_a, _) in zip(self.attrs, per_g, tgt):      # loss_ij = sum over attributes (:1932; exp-3 :2146)
@@ -406,6 +443,7 @@ class FairnessTrainer:
                 d_img = d_fair if d_img is None else d_img.add_(d_fair)
             else:
                 self.clf._ctx = None
+            self._mark("R3_bwd_vae")
             vscale = _pow2_scale(float(d_img.abs().max()), 64.0)
             dz = self.vae.backward_images(d_img, vscale)
             g = dz * (1.0 / self.vae.config.scaling_factor)          # dL/dx_final  [B,4,h,w] fp32
@@ -413,6 +451,7 @@ class FairnessTrainer:
             gs = args.guidance_scale
             gscale = _pow2_scale(float(g.abs().max()) * float(abs(coefs).max()) * max(abs(gs), abs(1 - gs)), 64.0)
             out.update(g=g, coefs=coefs, gscale=gscale)
+            self._mark("R3_bwd_unet")
             if train_unet or train_te:
                 for i in range(S):
                     if i in ctxs:
@@ -430,7 +469,9 @@ class FairnessTrainer:
             self.vae._ctx = self.clf._ctx = None
         ctxs.clear()
         # ---- gradient sync, guard, update (:1998-2029)
+        self._mark("sync_update")
         out["grad_is_finite"] = self.sync_and_update(N_backward)
+        self._mark("end")
         return out
 
     def sync_and_update(self, N_backward, apply=True):

@@ -71,6 +71,9 @@ typedef struct fd_gemm_desc {
 int fd_gemm(const fd_gemm_desc* d, void* stream);
 /* tile variant fd_gemm would pick for this problem, as BM*1000+BN (128128 / 128064 / 64064) */
 int fd_gemm_tile(const fd_gemm_desc* d);
+/* name of the kernel fd_gemm launches for this problem as rocprofv3 --kernel-trace spells it (host buffer ``buf`` of ``n`` bytes);
+ * returns the split-K factor (>1: a splitk_reduce_kernel follows the GEMM).  Measurement aid for bench.py's roofline. */
+int fd_gemm_kernel_name(const fd_gemm_desc* d, char* buf, int n);
 
 /* Direct convolution for tiny channel counts (conv_in 4->320, conv_out dgrad, VAE post_quant 1x1,
  * classifier stem).  x: [B,Cin,H,W] (nchw!=0) or [B,H,W,Cin]; w: fp32 [k*k*Cin, Cout]; y: fp16 [B,Ho,Wo,Cout]. */

@@ -1,6 +1,7 @@
 """fp32 PyTorch restatement of transformers==4.30.0 ``CLIPTextModel`` with the
 diffusers==0.19.3 text-encoder LoRA patch (``PatchedLoraProjection``).
-TEST ORACLE -- parity unpinned (see oracle/__init__.py).
+TEST ORACLE -- PINNED against the installed transformers ``CLIPTextModel`` on shared random weights (causal + padding mask, quick_gelu;
+tests/test_cpu.py::test_oracle_clip_text_pinned_against_transformers); the LoRA patch on top of it is restated (diffusers absent).
 
 Reference call sites: exp-1-debias-gender/1-main-debias.py:726-729 (load),
 :829-883 (``LoraLoaderMixin._modify_text_encoder(text_encoder, dtype=float32, rank,

@@ -364,7 +364,7 @@ def test_checkpoint_round_trip_export_and_rolling_cleanup(tmp_path):
     torch.manual_seed(123)
     path = ck.save_state(a, os.path.join(d, "checkpoint_tmp-20"), 20)
     expect_next = torch.rand(3)
-    assert sorted(os.listdir(path)) == ["text_encoder_lora.pth", "text_encoder_lora_EMA.pth", "trainer_state.pth", "unet_lora.pth", "unet_lora_EMA.pth"]
+    assert sorted(os.listdir(path)) == ["rng_rank0.pth", "text_encoder_lora.pth", "text_encoder_lora_EMA.pth", "trainer_state.pth", "unet_lora.pth", "unet_lora_EMA.pth"]
     sd = torch.load(os.path.join(path, "unet_lora.pth"))
     k0 = "down_blocks.0.attentions.0.transformer_blocks.0.attn1.processor.to_q_lora.down.weight"
     assert k0 in sd and sd[k0].dtype == torch.float32 and sd[k0].device.type == "cpu" and len(sd) == 256
@@ -640,3 +640,44 @@ def test_exp5_prompt_mix(tmp_path):
     files["prompt_sports_path"] = str(tmp_path / "missing.json")
     with pytest.raises(FileNotFoundError):
         load_prompts(types.SimpleNamespace(prompt_occupation_path=str(occ), synthetic=False, **files))
+
+
+def test_oracle_clip_text_pinned_against_transformers():
+    """oracle.nn_clip.CLIPTextModel == the installed transformers CLIPTextModel on the same random weights, called the way the
+    reference calls it (1-main-debias.py:1011-1014, :1078-1081, :1087-1099): causal mask PLUS the tokenizer's attention_mask, for the
+    prompt (all ones) and for the uncond "" prompt padded to L with mask [1,1,0,...,0]; hidden_act quick_gelu; output [0] =
+    last_hidden_state.  (transformers 5.x drops the ``text_model.`` key prefix of 4.30 -- the oracle keeps the 4.30 names.)"""
+    from transformers import CLIPTextConfig as HFConfig, CLIPTextModel as HFModel
+    from oracle import nn_clip as C
+    kw = dict(vocab_size=1000, hidden_size=64, intermediate_size=128, num_hidden_layers=3, num_attention_heads=4, max_position_embeddings=77)
+    torch.manual_seed(0)
+    hf = HFModel(HFConfig(hidden_act="quick_gelu", layer_norm_eps=1e-5, bos_token_id=998, eos_token_id=999, pad_token_id=999,
+                          attn_implementation="eager", **kw)).eval()
+    sd = {}
+    for k, v in hf.state_dict().items():
+        if "position_ids" in k:
+            continue
+        sd[k if k.startswith("text_model.") else "text_model." + k] = v
+    mine = C.CLIPTextModel(C.CLIPTextConfig(**kw)).eval()
+    missing, unexpected = mine.load_state_dict(sd, strict=False)
+    assert not missing and not unexpected, (missing, unexpected)
+    # and the product's inventory carries exactly these (4.30) names and shapes
+    from finetune_fair_diffusion_amd import weights as W
+    shapes = W.clip_param_shapes(W.CLIPTextConfig(**{k: v for k, v in kw.items() if k != "max_position_embeddings"}))
+    assert {k: tuple(v.shape) for k, v in sd.items()} == {k: tuple(v) for k, v in shapes.items()}
+    L = 9
+    ids = torch.tensor([[998, 5, 17, 400, 23, 8, 77, 300, 999], [998] + [999] * (L - 1)])
+    mask = torch.tensor([[1] * L, [1, 1] + [0] * (L - 2)])
+    with torch.no_grad():
+        a = hf(input_ids=ids, attention_mask=mask)[0]
+        b = mine(ids, mask)[0]
+        a1 = hf(input_ids=ids[:1], attention_mask=mask[:1])[0]
+    assert a.shape == b.shape == (2, L, 64)
+    # rows whose query position attends to at least one unmasked key are defined identically; in the uncond sequence every query
+    # row i >= 0 sees key 0 (BOS) through the causal mask, so all rows are comparable
+    assert float((a - b).abs().max()) < 1e-5 * float(a.abs().max()), float((a - b).abs().max())
+    assert float((a1 - b[:1]).abs().max()) < 1e-5 * float(a.abs().max())
+    # the padding mask matters: without it the uncond sequence's rows 2.. change
+    with torch.no_grad():
+        c = mine(ids, None)[0]
+    assert float((c[1, 2:] - b[1, 2:]).abs().max()) > 1e-3 and float((c[0] - b[0]).abs().max()) < 1e-6

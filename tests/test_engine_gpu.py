@@ -300,6 +300,8 @@ def test_r1_r3_forward_bit_identical_and_shared_mode(dev):
     tr = FairnessTrainer(args, pm["text_encoder"], pm["unet"], pm["vae"], pm["classifier"], pm["scheduler"], eval_unet=pm["eval_unet"], device=dev)
     grads = []
     tr.sync_and_update = lambda nb, apply=True: (grads.append(tr.banks[0].grad.clone()), True)[1]   # capture, do not update
+    assert tr.share_r1_r3                # the default; FD_NO_SHARE=1 / share_r1_r3=False executes R1 and R3 separately like the reference
+    tr.share_r1_r3 = False
     out = tr.train_step(tokens, noises, 4)
     assert torch.equal(out["images"], out["images_grad"])
     tr.share_r1_r3 = True

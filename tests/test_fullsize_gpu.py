@@ -1,0 +1,242 @@
+"""SD-v1.5-SIZE parity (GPU): the networks exactly as bench.py times them (channels 320-1280, head dims 40/80/160, 64x64 latents,
+L = 13 prompt tokens, 512x512 images) against the CPU fp32 oracle on shared synthetic weights.  These are the shapes that select the
+256x320 / 128x320 big-tile and split-K GEMM variants, the 1280-channel up-sampling phase kernels, attn<40> at 4096 tokens, the
+CFG-prefix path and the kept-activation schedule -- assembled, not kernel by kernel.
+
+Reference call shapes: exp-1-debias-gender/1-main-debias.py:1074-1134 (rollout), :1058-1059 (VAE decode), :1746-2029 (step).
+Tolerances as in the tiny-model tests: network outputs 2e-2 of max|ref|, LoRA gradients 5e-2 per tensor family, loss 1e-2
+(fp16 activations vs the fp32 oracle); the zero-initialised-``up`` training regime within 5 % on the change of eps.
+"""
+import math
+import os
+import sys
+import time
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import util_models as U  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+L = 13
+
+
+def relerr(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-20))
+
+
+def check(name, a, b, tol):
+    e = relerr(a, b)
+    print(f"[{name}] rel max err {e:.3e} (tol {tol:.1e})  max|ref|={float(b.abs().max()):.3e}")
+    assert math.isfinite(e) and e <= tol, f"{name}: {e} > {tol}"
+
+
+def sd15_tokens():
+    from finetune_fair_diffusion_amd import factory
+    return factory.synthetic_tokens(L, 49408)
+
+
+@pytest.fixture(scope="module")
+def full(dev):
+    torch.set_num_threads(min(os.cpu_count() or 1, 64))
+    t0 = time.time()
+    om = U.oracle_models(train_unet=True, train_te=False, lora_up_std=0.02, size="sd15", eval_copies=False)
+    pm = U.product_models(om["sds"], dev, train_unet=True, train_te=False, size="sd15", eval_copies=True)
+    print(f"[fixture] SD-v1.5-size oracle + product built in {time.time() - t0:.1f} s on {torch.get_num_threads()} threads")
+    return om, pm
+
+
+class _Frozen:
+    """The frozen original U-Net of R2 (:1844-1858) without a second 3.4 GB fp32 copy: the same module with its LoRA processors
+    detached for the duration of a call."""
+
+    def __init__(self, unet):
+        self.u = unet
+
+    def __call__(self, *a, **k):
+        procs = dict(self.u.attn_processors)
+        self.u.set_attn_processor({n: None for n in procs})
+        try:
+            return self.u(*a, **k)
+        finally:
+            self.u.set_attn_processor(procs)
+
+
+def _pair_embeddings(om, dev):
+    from oracle import fair_step as fs
+    with torch.no_grad():
+        enc = fs.encode_prompts(om["text_encoder"], *sd15_tokens(), 1)     # [2, L, 768] (uncond, cond)
+    return enc
+
+
+def _lora_grad_families(om, bank, tol):
+    sd_o = {n: p.grad for n, p in zip(om["unet_lora_layers"].state_dict().keys(), om["unet_lora_layers"].parameters())}
+    for fam in ("attn1.processor.to_q_lora.up", "attn1.processor.to_k_lora.down", "attn1.processor.to_v_lora.up", "attn1.processor.to_out_lora.down",
+                "attn2.processor.to_q_lora.down", "attn2.processor.to_k_lora.up", "attn2.processor.to_v_lora.down", "attn2.processor.to_out_lora.up"):
+        for level in ("down_blocks.0", "down_blocks.1", "down_blocks.2", "mid_block", "up_blocks.1", "up_blocks.2", "up_blocks.3"):
+            names = [n for n in sd_o if fam in n and n.startswith(level)]
+            assert names, (fam, level)
+            ref = torch.cat([sd_o[n].flatten() for n in names])
+            got = torch.cat([bank.grad_view(n).flatten() for n in names])
+            check(f"SD15 unet lora grads {level} {fam}", got, ref, tol)
+
+
+def test_sd15_unet_cfg_pair_forward_and_lora_gradient(full, dev):
+    """(a) One U-Net call of the rollout (:1118-1122): CFG pair of one latent (batch 2, 64x64, L=13) forward, then the LoRA gradient
+    for a random upstream gradient -- per level (320/640/1280 channels) and per LoRA tensor family."""
+    om, pm = full
+    enc = _pair_embeddings(om, dev)
+    x1 = torch.randn(1, 4, 64, 64, generator=torch.Generator().manual_seed(1))
+    x = torch.cat([x1, x1])
+    t = 601
+    unet_o, unet_p = om["unet"], pm["unet"]
+    t0 = time.time()
+    eps_o = unet_o(x.half().float(), torch.tensor(t), encoder_hidden_states=enc.half().float()).sample
+    print(f"oracle SD15 U-Net forward (batch 2): {time.time() - t0:.1f} s")
+    unet_p.prepare_timesteps([t])
+    unet_p.prepare_prompt(enc.to(dev).half(), record=True)
+    eps_pair = unet_p.forward_step(x1.to(dev), 0, record=False, pair=True).view(2, 4, 64, 64)     # the rollout's path (shared CFG prefix)
+    check("SD15 unet eps (CFG-pair prefix path)", eps_pair, eps_o, 2e-2)
+    eps_p = unet_p.forward_step(x.to(dev), 0, record=True).view(2, 4, 64, 64)
+    check("SD15 unet eps (duplicated batch)", eps_p, eps_o, 2e-2)
+    assert torch.equal(eps_pair, eps_p)
+    g = torch.randn(eps_o.shape, generator=torch.Generator().manual_seed(2))
+    for p in om["lora_params"]:
+        p.grad = None
+    t0 = time.time()
+    (eps_o * g).sum().backward()
+    print(f"oracle SD15 U-Net backward: {time.time() - t0:.1f} s")
+    bank = unet_p.lora_bank
+    bank.grad.zero_()
+    gs = 64.0
+    unet_p.backward_step((g * gs).to(dev), gs)
+    unet_p.finish_prompt_backward(gs, need_denc=False)
+    _lora_grad_families(om, bank, 5e-2)
+    refg = torch.cat([p.grad.flatten() for p in om["unet_lora_layers"].parameters()])
+    got = torch.cat([bank.grad_view(n).flatten() for n in om["unet_lora_layers"].state_dict().keys()])
+    cos = float(F.cosine_similarity(got.cpu().double(), refg.double(), dim=0))
+    print("cosine(all SD15 LoRA grads) =", cos)
+    assert cos > 0.9995
+
+
+def test_sd15_vae_decode_512_forward_and_dz(full, dev):
+    """(b) AutoencoderKL.decode of one 64x64 latent to 512x512 (:1058-1059) and dL/dz for a random image gradient."""
+    om, pm = full
+    z = torch.randn(1, 4, 64, 64, generator=torch.Generator().manual_seed(4))
+    zr = z.clone().requires_grad_(True)
+    t0 = time.time()
+    img_o = om["vae"].decode(zr).sample.clamp(-1, 1)
+    img_p = pm["vae"].decode_images(z.to(dev), record=True)
+    assert img_p.shape == (1, 3, 512, 512)
+    check("SD15 vae images 512^2", img_p, img_o, 2e-2)
+    g = torch.randn(img_o.shape, generator=torch.Generator().manual_seed(5)) * 1e-3
+    (img_o * g).sum().backward()
+    print(f"oracle VAE decode + backward: {time.time() - t0:.1f} s")
+    dz = pm["vae"].backward_images(g.to(dev), 2.0 ** 14)
+    check("SD15 vae dz", dz, zr.grad, 5e-2)
+
+
+def test_sd15_full_step_b2_s2(full, dev):
+    """(c) One complete training step at SD-v1.5 size, B=2, S=2, LoRA r=4 on the U-Net (:1746-2029): R1 images, class probabilities,
+    exact dynamic targets, per-image loss_fair and the raw LoRA gradient vs the oracle's autograd step."""
+    from oracle import fair_step as fs
+    from finetune_fair_diffusion_amd.step import FairnessTrainer
+    om, pm = full
+    eval_unet_o = _Frozen(om["unet"])                 # frozen original: same base weights with the LoRA branch switched off
+    args = U.make_args(train_unet=True, train_text_encoder=False, size_face=224)
+    tokens = sd15_tokens()
+    B, S = 2, 2
+    noises = torch.randn(B, 4, 64, 64, generator=torch.Generator().manual_seed(5991))
+    models_o = dict(text_encoder=om["text_encoder"], unet=om["unet"], vae=om["vae"], classifier=om["classifier"], scheduler=om["scheduler"],
+                    eval_text_encoder=om["text_encoder"], eval_unet=eval_unet_o)
+    for p in om["lora_params"]:
+        p.grad = None
+    t0 = time.time()
+    ref = fs.fairness_step(models_o, tokens, noises, S, dict(train_GPU_batch_size=3, val_GPU_batch_size=8, uncertainty_threshold=0.6, factor2=0.2,
+                                                             size_face=224))
+    print(f"oracle full step B={B} S={S}: {time.time() - t0:.1f} s")
+    args.uncertainty_threshold = 0.6                  # B=2: keep both targets so the CE terms are exercised
+    tr = FairnessTrainer(args, pm["text_encoder"], pm["unet"], pm["vae"], pm["classifier"], pm["scheduler"], eval_unet=pm["eval_unet"], device=dev)
+    grads = {}
+    tr.sync_and_update = lambda nb, apply=True: (grads.__setitem__(0, tr.banks[0].grad.clone()), True)[1]
+    out = tr.train_step(tokens, noises, S)
+    check("SD15 step: R1 images", out["images"], ref["images"], 3e-2)
+    check("SD15 step: R2 images", out["images_ori"], ref["images_ori"], 3e-2)
+    check("SD15 step: probs", out["probs"], ref["probs"], 2e-2)
+    assert out["targets"].tolist() == ref["targets"].tolist() and (ref["targets"] != -1).all(), (out["targets"], ref["targets"])
+    check("SD15 step: loss_fair", out["loss_fair"], ref["loss_fair"], 1e-2)
+    names = list(om["unet_lora_layers"].state_dict().keys())
+    refg = torch.cat([p.grad.flatten() for p in om["unet_lora_layers"].parameters()])
+    got = torch.cat([tr.banks[0].view(n, grads[0]).flatten() for n in names])
+    cos = float(F.cosine_similarity(got.cpu().double(), refg.double(), dim=0))
+    print("cosine(SD15 step unet grads) =", cos, " norm ratio =", float(got.norm().cpu() / refg.norm()))
+    assert cos > 0.97 and 0.8 < float(got.norm().cpu() / refg.norm()) < 1.25
+
+
+@pytest.mark.parametrize("rank", [4, 50])
+def test_sd15_zero_init_up_training_regime(full, dev, rank):
+    """(d) The regime real runs live in: ``up = 0`` (diffusers LoRALinearLayer init), then AdamW steps of lr 5e-5 -- |up| ~ 5e-5 is
+    below the fp16 normal minimum (6.1e-5), so the fp16 operand copies of ``up`` sit in subnormals for the first steps.  Two AdamW
+    steps on L = <eps, g>; the change of eps must match the oracle's within 5 % (rank 4 and the reference's real rank 50 -> pad 64)."""
+    from finetune_fair_diffusion_amd import ops, weights as W
+    from oracle import nn_unet
+    om, pm = full
+    unet_o, unet_p = om["unet"], pm["unet"]
+    keep = (om.get("unet_lora_layers"), unet_p.lora_bank)
+    layers = nn_unet.make_unet_lora(unet_o, rank)
+    sd = W.synthetic_state_dict(W.unet_lora_param_shapes(W.UNetConfig(), rank), seed=77)      # down ~ N(0, 1/r), up = 0
+    assert all(float(v.abs().max()) == 0 for k, v in sd.items() if ".up." in k)
+    layers.load_named(sd)
+    for p in layers.parameters():
+        p.requires_grad_(True)
+    bank = unet_p.add_lora(rank, sd)
+    enc = _pair_embeddings(om, dev)
+    x1 = torch.randn(1, 4, 64, 64, generator=torch.Generator().manual_seed(21))
+    x = torch.cat([x1, x1])
+    g = torch.randn(2, 4, 64, 64, generator=torch.Generator().manual_seed(22))
+    t = 401
+    opt = torch.optim.AdamW(list(layers.parameters()), lr=5e-5, betas=(0.9, 0.999), weight_decay=1e-2, eps=1e-8)
+    unet_p.prepare_timesteps([t])
+    gs = 64.0
+    eps_o, eps_p = [], []
+    for it in range(3):
+        unet_p.prepare_prompt(enc.to(dev).half(), record=True)
+        e_p = unet_p.forward_step(x.to(dev), 0, record=it < 2).view(2, 4, 64, 64)
+        eps_p.append(e_p.float().cpu())
+        if it < 2:
+            opt.zero_grad()
+            e_o = unet_o(x.half().float(), torch.tensor(t), encoder_hidden_states=enc.half().float()).sample
+            (e_o * g).sum().backward()
+            opt.step()
+            bank.grad.zero_()
+            unet_p.backward_step((g * gs).to(dev), gs)
+            unet_p.finish_prompt_backward(gs, need_denc=False)
+            ops.adamw_ema(bank.flat, bank.grad, bank.exp_avg, bank.exp_avg_sq, bank.ema, 5e-5, 0.9, 0.999, 1e-8, 1e-2, it + 1, 1.0)
+            unet_p.refresh_lora()
+        else:
+            with torch.no_grad():
+                e_o = unet_o(x.half().float(), torch.tensor(t), encoder_hidden_states=enc.half().float()).sample
+        eps_o.append(e_o.detach())
+    check(f"r={rank}: eps at up = 0", eps_p[0], eps_o[0], 2e-2)
+    # parameters after two steps
+    names = list(layers.state_dict().keys())
+    ref_up = torch.cat([p.detach().flatten() for n, p in zip(names, layers.parameters()) if ".up." in n])
+    got_up = torch.cat([bank.view(n).flatten() for n in names if ".up." in n]).cpu()
+    print(f"r={rank}: |up| after 2 steps: mean {float(ref_up.abs().mean()):.2e} (fp16 normal min 6.1e-5); sign agreement "
+          f"{float((ref_up.sign() == got_up.sign()).float().mean()):.4f}")
+    assert float((ref_up.sign() == got_up.sign()).float().mean()) > 0.97
+    for k in (1, 2):
+        d_o, d_p = eps_o[k] - eps_o[0], eps_p[k] - eps_p[0]
+        # eps is fp16-rounded (values O(1), ulp ~ 1e-3) while the change is O(1e-3..1e-2): compare the change by projection on the
+        # oracle's change (a scalar gain, robust to the rounding noise of the difference) and by direction
+        gain = float((d_p * d_o).sum() / (d_o * d_o).sum())
+        cos = float(F.cosine_similarity(d_p.flatten().double(), d_o.flatten().double(), dim=0))
+        print(f"r={rank}: after {k} AdamW step(s): |d eps|_rms oracle {float(d_o.pow(2).mean().sqrt()):.3e} product {float(d_p.pow(2).mean().sqrt()):.3e}"
+              f"  gain {gain:.4f}  cosine {cos:.4f}")
+        assert abs(gain - 1) < 0.05, (rank, k, gain)
+    # restore the fixture's r=4 LoRA for the other tests
+    unet_o.set_attn_processor(dict(zip(keep[0].names, keep[0].layers)))
+    unet_p.add_lora(4, om["sds"]["unet_lora"])

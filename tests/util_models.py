@@ -11,6 +11,9 @@ TINY_VAE = dict(block_out_channels=(32, 64, 64, 64))
 TINY_CLIP = dict(vocab_size=1000, hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=2)
 
 
+SIZES = {"tiny": (TINY_UNET, TINY_VAE, TINY_CLIP), "sd15": ({}, {}, {})}   # "sd15": the dataclass defaults == SD-v1.5
+
+
 def tiny_tokens(L=7, vocab=1000):
     ids = torch.tensor([vocab - 1] + list(range(5, 5 + L - 2)) + [vocab - 2])
     mask = torch.ones(L, dtype=torch.long)
@@ -28,16 +31,18 @@ def make_args(**kw):
     return types.SimpleNamespace(**d)
 
 
-def oracle_models(rank=4, train_unet=True, train_te=False, num_classes=80, lora_up_std=0.02, seed=0):
-    """Returns dict of oracle modules + the state dicts they were loaded from."""
+def oracle_models(rank=4, train_unet=True, train_te=False, num_classes=80, lora_up_std=0.02, seed=0, size="tiny", eval_copies=True,
+                  clf_gain=1.4):
+    """Returns dict of oracle modules + the state dicts they were loaded from.  ``size``: "tiny" or "sd15" (SD-v1.5 shapes)."""
     from oracle import nn_clip, nn_mobilenet, nn_unet, nn_vae
     from oracle.dpm_solver import DPMSolverMultistepScheduler
-    ucfg, vcfg, ccfg = nn_unet.UNetConfig(**TINY_UNET), nn_vae.VAEConfig(**TINY_VAE), nn_clip.CLIPTextConfig(**TINY_CLIP)
+    UK, VK, CK = SIZES[size]
+    ucfg, vcfg, ccfg = nn_unet.UNetConfig(**UK), nn_vae.VAEConfig(**VK), nn_clip.CLIPTextConfig(**CK)
     sds = dict(
-        unet=W.synthetic_state_dict(W.unet_param_shapes(W.UNetConfig(**TINY_UNET)), seed=seed + 1),
-        vae=W.synthetic_state_dict(W.vae_param_shapes(W.VAEConfig(**TINY_VAE)), seed=seed + 2),
-        clip=W.synthetic_state_dict(W.clip_param_shapes(W.CLIPTextConfig(**TINY_CLIP)), seed=seed + 3),
-        clf=W.synthetic_state_dict(W.mobilenet_param_shapes(num_classes), seed=seed + 4, gain=1.4),
+        unet=W.synthetic_state_dict(W.unet_param_shapes(W.UNetConfig(**UK)), seed=seed + 1),
+        vae=W.synthetic_state_dict(W.vae_param_shapes(W.VAEConfig(**VK)), seed=seed + 2),
+        clip=W.synthetic_state_dict(W.clip_param_shapes(W.CLIPTextConfig(**CK)), seed=seed + 3),
+        clf=W.synthetic_state_dict(W.mobilenet_param_shapes(num_classes), seed=seed + 4, gain=clf_gain),
     )
     # the frozen models are cast to fp16 in the reference (:761-763): make the oracle see fp16-representable weights
     for k in ("unet", "vae", "clip", "clf"):
@@ -46,22 +51,22 @@ def oracle_models(rank=4, train_unet=True, train_te=False, num_classes=80, lora_
                 sds[k][n] = t.half().float()
     unet = nn_unet.UNet2DConditionModel(ucfg)
     unet.load_state_dict(sds["unet"], strict=True)
-    eval_unet = copy.deepcopy(unet)
+    eval_unet = copy.deepcopy(unet) if (eval_copies and train_unet) or size == "tiny" else unet
     vae = nn_vae.AutoencoderKLDecoder(vcfg)
     vae.load_state_dict(sds["vae"], strict=True)
     te = nn_clip.CLIPTextModel(ccfg)
     te.load_state_dict(sds["clip"], strict=True)
-    eval_te = copy.deepcopy(te)
+    eval_te = copy.deepcopy(te) if (eval_copies and train_te) or size == "tiny" else te
     clf = nn_mobilenet.MobileNetV3Large(num_classes).eval()
     clf.load_state_dict(sds["clf"], strict=True)
-    for m in (unet, eval_unet, vae, te, eval_te, clf):
+    for m in {id(m): m for m in (unet, eval_unet, vae, te, eval_te, clf)}.values():
         m.requires_grad_(False)
     out = dict(unet=unet, eval_unet=eval_unet, vae=vae, text_encoder=te, eval_text_encoder=eval_te, classifier=clf,
                scheduler=DPMSolverMultistepScheduler(), sds=sds, lora_params=[])
     g = torch.Generator().manual_seed(seed + 10)
     if train_unet:
         layers = nn_unet.make_unet_lora(unet, rank)
-        sd = W.synthetic_state_dict(W.unet_lora_param_shapes(W.UNetConfig(**TINY_UNET), rank), seed=seed + 5)
+        sd = W.synthetic_state_dict(W.unet_lora_param_shapes(W.UNetConfig(**UK), rank), seed=seed + 5)
         for n in sd:
             if ".up." in n:
                 sd[n] = torch.randn(sd[n].shape, generator=g) * lora_up_std
@@ -73,7 +78,7 @@ def oracle_models(rank=4, train_unet=True, train_te=False, num_classes=80, lora_
         out["lora_params"] += list(layers.parameters())
     if train_te:
         params = nn_clip.modify_text_encoder(te, rank)
-        sd = W.synthetic_state_dict(W.clip_lora_param_shapes(W.CLIPTextConfig(**TINY_CLIP), rank), seed=seed + 6)
+        sd = W.synthetic_state_dict(W.clip_lora_param_shapes(W.CLIPTextConfig(**CK), rank), seed=seed + 6)
         for n in sd:
             if ".up." in n:
                 sd[n] = torch.randn(sd[n].shape, generator=g) * lora_up_std
@@ -87,18 +92,19 @@ def oracle_models(rank=4, train_unet=True, train_te=False, num_classes=80, lora_
     return out
 
 
-def product_models(sds, dev, rank=4, train_unet=True, train_te=False, num_classes=80):
+def product_models(sds, dev, rank=4, train_unet=True, train_te=False, num_classes=80, size="tiny", eval_copies=True):
     from finetune_fair_diffusion_amd.classifier import MobileNetV3Large
     from finetune_fair_diffusion_amd.scheduler import DPMSolverMultistepScheduler
     from finetune_fair_diffusion_amd.text_encoder import CLIPTextModel
     from finetune_fair_diffusion_amd.unet import UNet2DConditionModel
     from finetune_fair_diffusion_amd.vae import AutoencoderKL
-    ucfg, vcfg, ccfg = W.UNetConfig(**TINY_UNET), W.VAEConfig(**TINY_VAE), W.CLIPTextConfig(**TINY_CLIP)
+    UK, VK, CK = SIZES[size]
+    ucfg, vcfg, ccfg = W.UNetConfig(**UK), W.VAEConfig(**VK), W.CLIPTextConfig(**CK)
     unet = UNet2DConditionModel(ucfg, sds["unet"], dev)
-    eval_unet = UNet2DConditionModel(ucfg, sds["unet"], dev) if train_unet else None
+    eval_unet = UNet2DConditionModel(ucfg, sds["unet"], dev) if (train_unet and eval_copies) else None
     vae = AutoencoderKL(vcfg, sds["vae"], dev)
     te = CLIPTextModel(ccfg, sds["clip"], dev)
-    eval_te = CLIPTextModel(ccfg, sds["clip"], dev) if train_te else None
+    eval_te = CLIPTextModel(ccfg, sds["clip"], dev) if (train_te and eval_copies) else None
     clf = MobileNetV3Large(sds["clf"], dev, num_classes)
     if train_unet:
         unet.add_lora(rank, sds["unet_lora"])
