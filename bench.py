@@ -57,6 +57,8 @@ def main():
     ap.add_argument("--tiny", action="store_true", help="tiny model config (plumbing check only; not a valid bench line)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU plumbing checks)")
     ap.add_argument("--share_gpu0", action="store_true", help="plumbing check: every rank uses cuda:0")
+    ap.add_argument("--force_collectives", action="store_true", help="initialise the process group and run the step's collectives even at world size 1 (RCCL smoke on a one-GPU box)")
+    ap.add_argument("--experiment", default="exp-1", choices=["exp-1", "exp-3", "exp-4", "exp-5"], help="exp-3/4/5: multi-attribute head + OT targets (not the headline config)")
     ap.add_argument("--no_regularisers", action="store_true", help="drop the CLIP/DINOv2 image-semantics and SFNet face-realism terms (loss_fair only)")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--cpu_baseline_full", action="store_true", help="cfg1-size oracle step (B=2, S=4), warm-up + median of 3 (~15 min)")
@@ -73,20 +75,24 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    if world > 1 or a.force_collectives:
+        if a.force_collectives:    # single-rank RCCL smoke: every collective of the step runs through RCCL on hardware
+            os.environ["FD_FORCE_COLLECTIVES"] = "1"
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29541")
         if a.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
         else:
-            dist.init_process_group(a.backend)
+            dist.init_process_group(a.backend, rank=rank, world_size=world)
 
     from finetune_fair_diffusion_amd import factory, ops
-    args = factory.default_args(train_unet=True, train_text_encoder=False, rank=a.rank, train_images_per_prompt_GPU=a.batch,
+    args = factory.default_args(experiment=a.experiment, train_unet=True, train_text_encoder=False, rank=a.rank, train_images_per_prompt_GPU=a.batch,
                                 train_GPU_batch_size=3, val_GPU_batch_size=8, mixed_precision="fp16",
                                 size_face=64 if a.tiny else 224, img_size_small=56 if a.tiny else 224,
                                 weight_loss_img=0.0 if a.no_regularisers else 8.0,   # debias-unet.yaml:4
                                 weight_loss_face=0.0 if a.no_regularisers else 1.0)  # debias-unet.yaml:5
     cfgs = factory.TINY if a.tiny else factory.SD15
-    tr, models = factory.build_trainer(args, dev, cfgs=cfgs, seed=0, rank=rank, world_size=world, regularisers=not a.no_regularisers,
+    tr, models = factory.build_trainer(args, dev, cfgs=cfgs, seed=0, rank=rank, world_size=world, regularisers=not a.no_regularisers, experiment=a.experiment,
                                        lora_up_std=0.01)   # up != 0 as after one warm-up optimiser step
     L = 13
     tokens = factory.synthetic_tokens(L, cfgs["clip"].vocab_size)
@@ -99,7 +105,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()      # this rank's work is done before it enters the barrier ...
-        if world > 1:
+        if world > 1 or a.force_collectives:
             dist.barrier()
             torch.cuda.synchronize()  # ... and the barrier's own collective has completed before the clock is read
 
@@ -182,6 +188,11 @@ def main():
         tr.share_r1_r3 = True
     if world > 1:
         dist.barrier()
+    if a.experiment != "exp-1":
+        line["config"]["experiment"] = a.experiment
+        line["config"]["ot_host_solve_ms"], line["config"]["ot_exposed_wait_ms"] = [round(v, 2) for v in tr.last_ot_ms]
+    if a.force_collectives:
+        line["config"]["collectives"] = "RCCL process group of world size %d: probability all-gather + flat LoRA-gradient all-reduce executed" % world
 
     if rank == 0 and world == 1 and not a.no_cpu_baseline and not a.tiny:
         del tr, models
@@ -190,7 +201,7 @@ def main():
 
     if rank == 0:
         print(json.dumps(line))
-    if world > 1:
+    if world > 1 or a.force_collectives:
         dist.destroy_process_group()
 
 

@@ -37,9 +37,9 @@ def synthetic_tokens(L=13, vocab=49408, seed=1):
     return ids, mask, uids, umask
 
 
-def default_args(**kw):
+def default_args(experiment="exp-1", **kw):
     from .cli import parse_args
-    a = vars(parse_args([]))
+    a = vars(parse_args([], experiment=experiment))
     a.update(kw)
     return types.SimpleNamespace(**a)
 
@@ -92,7 +92,9 @@ def build_trainer(args, device, cfgs=SD15, seed=0, rank=0, world_size=1, experim
                     bank.view(n).copy_((torch.randn(bank.shape(n), generator=g) * lora_up_std).to(device))
             bank.ema.copy_(bank.flat)
             te.refresh_lora()
-    if world_size > 1:  # identical LoRA init on every rank (:820-821, :848-854): one flat broadcast per bank
+    import os
+    import torch.distributed as _d
+    if world_size > 1 or (os.environ.get("FD_FORCE_COLLECTIVES") is not None and _d.is_available() and _d.is_initialized()):  # identical LoRA init on every rank (:820-821, :848-854): one flat broadcast per bank
         import torch.distributed as dist
         for m in (unet if args.train_unet else None, te if args.train_text_encoder else None):
             if m is not None:

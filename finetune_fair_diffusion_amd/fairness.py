@@ -218,27 +218,19 @@ def _cells(attr_sizes):
 
 
 @torch.no_grad()
-def generate_dynamic_targets_multi(probs_list, class_cdfs, num_samples_per_device=100, generator=None, allreduce=None,
-                                   age_asymmetric=False):
-    """Dynamic targets for several attributes at once (exp-3-debias-gender-race/1-main-debias.py:1459-1569,
-    exp-4-debias-gender-race-age/1-main-debias.py:1477-1615).
-
-    probs_list: per attribute a CPU tensor [n, k_a] (-1 rows = no face).  class_cdfs: per attribute the upper CDF
-    edges used to turn a uniform draw into a class (gender [0.5, 1], race [.25,.5,.75,1], age [.75, 1]).
-    For each of ``num_samples_per_device`` Monte-Carlo draws of a balanced class assignment the faces are optimally
-    transported onto the drawn cell counts; the plans are summed (and all-reduced over ranks, ``allreduce`` callable),
-    normalised, marginalised per attribute.  Returns [(targets [n] long, uncertainty [n])] per attribute.
-    ``age_asymmetric``: exp-4's cost doubles the first age coordinate when the target is the second class (`exp-4:1551-1556`)."""
+def mc_transport_plan(probs_list, class_cdfs, num_samples_per_device=100, generator=None, age_asymmetric=False):
+    """The rank-local, host-heavy half of the multi-attribute dynamic targets (exp-3 `:1488-1536`, exp-4 `:1517-1569`): for each of
+    ``num_samples_per_device`` Monte-Carlo draws of a balanced class assignment the faces are optimally transported onto the drawn
+    cell counts; returns (idx [n] bool of faces, summed plans [N, K] fp32, attribute sizes) -- or (idx, None, sizes) without faces.
+    It depends only on the gathered probabilities, so the step runs it on a worker thread underneath the R2 rollout."""
     n = probs_list[0].shape[0]
     sizes = [p.shape[1] for p in probs_list]
     idx = torch.ones(n, dtype=torch.bool)
     for p in probs_list:
         idx &= (p != -1).all(dim=-1)
-    out_t = [torch.full([n], -1, dtype=torch.long) for _ in sizes]
-    out_u = [torch.full([n], -1.0, dtype=torch.float32) for _ in sizes]
     N = int(idx.sum())
     if N == 0:
-        return list(zip(out_t, out_u))
+        return idx, None, sizes
     P = [p[idx].float().numpy() for p in probs_list]
     cells = _cells(sizes)
     K = len(cells)
@@ -270,17 +262,47 @@ def generate_dynamic_targets_multi(probs_list, class_cdfs, num_samples_per_devic
         cell_idx = sum(draws[a][s] * radix[a] for a in range(len(sizes)))
         counts = np.bincount(cell_idx, minlength=K)
         tp += _ot_assign(M, counts)
-    tp = torch.tensor(tp, dtype=torch.float32)
-    if allreduce is not None:
-        tp = allreduce(tp)
+    return idx, torch.tensor(tp, dtype=torch.float32), sizes
+
+
+@torch.no_grad()
+def targets_from_plan(idx, tp, sizes):
+    """Normalise the (all-reduced) summed plan, marginalise per attribute, argmax / 1 - max (`:1538-1553`)."""
+    n = idx.shape[0]
+    out_t = [torch.full([n], -1, dtype=torch.long) for _ in sizes]
+    out_u = [torch.full([n], -1.0, dtype=torch.float32) for _ in sizes]
+    if tp is None:
+        return list(zip(out_t, out_u))
+    cells = _cells(sizes)
     tp = tp / tp[0, :].sum()
     for a in range(len(sizes)):
-        marg = torch.zeros(N, sizes[a])
+        marg = torch.zeros(tp.shape[0], sizes[a])
         for j, cell in enumerate(cells):
             marg[:, cell[a]] += tp[:, j]
         out_t[a][idx] = marg.argmax(dim=-1)
         out_u[a][idx] = 1 - marg.max(dim=-1).values
     return list(zip(out_t, out_u))
+
+
+@torch.no_grad()
+def generate_dynamic_targets_multi(probs_list, class_cdfs, num_samples_per_device=100, generator=None, allreduce=None,
+                                   age_asymmetric=False, return_plan=False):
+    """Dynamic targets for several attributes at once (exp-3-debias-gender-race/1-main-debias.py:1459-1569,
+    exp-4-debias-gender-race-age/1-main-debias.py:1477-1615).
+
+    probs_list: per attribute a CPU tensor [n, k_a] (-1 rows = no face).  class_cdfs: per attribute the upper CDF
+    edges used to turn a uniform draw into a class (gender [0.5, 1], race [.25,.5,.75,1], age [.75, 1]).
+    The Monte-Carlo plans (``mc_transport_plan``) are summed (and all-reduced over ranks, ``allreduce`` callable),
+    normalised, marginalised per attribute (``targets_from_plan``).  Returns [(targets [n] long, uncertainty [n])] per attribute
+    (plus the normalised plan with ``return_plan``).
+    ``age_asymmetric``: exp-4's cost doubles the first age coordinate when the target is the second class (`exp-4:1551-1556`)."""
+    idx, tp, sizes = mc_transport_plan(probs_list, class_cdfs, num_samples_per_device, generator, age_asymmetric)
+    if tp is not None and allreduce is not None:
+        tp = allreduce(tp)
+    res = targets_from_plan(idx, tp, sizes)
+    if return_plan:
+        return res, (None if tp is None else tp / tp[0, :].sum())
+    return res
 
 
 # per experiment: (factor1 flags, factor2 flags, confidence-level flag) of the regulariser terms, in attribute order

@@ -47,6 +47,14 @@ def to_uint8_hwc(images):
     return x.mul(255).to(torch.uint8).permute(0, 2, 3, 1).contiguous().cpu().numpy()
 
 
+def generate_image(tr, tokens, noises, num_denoising_steps=30):
+    """``generate_image`` of gen-images.py:112-175 on the trainer's no-grad rollout: tokens of ONE prompt (prompt ids/mask, uncond
+    ids/mask), noises [N,4,h,w] -> images [N,3,H,W] in [-1,1] (fp16)."""
+    enc = tr.encode_pair(tr.te, tokens)
+    x, _, _ = tr.rollout(tr.unet, enc, noises.to(tr.device, torch.float32), num_denoising_steps)
+    return tr.decode(x)
+
+
 def main(args, cfgs=None):
     if args.load_prefix_embedding_from:
         raise NotImplementedError("--load_prefix_embedding_from (exp-2 prefix-token tuning) is outside this build's scope")
@@ -93,11 +101,9 @@ def main(args, cfgs=None):
             continue
         noises = torch.cat(noises)
         tokens = tokenizer(prompt)
-        enc = tr.encode_pair(tr.te, tokens)
         for b in range(math.ceil(len(paths) / args.batch_size)):
             nb = noises[b * args.batch_size:(b + 1) * args.batch_size].to(device)
-            x, _, _ = tr.rollout(tr.unet, enc, nb, args.num_denoising_steps)
-            imgs = to_uint8_hwc(tr.decode(x))
+            imgs = to_uint8_hwc(generate_image(tr, tokens, nb, args.num_denoising_steps))
             for img, path in zip(imgs, paths[b * args.batch_size:(b + 1) * args.batch_size]):
                 Image.fromarray(img).save(path)
                 written.append(path)

@@ -23,6 +23,8 @@ rather than silently dropped.
 """
 import math
 import os
+import threading
+import time
 
 import torch
 import torch.distributed as dist
@@ -31,7 +33,7 @@ import torch.nn.functional as F
 from . import ops
 from .fairness import (EXPERIMENT_ATTRS, EXPERIMENT_REG_FLAGS, SyntheticFaceProvider, face_grad_factors, face_grad_factors_multi,
                        fair_loss_and_grad, gen_dynamic_weights, gen_dynamic_weights_multi,
-                       generate_dynamic_targets, generate_dynamic_targets_multi, microbatch_weights)
+                       generate_dynamic_targets, mc_transport_plan, microbatch_weights, targets_from_plan)
 from .layers import F16, F32
 from .lr_schedule import lr_lambda
 from .vit import feature_loss_and_grad
@@ -108,6 +110,9 @@ class FairnessTrainer:
         _, self.attrs, self.class_cdfs, self.age_asym = EXPERIMENT_ATTRS[experiment]
         self.target_rng = torch.Generator().manual_seed(1234 + rank)
         self.rank, self.world = rank, world_size
+        # collectives run whenever there is more than one rank -- or, with FD_FORCE_COLLECTIVES=1 and an initialised process group, on a
+        # single rank too (the only way to drive the RCCL code path on a one-GPU box: RCCL refuses two ranks on one device)
+        self.collectives = world_size > 1 or (os.environ.get("FD_FORCE_COLLECTIVES") is not None and dist.is_available() and dist.is_initialized())
         self.device = device or unet.device
         self.banks = []
         if getattr(args, "train_unet", False):
@@ -133,6 +138,10 @@ class FairnessTrainer:
         # per-phase wall-clock of the last step (HIP events on the launch stream; read with phase_ms()); None = off
         self.timers = None
         self._marks = []
+        # exp-3/4/5: run the Monte-Carlo OT solves on a worker thread underneath R2 (False = inline, like the reference)
+        self.overlap_targets = os.environ.get("FD_NO_OT_OVERLAP") is None
+        self.last_ot_ms = (0.0, 0.0)
+        self._tgt = None
 
     # ------------------------------------------------------------------ per-phase timing (R1 / R2 / R3-fwd / R3-bwd / sync)
     def _mark(self, name):
@@ -208,9 +217,17 @@ class FairnessTrainer:
         per = []
         sel = ind.nonzero().view(-1)
         logits = None
+        logits_dev = None
         if len(sel):
             chips = ops.crop_resize(images[sel.to(images.device)].contiguous() if len(sel) != N else images, boxes[sel].to(self.device).contiguous(), -1.0, S)
-            logits = self.clf.forward(chips, record=record).float().cpu()
+            logits_dev = self.clf.forward(chips, record=record).float()
+            logits = logits_dev.cpu()
+        if self.collectives:
+            # exchange point 1 stays on the device: [N, sum k] probabilities (-1 rows = no face) for ONE all-gather of all attributes
+            pd = torch.full((N, sum(k for _, _, k in self.attrs)), -1.0, dtype=F32, device=self.device)
+            if logits_dev is not None:
+                pd[sel.to(self.device)] = torch.cat([torch.softmax(logits_dev[:, c0:c0 + k], dim=-1) for _, c0, k in self.attrs], dim=1)
+            self._probs_dev = pd
         for name, c0, k in self.attrs:
             probs = torch.full((N, k), -1.0)
             preds = torch.full((N,), -1, dtype=torch.long)
@@ -260,34 +277,69 @@ class FairnessTrainer:
         best = cand.gather(1, exact.argmax(dim=-1, keepdim=True))[:, 0]
         return self.face_db[best]
 
-    def dynamic_targets(self, per, B):
-        """Global dynamic targets for this rank's B images from the gathered probabilities of all ranks (:1831-1837;
-        exp-3 :2016-2025).  Returns per attribute (targets [B], uncertainty [B])."""
-        args = self.args
-        gathered = [self.gather_probs(a["probs"]) for a in per]
-        if len(per) == 1:
-            t, u = generate_dynamic_targets(gathered[0], w_uncertainty=True)
-            res = [(t, u)]
+    def start_dynamic_targets(self, per, B):
+        """Global dynamic targets for this rank's B images from the gathered probabilities of all ranks (:1831-1837; exp-3 :2016-2025),
+        first half: ONE all-gather for all attributes (device tensors in, one host copy out), then
+          * exp-1: the binomial-rank targets, inline (microseconds);
+          * exp-3/4/5: the 100 Monte-Carlo transport solves of this rank start on a WORKER THREAD -- they only need the gathered
+            probabilities, and nothing needs the targets before R3's loss, so they run underneath the R2 rollout that the main thread
+            keeps enqueueing (the reference solves them serially between R1 and R2 on every rank, exp-3 `:1488-1536`)."""
+        if not self.collectives:
+            gathered = [a["probs"] for a in per]
         else:
-            def allreduce(tp):   # exchange point c11: sum of the per-rank Monte-Carlo transport plans
-                if self.world == 1:
-                    return tp
+            allp = self.gather_probs(self._probs_dev)                  # [world*B, sum k] on the host
+            gathered, c = [], 0
+            for _, _, k in self.attrs:
+                gathered.append(allp[:, c:c + k].contiguous())
+                c += k
+        self._tgt = dict(B=B, single=len(per) == 1)
+        if len(per) == 1:
+            self._tgt["res"] = [generate_dynamic_targets(gathered[0], w_uncertainty=True)]
+            return
+
+        def work():
+            t0 = time.perf_counter()
+            self._tgt["plan"] = mc_transport_plan(gathered, self.class_cdfs, 100, self.target_rng, self.age_asym)
+            self._tgt["solve_ms"] = 1e3 * (time.perf_counter() - t0)
+        if self.overlap_targets:
+            th = threading.Thread(target=work, daemon=True)
+            th.start()
+            self._tgt["thread"] = th
+        else:
+            work()
+
+    def finish_dynamic_targets(self):
+        """Second half: join the solver, ONE all-reduce of the summed plans (exchange point c11), marginals, threshold, this rank's slice.
+        ``last_ot_ms`` = (host solve time, time the main thread actually waited here)."""
+        st, args, B = self._tgt, self.args, self._tgt["B"]
+        t0 = time.perf_counter()
+        if not st["single"]:
+            if "thread" in st:
+                st["thread"].join()
+            idx, tp, sizes = st["plan"]
+            if tp is not None and self.collectives:
                 t = tp.to(self.device)
                 dist.all_reduce(t, op=dist.ReduceOp.SUM)
-                return t.cpu()
-            res = generate_dynamic_targets_multi(gathered, self.class_cdfs, 100, self.target_rng, allreduce, self.age_asym)
+                tp = t.cpu()
+            st["res"] = targets_from_plan(idx, tp, sizes)
+            self.last_ot_ms = (st.get("solve_ms", 0.0), 1e3 * (time.perf_counter() - t0))
         out = []
-        for t, u in res:
+        for t, u in st["res"]:
             t = t.clone()
             t[u > args.uncertainty_threshold] = -1
             out.append((t[B * self.rank:B * (self.rank + 1)], u[B * self.rank:B * (self.rank + 1)]))
+        self._tgt = None
         return out
+
+    def dynamic_targets(self, per, B):
+        self.start_dynamic_targets(per, B)
+        return self.finish_dynamic_targets()
 
     # ------------------------------------------------------------------ the two exchange points of the step (SURVEY 8e)
     def gather_probs(self, probs):
         """(1) all-gather of the per-rank class probabilities [B,k] so every rank derives identical global targets
         (:1805-1837; the reference also gathers images/boxes/preds for plotting only)."""
-        if self.world == 1:
+        if not getattr(self, "collectives", self.world > 1):
             return probs
         pg = probs.to(self.device).contiguous()
         gl = [torch.empty_like(pg) for _ in range(self.world)]
@@ -296,7 +348,7 @@ class FairnessTrainer:
 
     def allreduce_grads(self):
         """(2) ONE all-reduce(SUM) per flat fp32 LoRA-gradient buffer (RCCL over xGMI on the GPU box)."""
-        if self.world > 1:
+        if getattr(self, "collectives", self.world > 1):
             for bank in self.banks:
                 dist.all_reduce(bank.grad, op=dist.ReduceOp.SUM)
 
@@ -331,11 +383,9 @@ class FairnessTrainer:
             images = torch.cat([self.decode(x) for x in lats])
         self._mark("classify_targets")
         ind, boxes, per = self.classify(images, record=share)
-        # ---- dynamic targets from the global batch (:1805-1837)
-        tgt = self.dynamic_targets(per, B)
-        targets = tgt[0][0]
-        out.update(images=images, probs=per[0]["probs"], preds=per[0]["preds"], targets=targets, uncertainty=tgt[0][1],
-                   targets_by_attr={a["name"]: t for a, (t, _) in zip(per, tgt)})
+        # ---- dynamic targets from the global batch (:1805-1837): gathered now, solved underneath R2, consumed by R3's loss
+        self.start_dynamic_targets(per, B)
+        out.update(images=images, probs=per[0]["probs"], preds=per[0]["preds"])
         # ---- R2: images from the frozen original models (:1844-1858)
         self._mark("R2_rollout")
         enc_ori = self.encode_pair(self.eval_te, tokens) if self.eval_te is not self.te else enc
@@ -354,6 +404,9 @@ class FairnessTrainer:
             face_ori = torch.zeros((B, 512), dtype=F32, device=dev)
             if len(idx_o):
                 face_ori[idx_o.long()] = F.normalize(face_features(self.face_net, ch_o)[0], dim=-1)
+        tgt = self.finish_dynamic_targets()
+        targets = tgt[0][0]
+        out.update(targets=targets, uncertainty=tgt[0][1], targets_by_attr={a["name"]: t for a, (t, _) in zip(per, tgt)})
         # ---- R3: rollout with gradient (:1889-1933), all micro-batches at once with weights 1/n_j
         w, N_backward = microbatch_weights(B, args.train_GPU_batch_size)
         if share:

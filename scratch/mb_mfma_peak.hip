@@ -61,7 +61,65 @@ static void run(const char* name, int waves, int blocks) {
     hipFree(out);
 }
 
+// ---- (3) reconciliation with MI355X_MICROARCH.md (2495 TF measured with 32x32x16): shape x data fill x effective clock.
+// The chip clocks to its power budget (guide, "DVFS give-back"): zero operands run at ~2.3-2.4 GHz, random operands at ~1.9-2.0 GHz.
+typedef float f16v __attribute__((ext_vector_type(16)));
+template <int SHAPE>   // 16: v_mfma_f32_16x16x32_f16 (8x5 accumulators)   32: v_mfma_f32_32x32x16_f16 (4x2 accumulators of 16 regs)
+__global__ __launch_bounds__(512) void mfma_clock(float* out, long long* cyc, int iters, float fill) {
+    const int lane = threadIdx.x & 63;
+    h8 a[8], b[5];
+    for (int i = 0; i < 8; i++) for (int e = 0; e < 8; e++) a[i][e] = (_Float16)(fill * (0.37f + 0.001f * ((lane * 7 + i * 3 + e * 5) % 97)) * ((lane + e + i) & 1 ? 1.f : -1.f));
+    for (int j = 0; j < 5; j++) for (int e = 0; e < 8; e++) b[j][e] = (_Float16)(fill * (0.21f + 0.002f * ((lane * 5 + j * 11 + e * 3) % 89)) * ((lane + e + j) & 2 ? 1.f : -1.f));
+    const long long t0 = clock64();
+    float keep = 0.f;
+    if (SHAPE == 16) {
+        f4 acc[8][5];
+        for (int i = 0; i < 8; i++) for (int j = 0; j < 5; j++) acc[i][j] = f4{0, 0, 0, 0};
+        for (int it = 0; it < iters; it++)
+            #pragma unroll
+            for (int i = 0; i < 8; i++)
+                #pragma unroll
+                for (int j = 0; j < 5; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], b[j], acc[i][j], 0, 0, 0);
+        for (int i = 0; i < 8; i++) for (int j = 0; j < 5; j++) keep += acc[i][j][0] + acc[i][j][3];
+    } else {
+        f16v acc[4][2];
+        for (int i = 0; i < 4; i++) for (int j = 0; j < 2; j++) for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
+        for (int it = 0; it < iters; it++)
+            #pragma unroll
+            for (int i = 0; i < 4; i++)
+                #pragma unroll
+                for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], b[j], acc[i][j], 0, 0, 0);
+        for (int i = 0; i < 4; i++) for (int j = 0; j < 2; j++) keep += acc[i][j][0] + acc[i][j][15];
+    }
+    const long long t1 = clock64();
+    if (threadIdx.x == 0 && blockIdx.x == 0) cyc[0] = t1 - t0;
+    if (keep == 12345.678f) out[threadIdx.x] = keep;
+}
+
+template <int SHAPE>
+static void run_clock(const char* name, float fill) {
+    float* out; long long* cyc; hipMalloc(&out, 4096); hipMalloc(&cyc, 8);
+    const int iters = SHAPE == 16 ? 20000 : 50000;
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int rep = 0; rep < 3; rep++) {
+        hipEventRecord(e0);
+        hipLaunchKernelGGL((mfma_clock<SHAPE>), dim3(256 * 4), dim3(512), 0, 0, out, cyc, iters, fill);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        long long c; hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost);
+        const double per_wave = SHAPE == 16 ? 2.0 * 16 * 16 * 32 * 40 : 2.0 * 32 * 32 * 16 * 8;
+        const double flop = per_wave * (double)iters * 8 * 256 * 4;
+        // block 0's wave runs 1/4 of the launch's wall time (4 blocks per CU run back to back): clock = its cycles / (ms / 4)
+        if (rep == 2) printf("%-52s %8.3f ms  %8.1f TFLOP/s   one-block cycles %lld (s_memtime ticks; 100 MHz reference clock on this part if << GHz)\n", name, ms, flop / ms * 1e-9, c);
+    }
+    hipFree(out); hipFree(cyc);
+}
+
 int main() {
+    run_clock<16>("16x16x32 f16, 8x5 acc, ZERO operands", 0.f);
+    run_clock<16>("16x16x32 f16, 8x5 acc, signed non-trivial operands", 1.f);
+    run_clock<32>("32x32x16 f16, 4x2 acc, ZERO operands", 0.f);
+    run_clock<32>("32x32x16 f16, 4x2 acc, signed non-trivial operands", 1.f);
     run<8, 5, false>("regs only 8x5 acc (conv 8-wave shape)", 8, 256);
     run<8, 5, false>("regs only 8x5 acc, 2 WG/CU", 8, 512);
     run<4, 5, false, 16>("regs only 4x5 acc (16-wave shape)", 16, 256);

@@ -262,15 +262,17 @@ def test_multi_attribute_targets_product_vs_oracle(exp):
     probs = [torch.softmax(torch.randn(n, k, generator=g) * 2, -1) for _, _, k in attrs]
     for p in probs:
         p[5] = -1  # a missing face
-    rp = prod(probs, cdfs, 25, torch.Generator().manual_seed(9), None, asym)
+    rp, tp_p = prod(probs, cdfs, 25, torch.Generator().manual_seed(9), None, asym, return_plan=True)
     (ro, tp) = orc(probs, cdfs, 25, torch.Generator().manual_seed(9), asym)
     assert abs(float(tp.sum(dim=1).max()) - 1) < 1e-5
+    # identical Monte-Carlo draws, two independent solvers (assignment on the sink-replicated costs vs the transport LP): with
+    # generic (random, tie-free) costs the optimal plan of every draw is unique, so the AVERAGED PLANS agree to rounding -- and with
+    # them every marginal, target and uncertainty (compare tp itself, not loose uncertainties)
+    assert tp_p.shape == tp.shape and float((tp_p - tp).abs().max()) < 1e-6, float((tp_p - tp).abs().max())
     for (tpd, upd), (tor, uor) in zip(rp, ro):
         assert tpd[5] == -1 and tor[5] == -1
-        # identical Monte-Carlo draws; the two solvers may break cost ties differently -> compare the averaged plan
-        assert np.abs(upd.numpy() - uor.numpy()).max() < 0.1
-        confident = (uor < 0.35) & (uor >= 0)
-        assert torch.equal(tpd[confident], tor[confident])
+        assert np.abs(upd.numpy() - uor.numpy()).max() < 1e-5
+        assert torch.equal(tpd, tor)
 
 
 # ------------------------------------------------------------------------------------------ CLI of exp-3/4/5, lr schedule, checkpoints

@@ -736,3 +736,190 @@ def test_train_driver_runs_full_loss(tmp_path, experiment):
         assert r["grad_is_finite"] and r["loss_CLIP"] is not None and r["loss_DINO"] is not None and r["loss_face"] is not None
         assert 0 <= r["loss_CLIP"] < 2 and 0 <= r["loss_face"] < 2
     assert tr.clf.num_classes == (80 if experiment == "exp-1" else 8)
+
+
+# ------------------------------------------------------------------------------------------ BASELINE configs[2] / configs[3] at test size
+def _oracle_multi_targets(om, tokens, noises, S, attrs, cdfs, asym, seed, thr):
+    """The oracle's own R1 -> classifier -> Monte-Carlo OT (LP solver) targets (exp-3 :2016-2025, exp-4 :2157-2170)."""
+    from oracle import fair_step as fs
+    with torch.no_grad():
+        img = fs.generate_image_no_gradient(tokens, noises, S, om["text_encoder"], om["unet"], om["vae"], om["scheduler"])
+        ind, _, chips = fs.SyntheticFaceProvider(64)(img)
+        lo = om["classifier"](chips[ind])
+    probs = []
+    for _, c0, k in attrs:
+        p = torch.ones(noises.shape[0], k) * (-1)
+        p[ind] = torch.softmax(lo[:, c0:c0 + k], dim=-1)
+        probs.append(p)
+    res, tp = fs.generate_dynamic_targets_multi(probs, cdfs, 100, torch.Generator().manual_seed(seed), asym)
+    out = {}
+    for (name, _, _), (t, u) in zip(attrs, res):
+        t = t.clone()
+        t[u > thr] = -1
+        out[name] = t
+    return out, img, probs
+
+
+@pytest.mark.parametrize("experiment,mode", [("exp-3", "both"), ("exp-4", "unet")])
+def test_full_step_multi_attribute_with_oracle_ot_targets(dev, experiment, mode):
+    """BASELINE configs[2] (exp-3, LoRA on text encoder AND U-Net) and configs[3] (exp-4: gender x race x age, 8-logit head, 75/25 age
+    prior, asymmetric age cost; exp-4-debias-gender-race-age/1-main-debias.py:1477-1615, :2236-2283) at test size.
+    The ORACLE derives the OT targets itself (own R1, own classifier pass, transport LP); the product must arrive at the same targets
+    from its own R1 with the same Monte-Carlo stream (assignment solver, worker thread under R2); both sides then train on them:
+    per-attribute CE terms and the LoRA gradients of every trained bank."""
+    from oracle import fair_step as fs
+    from finetune_fair_diffusion_amd.fairness import EXPERIMENT_ATTRS
+    from finetune_fair_diffusion_amd.step import FairnessTrainer
+    ncls, attrs, cdfs, asym = EXPERIMENT_ATTRS[experiment]
+    tu, tt = True, mode == "both"
+    om = U.oracle_models(train_unet=tu, train_te=tt, lora_up_std=0.05, num_classes=ncls)
+    pm = U.product_models(om["sds"], dev, train_unet=tu, train_te=tt, num_classes=ncls)
+    thr = 0.7
+    args = U.make_args(train_unet=tu, train_text_encoder=tt, uncertainty_threshold=thr)
+    tokens = U.tiny_tokens()
+    B, S = 5, 3
+    noises = torch.randn(B, 4, 32, 32, generator=torch.Generator().manual_seed(17))
+    tg_o, img_o, probs_o = _oracle_multi_targets(om, tokens, noises, S, attrs, cdfs, asym, seed=4321, thr=thr)
+    tr = FairnessTrainer(args, pm["text_encoder"], pm["unet"], pm["vae"], pm["classifier"], pm["scheduler"], eval_text_encoder=pm["eval_text_encoder"],
+                         eval_unet=pm["eval_unet"], experiment=experiment, device=dev)
+    tr.target_rng.manual_seed(4321)
+    grads = {}
+
+    def spy(N_backward, apply_=True):
+        for i, b in enumerate(tr.banks):
+            grads[i] = b.grad.clone()
+        return True
+    tr.sync_and_update = spy
+    out = tr.train_step(tokens, noises, S)
+    check(f"{experiment} R1 images", out["images"], img_o, 3e-2)
+    tg = out["targets_by_attr"]
+    assert list(tg) == [a[0] for a in attrs]
+    for name in tg:
+        assert tg[name].tolist() == tg_o[name].tolist(), (name, tg[name], tg_o[name])
+    assert sum(int((t != -1).sum()) for t in tg_o.values()) >= 4          # the CE terms are exercised
+    print(f"{experiment}: OT host solve {tr.last_ot_ms[0]:.1f} ms, main thread waited {tr.last_ot_ms[1]:.2f} ms;  targets",
+          {k: v.tolist() for k, v in tg_o.items()})
+    models_o = dict(text_encoder=om["text_encoder"], unet=om["unet"], vae=om["vae"], classifier=om["classifier"], scheduler=om["scheduler"])
+    for p in om["lora_params"]:
+        p.grad = None
+    ref = fs.fairness_step_multi(models_o, tokens, noises, S, dict(train_GPU_batch_size=3, size_face=64), attrs, tg_o)
+    for name, _, _ in attrs:
+        check(f"{experiment} loss_fair_{name}", out["loss_fair_by_attr"][name], ref["losses"][name], 2e-2)
+    banks = iter(range(len(tr.banks)))
+    i = next(banks)
+    names = list(om["unet_lora_layers"].state_dict().keys())
+    refg = torch.cat([p.grad.flatten() for p in om["unet_lora_layers"].parameters()])
+    got = torch.cat([tr.banks[i].view(n, grads[i]).flatten() for n in names])
+    cos = float(F.cosine_similarity(got.cpu().double(), refg.double(), dim=0))
+    print(f"cosine({experiment} unet grads) =", cos, " norm ratio =", float(got.norm().cpu() / refg.norm()))
+    assert cos > 0.97 and 0.8 < float(got.norm().cpu() / refg.norm()) < 1.25
+    if tt:
+        i = next(banks)
+        names = list(om["te_lora_named"].keys())
+        refg = torch.cat([om["te_lora_named"][n].grad.flatten() for n in names])
+        got = torch.cat([tr.banks[i].view(n, grads[i]).flatten() for n in names])
+        cos = float(F.cosine_similarity(got.cpu().double(), refg.double(), dim=0))
+        print(f"cosine({experiment} text-encoder grads) =", cos, " norm ratio =", float(got.norm().cpu() / refg.norm()))
+        assert cos > 0.97 and 0.8 < float(got.norm().cpu() / refg.norm()) < 1.25
+
+
+def test_generate_image_matches_oracle_at_30_steps(dev):
+    """gen-images.py:112-175 (``generate_image``, 30 DPM-Solver++ steps, guidance 7.5) with exported U-Net + text-encoder LoRA vs
+    ``oracle.generate_image_no_gradient``: float images and the uint8 pixels the consumer writes (VERDICT r1 hygiene item)."""
+    from oracle import fair_step as fs
+    from finetune_fair_diffusion_amd import generate
+    from finetune_fair_diffusion_amd.step import FairnessTrainer
+    om = U.oracle_models(train_unet=True, train_te=True, lora_up_std=0.05)
+    pm = U.product_models(om["sds"], dev, train_unet=True, train_te=True)
+    tr = FairnessTrainer(U.make_args(train_unet=True, train_text_encoder=True), pm["text_encoder"], pm["unet"], pm["vae"], pm["classifier"], pm["scheduler"],
+                         eval_text_encoder=pm["eval_text_encoder"], eval_unet=pm["eval_unet"], device=dev)
+    tokens = U.tiny_tokens()
+    noises = torch.randn(3, 4, 32, 32, generator=torch.Generator().manual_seed(1997))
+    ref = fs.generate_image_no_gradient(tokens, noises, 30, om["text_encoder"], om["unet"], om["vae"], om["scheduler"], 7.5)
+    img = generate.generate_image(tr, tokens, noises, 30)
+    check("generate_image, S=30", img, ref, 3e-2)
+    a = generate.to_uint8_hwc(img).astype(np.int32)
+    b = (ref * 0.5 + 0.5).mul(255).to(torch.uint8).permute(0, 2, 3, 1).numpy().astype(np.int32)
+    print("uint8 pixels: mean |diff| =", float(np.abs(a - b).mean()), " max =", int(np.abs(a - b).max()))
+    assert np.abs(a - b).mean() < 1.0 and np.abs(a - b).max() <= 8
+
+
+# ------------------------------------------------------------------------------------------ smooth-head end-to-end chain (VERDICT r1 weak 3)
+class _SmoothHeadProduct:
+    """Test double with the classifier's contract (num_classes, forward(chips, record), backward(d_logits, gscale), _ctx) but NO
+    discontinuity: logits = W2 hardswish(W1 vec(chips) + b1) + b2, on the product's own kernels through the C-ABI (MFMA GEMMs,
+    fd_act_fwd/bwd).  With it the only non-smooth op left between the LoRA weights and the loss is images.clamp(-1, 1)."""
+
+    def __init__(self, w1, b1, w2, b2, dev):
+        self.w1, self.w2 = w1.to(dev).half().contiguous(), w2.to(dev).half().contiguous()
+        self.w1T, self.w2T = self.w1.t().contiguous(), self.w2.t().contiguous()
+        self.b1, self.b2 = b1.to(dev).float().contiguous(), b2.to(dev).float().contiguous()
+        self.num_classes, self._ctx = w2.shape[0], None
+
+    def forward(self, chips, record=False):
+        from finetune_fair_diffusion_amd import ops
+        n = chips.shape[0]
+        x = torch.zeros(((n + 7) // 8 * 8, self.w1.shape[1]), dtype=torch.float16, device=chips.device)
+        x[:n] = chips.reshape(n, -1)
+        z1 = ops.gemm(x, self.w1, bias=self.b1)
+        h = ops.act_fwd(z1, "hardswish")
+        logits = ops.gemm(h, self.w2, bias=self.b2, out_dtype=torch.float32)
+        if record:
+            self._ctx = dict(z1=z1, n=n, shape=chips.shape)
+        return logits[:n]
+
+    def backward(self, d_logits, gscale):
+        from finetune_fair_diffusion_amd import ops
+        c = self._ctx
+        d = torch.zeros((c["z1"].shape[0], self.num_classes), dtype=torch.float32, device=d_logits.device)
+        d[:c["n"]] = d_logits
+        dh = ops.gemm(ops.to_f16(d.contiguous(), gscale), self.w2T)
+        dz = ops.act_bwd(c["z1"], dh, "hardswish")
+        dx = ops.gemm(dz, self.w1T, out_dtype=torch.float32, alpha=1.0 / gscale)
+        self._ctx = None
+        return dx[:c["n"]].reshape(c["shape"]).contiguous()
+
+
+def test_full_step_smooth_head_pins_unet_chain_end_to_end(dev):
+    """The complete step (R1, targets, R2, R3 backward through VAE + truncated 4-step chain into the U-Net LoRA) with a SMOOTH
+    classifier head: without the ReLU mask flips of the random-weight MobileNetV3 the end-to-end LoRA gradient must match the
+    oracle's autograd to 1e-2 of its max-norm and loss_fair to 1e-3 (north_star: 'loss ... within 1e-3')."""
+    from oracle import fair_step as fs
+    from finetune_fair_diffusion_amd.step import FairnessTrainer
+    om = U.oracle_models(train_unet=True, train_te=False, lora_up_std=0.05)
+    pm = U.product_models(om["sds"], dev, train_unet=True, train_te=False)
+    g = torch.Generator().manual_seed(99)
+    K, Hd, C = 3 * 64 * 64, 256, 80
+    w1 = (torch.randn(Hd, K, generator=g) * (2.0 / K ** 0.5)).half().float()
+    b1 = torch.randn(Hd, generator=g) * 0.1
+    w2 = (torch.randn(C, Hd, generator=g) * (2.0 / Hd ** 0.5)).half().float()
+    b2 = torch.randn(C, generator=g) * 0.1
+    head_o = torch.nn.Sequential(torch.nn.Flatten(), torch.nn.Linear(K, Hd), torch.nn.Hardswish(), torch.nn.Linear(Hd, C)).requires_grad_(False)
+    head_o[1].weight.copy_(w1); head_o[1].bias.copy_(b1); head_o[3].weight.copy_(w2); head_o[3].bias.copy_(b2)
+    head_p = _SmoothHeadProduct(w1, b1, w2, b2, dev)
+    args = U.make_args(train_unet=True, train_text_encoder=False, uncertainty_threshold=0.7)
+    tokens = U.tiny_tokens()
+    B, S = 4, 4
+    noises = torch.randn(B, 4, 32, 32, generator=torch.Generator().manual_seed(5991))
+    models_o = dict(text_encoder=om["text_encoder"], unet=om["unet"], vae=om["vae"], classifier=head_o, scheduler=om["scheduler"],
+                    eval_text_encoder=om["text_encoder"], eval_unet=om["eval_unet"])
+    for p in om["lora_params"]:
+        p.grad = None
+    ref = fs.fairness_step(models_o, tokens, noises, S, dict(train_GPU_batch_size=3, val_GPU_batch_size=8, uncertainty_threshold=0.7, factor2=0.2,
+                                                             size_face=64))
+    tr = FairnessTrainer(args, pm["text_encoder"], pm["unet"], pm["vae"], head_p, pm["scheduler"], eval_unet=pm["eval_unet"], device=dev)
+    grads = {}
+    tr.sync_and_update = lambda nb, apply=True: (grads.__setitem__(0, tr.banks[0].grad.clone()), True)[1]
+    out = tr.train_step(tokens, noises, S)
+    assert out["targets"].tolist() == ref["targets"].tolist() and int((ref["targets"] != -1).sum()) >= 3
+    check("smooth head: probs", out["probs"], ref["probs"], 5e-3)
+    err = float((out["loss_fair"] - ref["loss_fair"]).abs().max())
+    print("smooth head: loss_fair product", out["loss_fair"].tolist(), "oracle", ref["loss_fair"].tolist(), " max |err| =", err)
+    assert err <= 1e-3
+    names = list(om["unet_lora_layers"].state_dict().keys())
+    refg = torch.cat([p.grad.flatten() for p in om["unet_lora_layers"].parameters()])
+    got = torch.cat([tr.banks[0].view(n, grads[0]).flatten() for n in names])
+    cos = float(F.cosine_similarity(got.cpu().double(), refg.double(), dim=0))
+    print("smooth head: cosine(unet LoRA grads) =", cos, " norm ratio =", float(got.norm().cpu() / refg.norm()))
+    check("smooth head: end-to-end unet LoRA gradient (max-norm)", got, refg, 1e-2)
+    assert cos > 0.9995

@@ -102,7 +102,9 @@ def test_sd15_unet_cfg_pair_forward_and_lora_gradient(full, dev):
     check("SD15 unet eps (CFG-pair prefix path)", eps_pair, eps_o, 2e-2)
     eps_p = unet_p.forward_step(x.to(dev), 0, record=True).view(2, 4, 64, 64)
     check("SD15 unet eps (duplicated batch)", eps_p, eps_o, 2e-2)
-    assert torch.equal(eps_pair, eps_p)
+    # N = 1 vs the duplicated batch of 2 select different GEMM tiles at this size (M = 4096 vs 8192 rows): equal to fp16 rounding, not
+    # bitwise (bit-identity holds for equal batch sizes: test_unet_cfg_pair_prefix_sharing, test_r1_r3_forward_bit_identical...)
+    check("SD15 unet eps: prefix path vs duplicated batch", eps_pair, eps_p, 4e-3)
     g = torch.randn(eps_o.shape, generator=torch.Generator().manual_seed(2))
     for p in om["lora_params"]:
         p.grad = None
