@@ -60,6 +60,7 @@ def main():
     ap.add_argument("--force_collectives", action="store_true", help="initialise the process group and run the step's collectives even at world size 1 (RCCL smoke on a one-GPU box)")
     ap.add_argument("--experiment", default="exp-1", choices=["exp-1", "exp-3", "exp-4", "exp-5"], help="exp-3/4/5: multi-attribute head + OT targets (not the headline config)")
     ap.add_argument("--no_regularisers", action="store_true", help="drop the CLIP/DINOv2 image-semantics and SFNet face-realism terms (loss_fair only)")
+    ap.add_argument("--dump_shapes", default=None, help="CSV of the roofline pass's GEMM/conv launches grouped by kernel and shape")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--cpu_baseline_full", action="store_true", help="cfg1-size oracle step (B=2, S=4), warm-up + median of 3 (~15 min)")
     ap.add_argument("--no_roofline", action="store_true")
@@ -157,6 +158,11 @@ def main():
         tr.timers = True
         one_step()
         summ = ops.TIMER.summary()
+        if a.dump_shapes:
+            with open(a.dump_shapes, "w") as f:
+                f.write("kernel,M,N,K,K2,conv_mode,act,residual,split,launches,total_ms,avg_us,tflops\n")
+                for r in ops.TIMER.shape_table():
+                    f.write(",".join(['"%s"' % r[0]] + [str(v) for v in r[1:10]] + ["%.3f" % r[10], "%.2f" % r[11], "%.1f" % r[12]]) + "\n")
         ops.TIMER = None
         phases = tr.phase_ms()
         tr.timers = None

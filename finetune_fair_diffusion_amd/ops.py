@@ -51,6 +51,7 @@ class OpTimer:
     (torch's current stream); used by bench.py's roofline pass, never inside the timed region."""
 
     def __init__(self):
+        self.shapes = []   # (M, N, K, K2, conv_mode or -1, act, has_residual, split) per record
         self.records = []  # (rocprof kernel name, flops, algorithmic bytes, start_event, end_event, is_split_k)
 
     def summary(self):
@@ -60,7 +61,16 @@ class OpTimer:
             ms = a.elapsed_time(b)
             e = agg.setdefault(variant, [0, 0.0, 0.0, 0.0, 0])
             e[0] += 1; e[1] += flops; e[2] += ms; e[3] += nbytes; e[4] += int(split)
+        self.by_shape = {}
+        for (variant, flops, nbytes, a, b, split), shp in zip(self.records, self.shapes):
+            e = self.by_shape.setdefault((variant,) + shp, [0, 0.0, 0.0])
+            e[0] += 1; e[1] += flops; e[2] += a.elapsed_time(b)
         return {k: dict(launches=v[0], flops=v[1], ms=v[2], bytes=v[3], splitk_launches=v[4]) for k, v in agg.items()}
+
+    def shape_table(self):
+        """[(kernel, M, N, K, K2, conv_mode, act, residual, split, launches, total ms, avg us, TFLOP/s)] sorted by total time."""
+        rows = [k + (v[0], v[2], 1e3 * v[2] / v[0], v[1] / (v[2] * 1e-3) / 1e12) for k, v in self.by_shape.items()]
+        return sorted(rows, key=lambda r: -r[10])
 
 
 TIMER = None
@@ -86,6 +96,7 @@ def _gemm_call(d, conv):
     # keyed by the rocprof kernel name: split-K and plain launches of one instantiation are ONE entry (the events bracket the
     # splitk_reduce_kernel of a split launch together with its GEMM)
     TIMER.records.append((buf.value.decode(), flops, nbytes, a, b, split > 1))
+    TIMER.shapes.append((d.M, d.N, d.K, d.K2, d.conv_mode if conv else -1, int(d.act), int(bool(d.residual)), split))
 
 
 def _chk(t, dtype=F16):

@@ -134,11 +134,23 @@ def test_sd15_vae_decode_512_forward_and_dz(full, dev):
     img_p = pm["vae"].decode_images(z.to(dev), record=True)
     assert img_p.shape == (1, 3, 512, 512)
     check("SD15 vae images 512^2", img_p, img_o, 2e-2)
-    g = torch.randn(img_o.shape, generator=torch.Generator().manual_seed(5)) * 1e-3
-    (img_o * g).sum().backward()
+    # (i) a smooth upstream gradient pins the chain tightly; (ii) a white-noise one is dominated by the clamp(-1,1) mask: 11.7 % of this
+    # random-weight decoder's pixels saturate, the ones within fp16 rounding of +-1 pass or block their (uncorrelated) gradient
+    # differently in fp16 and fp32 -> compared by direction and norm (measured: cosine 0.9997, ratio 0.9995, max-norm 0.11)
+    gs_ = (torch.linspace(-1, 1, 512)[None, None, :, None] * torch.linspace(1, -1, 512)[None, None, None, :]).expand(1, 3, 512, 512).contiguous() * 1e-3
+    (img_o * gs_).sum().backward()
     print(f"oracle VAE decode + backward: {time.time() - t0:.1f} s")
+    dz = pm["vae"].backward_images(gs_.to(dev), 2.0 ** 14)
+    check("SD15 vae dz (smooth upstream gradient)", dz, zr.grad, 2e-2)
+    zr.grad = None
+    g = torch.randn(img_o.shape, generator=torch.Generator().manual_seed(5)) * 1e-3
+    (om["vae"].decode(zr).sample.clamp(-1, 1) * g).sum().backward()
+    pm["vae"].decode_images(z.to(dev), record=True)
     dz = pm["vae"].backward_images(g.to(dev), 2.0 ** 14)
-    check("SD15 vae dz", dz, zr.grad, 5e-2)
+    cos = float(F.cosine_similarity(dz.flatten().cpu().double(), zr.grad.flatten().double(), dim=0))
+    ratio = float(dz.norm().cpu() / zr.grad.norm())
+    print(f"SD15 vae dz (white-noise upstream gradient): cosine {cos:.5f}  norm ratio {ratio:.4f}  rel max err {relerr(dz, zr.grad):.3e}")
+    assert cos > 0.999 and 0.99 < ratio < 1.01
 
 
 def test_sd15_full_step_b2_s2(full, dev):
