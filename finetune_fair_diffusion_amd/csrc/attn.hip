@@ -15,7 +15,7 @@
 
 #define LOG2E 1.4426950408889634f
 
-__device__ __forceinline__ f32x16 mfma32(f16x8 a, f16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x16 mfma32(f16x8 a, f16x8 b, f32x16 c) { return FD_MFMA_32x32x16(a, b, c); }
 __device__ __forceinline__ f32x16 zero16() {
     f32x16 z;
 #pragma unroll

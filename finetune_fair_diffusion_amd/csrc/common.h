@@ -4,7 +4,20 @@
 #include <stdint.h>
 #include "../../include/fairdiff_hip.h"
 
+// The working dtype "wd" of the path: fp16 in the reference's configs 1-4 (`mixed_precision fp16`), bf16 in BASELINE
+// configs[4].  One source, two libraries with the same C-ABI: libfairdiff_hip.so (fp16) and libfairdiff_hip_bf16.so (-DFD_BF16).
+// ``f16`` is the name of that 16-bit storage type throughout the kernels; arithmetic is always fp32.
+#ifdef FD_BF16
+typedef __bf16 f16;
+#define FD_MFMA_16x16x32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
+#define FD_MFMA_32x32x16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
+#define FD_WD_NAME "bf16"
+#else
 typedef _Float16 f16;
+#define FD_MFMA_16x16x32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0)
+#define FD_MFMA_32x32x16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
+#define FD_WD_NAME "fp16"
+#endif
 typedef f16 f16x2 __attribute__((ext_vector_type(2)));
 typedef f16 f16x4 __attribute__((ext_vector_type(4)));
 typedef f16 f16x8 __attribute__((ext_vector_type(8)));

@@ -389,7 +389,7 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(fd_gemm_desc p, int ntm,
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
+                acc[i][j] = FD_MFMA_16x16x32(bf[j], af[i], acc[i][j]);
     }
 
     const bool lds_epi = p.out_dtype == FD_OUT_F16 && (p.N & 7) == 0 && (p.ldc & 7) == 0 && (!p.residual || (p.ldr & 7) == 0) &&
@@ -460,8 +460,8 @@ __device__ __forceinline__ void mma_k32(f32x4 (&acc)[TM][TN], uint32_t a_addr, u
         tie(ring[s % R]);
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
-            if constexpr (BRES) acc[s][r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(res[r], ring[s % R], acc[s][r], 0, 0, 0);
-            else acc[r][s] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ring[s % R], res[r], acc[r][s], 0, 0, 0);
+            if constexpr (BRES) acc[s][r] = FD_MFMA_16x16x32(res[r], ring[s % R], acc[s][r]);
+            else acc[r][s] = FD_MFMA_16x16x32(ring[s % R], res[r], acc[r][s]);
         }
         __builtin_amdgcn_sched_barrier(0);
     });
@@ -706,7 +706,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_big_kernel(fd_gemm_desc p
                         f16x8 a2 = a1;
                         if (i + 2 < TM) a2 = *(const f16x8*)(Ab + (i + 2) * 16 * 64 + slot);
 #pragma unroll
-                        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], a0, acc[i][j], 0, 0, 0);
+                        for (int j = 0; j < TN; ++j) acc[i][j] = FD_MFMA_16x16x32(bf[j], a0, acc[i][j]);
                         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                         __builtin_amdgcn_sched_group_barrier(0x008, TN, 0);
                         a0 = a1;
@@ -723,7 +723,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_big_kernel(fd_gemm_desc p
                         f16x8 b2 = b1;
                         if (j + 2 < TN) b2 = *(const f16x8*)(Bb + (j + 2) * 16 * 64 + slot);
 #pragma unroll
-                        for (int i = 0; i < TM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b0, af[i], acc[i][j], 0, 0, 0);
+                        for (int i = 0; i < TM; ++i) acc[i][j] = FD_MFMA_16x16x32(b0, af[i], acc[i][j]);
                         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                         __builtin_amdgcn_sched_group_barrier(0x008, TM, 0);
                         b0 = b1;
@@ -872,7 +872,7 @@ __global__ __launch_bounds__(KS * 64) void gemm_skinny_kernel(fd_gemm_desc p) {
                     f16x8 bf = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
                     if (n < p.N) bf = *(const f16x8*)(B + (int64_t)n * p.ldb + (int64_t)(k0 + c) * 32);   // one B fragment feeds RT row tiles
 #pragma unroll
-                    for (int r = 0; r < RT; ++r) acc[r][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf, af[r][c], acc[r][j], 0, 0, 0);
+                    for (int r = 0; r < RT; ++r) acc[r][j] = FD_MFMA_16x16x32(bf, af[r][c], acc[r][j]);
                 }
             }
         }

@@ -22,4 +22,5 @@ int fd_check_launch(const char* what) {
 }
 
 extern "C" const char* fd_last_error(void) { return g_err; }
-extern "C" int fd_version(void) { return 1; }
+extern "C" int fd_version(void) { return 2; }
+extern "C" const char* fd_working_dtype(void) { return FD_WD_NAME; }

@@ -58,8 +58,10 @@ def generate_image(tr, tokens, noises, num_denoising_steps=30):
 def main(args, cfgs=None):
     if args.load_prefix_embedding_from:
         raise NotImplementedError("--load_prefix_embedding_from (exp-2 prefix-token tuning) is outside this build's scope")
-    if args.mixed_precision != "fp16":
-        raise NotImplementedError("this build computes in fp16 (the reference's default); bf16/fp32 inference is not built")
+    from .lib import WORKING_DTYPE
+    if args.mixed_precision != WORKING_DTYPE:
+        raise NotImplementedError(f"--mixed_precision {args.mixed_precision}: this process runs the {WORKING_DTYPE} library (fp16 and bf16 are "
+                                  "built; select with FD_DTYPE or the flag on the command line; fp32 inference is not built)")
     if not torch.cuda.is_available():
         raise RuntimeError("finetune_fair_diffusion_amd.generate needs an MI355X (HIP device); there is no CPU path")
     from PIL import Image

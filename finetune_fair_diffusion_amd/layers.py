@@ -8,7 +8,7 @@ import torch
 
 from . import ops
 
-F16, F32 = torch.float16, torch.float32
+F16, F32 = ops.F16, ops.F32
 
 
 class Linear:

@@ -9,7 +9,12 @@ import os
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("FAIRDIFF_LIB") or os.path.join(_HERE, "libfairdiff_hip.so")   # override: A/B builds of the same ABI
+# The 16-bit working dtype of the process ("wd" of SURVEY 8a) is fixed before the package is imported: FD_DTYPE=fp16 (default; the
+# reference's mixed_precision fp16) or bf16 (BASELINE configs[4]).  It selects the library -- same sources, same C-ABI, built twice
+# (csrc/Makefile) -- and ``ops.F16``, the torch dtype every activation / frozen weight is held in.
+WORKING_DTYPE = {"fp16": "fp16", "f16": "fp16", "half": "fp16", "bf16": "bf16", "bfloat16": "bf16"}[os.environ.get("FD_DTYPE", "fp16").lower()]
+_DEFAULT_LIB = "libfairdiff_hip.so" if WORKING_DTYPE == "fp16" else "libfairdiff_hip_bf16.so"
+LIB_PATH = os.environ.get("FAIRDIFF_LIB") or os.path.join(_HERE, _DEFAULT_LIB)   # override: A/B builds of the same ABI
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "fairdiff_hip.h")
 
 
@@ -73,7 +78,15 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
         fn.restype = ret
         fn.argtypes = argtypes
+    built = lib.fd_working_dtype().decode()
+    if built != WORKING_DTYPE:
+        raise RuntimeError(f"{LIB_PATH} was built for {built} but this process runs with FD_DTYPE={WORKING_DTYPE}")
     return lib
+
+
+def torch_working_dtype():
+    import torch
+    return torch.float16 if WORKING_DTYPE == "fp16" else torch.bfloat16
 
 
 _lib = None

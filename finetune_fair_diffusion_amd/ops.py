@@ -12,7 +12,7 @@ from . import lib as _lib
 
 ACT = dict(none=0, silu=1, quick_gelu=2, gelu=3, relu=4, hardswish=5, hardsigmoid=6, geglu=7)
 CONV_NORMAL, CONV_STRIDE2, CONV_UP2, CONV_TRANS2 = 0, 1, 2, 3
-F16, F32 = torch.float16, torch.float32
+F16, F32 = _lib.torch_working_dtype(), torch.float32      # F16 = the 16-bit WORKING dtype (fp16, or bf16 under FD_DTYPE=bf16)
 
 
 def _stream():
@@ -467,6 +467,30 @@ def attn_bwd(q, k, v, o, do, lse, B, H, Tq, Tk, d, kv_div=1, scale=None, kt=None
     _call("fd_attn_bwd_dkdv", _p(q), _p(qt), _p(k), _p(v), _p(do), _p(dot), _p(lse), _p(Dd), _p(dk), _p(dv), B, H, Tq, Tk, Tkr, d, kv_div, scale,
           _stream())
     return dq, dk, dv
+
+
+# FP8 (e4m3) self-attention forward -- BASELINE configs[4]; switched on by FD_FP8_ATTN=1 / bench.py --fp8_attn (not the headline config)
+FP8_ATTN = os.environ.get("FD_FP8_ATTN") is not None
+
+
+def fp8_attn_ok(T, d):
+    return FP8_ATTN and T % 64 == 0 and d in (40, 80, 160)
+
+
+def attn_fwd_fp8(q, k, v, B, H, T, d, scale=None, need_lse=False):
+    """Self-attention forward with e4m3 QK^T / PV (per-row Q scale, per-64-key-tile K and V scales); o, lse as ``attn_fwd``."""
+    DK8, DV8 = (d + 15) // 16 * 16, (d + 31) // 32 * 32
+    dev = q.device
+    k8 = torch.empty((B, H, T, DK8), dtype=torch.uint8, device=dev)
+    v8t = torch.empty((B, H, DV8, T), dtype=torch.uint8, device=dev)
+    sk = torch.empty((B, H, T // 64), dtype=F32, device=dev)
+    sv = torch.empty((B, H, T // 64), dtype=F32, device=dev)
+    _call("fd_attn_fp8_quant_kv", _p(_chk(k)), _p(_chk(v)), _p(k8), _p(v8t), _p(sk), _p(sv), B, H, T, d, _stream())
+    o = torch.empty_like(q)
+    lse = torch.empty((B, H, T), dtype=F32, device=dev) if need_lse else None
+    _call("fd_attn_fwd_fp8", _p(_chk(q)), _p(k8), _p(v8t), _p(sk), _p(sv), _p(o), _p(lse), B, H, T, d, scale if scale is not None else d ** -0.5,
+          _stream())
+    return (o, lse) if need_lse else o
 
 
 # ----------------------------------------------------------------------------- LoRA / scheduler / optimizer

@@ -125,8 +125,11 @@ class TransformerBlock:
         else:
             t1 = None
             q, k, v = ops.gemm(n1, self.q1.w), ops.gemm(n1, self.k1.w), ops.gemm(n1, self.v1.w)
-        vt = ops.transpose_btc(v, B, HW, C)
-        o, lse = ops.attn_fwd(q, k, vt, B, h, HW, HW, d, 1, need_lse=True)
+        if ops.fp8_attn_ok(HW, d):       # BASELINE configs[4]: e4m3 QK^T / PV in self-attention (the backward stays in the working dtype)
+            o, lse = ops.attn_fwd_fp8(q, k, v, B, h, HW, d, need_lse=True)
+        else:
+            vt = ops.transpose_btc(v, B, HW, C)
+            o, lse = ops.attn_fwd(q, k, vt, B, h, HW, HW, d, 1, need_lse=True)
         h1, to1 = lora_linear_fwd(o, self.o1, l1.out if l1 else None, residual=h0)
         n2, ln2 = ops.layernorm(h1, self.ln2.gamma, self.ln2.beta, 1e-5, save_stats=True)
         l2 = self.lora2

@@ -42,6 +42,9 @@ enum { FD_CONV_NORMAL = 0, FD_CONV_STRIDE2 = 1, FD_CONV_UP2 = 2, FD_CONV_TRANS2 
 
 const char* fd_last_error(void);
 int fd_version(void);
+/* "fp16" (libfairdiff_hip.so: the reference's mixed_precision fp16, configs 1-4) or "bf16" (libfairdiff_hip_bf16.so, built from the same
+ * sources with -DFD_BF16: BASELINE configs[4]).  Every "fp16" in the prototypes below means this 16-bit working dtype. */
+const char* fd_working_dtype(void);
 
 /* ---- MFMA GEMM  C[M,N] = act(alpha * (A[M,K] . B[N,K]^T + A2[M,K2] . B2[N,K2]^T) + bias + rowbias) + residual
  * Replaces torch.nn.Linear / 1x1 Conv2d inside diffusers Attention/FeedForward/Transformer2DModel/
@@ -138,6 +141,17 @@ int fd_attn_bwd_dq(const void* q, const void* k, const void* v, const void* kt, 
 int fd_attn_bwd_dkdv(const void* q, const void* qt, const void* k, const void* v, const void* d_o, const void* d_ot,
                      const float* lse, const float* D, void* dk, void* dv, int B, int H, int Tq, int Tk, int Tkr, int d,
                      int kv_div, float scale, void* stream);
+
+/* ---- FP8 (OCP e4m3fn) self-attention forward: BASELINE configs[4] "bf16 + MFMA fp8 attention" (per-tile scaled QK^T / PV,
+ * self-attention only).  Same reference op as fd_attn_fwd for the attn1 layers; the reference itself only ran fp16 (:401-405).
+ * fd_attn_fp8_quant_kv: k, v [B,T,H*d] (working dtype) -> k8 [B,H,T,DK8] (DK8 = d rounded up to 16), v8t [B,H,DV8,T] (DV8 = d rounded
+ * up to 32) e4m3 bytes, zero padded, with one dequantisation scale per (b, h, 64-key tile): sk, sv [B,H,T/64] fp32 (= amax / 448).
+ * fd_attn_fwd_fp8: q [B,T,H*d] (quantised in registers, one scale per query row), both contractions on v_mfma_f32_32x32x16_fp8_fp8,
+ * fp32 softmax statistics; o [B,T,H*d] working dtype and lse [B,H,T] exactly as fd_attn_fwd (the backward kernels consume them).
+ * T % 64 == 0, d in {40, 80, 160}.                                                                                               */
+int fd_attn_fp8_quant_kv(const void* k, const void* v, void* k8, void* v8t, float* sk, float* sv, int B, int H, int T, int d, void* stream);
+int fd_attn_fwd_fp8(const void* q, const void* k8, const void* v8t, const float* sk, const float* sv, void* o, float* lse, int B, int H,
+                    int T, int d, float scale, void* stream);
 
 /* ---- masked attention of the CLIP text encoder (transformers CLIPAttention; reference call sites :1011-1014, :1078-1081).
  * q,k,v,o: [B,T,H*d] fp16, T<=128, d<=128; key_valid [B,T] int32 or NULL; P [B,H,T,T] fp32 (saved probabilities) or NULL */

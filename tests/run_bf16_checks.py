@@ -1,0 +1,186 @@
+"""bf16 working-dtype checks (BASELINE configs[4]) -- run as a SCRIPT in its own process because the working dtype of a process is fixed
+at import (FD_DTYPE=bf16 selects libfairdiff_hip_bf16.so); tests/test_bf16_gpu.py launches it with and without FD_FP8_ATTN=1.
+
+Bands (bf16 has 8 significand bits against fp16's 11, i.e. 8x the rounding step; the reference itself never ran bf16):
+  kernels vs fp32 torch           2e-2 of max|ref|   (fp16 library: 2e-3 .. 5e-3)
+  tiny U-Net eps vs fp32 oracle   8e-2               (fp16: 2e-2);  LoRA gradients per family 2e-1 (fp16: 5e-2), cosine > 0.995
+  SD-v1.5-size U-Net eps          8e-2, with FD_FP8_ATTN=1 (e4m3 self-attention at all four levels) 1.2e-1
+  full tiny training step         images 1e-1, exact targets, loss_fair 5e-2, gradient cosine > 0.95
+"""
+import math
+import os
+import sys
+import time
+
+import torch
+import torch.nn.functional as F
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(HERE))
+assert os.environ.get("FD_DTYPE") == "bf16", "run with FD_DTYPE=bf16"
+import util_models as U  # noqa: E402
+from finetune_fair_diffusion_amd import lib, ops  # noqa: E402
+
+FP8 = os.environ.get("FD_FP8_ATTN") is not None
+dev = torch.device("cuda:0")
+assert lib.get().fd_working_dtype().decode() == "bf16" and ops.F16 == torch.bfloat16
+BF = torch.bfloat16
+
+
+def relerr(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-20))
+
+
+def check(name, a, b, tol):
+    e = relerr(a, b)
+    print(f"[bf16{'+fp8' if FP8 else ''}: {name}] rel max err {e:.3e} (tol {tol:.1e})")
+    assert math.isfinite(e) and e <= tol, f"{name}: {e} > {tol}"
+
+
+def rnd(*shape, seed, scale=1.0):
+    return (torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale).to(dev).to(BF)
+
+
+def kernels():
+    a, b = rnd(4096, 1280, seed=1), rnd(320, 1280, seed=2)
+    check("gemm 4096x320x1280", ops.gemm(a, b), a.float() @ b.float().t(), 1e-2)
+    a, b = rnd(65536, 320, seed=3), rnd(320, 320, seed=4)
+    bias = torch.randn(320, generator=torch.Generator().manual_seed(5)).to(dev)
+    res = rnd(65536, 320, seed=6)
+    check("gemm 65536x320x320 + bias + residual (256x320 tile)", ops.gemm(a, b, bias=bias, residual=res), a.float() @ b.float().t() + bias + res.float(), 1e-2)
+    x = rnd(2 * 32 * 32, 320, seed=7)
+    w = rnd(320, 9 * 320, seed=8, scale=0.02)
+    ref = F.conv2d(x.float().reshape(2, 32, 32, 320).permute(0, 3, 1, 2), w.float().reshape(320, 3, 3, 320).permute(0, 3, 1, 2), padding=1)
+    y, _, _ = ops.conv3x3(x, w, 2, 32, 32)
+    check("conv3x3 320->320 @32^2", y.reshape(2, 32, 32, 320).permute(0, 3, 1, 2), ref, 1e-2)
+    g, st = ops.groupnorm(x, None, 2, 1024, 32, 1e-5, torch.ones(320, device=dev), torch.zeros(320, device=dev), True)
+    check("groupnorm+silu", g.reshape(2, 1024, 320), F.silu(F.group_norm(x.float().reshape(2, 1024, 320).permute(0, 2, 1), 32, eps=1e-5)).permute(0, 2, 1), 2e-2)
+    n = ops.layernorm(x, torch.ones(320, device=dev), torch.zeros(320, device=dev))
+    check("layernorm", n, F.layer_norm(x.float(), (320,)), 2e-2)
+    B, H, T, d = 2, 8, 1024, 40
+    C = H * d
+    q, k, v = rnd(B, T, C, seed=11), rnd(B, T, C, seed=12), rnd(B, T, C, seed=13)
+    qr, kr, vr = (t.float().requires_grad_(True) for t in (q, k, v))
+    def sp(t):
+        return t.reshape(B, T, H, d).permute(0, 2, 1, 3)
+    s = sp(qr) @ sp(kr).transpose(-1, -2) * d ** -0.5
+    oref = (torch.softmax(s, -1) @ sp(vr)).permute(0, 2, 1, 3).reshape(B, T, C)
+    vt = ops.transpose_btc(v.reshape(B * T, C), B, T, C)
+    o, lse = ops.attn_fwd(q.reshape(B * T, C), k.reshape(B * T, C), vt, B, H, T, T, d, 1, need_lse=True)
+    check("attention fwd d=40", o.reshape(B, T, C), oref, 2e-2)
+    do = rnd(B, T, C, seed=14)
+    oref.backward(do.float())
+    dq, dk, dv = ops.attn_bwd(q.reshape(B * T, C), k.reshape(B * T, C), v.reshape(B * T, C), o, do.reshape(B * T, C), lse, B, H, T, T, d, 1)
+    check("attention dq", dq.reshape(B, T, C), qr.grad, 3e-2)
+    check("attention dk", dk.reshape(B, T, C), kr.grad, 3e-2)
+    check("attention dv", dv.reshape(B, T, C), vr.grad, 3e-2)
+    o8 = ops.attn_fwd_fp8(q.reshape(B * T, C), k.reshape(B * T, C), v.reshape(B * T, C), B, H, T, d)
+    check("fp8 attention fwd (bf16 in/out) vs fp32", o8.reshape(B, T, C), oref, 6e-2)
+    check("fp8 attention fwd vs the bf16 kernel", o8.reshape(B, T, C), o.reshape(B, T, C), 6e-2)
+
+
+def tiny_unet_and_step():
+    from oracle import fair_step as fs
+    from finetune_fair_diffusion_amd.step import FairnessTrainer
+    om = U.oracle_models(train_unet=True, train_te=True, lora_up_std=0.05)
+    # the oracle sees bf16-representable frozen weights (the reference casts the frozen models to the working dtype, :761-763)
+    for name in ("unet", "vae", "text_encoder", "classifier", "eval_unet", "eval_text_encoder"):
+        for p in om[name].parameters():
+            if not p.requires_grad:
+                p.data = p.data.to(BF).float()
+    sds = {k: ({n: (t.to(BF).float() if t.is_floating_point() and k in ("unet", "vae", "clip", "clf") else t) for n, t in sd.items()})
+           for k, sd in om["sds"].items()}
+    pm = U.product_models(sds, dev, train_unet=True, train_te=True)
+    tokens = U.tiny_tokens()
+    N = 2
+    with torch.no_grad():
+        enc_o = fs.encode_prompts(om["text_encoder"], *tokens, N)
+    x = torch.randn(2 * N, 4, 32, 32, generator=torch.Generator().manual_seed(1))
+    eps_o = om["unet"](x.to(BF).float(), torch.tensor(601), encoder_hidden_states=enc_o.to(BF).float()).sample
+    up = pm["unet"]
+    up.prepare_timesteps([601])
+    up.prepare_prompt(torch.stack([enc_o[0], enc_o[N]]).to(dev).to(BF), record=True)
+    eps_p = up.forward_step(x.to(dev), 0, record=True).view(2 * N, 4, 32, 32)
+    check("tiny unet eps", eps_p, eps_o, 8e-2)
+    g = torch.randn(eps_o.shape, generator=torch.Generator().manual_seed(2))
+    for p in om["lora_params"]:
+        p.grad = None
+    (eps_o * g).sum().backward()
+    up.lora_bank.grad.zero_()
+    up.backward_step((g * 64.0).to(dev), 64.0)
+    up.finish_prompt_backward(64.0, need_denc=False)
+    names = list(om["unet_lora_layers"].state_dict().keys())
+    refg = torch.cat([p.grad.flatten() for p in om["unet_lora_layers"].parameters()])
+    got = torch.cat([up.lora_bank.grad_view(n).flatten() for n in names])
+    cos = float(F.cosine_similarity(got.cpu().double(), refg.double(), dim=0))
+    print("cosine(tiny unet LoRA grads, bf16) =", cos)
+    check("tiny unet LoRA grads (all)", got, refg, 2e-1)
+    assert cos > 0.995
+    # a complete training step (U-Net + text-encoder LoRA)
+    args = U.make_args(train_unet=True, train_text_encoder=True, uncertainty_threshold=0.7)
+    B, S = 4, 4
+    noises = torch.randn(B, 4, 32, 32, generator=torch.Generator().manual_seed(5991))
+    models_o = dict(text_encoder=om["text_encoder"], unet=om["unet"], vae=om["vae"], classifier=om["classifier"], scheduler=om["scheduler"],
+                    eval_text_encoder=om["eval_text_encoder"], eval_unet=om["eval_unet"])
+    for p in om["lora_params"]:
+        p.grad = None
+    ref = fs.fairness_step(models_o, tokens, noises, S, dict(train_GPU_batch_size=3, val_GPU_batch_size=8, uncertainty_threshold=0.7, factor2=0.2, size_face=64))
+    tr = FairnessTrainer(args, pm["text_encoder"], pm["unet"], pm["vae"], pm["classifier"], pm["scheduler"], eval_text_encoder=pm["eval_text_encoder"],
+                         eval_unet=pm["eval_unet"], device=dev)
+    grads = {}
+    tr.sync_and_update = lambda nb, apply=True: (grads.update({i: b.grad.clone() for i, b in enumerate(tr.banks)}), True)[1]
+    out = tr.train_step(tokens, noises, S)
+    check("step: R1 images", out["images"], ref["images"], 1e-1)
+    check("step: probs", out["probs"], ref["probs"], 6e-2)
+    print("targets", out["targets"].tolist(), ref["targets"].tolist(), " loss_fair", out["loss_fair"].tolist(), ref["loss_fair"].tolist())
+    assert out["targets"].tolist() == ref["targets"].tolist() and out["grad_is_finite"]
+    check("step: loss_fair", out["loss_fair"], ref["loss_fair"], 5e-2)
+    got = torch.cat([tr.banks[0].view(n, grads[0]).flatten() for n in names])
+    refg = torch.cat([p.grad.flatten() for p in om["unet_lora_layers"].parameters()])
+    cos = float(F.cosine_similarity(got.cpu().double(), refg.double(), dim=0))
+    print("cosine(step unet grads, bf16) =", cos)
+    assert cos > 0.95
+
+
+def sd15_unet():
+    from oracle import fair_step as fs
+    from finetune_fair_diffusion_amd import factory
+    torch.set_num_threads(min(os.cpu_count() or 1, 64))
+    om = U.oracle_models(train_unet=True, train_te=False, lora_up_std=0.02, size="sd15", eval_copies=False)
+    for name in ("unet", "text_encoder"):
+        for p in om[name].parameters():
+            if not p.requires_grad:
+                p.data = p.data.to(BF).float()
+    sds = {k: ({n: (t.to(BF).float() if t.is_floating_point() and k in ("unet", "vae", "clip", "clf") else t) for n, t in sd.items()})
+           for k, sd in om["sds"].items()}
+    from finetune_fair_diffusion_amd import weights as W
+    from finetune_fair_diffusion_amd.unet import UNet2DConditionModel
+    unet_p = UNet2DConditionModel(W.UNetConfig(), sds["unet"], dev)
+    unet_p.add_lora(4, sds["unet_lora"])
+    tokens = factory.synthetic_tokens(13, 49408)
+    with torch.no_grad():
+        enc = fs.encode_prompts(om["text_encoder"], *tokens, 1)
+        x1 = torch.randn(1, 4, 64, 64, generator=torch.Generator().manual_seed(1))
+        t0 = time.time()
+        eps_o = om["unet"](torch.cat([x1, x1]).to(BF).float(), torch.tensor(601), encoder_hidden_states=enc.to(BF).float()).sample
+        print(f"oracle SD15 U-Net forward: {time.time() - t0:.1f} s")
+    unet_p.prepare_timesteps([601])
+    unet_p.prepare_prompt(enc.to(dev).to(BF), record=False)
+    eps_p = unet_p.forward_step(x1.to(dev), 0, record=False, pair=True).view(2, 4, 64, 64)
+    check("SD15 unet eps" + (" with e4m3 self-attention at 64^2/32^2/16^2/8^2" if FP8 else ""), eps_p, eps_o, 1.2e-1 if FP8 else 8e-2)
+    rms = float((eps_p.float().cpu() - eps_o).pow(2).mean().sqrt() / eps_o.pow(2).mean().sqrt())
+    print(f"SD15 unet eps rel RMS err = {rms:.3e}")
+    assert rms < (3e-2 if FP8 else 2e-2)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["kernels", "tiny", "sd15"]
+    if "kernels" in which:
+        kernels()
+    if "tiny" in which:
+        tiny_unet_and_step()
+    if "sd15" in which:
+        sd15_unet()
+    print("BF16 CHECKS PASSED" + (" (fp8 attention on)" if FP8 else ""))

@@ -234,6 +234,37 @@ def test_library_exports_every_header_symbol():
     d = lib.GemmDesc()
     assert L.fd_gemm(ctypes.byref(d), None) == -1 and b"null operand" in L.fd_last_error()
     assert L.fd_layernorm_fwd(None, None, None, None, None, 4, 12, 1e-5, None) == -1
+    assert L.fd_working_dtype() == b"fp16" and "fd_attn_fwd_fp8" in protos and "fd_attn_fp8_quant_kv" in protos
+    # the bf16 build (BASELINE configs[4]) of the same sources exports the same C-ABI
+    path = os.path.join(os.path.dirname(lib.LIB_PATH), "libfairdiff_hip_bf16.so")
+    assert os.path.exists(path), "libfairdiff_hip_bf16.so missing: run __graft_entry__.build()"
+    Lb = ctypes.CDLL(path)
+    for name in protos:
+        assert hasattr(Lb, name), name
+    Lb.fd_working_dtype.restype = ctypes.c_char_p
+    assert Lb.fd_working_dtype() == b"bf16"
+    # a library of the wrong working dtype is refused, not silently used
+    import subprocess, sys
+    r = subprocess.run([sys.executable, "-c", "from finetune_fair_diffusion_amd import lib; lib.load()"],
+                       env=dict(os.environ, FD_DTYPE="bf16", FAIRDIFF_LIB=lib.LIB_PATH), capture_output=True, text=True, cwd=os.path.dirname(HERE))
+    assert r.returncode != 0 and "was built for fp16" in r.stderr
+
+
+def test_working_dtype_preselection_from_the_reference_flag(tmp_path):
+    """``--mixed_precision bf16`` (exp-1 main:401-405) or a --config YAML carrying it selects the bf16 library before the package binds its
+    dtype; an explicit FD_DTYPE wins."""
+    import subprocess, sys
+    code = "from finetune_fair_diffusion_amd import lib; print(lib.WORKING_DTYPE, lib.LIB_PATH.rsplit('/', 1)[1])"
+    env = {k: v for k, v in os.environ.items() if k not in ("FD_DTYPE", "FAIRDIFF_LIB")}
+    run = lambda argv, e=env: subprocess.run([sys.executable, "-c", code] + argv, env=e, capture_output=True, text=True, cwd=os.path.dirname(HERE)).stdout.split()  # noqa: E731
+    assert run([]) == ["fp16", "libfairdiff_hip.so"]
+    assert run(["--mixed_precision", "bf16"]) == ["bf16", "libfairdiff_hip_bf16.so"]
+    assert run(["--mixed_precision=bf16"])[0] == "bf16"
+    y = tmp_path / "c.yaml"
+    y.write_text("mixed_precision: bf16\nrank: 4\n")
+    assert run(["--config", str(y)])[0] == "bf16"
+    assert run(["--config", str(y), "--mixed_precision", "fp16"])[0] == "fp16"
+    assert run(["--mixed_precision", "bf16"], dict(env, FD_DTYPE="fp16"))[0] == "fp16"
 
 
 def test_product_fails_loudly_without_library(monkeypatch):

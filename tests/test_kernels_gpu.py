@@ -305,6 +305,25 @@ def test_attention_fwd_bwd(ops, dev, B, H, Tq, Tk, d, kv_div):
     check("attn dv", dv.reshape(Bk, Tk, C), vr.grad, 5e-3)
 
 
+@pytest.mark.parametrize("B,H,T,d", [(2, 8, 1024, 40), (1, 8, 4096, 40), (2, 8, 256, 80), (2, 4, 256, 160), (1, 2, 64, 160)])
+def test_attention_fwd_fp8_band(ops, dev, B, H, T, d):
+    """BASELINE configs[4]: e4m3 QK^T / PV self-attention forward (per-row Q scale, per-64-key-tile K / V scales, fp32 softmax).
+    The reference never ran fp8, so acceptance is a stated BAND: vs the fp32 reference O within 6e-2 of max|O| and 6e-2 relative RMS (the
+    16-bit kernel sits at 3e-3), LSE within 3e-2 absolute; and vs the 16-bit path of this library the same band."""
+    C = H * d
+    q, k, v = rnd(B, T, C, dev=dev, seed=1), rnd(B, T, C, dev=dev, seed=2), rnd(B, T, C, dev=dev, seed=3)
+    oref, lref = _attn_ref(q.float(), k.float(), v.float(), H)
+    o8, lse8 = ops.attn_fwd_fp8(q.reshape(B * T, C), k.reshape(B * T, C), v.reshape(B * T, C), B, H, T, d, need_lse=True)
+    vt = ops.transpose_btc(v.reshape(B * T, C), B, T, C)
+    o16, lse16 = ops.attn_fwd(q.reshape(B * T, C), k.reshape(B * T, C), vt, B, H, T, T, d, 1, need_lse=True)
+    rms = float((o8.reshape(B, T, C).float() - oref).pow(2).mean().sqrt() / oref.pow(2).mean().sqrt())
+    print(f"fp8 attention d={d} T={T}: rel RMS err vs fp32 {rms:.3e}; max|lse err| {float((lse8 - lref).abs().max()):.3e}")
+    check("attn fp8 fwd vs fp32", o8.reshape(B, T, C), oref, 6e-2)
+    check("attn fp8 fwd vs 16-bit path", o8.reshape(B, T, C), o16.reshape(B, T, C).float(), 6e-2)
+    assert rms < 6e-2              # RMS error relative to the RMS of O
+    assert float((lse8 - lref).abs().max()) < 3e-2
+
+
 @pytest.mark.parametrize("M,N,R", [(4096, 320, 4), (1000, 1280, 50), (777, 768, 16)])
 def test_lora_wgrad(ops, dev, M, N, R):
     RP = (R + 7) // 8 * 8
