@@ -123,7 +123,7 @@ __device__ __forceinline__ void zero_col_pad(f16* dst) {
 template <int D>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const f16* __restrict__ Q, const f16* __restrict__ K, const f16* __restrict__ Vt,
                                                        f16* __restrict__ O, float* __restrict__ LSE, int H, int Tq, int Tk, int Tkp,
-                                                       int Tkr, int kv_div, float scale) {
+                                                       int Tkr, int kv_div, float scale, int ldq, int ldk) {
     constexpr int DK = (D + 15) / 16 * 16, DV = (D + 31) / 32 * 32, DKP = DK + 8;
     constexpr int NKS = DK / 16, NDV = DV / 32;
     extern __shared__ __attribute__((aligned(16))) f16 smem[];
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const f16* __restrict__ Q
     for (int ks = 0; ks < NKS; ++ks) {
         const int col = ks * 16 + g * 8;
         qf[ks] = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
-        if (tvalid && col < D) qf[ks] = *(const f16x8*)(Q + ((int64_t)b * Tq + t) * C + h * D + col);
+        if (tvalid && col < D) qf[ks] = *(const f16x8*)(Q + ((int64_t)b * Tq + t) * ldq + h * D + col);
     }
     f32x16 oacc[NDV];
 #pragma unroll
@@ -151,17 +151,17 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const f16* __restrict__ Q
     float m_run = -INFINITY, l_run = 0.f;
     const float sl2 = scale * LOG2E;
 
-    const f16* Kb = K + (int64_t)bk * Tkr * C + h * D;
+    const f16* Kb = K + (int64_t)bk * Tkr * ldk + h * D;
     const f16* Vtb = Vt + ((int64_t)bk * C + h * D) * Tkp;
 
     TileRegs<D> kreg, vreg;
     TilePlan<D> kplan, vplan;
-    plan_rows<D>(kplan, C);
+    plan_rows<D>(kplan, ldk);
     plan_cols<D>(vplan, Tkp);
     zero_row_pad<D, DKP>(Ks);
     zero_col_pad<D, DV>(Vts);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // Q fragments landed: no VM event may pend on them inside the loop
-    load_rows<D>(kreg, Kb, C, 0, Tk);
+    load_rows<D>(kreg, Kb, ldk, 0, Tk);
     load_cols<D>(vreg, Vtb, Tkp, 0, Tkp);
     for (int k0 = 0; k0 < Tk; k0 += 64) {
         __syncthreads();
@@ -181,10 +181,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const f16* __restrict__ Q
         // next tile's loads are issued behind the QK^T MFMAs and fly under the softmax and the PV MFMAs (issued in front of them the
         // compiler parks an s_waitcnt vmcnt(0) before the first MFMA and the whole load latency is exposed every tile)
         if (k0 + 128 <= Tk) {                 // next tile is an interior one: planned, unchecked loads
-            load_planned<D>(kreg, Kb + (int64_t)(k0 + 64) * C, kplan);
+            load_planned<D>(kreg, Kb + (int64_t)(k0 + 64) * ldk, kplan);
             load_planned<D>(vreg, Vtb + (k0 + 64), vplan);
         } else if (k0 + 64 < Tk) {
-            load_rows<D>(kreg, Kb, C, k0 + 64, Tk);
+            load_rows<D>(kreg, Kb, ldk, k0 + 64, Tk);
             load_cols<D>(vreg, Vtb, Tkp, k0 + 64, Tkp);
         }
         // online softmax on the raw scores: p = exp2(s*sl2 - m*sl2) is one FMA + one v_exp per element; the
@@ -278,7 +278,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const f16* __restrict_
                                                           const f16* __restrict__ Kt, const f16* __restrict__ dO,
                                                           const float* __restrict__ LSE, float* __restrict__ Dd, f16* __restrict__ dQ,
                                                           const f16* __restrict__ O, int H, int Tq, int Tk, int Tkp, int Tkr, int kv_div,
-                                                          float scale) {
+                                                          float scale, int ldq, int ldkv, int lddq) {
     constexpr int DK = (D + 15) / 16 * 16, DV = (D + 31) / 32 * 32, DKP = DK + 8;
     constexpr int NKS = DK / 16, NDV = DV / 32;
     extern __shared__ __attribute__((aligned(16))) f16 smem[];
@@ -301,7 +301,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const f16* __restrict_
         qf[ks] = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
         gf[ks] = qf[ks];
         if (tvalid && col < D) {
-            qf[ks] = *(const f16x8*)(Q + ((int64_t)b * Tq + t) * C + h * D + col);
+            qf[ks] = *(const f16x8*)(Q + ((int64_t)b * Tq + t) * ldq + h * D + col);
             gf[ks] = *(const f16x8*)(dO + ((int64_t)b * Tq + t) * C + h * D + col);
         }
     }
@@ -328,8 +328,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const f16* __restrict_
 #pragma unroll
     for (int i = 0; i < NDV; ++i) acc[i] = zero16();
 
-    const f16* Kb = K + (int64_t)bk * Tkr * C + h * D;
-    const f16* Vb = V + (int64_t)bk * Tkr * C + h * D;
+    const f16* Kb = K + (int64_t)bk * Tkr * ldkv + h * D;
+    const f16* Vb = V + (int64_t)bk * Tkr * ldkv + h * D;
     const f16* Ktb = Kt + ((int64_t)bk * C + h * D) * Tkp;
 
     constexpr bool PF = D <= 80;      // register prefetch where the register file has room
@@ -338,15 +338,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const f16* __restrict_
     zero_row_pad<D, DKP>(Vs);
     zero_col_pad<D, DV>(Kts);
     if (PF) {
-        load_rows<D>(kreg, Kb, C, 0, Tk);
-        load_rows<D>(vreg, Vb, C, 0, Tk);
+        load_rows<D>(kreg, Kb, ldkv, 0, Tk);
+        load_rows<D>(vreg, Vb, ldkv, 0, Tk);
         load_cols<D>(ktreg, Ktb, Tkp, 0, Tkp);
     }
     for (int k0 = 0; k0 < Tk; k0 += 64) {
         __syncthreads();
         if (!PF) {
-            load_rows<D>(kreg, Kb, C, k0, Tk);
-            load_rows<D>(vreg, Vb, C, k0, Tk);
+            load_rows<D>(kreg, Kb, ldkv, k0, Tk);
+            load_rows<D>(vreg, Vb, ldkv, k0, Tk);
             load_cols<D>(ktreg, Ktb, Tkp, k0, Tkp);
         }
         store_rows<D, DKP>(kreg, Ks);
@@ -366,8 +366,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const f16* __restrict_
             }
             // next tile's loads go out behind the first MFMA group (in front of it the compiler waits for them at once, see forward)
             if (kt == 0 && PF && k0 + 64 < Tk) {
-                load_rows<D>(kreg, Kb, C, k0 + 64, Tk);
-                load_rows<D>(vreg, Vb, C, k0 + 64, Tk);
+                load_rows<D>(kreg, Kb, ldkv, k0 + 64, Tk);
+                load_rows<D>(vreg, Vb, ldkv, k0 + 64, Tk);
                 load_cols<D>(ktreg, Ktb, Tkp, k0 + 64, Tkp);
             }
 #pragma unroll
@@ -386,7 +386,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const f16* __restrict_
             }
     }
     if (tvalid) {
-        f16* P = dQ + ((int64_t)b * Tq + t) * C + h * D;
+        f16* P = dQ + ((int64_t)b * Tq + t) * lddq + h * D;
 #pragma unroll
         for (int i = 0; i < NDV; ++i)
 #pragma unroll
@@ -409,7 +409,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const f16* __restric
                                                             const f16* __restrict__ V, const f16* __restrict__ dO,
                                                             const f16* __restrict__ dOt, const float* __restrict__ LSE,
                                                             const float* __restrict__ Dd, void* __restrict__ dKo, void* __restrict__ dVo,
-                                                            int H, int Tq, int Tk, int Tkr, int kv_div, float scale) {
+                                                            int H, int Tq, int Tk, int Tkr, int kv_div, float scale, int ldq, int ldkv, int lddkv) {
     constexpr int DK = (D + 15) / 16 * 16, DV = (D + 31) / 32 * 32, DKP = DK + 8;
     constexpr int NKS = DK / 16, NDV = DV / 32;
     extern __shared__ __attribute__((aligned(16))) f16 smem[];
@@ -435,8 +435,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const f16* __restric
         kf[ks] = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
         vf[ks] = kf[ks];
         if (kvalid && col < D) {
-            kf[ks] = *(const f16x8*)(K + ((int64_t)bk * Tkr + key) * C + h * D + col);
-            vf[ks] = *(const f16x8*)(V + ((int64_t)bk * Tkr + key) * C + h * D + col);
+            kf[ks] = *(const f16x8*)(K + ((int64_t)bk * Tkr + key) * ldkv + h * D + col);
+            vf[ks] = *(const f16x8*)(V + ((int64_t)bk * Tkr + key) * ldkv + h * D + col);
         }
     }
     f32x16 dk[NDV], dv[NDV];
@@ -444,7 +444,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const f16* __restric
     for (int i = 0; i < NDV; ++i) { dk[i] = zero16(); dv[i] = zero16(); }
     const float sl2 = scale * LOG2E;
 
-    const f16* Qb = Q + (int64_t)b * Tq * C + h * D;
+    const f16* Qb = Q + (int64_t)b * Tq * ldq + h * D;
     const f16* Gb = dO + (int64_t)b * Tq * C + h * D;
     const f16* Qtb = Qt + ((int64_t)b * C + h * D) * Tq;
     const f16* Gtb = dOt + ((int64_t)b * C + h * D) * Tq;
@@ -458,7 +458,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const f16* __restric
     zero_col_pad<D, DV>(Qts);
     zero_col_pad<D, DV>(Gts);
     if (PF) {
-        load_rows<D>(qreg, Qb, C, 0, Tq);
+        load_rows<D>(qreg, Qb, ldq, 0, Tq);
         load_rows<D>(greg, Gb, C, 0, Tq);
         load_cols<D>(qtreg, Qtb, Tq, 0, Tq);
         load_cols<D>(gtreg, Gtb, Tq, 0, Tq);
@@ -466,7 +466,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const f16* __restric
     for (int q0 = 0; q0 < Tq; q0 += 64) {
         __syncthreads();
         if (!PF) {
-            load_rows<D>(qreg, Qb, C, q0, Tq);
+            load_rows<D>(qreg, Qb, ldq, q0, Tq);
             load_rows<D>(greg, Gb, C, q0, Tq);
             load_cols<D>(qtreg, Qtb, Tq, q0, Tq);
             load_cols<D>(gtreg, Gtb, Tq, q0, Tq);
@@ -493,7 +493,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const f16* __restric
                 dp = mfma32(ga, vf[ks], dp);
             }
             if (qt == 0 && PF && q0 + 64 < Tq) {       // prefetch behind the first MFMA group (see forward)
-                load_rows<D>(qreg, Qb, C, q0 + 64, Tq);
+                load_rows<D>(qreg, Qb, ldq, q0 + 64, Tq);
                 load_rows<D>(greg, Gb, C, q0 + 64, Tq);
                 load_cols<D>(qtreg, Qtb, Tq, q0 + 64, Tq);
                 load_cols<D>(gtreg, Gtb, Tq, q0 + 64, Tq);
@@ -518,7 +518,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const f16* __restric
             }
     }
     if (kvalid) {
-        const int64_t off = ((int64_t)bk * Tkr + key) * C + h * D;
+        const int64_t off = ((int64_t)bk * Tkr + key) * lddkv + h * D;
 #pragma unroll
         for (int i = 0; i < NDV; ++i)
 #pragma unroll
@@ -573,13 +573,16 @@ template <int D> static constexpr size_t dkdv_lds() {
     }
 
 extern "C" int fd_attn_fwd(const void* q, const void* k, const void* vt, void* o, float* lse, int B, int H, int Tq, int Tk, int Tkp, int Tkr,
-                           int d, int kv_div, float scale, void* stream) {
+                           int d, int kv_div, float scale, int ldq, int ldk, void* stream) {
+    if (ldq <= 0) ldq = H * d;
+    if (ldk <= 0) ldk = H * d;
+    FD_REQUIRE((ldq & 7) == 0 && (ldk & 7) == 0, "fd_attn_fwd: row strides must be multiples of 8");
     FD_REQUIRE(B > 0 && H > 0 && Tq > 0 && Tk > 0 && Tkp >= Tk && (Tkp & 7) == 0 && Tkr >= Tk && kv_div >= 1, "fd_attn_fwd: bad shape");
     dim3 grid((Tq + 127) / 128, H, B);
 #define CALL(DD)                                                                                                                      \
     ALLOW_LDS(attn_fwd_kernel<DD>, fwd_lds<DD>());                                                                                    \
     hipLaunchKernelGGL(attn_fwd_kernel<DD>, grid, dim3(256), fwd_lds<DD>(), (hipStream_t)stream, (const f16*)q, (const f16*)k,        \
-                       (const f16*)vt, (f16*)o, lse, H, Tq, Tk, Tkp, Tkr, kv_div, scale)
+                       (const f16*)vt, (f16*)o, lse, H, Tq, Tk, Tkp, Tkr, kv_div, scale, ldq, ldk)
     FD_DISPATCH_D(d, CALL)
 #undef CALL
     return fd_check_launch("fd_attn_fwd");
@@ -596,13 +599,17 @@ extern "C" int fd_attn_bwd_prep(const void* o, const void* d_o, float* D, int B,
 
 extern "C" int fd_attn_bwd_dq(const void* q, const void* k, const void* v, const void* kt, const void* d_o, const float* lse, float* D,
                               const void* o, void* dq, int B, int H, int Tq, int Tk, int Tkp, int Tkr, int d, int kv_div, float scale,
-                              void* stream) {
+                              int ldq, int ldkv, int lddq, void* stream) {
+    if (ldq <= 0) ldq = H * d;
+    if (ldkv <= 0) ldkv = H * d;
+    if (lddq <= 0) lddq = H * d;
+    FD_REQUIRE((ldq & 7) == 0 && (ldkv & 7) == 0 && (lddq & 3) == 0, "fd_attn_bwd_dq: row strides");
     FD_REQUIRE(B > 0 && H > 0 && Tq > 0 && Tk > 0 && Tkp >= Tk && (Tkp & 7) == 0 && Tkr >= Tk && kv_div >= 1, "fd_attn_bwd_dq: bad shape");
     dim3 grid((Tq + 127) / 128, H, B);
 #define CALL(DD)                                                                                                                      \
     ALLOW_LDS(attn_bwd_dq_kernel<DD>, dq_lds<DD>());                                                                                  \
     hipLaunchKernelGGL(attn_bwd_dq_kernel<DD>, grid, dim3(256), dq_lds<DD>(), (hipStream_t)stream, (const f16*)q, (const f16*)k,      \
-                       (const f16*)v, (const f16*)kt, (const f16*)d_o, lse, D, (f16*)dq, (const f16*)o, H, Tq, Tk, Tkp, Tkr, kv_div, scale)
+                       (const f16*)v, (const f16*)kt, (const f16*)d_o, lse, D, (f16*)dq, (const f16*)o, H, Tq, Tk, Tkp, Tkr, kv_div, scale, ldq, ldkv, lddq)
     FD_DISPATCH_D(d, CALL)
 #undef CALL
     return fd_check_launch("fd_attn_bwd_dq");
@@ -610,7 +617,11 @@ extern "C" int fd_attn_bwd_dq(const void* q, const void* k, const void* v, const
 
 extern "C" int fd_attn_bwd_dkdv(const void* q, const void* qt, const void* k, const void* v, const void* d_o, const void* d_ot,
                                 const float* lse, const float* D, void* dk, void* dv, int B, int H, int Tq, int Tk, int Tkr, int d,
-                                int kv_div, float scale, void* stream) {
+                                int kv_div, float scale, int ldq, int ldkv, int lddkv, void* stream) {
+    if (ldq <= 0) ldq = H * d;
+    if (ldkv <= 0) ldkv = H * d;
+    if (lddkv <= 0) lddkv = H * d;
+    FD_REQUIRE((ldq & 7) == 0 && (ldkv & 7) == 0 && (lddkv & 3) == 0, "fd_attn_bwd_dkdv: row strides");
     FD_REQUIRE(B > 0 && H > 0 && Tq > 0 && Tk > 0 && (Tq & 7) == 0 && Tkr >= Tk && kv_div >= 1, "fd_attn_bwd_dkdv: bad shape (Tq %% 8)");
     dim3 grid((Tk + 127) / 128, H, B);
 #define CALL(DD)                                                                                                                       \
@@ -618,12 +629,12 @@ extern "C" int fd_attn_bwd_dkdv(const void* q, const void* qt, const void* k, co
         ALLOW_LDS((attn_bwd_dkdv_kernel<DD, true>), dkdv_lds<DD>());                                                                     \
         hipLaunchKernelGGL((attn_bwd_dkdv_kernel<DD, true>), grid, dim3(256), dkdv_lds<DD>(), (hipStream_t)stream, (const f16*)q,      \
                            (const f16*)qt, (const f16*)k, (const f16*)v, (const f16*)d_o, (const f16*)d_ot, lse, D, dk, dv, H, Tq, Tk, \
-                           Tkr, kv_div, scale);                                                                                             \
+                           Tkr, kv_div, scale, ldq, ldkv, lddkv);                                                                           \
     } else {                                                                                                                           \
         ALLOW_LDS((attn_bwd_dkdv_kernel<DD, false>), dkdv_lds<DD>());                                                                    \
         hipLaunchKernelGGL((attn_bwd_dkdv_kernel<DD, false>), grid, dim3(256), dkdv_lds<DD>(), (hipStream_t)stream, (const f16*)q,     \
                            (const f16*)qt, (const f16*)k, (const f16*)v, (const f16*)d_o, (const f16*)d_ot, lse, D, dk, dv, H, Tq, Tk, \
-                           Tkr, kv_div, scale);                                                                                             \
+                           Tkr, kv_div, scale, ldq, ldkv, lddkv);                                                                           \
     }
     FD_DISPATCH_D(d, CALL)
 #undef CALL

@@ -37,12 +37,11 @@ __device__ __forceinline__ uint32_t pk4_fp8(float a, float b, float c, float d) 
 template <int D>
 __global__ __launch_bounds__(256) void attn_fp8_quant_kv_kernel(const f16* __restrict__ K, const f16* __restrict__ V, uint8_t* __restrict__ K8,
                                                                 uint8_t* __restrict__ V8t, float* __restrict__ SK, float* __restrict__ SV, int H,
-                                                                int T) {
+                                                                int T, int ldkv) {
     constexpr int DK8 = (D + 15) / 16 * 16, DV8 = (D + 31) / 32 * 32;
     __shared__ float red[8];
     __shared__ float vt[64][D + 1];
     const int tile = blockIdx.x, h = blockIdx.y, b = blockIdx.z, nT = gridDim.x;
-    const int C = H * D;
     const int tid = threadIdx.x, key = tid >> 2, part = tid & 3;
     const int t = tile * 64 + key;
     // ---- K: per-thread slice of one key row
@@ -52,7 +51,7 @@ __global__ __launch_bounds__(256) void attn_fp8_quant_kv_kernel(const f16* __res
 #pragma unroll
     for (int j = 0; j < PER; ++j) {
         const int c = part * PER + j;
-        kv[j] = (t < T && c < D) ? (float)K[((int64_t)b * T + t) * C + h * D + c] : 0.f;
+        kv[j] = (t < T && c < D) ? (float)K[((int64_t)b * T + t) * ldkv + h * D + c] : 0.f;
         amax = fmaxf(amax, fabsf(kv[j]));
     }
     amax = wave_max(amax);
@@ -69,7 +68,7 @@ __global__ __launch_bounds__(256) void attn_fp8_quant_kv_kernel(const f16* __res
     float vmax = 0.f;
     for (int i = tid; i < 64 * D; i += 256) {
         const int r = i / D, c = i - r * D;
-        const float x = (tile * 64 + r < T) ? (float)V[((int64_t)b * T + tile * 64 + r) * C + h * D + c] : 0.f;
+        const float x = (tile * 64 + r < T) ? (float)V[((int64_t)b * T + tile * 64 + r) * ldkv + h * D + c] : 0.f;
         vt[r][c] = x;
         vmax = fmaxf(vmax, fabsf(x));
     }
@@ -103,7 +102,7 @@ __global__ __launch_bounds__(256) void attn_fp8_quant_kv_kernel(const f16* __res
 template <int D>
 __global__ __launch_bounds__(256) void attn_fwd_fp8_kernel(const f16* __restrict__ Q, const uint8_t* __restrict__ K8, const uint8_t* __restrict__ V8t,
                                                            const float* __restrict__ SK, const float* __restrict__ SV, f16* __restrict__ O,
-                                                           float* __restrict__ LSE, int H, int T, float scale) {
+                                                           float* __restrict__ LSE, int H, int T, float scale, int ldq) {
     constexpr int DK8 = (D + 15) / 16 * 16, DV8 = (D + 31) / 32 * 32;
     constexpr int NKS = DK8 / 16, NDV = DV8 / 32;
     constexpr int KLD = DK8 + 8;          // LDS row strides in bytes: conflict-free for the 8-byte / 4-byte fragment reads
@@ -127,7 +126,7 @@ __global__ __launch_bounds__(256) void attn_fwd_fp8_kernel(const f16* __restrict
     for (int ks = 0; ks < NKS; ++ks) {
         const int col = ks * 16 + g * 8;
         f16x8 x = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
-        if (tvalid && col < D) x = *(const f16x8*)(Q + ((int64_t)b * T + t) * C + h * D + col);
+        if (tvalid && col < D) x = *(const f16x8*)(Q + ((int64_t)b * T + t) * ldq + h * D + col);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             qv[ks][j] = (float)x[j];
@@ -290,25 +289,29 @@ template <int D> static constexpr size_t fp8_lds() {
     return (size_t)64 * ((D + 15) / 16 * 16 + 8) + (size_t)((D + 31) / 32 * 32) * 68;
 }
 
-extern "C" int fd_attn_fp8_quant_kv(const void* k, const void* v, void* k8, void* v8t, float* sk, float* sv, int B, int H, int T, int d, void* stream) {
+extern "C" int fd_attn_fp8_quant_kv(const void* k, const void* v, void* k8, void* v8t, float* sk, float* sv, int B, int H, int T, int d, int ldkv,
+                                    void* stream) {
     FD_REQUIRE(B > 0 && H > 0 && T > 0 && (T & 63) == 0, "fd_attn_fp8_quant_kv: T must be a positive multiple of 64");
+    if (ldkv <= 0) ldkv = H * d;
     dim3 grid(T / 64, H, B);
     switch (d) {
-        case 40: hipLaunchKernelGGL(attn_fp8_quant_kv_kernel<40>, grid, dim3(256), 0, (hipStream_t)stream, (const f16*)k, (const f16*)v, (uint8_t*)k8, (uint8_t*)v8t, sk, sv, H, T); break;
-        case 80: hipLaunchKernelGGL(attn_fp8_quant_kv_kernel<80>, grid, dim3(256), 0, (hipStream_t)stream, (const f16*)k, (const f16*)v, (uint8_t*)k8, (uint8_t*)v8t, sk, sv, H, T); break;
-        case 160: hipLaunchKernelGGL(attn_fp8_quant_kv_kernel<160>, grid, dim3(256), 0, (hipStream_t)stream, (const f16*)k, (const f16*)v, (uint8_t*)k8, (uint8_t*)v8t, sk, sv, H, T); break;
+        case 40: hipLaunchKernelGGL(attn_fp8_quant_kv_kernel<40>, grid, dim3(256), 0, (hipStream_t)stream, (const f16*)k, (const f16*)v, (uint8_t*)k8, (uint8_t*)v8t, sk, sv, H, T, ldkv); break;
+        case 80: hipLaunchKernelGGL(attn_fp8_quant_kv_kernel<80>, grid, dim3(256), 0, (hipStream_t)stream, (const f16*)k, (const f16*)v, (uint8_t*)k8, (uint8_t*)v8t, sk, sv, H, T, ldkv); break;
+        case 160: hipLaunchKernelGGL(attn_fp8_quant_kv_kernel<160>, grid, dim3(256), 0, (hipStream_t)stream, (const f16*)k, (const f16*)v, (uint8_t*)k8, (uint8_t*)v8t, sk, sv, H, T, ldkv); break;
         default: fd_set_error("fd_attn_fp8_quant_kv: head dim %d not built (40 / 80 / 160)", d); return FD_ERR_ARG;
     }
     return fd_check_launch("fd_attn_fp8_quant_kv");
 }
 
 extern "C" int fd_attn_fwd_fp8(const void* q, const void* k8, const void* v8t, const float* sk, const float* sv, void* o, float* lse, int B, int H,
-                               int T, int d, float scale, void* stream) {
+                               int T, int d, float scale, int ldq, void* stream) {
     FD_REQUIRE(B > 0 && H > 0 && T > 0 && (T & 63) == 0, "fd_attn_fwd_fp8: T must be a positive multiple of 64");
+    if (ldq <= 0) ldq = H * d;
+    FD_REQUIRE((ldq & 7) == 0, "fd_attn_fwd_fp8: ldq %% 8");
     dim3 grid((T + 127) / 128, H, B);
 #define CALL8(DD)                                                                                                                              \
     hipLaunchKernelGGL(attn_fwd_fp8_kernel<DD>, grid, dim3(256), fp8_lds<DD>(), (hipStream_t)stream, (const f16*)q, (const uint8_t*)k8,       \
-                       (const uint8_t*)v8t, sk, sv, (f16*)o, lse, H, T, scale)
+                       (const uint8_t*)v8t, sk, sv, (f16*)o, lse, H, T, scale, ldq)
     switch (d) {
         case 40: CALL8(40); break;
         case 80: CALL8(80); break;

@@ -166,7 +166,7 @@ extern "C" int fd_copy_cols(const void* src, int64_t lds, void* dst, int64_t ldd
 }
 
 // ---------------------------------------------------------------- [B,T,C] -> [B,C,Tp] (zero-padded keys), 64x64 LDS tiles
-__global__ __launch_bounds__(256) void transpose_btc_kernel(const f16* x, f16* y, int T, int C, int Tp) {
+__global__ __launch_bounds__(256) void transpose_btc_kernel(const f16* x, f16* y, int T, int C, int Tp, int64_t ldx) {
     __shared__ f16 tile[64][66];
     const int b = blockIdx.z, t0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
     const int tid = threadIdx.x;
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256) void transpose_btc_kernel(const f16* x, f16* y
         const int ch = tid + i * 256;  // 512 chunks: row = ch/8 (t), col chunk = ch%8
         const int tr = ch >> 3, cc = (ch & 7) * 8;
         f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (t0 + tr < T && c0 + cc < C) v = *(const f16x8*)(x + ((int64_t)b * T + t0 + tr) * C + c0 + cc);
+        if (t0 + tr < T && c0 + cc < C) v = *(const f16x8*)(x + ((int64_t)b * T + t0 + tr) * ldx + c0 + cc);
 #pragma unroll
         for (int j = 0; j < 8; ++j) tile[tr][cc + j] = v[j];
     }
@@ -192,10 +192,11 @@ __global__ __launch_bounds__(256) void transpose_btc_kernel(const f16* x, f16* y
         }
     }
 }
-extern "C" int fd_transpose_btc(const void* x, void* y, int B, int T, int C, int Tp, void* stream) {
-    FD_REQUIRE((C & 7) == 0 && (Tp & 7) == 0 && Tp >= T, "fd_transpose_btc: C%%8, Tp%%8, Tp>=T");
+extern "C" int fd_transpose_btc(const void* x, int64_t ldx, void* y, int B, int T, int C, int Tp, void* stream) {
+    if (ldx <= 0) ldx = C;
+    FD_REQUIRE((C & 7) == 0 && (Tp & 7) == 0 && Tp >= T && (ldx & 7) == 0, "fd_transpose_btc: C%%8, Tp%%8, ldx%%8, Tp>=T");
     dim3 grid((Tp + 63) / 64, (C + 63) / 64, B);
-    hipLaunchKernelGGL(transpose_btc_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const f16*)x, (f16*)y, T, C, Tp);
+    hipLaunchKernelGGL(transpose_btc_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const f16*)x, (f16*)y, T, C, Tp, ldx);
     return fd_check_launch("fd_transpose_btc");
 }
 

@@ -37,11 +37,13 @@ _gemm_ws = {}
 
 
 def gemm_workspace():
-    """64 MiB fp32 split-K workspace per device (owned by the caller of the C-ABI, as every buffer is)."""
-    key = torch.cuda.current_device()
+    """64 MiB fp32 split-K workspace per (device, stream) -- kernels of two streams may run concurrently (step.py runs the R1 and R2
+    rollouts on two streams) and must not share it (owned by the caller of the C-ABI, as every buffer is)."""
+    dev = torch.cuda.current_device()
+    key = (dev, torch.cuda.current_stream().cuda_stream)
     t = _gemm_ws.get(key)
     if t is None:
-        t = torch.empty(16 << 20, dtype=F32, device=torch.device("cuda", key))
+        t = torch.empty(16 << 20, dtype=F32, device=torch.device("cuda", dev))
         _gemm_ws[key] = t
     return t
 
@@ -305,7 +307,7 @@ _scratch = {}
 
 
 def scratch(nfloats, device):
-    key = (device.index if device.index is not None else torch.cuda.current_device())
+    key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream)
     t = _scratch.get(key)
     if t is None or t.numel() < nfloats:
         t = torch.empty(max(nfloats, 1 << 22), dtype=F32, device=device)
@@ -393,10 +395,17 @@ def copy_cols(src, dst, cols):
     _call("fd_copy_cols", _p(src), src.stride(0), _p(dst), dst.stride(0), src.shape[0], cols, _stream())
 
 
+def _rows(t):
+    """2-D fp16 operand whose rows may be strided (a column slice of a wider buffer): returns its row stride in elements."""
+    assert t.dtype == F16 and t.dim() == 2 and t.stride(1) == 1, (t.dtype, t.shape, t.stride())
+    return t.stride(0)
+
+
 def transpose_btc(x, B, T, C, Tp=None):
+    """x [B*T, C] (rows may be strided) -> [B, C, Tp]."""
     Tp = Tp or ((T + 7) // 8 * 8)
     y = torch.empty((B, C, Tp), dtype=F16, device=x.device)
-    _call("fd_transpose_btc", _p(_chk(x)), _p(y), B, T, C, Tp, _stream())
+    _call("fd_transpose_btc", _p(x), _rows(x), _p(y), B, T, C, Tp, _stream())
     return y
 
 
@@ -434,38 +443,49 @@ def to_f32(x, scale=1.0):
 
 # ----------------------------------------------------------------------------- attention
 def attn_fwd(q, k, vt, B, H, Tq, Tk, d, kv_div=1, scale=None, need_lse=False, kv_rows=None):
-    """``kv_rows``: rows per batch item of the k buffer when it is row-padded beyond the Tk keys (ViT token buffers)."""
+    """q [B*Tq, H*d], k [Bk*Tkr, H*d] (2-D; rows may be strided: column slices of a wider buffer), vt [Bk, H*d, Tkp].
+    ``kv_rows``: rows per batch item of the k buffer when it is row-padded beyond the Tk keys (ViT token buffers)."""
     Tkp = vt.shape[-1]
     Tkr = kv_rows or Tk
-    o = torch.empty_like(q)
+    o = torch.empty((q.shape[0], H * d), dtype=F16, device=q.device)
     lse = torch.empty((B, H, Tq), dtype=F32, device=q.device) if need_lse else None
-    _call("fd_attn_fwd", _p(_chk(q)), _p(_chk(k)), _p(_chk(vt)), _p(o), _p(lse), B, H, Tq, Tk, Tkp, Tkr, d, kv_div,
-          scale if scale is not None else d ** -0.5, _stream())
+    _call("fd_attn_fwd", _p(q), _p(k), _p(_chk(vt)), _p(o), _p(lse), B, H, Tq, Tk, Tkp, Tkr, d, kv_div,
+          scale if scale is not None else d ** -0.5, _rows(q), _rows(k), _stream())
     return (o, lse) if need_lse else o
 
 
-def attn_bwd(q, k, v, o, do, lse, B, H, Tq, Tk, d, kv_div=1, scale=None, kt=None, dk_acc=None, dv_acc=None, kv_rows=None):
-    """Returns (dq, dk, dv).  With kv_div>1 (shared K/V) dk/dv are accumulated into the fp32 buffers dk_acc/dv_acc."""
+def attn_bwd(q, k, v, o, do, lse, B, H, Tq, Tk, d, kv_div=1, scale=None, kt=None, dk_acc=None, dv_acc=None, kv_rows=None, dqkv=None):
+    """Returns (dq, dk, dv).  With kv_div>1 (shared K/V) dk/dv are accumulated into the fp32 buffers dk_acc/dv_acc.
+    q, k, v are 2-D and may be column slices of a wider buffer; with ``dqkv`` [M, 3*H*d] (self-attention, kv_div == 1) the three
+    gradients are written as its column slices (returned as views), so that the projections' input gradient is ONE GEMM over K = 3*H*d."""
     scale = scale if scale is not None else d ** -0.5
     Tkr = kv_rows or Tk
     C = H * d
+    assert _rows(k) == _rows(v)
     Dd = torch.empty((B, H, Tq), dtype=F32, device=q.device)     # D = rowsum(dO*O): produced inside the dq kernel, read by dk/dv
     Bk = B // kv_div
     if kt is None:
         kt = transpose_btc(k, Bk, Tkr, C)
     Tkp = kt.shape[-1]
-    dq = torch.empty_like(q)
-    _call("fd_attn_bwd_dq", _p(_chk(q)), _p(_chk(k)), _p(_chk(v)), _p(kt), _p(_chk(do)), _p(lse), _p(Dd), _p(_chk(o)), _p(dq), B, H, Tq, Tk, Tkp, Tkr, d,
-          kv_div, scale, _stream())
+    if dqkv is not None:
+        assert kv_div == 1 and dqkv.shape == (q.shape[0], 3 * C) and dqkv.is_contiguous() and Tkr == Tk and dqkv.dtype == F16
+        dq, dk, dv = dqkv[:, :C], dqkv[:, C:2 * C], dqkv[:, 2 * C:]
+        lddkv = 3 * C
+    else:
+        dq = torch.empty((q.shape[0], C), dtype=F16, device=q.device)
+        lddkv = C
+        if kv_div > 1:
+            dk, dv = dk_acc, dv_acc
+            assert dk.dtype == F32 and dv.dtype == F32
+        else:
+            mk = torch.empty if Tkr == Tk else torch.zeros
+            dk, dv = mk((k.shape[0], C), dtype=F16, device=q.device), mk((k.shape[0], C), dtype=F16, device=q.device)
+    _call("fd_attn_bwd_dq", _p(q), _p(k), _p(v), _p(kt), _p(_chk(do)), _p(lse), _p(Dd), _p(_chk(o)), _p(dq), B, H, Tq, Tk, Tkp, Tkr, d,
+          kv_div, scale, _rows(q), _rows(k), _rows(dq), _stream())
     qt = transpose_btc(q, B, Tq, C, Tq)
     dot = transpose_btc(do, B, Tq, C, Tq)
-    if kv_div > 1:
-        dk, dv = dk_acc, dv_acc
-        assert dk.dtype == F32 and dv.dtype == F32
-    else:
-        dk, dv = (torch.empty_like(k), torch.empty_like(v)) if Tkr == Tk else (torch.zeros_like(k), torch.zeros_like(v))
     _call("fd_attn_bwd_dkdv", _p(q), _p(qt), _p(k), _p(v), _p(do), _p(dot), _p(lse), _p(Dd), _p(dk), _p(dv), B, H, Tq, Tk, Tkr, d, kv_div, scale,
-          _stream())
+          _rows(q), _rows(k), lddkv, _stream())
     return dq, dk, dv
 
 
@@ -485,11 +505,12 @@ def attn_fwd_fp8(q, k, v, B, H, T, d, scale=None, need_lse=False):
     v8t = torch.empty((B, H, DV8, T), dtype=torch.uint8, device=dev)
     sk = torch.empty((B, H, T // 64), dtype=F32, device=dev)
     sv = torch.empty((B, H, T // 64), dtype=F32, device=dev)
-    _call("fd_attn_fp8_quant_kv", _p(_chk(k)), _p(_chk(v)), _p(k8), _p(v8t), _p(sk), _p(sv), B, H, T, d, _stream())
-    o = torch.empty_like(q)
+    assert _rows(k) == _rows(v)
+    _call("fd_attn_fp8_quant_kv", _p(k), _p(v), _p(k8), _p(v8t), _p(sk), _p(sv), B, H, T, d, _rows(k), _stream())
+    o = torch.empty((q.shape[0], H * d), dtype=F16, device=dev)
     lse = torch.empty((B, H, T), dtype=F32, device=dev) if need_lse else None
-    _call("fd_attn_fwd_fp8", _p(_chk(q)), _p(k8), _p(v8t), _p(sk), _p(sv), _p(o), _p(lse), B, H, T, d, scale if scale is not None else d ** -0.5,
-          _stream())
+    _call("fd_attn_fwd_fp8", _p(q), _p(k8), _p(v8t), _p(sk), _p(sv), _p(o), _p(lse), B, H, T, d, scale if scale is not None else d ** -0.5,
+          _rows(q), _stream())
     return (o, lse) if need_lse else o
 
 

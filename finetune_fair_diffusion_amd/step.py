@@ -140,6 +140,9 @@ class FairnessTrainer:
         self._marks = []
         # exp-3/4/5: run the Monte-Carlo OT solves on a worker thread underneath R2 (False = inline, like the reference)
         self.overlap_targets = os.environ.get("FD_NO_OT_OVERLAP") is None
+        # R1 and R2 rollouts enqueued in lockstep on two HIP streams (FD_NO_CONCURRENT_R2=1: one after the other, as the reference does)
+        self.concurrent_r2 = os.environ.get("FD_NO_CONCURRENT_R2") is None
+        self._side = None
         self.last_ot_ms = (0.0, 0.0)
         self._tgt = None
 
@@ -165,6 +168,11 @@ class FairnessTrainer:
             out[n0] = out.get(n0, 0.0) + e0.elapsed_time(e1)
         return out
 
+    def _side_stream(self):
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        return self._side
+
     # ------------------------------------------------------------------ pieces
     def encode_pair(self, te, tokens, record=False):
         """tokens = (prompt_ids [L], prompt_mask [L], uncond_ids [L], uncond_mask [L]) -> enc [2,L,D] fp16, uncond first (:1035)."""
@@ -173,16 +181,17 @@ class FairnessTrainer:
         mask = torch.stack([um, pm]).to(self.device)
         return te.forward(ids, mask, record=record)[0]
 
-    def rollout(self, unet, enc, noises, S, keep_inputs=False, record_prompt=False, keep_activations=False):
-        """CFG denoising rollout (:1038-1056).  noises [N,4,h,w] fp32 on device.  Returns (x_final, [x_i], {i: ctx}).
+    def rollout_steps(self, unet, enc, noises, S, res, keep_inputs=False, record_prompt=False, keep_activations=False):
+        """CFG denoising rollout (:1038-1056) as a generator: yields after the launches of each denoising step so that two rollouts (R1
+        on the current stream, R2 on the side stream) can be enqueued in lockstep; fills ``res`` = dict(lat, inputs, ctxs).
         With ``keep_activations`` the per-step backward contexts are kept for as many timesteps as fit in HBM
         (288 GB holds the whole 20-step chain at batch 8); the remaining steps are recomputed in the backward."""
-        N = noises.shape[0]
         self.sch.set_timesteps(S)
         unet.prepare_timesteps(self.sch.timesteps)
         unet.prepare_prompt(enc, record=record_prompt)
         lat = noises.clone()
         state, inputs, ctxs = {}, [], {}
+        res.update(lat=lat, inputs=inputs, ctxs=ctxs)
         gs = self.args.guidance_scale
         budget = 0
         for i in range(S):
@@ -203,7 +212,14 @@ class FairnessTrainer:
                 else:
                     budget -= 1
             self.sch.cfg_step(i, eps, gs, lat, state)
-        return lat, inputs, ctxs
+            yield i
+
+    def rollout(self, unet, enc, noises, S, keep_inputs=False, record_prompt=False, keep_activations=False):
+        """noises [N,4,h,w] fp32 on device.  Returns (x_final, [x_i], {i: ctx})."""
+        res = {}
+        for _ in self.rollout_steps(unet, enc, noises, S, res, keep_inputs, record_prompt, keep_activations):
+            pass
+        return res["lat"], res["inputs"], res["ctxs"]
 
     def decode(self, lat, record=False):
         return self.vae.decode_images(lat * (1.0 / self.vae.config.scaling_factor), record=record)
@@ -369,30 +385,64 @@ class FairnessTrainer:
         train_unet = getattr(args, "train_unet", False) and self.unet.lora_bank is not None
         share = self.share_r1_r3 and vb >= B and self.eval_unet is not self.unet and (train_unet or train_te)
         shared = None
+        # R1 (finetuned model) and R2 (frozen original, :1844-1858) are independent until the loss: with ``concurrent_r2`` their denoising
+        # steps are enqueued in lockstep on two HIP streams, so the many launches that cannot fill 256 CUs on their own (16x16 / 8x8 levels,
+        # tail waves, latency-bound short-K GEMMs) overlap with the other rollout's work.  Same kernels, same results.
+        conc = self.concurrent_r2 and vb >= B and self.eval_unet is not self.unet
+        cur = torch.cuda.current_stream()
+        side = self._side_stream() if conc else None
+        r2 = {}
+        if conc:
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                enc_ori = self.encode_pair(self.eval_te, tokens)
+                g2 = self.rollout_steps(self.eval_unet, enc_ori, noises, S, r2)
         if share:
             enc = self.encode_pair(self.te, tokens, record=train_te)
-            x_final, inputs, ctxs = self.rollout(self.unet, enc, noises, S, keep_inputs=True, record_prompt=True,
-                                                 keep_activations=self.keep_activations)
+            r1 = {}
+            g1 = self.rollout_steps(self.unet, enc, noises, S, r1, keep_inputs=True, record_prompt=True, keep_activations=self.keep_activations)
+            for _ in g1:
+                if conc:
+                    with torch.cuda.stream(side):
+                        next(g2, None)
+            x_final, inputs, ctxs = r1["lat"], r1["inputs"], r1["ctxs"]
             self._mark("R1_vae")
             images = self.decode(x_final, record=True)
             shared = (enc, inputs, ctxs)
         else:
             enc = self.encode_pair(self.te, tokens)
-            lats = [self.rollout(self.unet, enc, noises[j:j + vb], S)[0] for j in range(0, B, vb)]
+            lats = []
+            for j in range(0, B, vb):
+                r1 = {}
+                for _ in self.rollout_steps(self.unet, enc, noises[j:j + vb], S, r1):
+                    if conc:
+                        with torch.cuda.stream(side):
+                            next(g2, None)
+                lats.append(r1["lat"])
             self._mark("R1_vae")
             images = torch.cat([self.decode(x) for x in lats])
+        if conc:
+            with torch.cuda.stream(side):
+                for _ in g2:           # (nothing left when both rollouts have S steps)
+                    pass
+                images_ori = self.decode(r2["lat"])
         self._mark("classify_targets")
         ind, boxes, per = self.classify(images, record=share)
         # ---- dynamic targets from the global batch (:1805-1837): gathered now, solved underneath R2, consumed by R3's loss
         self.start_dynamic_targets(per, B)
         out.update(images=images, probs=per[0]["probs"], preds=per[0]["preds"])
         # ---- R2: images from the frozen original models (:1844-1858)
-        self._mark("R2_rollout")
-        enc_ori = self.encode_pair(self.eval_te, tokens) if self.eval_te is not self.te else enc
-        lats = [self.rollout(self.eval_unet, enc_ori, noises[j:j + vb], S)[0] for j in range(0, B, vb)]
-        self._mark("R2_vae")
-        images_ori = torch.cat([self.decode(x) for x in lats])
-        self._mark("R2_classify_regularisers")
+        if conc:
+            self._mark("R2_tail_and_regularisers")
+            cur.wait_stream(side)              # everything downstream (classifier, feature encoders, loss) consumes images_ori on ``cur``
+            images_ori.record_stream(cur)
+        else:
+            self._mark("R2_rollout")
+            enc_ori = self.encode_pair(self.eval_te, tokens) if self.eval_te is not self.te else enc
+            lats = [self.rollout(self.eval_unet, enc_ori, noises[j:j + vb], S)[0] for j in range(0, B, vb)]
+            self._mark("R2_vae")
+            images_ori = torch.cat([self.decode(x) for x in lats])
+            self._mark("R2_classify_regularisers")
         ind_o, boxes_o, per_o = self.classify(images_ori)
         out.update(images_ori=images_ori, preds_ori=per_o[0]["preds"], probs_ori=per_o[0]["probs"])
         if self.use_img_loss:                                                    # :1860-1862

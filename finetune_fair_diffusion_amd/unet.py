@@ -49,9 +49,16 @@ class AttnLoRA:
     def refresh(self):
         for p in (self.q, self.k, self.v, self.out):
             p.refresh()
-        # stacked down matrices: one skinny GEMM gives t for q,k,v of self-attention
+        # self-attention: q, k, v run as ONE GEMM with stacked weights [3C, C]; their LoRA rank updates ride it as one second K-slab:
+        # t = n1 . down_qkv^T [M, 3rp] against the block-diagonal up matrix [3C, 3rp]
         if self.q.K == self.k.K:
-            self.down_qkv16 = torch.cat([self.q.down16, self.k.down16, self.v.down16], 0).contiguous()
+            self.down_qkv16 = torch.cat([self.q.down16, self.k.down16, self.v.down16], 0).contiguous()        # [3rp, C]
+            self.down_qkvT16 = self.down_qkv16.t().contiguous()                                                # [C, 3rp]
+            C, rp = self.q.N, self.q.rp
+            self.up_qkv16 = torch.zeros((3 * C, 3 * rp), dtype=F16, device=self.q.up16.device)
+            for i, p in enumerate((self.q, self.k, self.v)):
+                self.up_qkv16[i * C:(i + 1) * C, i * rp:(i + 1) * rp] = p.up16
+            self.upT_qkv16 = self.up_qkv16.t().contiguous()                                                    # [3rp, 3C]
         self.down_kv16 = torch.cat([self.k.down16, self.v.down16], 0).contiguous()
 
 
@@ -67,6 +74,9 @@ class TransformerBlock:
         b = p + "transformer_blocks.0."
         self.ln1, self.ln2, self.ln3 = Norm(sd, b + "norm1", dev), Norm(sd, b + "norm2", dev), Norm(sd, b + "norm3", dev)
         self.q1, self.k1, self.v1, self.o1 = (Linear(sd, b + "attn1." + n, dev) for n in ("to_q", "to_k", "to_v", "to_out.0"))
+        assert self.q1.bias is None and self.k1.bias is None and self.v1.bias is None     # diffusers Attention: to_q/k/v have no bias
+        self.wqkv = torch.cat([self.q1.w, self.k1.w, self.v1.w], 0).contiguous()            # [3C, C]: one GEMM, n1 is read once
+        self._wqkvT = None
         self.q2, self.k2, self.v2, self.o2 = (Linear(sd, b + "attn2." + n, dev) for n in ("to_q", "to_k", "to_v", "to_out.0"))
         ff1, self.ff2 = Linear(sd, b + "ff.net.0.proj", dev), Linear(sd, b + "ff.net.2", dev)
         # GEGLU is fused into the FF1 projection: weights with (value_c, gate_c) rows adjacent; recording forwards also keep the
@@ -117,14 +127,12 @@ class TransformerBlock:
         n1, ln1 = ops.layernorm(h0, self.ln1.gamma, self.ln1.beta, 1e-5, save_stats=True)  # stats are 8 B/row: always kept
         l1 = self.lora1
         if l1 is not None:
-            rp = l1.q.rp
             t1 = ops.gemm(n1, l1.down_qkv16)
-            q = ops.gemm(n1, self.q1.w, a2=t1[:, :rp], b2=l1.q.up16)
-            k = ops.gemm(n1, self.k1.w, a2=t1[:, rp:2 * rp], b2=l1.k.up16)
-            v = ops.gemm(n1, self.v1.w, a2=t1[:, 2 * rp:], b2=l1.v.up16)
+            qkv = ops.gemm(n1, self.wqkv, a2=t1, b2=l1.up_qkv16)
         else:
             t1 = None
-            q, k, v = ops.gemm(n1, self.q1.w), ops.gemm(n1, self.k1.w), ops.gemm(n1, self.v1.w)
+            qkv = ops.gemm(n1, self.wqkv)
+        q, k, v = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]           # column slices (row stride 3C): the attention kernels take strides
         if ops.fp8_attn_ok(HW, d):       # BASELINE configs[4]: e4m3 QK^T / PV in self-attention (the backward stays in the working dtype)
             o, lse = ops.attn_fwd_fp8(q, k, v, B, h, HW, d, need_lse=True)
         else:
@@ -147,7 +155,7 @@ class TransformerBlock:
         h3 = ops.gemm(gg, self.ff2.w, bias=self.ff2.bias, residual=h2)
         out = ops.gemm(h3, self.proj_out.w, bias=self.proj_out.bias, residual=xf)
         if rec:
-            ctx.append(dict(x=x, st=st, h0=h0, ln1=ln1, n1=n1, t1=t1, q=q, k=k, v=v, o=o, lse=lse, to1=to1, h1=h1, ln2=ln2, n2=n2,
+            ctx.append(dict(x=x, st=st, h0=h0, ln1=ln1, n1=n1, t1=t1, qkv=qkv, o=o, lse=lse, to1=to1, h1=h1, ln2=ln2, n2=n2,
                             tq2=tq2, q2=q2f, o2=o2, lse2=lse2, to2=to2, h2=h2, ln3=ln3, proj=proj, pair=pair))
         return out
 
@@ -188,13 +196,21 @@ class TransformerBlock:
         dh1 = ops.layernorm_bwd(c["h1"], dn2, self.ln2.gamma, c["ln2"], add=dh2)
         # attn1 (self)
         do1 = lora_linear_bwd(dh1, c["o"], c["to1"], self.o1, l1.out if l1 else None, gscale)
-        dq, dk, dv = ops.attn_bwd(c["q"], c["k"], c["v"], c["o"], do1, c["lse"], B, h, HW, HW, d, 1)
-        t1 = c["t1"]
-        rp = l1.q.rp if l1 else 0
-        sl = (lambda i: t1[:, i * rp:(i + 1) * rp]) if l1 else (lambda i: None)
-        dn1 = lora_linear_bwd(dq, c["n1"], sl(0), self.q1, l1.q if l1 else None, gscale, need_dx=need_dx)
-        dn1 = lora_linear_bwd(dk, c["n1"], sl(1), self.k1, l1.k if l1 else None, gscale, residual=dn1, need_dx=need_dx)
-        dn1 = lora_linear_bwd(dv, c["n1"], sl(2), self.v1, l1.v if l1 else None, gscale, residual=dn1, need_dx=need_dx)
+        qkv = c["qkv"]
+        dqkv = torch.empty_like(qkv)                                    # dq | dk | dv as column slices: one dgrad GEMM over K = 3C
+        ops.attn_bwd(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], c["o"], do1, c["lse"], B, h, HW, HW, d, 1, dqkv=dqkv)
+        if self._wqkvT is None:
+            self._wqkvT = self.wqkv.t().contiguous()                    # [C, 3C]
+        if l1 is not None:
+            t1, rp = c["t1"], l1.q.rp
+            u = ops.gemm(dqkv, l1.upT_qkv16)                             # [M, 3rp] = (dq up_q | dk up_k | dv up_v)
+            for i, pair in enumerate((l1.q, l1.k, l1.v)):
+                gd, gu = pair.grads()
+                ops.lora_wgrad(dqkv[:, i * C:(i + 1) * C], t1[:, i * rp:(i + 1) * rp], gu, pair.r, 1, pair.r, scale=1.0 / gscale)   # d up = dy^T t
+                ops.lora_wgrad(c["n1"], u[:, i * rp:(i + 1) * rp], gd, 1, pair.K, pair.r, scale=1.0 / gscale)                       # d down = u^T n1
+            dn1 = ops.gemm(dqkv, self._wqkvT, a2=u, b2=l1.down_qkvT16) if need_dx else None
+        else:
+            dn1 = ops.gemm(dqkv, self._wqkvT) if need_dx else None
         if not need_dx:
             return None
         dh0 = ops.layernorm_bwd(c["h0"], dn1, self.ln1.gamma, c["ln1"], add=dh1)

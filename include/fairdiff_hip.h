@@ -112,7 +112,7 @@ int fd_act_fwd(const void* x, void* y, int64_t n, int act, void* stream);
 int fd_act_bwd(const void* z, const void* dy, void* dx, int64_t n, int act, void* stream);
 int fd_add(const void* a, const void* b, void* y, int64_t n, float sa, float sb, void* stream);      /* y = sa*a + sb*b (fp16) */
 int fd_copy_cols(const void* src, int64_t lds, void* dst, int64_t ldd, int64_t M, int cols, void* stream); /* strided 2-D copy, fp16 */
-int fd_transpose_btc(const void* x /* [B,T,C] */, void* y /* [B,C,Tp] */, int B, int T, int C, int Tp, void* stream);
+int fd_transpose_btc(const void* x /* [B,T,C], row stride ldx (0 = C) */, int64_t ldx, void* y /* [B,C,Tp] */, int B, int T, int C, int Tp, void* stream);
 /* phase-major [4][B,H,W,C] (FD_CONV_UP2P output) -> channels-last [B,2H,2W,C] */
 int fd_phase_shuffle(const void* src, void* dst, int B, int H, int W, int C, void* stream);
 int fd_downsum2x2(const void* x /* [B,2H,2W,C] */, void* y /* [B,H,W,C] */, int B, int H, int W, int C, void* stream);
@@ -126,21 +126,24 @@ int fd_cast_f16_to_f32(const void* x, float* y, int64_t n, float scale, void* st
  * q:[B,Tq,H*d]  k:[Bk,Tkr,H*d] of which the first Tk rows are keys (Tkr>=Tk: row-padded token buffers of the ViTs)
  * vt:[Bk,H*d,Tkp] (V transposed, keys contiguous, Tkp>=Tk, Tkp%8==0)
  * sample b uses kv batch b / kv_div (cross-attention K/V are shared by each CFG half).
- * o:[B,Tq,H*d] fp16, lse:[B,H,Tq] fp32 (natural-log sum-exp of the scaled scores).                 */
+ * o:[B,Tq,H*d] fp16, lse:[B,H,Tq] fp32 (natural-log sum-exp of the scaled scores).
+ * ldq / ldk (and ldkv, lddq, lddkv below): row strides in elements of q, k/v and of the dq, dk/dv outputs; 0 = H*d (contiguous).
+ * Non-trivial strides let q, k, v (and dq, dk, dv) be column slices of ONE [M, 3*H*d] buffer: the self-attention projections run as a
+ * single GEMM with stacked weights and their input gradients as a single GEMM over K = 3*H*d.                                       */
 int fd_attn_fwd(const void* q, const void* k, const void* vt, void* o, float* lse, int B, int H, int Tq, int Tk,
-                int Tkp, int Tkr, int d, int kv_div, float scale, void* stream);
+                int Tkp, int Tkr, int d, int kv_div, float scale, int ldq, int ldk, void* stream);
 /* D[b,h,t] = sum_j dO*O */
 int fd_attn_bwd_prep(const void* o, const void* d_o, float* D, int B, int H, int T, int d, void* stream);
 /* dq from (q, k, v, kt:[Bk,H*d,Tkp], dO, lse, D).  With o != NULL the kernel computes D = rowsum(dO*O) itself and WRITES it to D
  * for fd_attn_bwd_dkdv (fd_attn_bwd_prep is then not needed); with o == NULL it reads D. */
 int fd_attn_bwd_dq(const void* q, const void* k, const void* v, const void* kt, const void* d_o, const float* lse,
                    float* D, const void* o, void* dq, int B, int H, int Tq, int Tk, int Tkp, int Tkr, int d, int kv_div, float scale,
-                   void* stream);
+                   int ldq, int ldkv, int lddq, void* stream);
 /* dk,dv from (q, qt:[B,H*d,Tq], k, v, dO, dOt:[B,H*d,Tq], lse, D). When kv_div>1 the kv batch is shared by
  * kv_div consecutive samples; dk/dv are then fp32 [Bk,Tk,H*d] accumulated with atomics, else fp16. */
 int fd_attn_bwd_dkdv(const void* q, const void* qt, const void* k, const void* v, const void* d_o, const void* d_ot,
                      const float* lse, const float* D, void* dk, void* dv, int B, int H, int Tq, int Tk, int Tkr, int d,
-                     int kv_div, float scale, void* stream);
+                     int kv_div, float scale, int ldq, int ldkv, int lddkv, void* stream);
 
 /* ---- FP8 (OCP e4m3fn) self-attention forward: BASELINE configs[4] "bf16 + MFMA fp8 attention" (per-tile scaled QK^T / PV,
  * self-attention only).  Same reference op as fd_attn_fwd for the attn1 layers; the reference itself only ran fp16 (:401-405).
@@ -149,9 +152,10 @@ int fd_attn_bwd_dkdv(const void* q, const void* qt, const void* k, const void* v
  * fd_attn_fwd_fp8: q [B,T,H*d] (quantised in registers, one scale per query row), both contractions on v_mfma_f32_32x32x16_fp8_fp8,
  * fp32 softmax statistics; o [B,T,H*d] working dtype and lse [B,H,T] exactly as fd_attn_fwd (the backward kernels consume them).
  * T % 64 == 0, d in {40, 80, 160}.                                                                                               */
-int fd_attn_fp8_quant_kv(const void* k, const void* v, void* k8, void* v8t, float* sk, float* sv, int B, int H, int T, int d, void* stream);
+int fd_attn_fp8_quant_kv(const void* k, const void* v, void* k8, void* v8t, float* sk, float* sv, int B, int H, int T, int d,
+                         int ldkv /* row stride of k and v, 0 = H*d */, void* stream);
 int fd_attn_fwd_fp8(const void* q, const void* k8, const void* v8t, const float* sk, const float* sv, void* o, float* lse, int B, int H,
-                    int T, int d, float scale, void* stream);
+                    int T, int d, float scale, int ldq /* row stride of q, 0 = H*d */, void* stream);
 
 /* ---- masked attention of the CLIP text encoder (transformers CLIPAttention; reference call sites :1011-1014, :1078-1081).
  * q,k,v,o: [B,T,H*d] fp16, T<=128, d<=128; key_valid [B,T] int32 or NULL; P [B,H,T,T] fp32 (saved probabilities) or NULL */

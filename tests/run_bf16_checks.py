@@ -77,8 +77,8 @@ def kernels():
     check("attention dk", dk.reshape(B, T, C), kr.grad, 3e-2)
     check("attention dv", dv.reshape(B, T, C), vr.grad, 3e-2)
     o8 = ops.attn_fwd_fp8(q.reshape(B * T, C), k.reshape(B * T, C), v.reshape(B * T, C), B, H, T, d)
-    check("fp8 attention fwd (bf16 in/out) vs fp32", o8.reshape(B, T, C), oref, 6e-2)
-    check("fp8 attention fwd vs the bf16 kernel", o8.reshape(B, T, C), o.reshape(B, T, C), 6e-2)
+    check("fp8 attention fwd (bf16 in/out) vs fp32 (white-noise inputs: the band of test_attention_fwd_fp8_band)", o8.reshape(B, T, C), oref, 1.8e-1)
+    check("fp8 attention fwd vs the bf16 kernel", o8.reshape(B, T, C), o.reshape(B, T, C), 1.8e-1)
 
 
 def tiny_unet_and_step():
@@ -169,7 +169,7 @@ def sd15_unet():
     unet_p.prepare_timesteps([601])
     unet_p.prepare_prompt(enc.to(dev).to(BF), record=False)
     eps_p = unet_p.forward_step(x1.to(dev), 0, record=False, pair=True).view(2, 4, 64, 64)
-    check("SD15 unet eps" + (" with e4m3 self-attention at 64^2/32^2/16^2/8^2" if FP8 else ""), eps_p, eps_o, 1.2e-1 if FP8 else 8e-2)
+    check("SD15 unet eps" + (" with e4m3 self-attention at 64^2/32^2/16^2/8^2" if FP8 else ""), eps_p, eps_o, 5e-2 if FP8 else 4e-2)
     rms = float((eps_p.float().cpu() - eps_o).pow(2).mean().sqrt() / eps_o.pow(2).mean().sqrt())
     print(f"SD15 unet eps rel RMS err = {rms:.3e}")
     assert rms < (3e-2 if FP8 else 2e-2)
