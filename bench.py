@@ -157,7 +157,7 @@ def main():
     # fwd, one backward) while the reference's algorithm counts 8*S*F_unet + 4*F_vae; both fractions are reported
     shared = bool(tr.share_r1_r3 and args.val_GPU_batch_size >= a.batch)
     f_exec = (6 if shared else 8) * a.S * F_UNET + (3 if shared else 4) * F_VAE
-    line["config"].update(r3_consumes_r1_forward=shared, r1_r2_rollouts_on_two_streams=bool(tr.concurrent_r2), executed_flop_per_image=f_exec,
+    line["config"].update(r3_consumes_r1_forward=shared, r1_r2_rollouts_on_two_streams=bool(tr.concurrent_r2), backward_timesteps_on_two_streams=bool(tr.concurrent_bwd), executed_flop_per_image=f_exec,
                           step_mfma_frac_executed=value / world * f_exec / MFMA_PEAK_F16)
 
     if rank == 0 and not a.no_roofline:
@@ -165,9 +165,9 @@ def main():
         # name) and the per-phase HIP events of the trainer
         ops.TIMER = ops.OpTimer()
         tr.timers = True
-        conc, tr.concurrent_r2 = tr.concurrent_r2, False     # kernels timed in isolation: the R1 / R2 rollouts one after the other on one stream
+        conc, tr.concurrent_r2, concb, tr.concurrent_bwd = tr.concurrent_r2, False, tr.concurrent_bwd, False     # kernels timed in isolation on one stream
         one_step()
-        tr.concurrent_r2 = conc
+        tr.concurrent_r2, tr.concurrent_bwd = conc, concb
         summ = ops.TIMER.summary()
         if a.dump_shapes:
             with open(a.dump_shapes, "w") as f:

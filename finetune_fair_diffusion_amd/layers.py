@@ -103,7 +103,9 @@ class LoRAPair:
         self.upT16 = self.up16.t().contiguous()      # [rp, N]
 
     def grads(self):
-        return self.bank.grad_view(self.dn), self.bank.grad_view(self.un)
+        """Views of this pair's gradients inside the bank's ACCUMULATION buffer (``bank.grad``, or the second buffer while the
+        backward of a timestep runs on the side stream, step.py)."""
+        return self.bank.view(self.dn, self.bank.accum), self.bank.view(self.un, self.bank.accum)
 
 
 class ParamBank:
@@ -125,6 +127,8 @@ class ParamBank:
         self.numel = off
         self.flat = torch.zeros(off, dtype=F32, device=dev)
         self.grad = torch.zeros(off, dtype=F32, device=dev)
+        self.accum = self.grad      # buffer the LoRA weight-gradient kernels add into
+        self._grad_alt = None
         self.exp_avg = torch.zeros(off, dtype=F32, device=dev)
         self.exp_avg_sq = torch.zeros(off, dtype=F32, device=dev)
         self.ema = torch.zeros(off, dtype=F32, device=dev)
@@ -138,6 +142,14 @@ class ParamBank:
 
     def grad_view(self, n):
         return self.view(n, self.grad)
+
+    @property
+    def grad_alt(self):
+        """Second accumulation buffer: timesteps whose backward runs on the side stream add here (no two streams update one buffer);
+        summed into ``grad`` once per step."""
+        if self._grad_alt is None:
+            self._grad_alt = torch.zeros_like(self.grad)
+        return self._grad_alt
 
     def load_state_dict(self, sd, strict=True):
         for n in self.names:

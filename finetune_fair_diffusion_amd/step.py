@@ -21,6 +21,7 @@ face-feature network and its feature database are attached (``face_net`` sfnet.p
 classifier's at the image and go through the VAE once.  A non-zero ``weight_loss_face`` without a face network is refused
 rather than silently dropped.
 """
+import contextlib
 import math
 import os
 import threading
@@ -58,6 +59,20 @@ def _ctx_bytes(obj, seen=None):
     if isinstance(obj, (list, tuple)):
         return sum(_ctx_bytes(v, seen) for v in obj)
     return 0
+
+
+def _record_stream(obj, stream):
+    """Tell the caching allocator that the tensors of a recorded-forward context are also used on ``stream`` (they were allocated on
+    the main stream): their memory is not handed out again before that stream's pending kernels have read them."""
+    if torch.is_tensor(obj):
+        if obj.is_cuda:
+            obj.record_stream(stream)
+    elif isinstance(obj, dict):
+        for v in obj.values():
+            _record_stream(v, stream)
+    elif isinstance(obj, (list, tuple)):
+        for v in obj:
+            _record_stream(v, stream)
 
 
 def _pow2_scale(amax, target):
@@ -142,6 +157,8 @@ class FairnessTrainer:
         self.overlap_targets = os.environ.get("FD_NO_OT_OVERLAP") is None
         # R1 and R2 rollouts enqueued in lockstep on two HIP streams (FD_NO_CONCURRENT_R2=1: one after the other, as the reference does)
         self.concurrent_r2 = os.environ.get("FD_NO_CONCURRENT_R2") is None
+        # backward of odd timesteps on the side stream (FD_NO_CONCURRENT_BWD=1: all on one stream)
+        self.concurrent_bwd = os.environ.get("FD_NO_CONCURRENT_BWD") is None
         self._side = None
         self.last_ot_ms = (0.0, 0.0)
         self._tgt = None
@@ -556,14 +573,35 @@ class FairnessTrainer:
             out.update(g=g, coefs=coefs, gscale=gscale)
             self._mark("R3_bwd_unet")
             if train_unet or train_te:
+                # The S per-timestep backwards are independent (the U-Net input is detached at every step, :1115): odd timesteps are
+                # enqueued on the side stream and accumulate their LoRA gradients into a second buffer, so that the many launches which
+                # cannot fill the chip alone overlap with the neighbouring timestep's.  Shared cross-attention dK/dV use fp32 atomics.
+                cur = torch.cuda.current_stream()
+                side = self._side_stream() if (self.concurrent_bwd and S > 1) else None
+                if side is not None:
+                    for bank in self.banks:
+                        bank.grad_alt.zero_()
+                    side.wait_stream(cur)
                 for i in range(S):
-                    if i in ctxs:
-                        self.unet._ctx = ctxs.pop(i)        # activations kept from the forward rollout
-                    else:                                   # gradient-checkpointed recompute of this timestep
-                        x = ops.to_f16(inputs[i])
-                        self.unet.forward_step(x if _CFG_PAIR else x.repeat(2, 1, 1, 1), i, record=True, pair=_CFG_PAIR)
-                    d = g * float(coefs[i] * gscale)
-                    self.unet.backward_step(torch.cat([d * (1.0 - gs), d * gs]), gscale)
+                    on_side = side is not None and (i & 1) == 1
+                    with (torch.cuda.stream(side) if on_side else contextlib.nullcontext()):
+                        if i in ctxs:
+                            self.unet._ctx = ctxs.pop(i)        # activations kept from the forward rollout
+                            if on_side:
+                                _record_stream(self.unet._ctx, side)
+                        else:                                   # gradient-checkpointed recompute of this timestep
+                            x = ops.to_f16(inputs[i])
+                            self.unet.forward_step(x if _CFG_PAIR else x.repeat(2, 1, 1, 1), i, record=True, pair=_CFG_PAIR)
+                        for bank in self.banks:
+                            bank.accum = bank.grad_alt if on_side else bank.grad
+                        d = g * float(coefs[i] * gscale)
+                        self.unet.backward_step(torch.cat([d * (1.0 - gs), d * gs]), gscale)
+                for bank in self.banks:
+                    bank.accum = bank.grad
+                if side is not None:
+                    cur.wait_stream(side)
+                    for bank in self.banks:
+                        bank.grad.add_(bank.grad_alt)
                 denc = self.unet.finish_prompt_backward(gscale, need_denc=train_te)
                 if train_te:
                     L = enc_g.shape[1]
