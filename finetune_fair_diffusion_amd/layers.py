@@ -128,7 +128,7 @@ class ParamBank:
         self.flat = torch.zeros(off, dtype=F32, device=dev)
         self.grad = torch.zeros(off, dtype=F32, device=dev)
         self.accum = self.grad      # buffer the LoRA weight-gradient kernels add into
-        self._grad_alt = None
+        self._grad_alt = {}
         self.exp_avg = torch.zeros(off, dtype=F32, device=dev)
         self.exp_avg_sq = torch.zeros(off, dtype=F32, device=dev)
         self.ema = torch.zeros(off, dtype=F32, device=dev)
@@ -143,13 +143,12 @@ class ParamBank:
     def grad_view(self, n):
         return self.view(n, self.grad)
 
-    @property
-    def grad_alt(self):
-        """Second accumulation buffer: timesteps whose backward runs on the side stream add here (no two streams update one buffer);
+    def grad_alt(self, k=1):
+        """k-th extra accumulation buffer: timesteps whose backward runs on side stream k add here (no two streams update one buffer);
         summed into ``grad`` once per step."""
-        if self._grad_alt is None:
-            self._grad_alt = torch.zeros_like(self.grad)
-        return self._grad_alt
+        if k not in self._grad_alt:
+            self._grad_alt[k] = torch.zeros_like(self.grad)
+        return self._grad_alt[k]
 
     def load_state_dict(self, sd, strict=True):
         for n in self.names:

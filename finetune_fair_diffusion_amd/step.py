@@ -159,6 +159,7 @@ class FairnessTrainer:
         self.concurrent_r2 = os.environ.get("FD_NO_CONCURRENT_R2") is None
         # backward of odd timesteps on the side stream (FD_NO_CONCURRENT_BWD=1: all on one stream)
         self.concurrent_bwd = os.environ.get("FD_NO_CONCURRENT_BWD") is None
+        self.bwd_streams = int(os.environ.get("FD_BWD_STREAMS", "2"))
         self._side = None
         self.last_ot_ms = (0.0, 0.0)
         self._tgt = None
@@ -185,10 +186,12 @@ class FairnessTrainer:
             out[n0] = out.get(n0, 0.0) + e0.elapsed_time(e1)
         return out
 
-    def _side_stream(self):
+    def _side_stream(self, k=1):
         if self._side is None:
-            self._side = torch.cuda.Stream(device=self.device)
-        return self._side
+            self._side = {}
+        if k not in self._side:
+            self._side[k] = torch.cuda.Stream(device=self.device)
+        return self._side[k]
 
     # ------------------------------------------------------------------ pieces
     def encode_pair(self, te, tokens, record=False):
@@ -573,17 +576,20 @@ class FairnessTrainer:
             out.update(g=g, coefs=coefs, gscale=gscale)
             self._mark("R3_bwd_unet")
             if train_unet or train_te:
-                # The S per-timestep backwards are independent (the U-Net input is detached at every step, :1115): odd timesteps are
-                # enqueued on the side stream and accumulate their LoRA gradients into a second buffer, so that the many launches which
-                # cannot fill the chip alone overlap with the neighbouring timestep's.  Shared cross-attention dK/dV use fp32 atomics.
+                # The S per-timestep backwards are independent (the U-Net input is detached at every step, :1115): they are dealt round-robin
+                # to ``bwd_streams`` HIP streams, each side stream accumulating its LoRA gradients into its own buffer, so that the many
+                # launches which cannot fill the chip alone overlap with a neighbouring timestep's.  Shared cross-attention dK/dV: fp32 atomics.
                 cur = torch.cuda.current_stream()
-                side = self._side_stream() if (self.concurrent_bwd and S > 1) else None
-                if side is not None:
+                nst = max(1, min(self.bwd_streams, S)) if self.concurrent_bwd else 1
+                sides = [self._side_stream(k) for k in range(1, nst)]
+                for k, side in enumerate(sides, 1):
                     for bank in self.banks:
-                        bank.grad_alt.zero_()
+                        bank.grad_alt(k).zero_()
                     side.wait_stream(cur)
                 for i in range(S):
-                    on_side = side is not None and (i & 1) == 1
+                    k = i % nst
+                    on_side = k > 0
+                    side = sides[k - 1] if on_side else None
                     with (torch.cuda.stream(side) if on_side else contextlib.nullcontext()):
                         if i in ctxs:
                             self.unet._ctx = ctxs.pop(i)        # activations kept from the forward rollout
@@ -593,15 +599,15 @@ class FairnessTrainer:
                             x = ops.to_f16(inputs[i])
                             self.unet.forward_step(x if _CFG_PAIR else x.repeat(2, 1, 1, 1), i, record=True, pair=_CFG_PAIR)
                         for bank in self.banks:
-                            bank.accum = bank.grad_alt if on_side else bank.grad
+                            bank.accum = bank.grad_alt(k) if on_side else bank.grad
                         d = g * float(coefs[i] * gscale)
                         self.unet.backward_step(torch.cat([d * (1.0 - gs), d * gs]), gscale)
                 for bank in self.banks:
                     bank.accum = bank.grad
-                if side is not None:
+                for k, side in enumerate(sides, 1):
                     cur.wait_stream(side)
                     for bank in self.banks:
-                        bank.grad.add_(bank.grad_alt)
+                        bank.grad.add_(bank.grad_alt(k))
                 denc = self.unet.finish_prompt_backward(gscale, need_denc=train_te)
                 if train_te:
                     L = enc_g.shape[1]
