@@ -159,7 +159,7 @@ class FairnessTrainer:
         self.concurrent_r2 = os.environ.get("FD_NO_CONCURRENT_R2") is None
         # backward of odd timesteps on the side stream (FD_NO_CONCURRENT_BWD=1: all on one stream)
         self.concurrent_bwd = os.environ.get("FD_NO_CONCURRENT_BWD") is None
-        self.bwd_streams = int(os.environ.get("FD_BWD_STREAMS", "2"))
+        self.bwd_streams = int(os.environ.get("FD_BWD_STREAMS", "3"))     # measured: 2 -> 1647, 3 -> 1589, 4 -> 1633 ms per step (run-to-run noise ~2 %)
         self._side = None
         self.last_ot_ms = (0.0, 0.0)
         self._tgt = None
