@@ -31,15 +31,18 @@ def f_img(S):
 
 def pmc_traffic(kernel, algorithmic_bytes_per_launch):
     """HBM-side bytes per launch of the dominant kernel from the committed PMC passes (FETCH_SIZE / WRITE_SIZE cannot be read from
-    inside a process; they are collected with rocprofv3 --pmc in separate runs on the kernel's own shapes, profiles/r01_pmc_traffic.json,
+    inside a process; they are collected with rocprofv3 --pmc in separate runs on the kernel's own shapes, profiles/r02_pmc_traffic.json,
     with the gfx950 corrections of MI355X_MICROARCH.md applied).  This run's per-launch figure = its mean ALGORITHMIC bytes per launch
     (exact, from every launch's M, N, K) x the measured traffic / algorithmic ratio of that kernel variant."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
-    if not os.path.exists(path):
-        return None, "no PMC summary committed"
-    d = json.load(open(path))["kernels"].get(kernel)
+    d = None
+    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", name)
+        if os.path.exists(path):
+            d = json.load(open(path))["kernels"].get(kernel)
+            if d is not None:
+                break
     if d is None:
-        return None, "no PMC summary for " + kernel
+        return None, "no PMC summary committed for " + kernel
     ratio = sum(x["hbm_bytes"] for x in d["shapes"]) / sum(x["algorithmic_bytes"] for x in d["shapes"])
     return algorithmic_bytes_per_launch * ratio, "bytes/launch = mean algorithmic bytes/launch of this run (%.1f MB) x %.2f, the rocprofv3 PMC ratio " \
         "(FETCH_SIZE x2 gfx950 correction + WRITE_SIZE) / algorithmic bytes on this kernel's shapes; Infinity-Cache hits are included" % (
