@@ -651,15 +651,22 @@ extern "C" int fd_gemm_tile(const fd_gemm_desc* dp) {
     if (!nobig && nb == 1 && (d.conv ? (d.Cin & 63) == 0 : (d.K + d.K2) >= bigk)) {
         const long phs = (d.conv && d.conv_mode == FD_CONV_UP2P) ? 4 : 1;    // four phases share the launch
         const long m256 = phs * ((d.M + 255) / 256), m128 = phs * ((d.M + 127) / 128);
+        // Minimum tile counts for the 320-wide tiles.  Round 1 tuned them per kernel in isolation (200 / 160: "fill 256 CUs"); under the
+        // multi-stream schedule of round 2 a launch that fills half the chip with efficient tiles beats one that fills it with smaller
+        // tiles or split-K partials, because another stream's launch takes the other half.  Whole-step A/B on one box
+        // (profiles/r02_tile_policy_ab.txt): 200/160 -> 1594-1606 ms, 128/100 -> 1548, 100/80 -> 1533-1538, 64/48 -> 1627, 32/32 -> 1663.
+        static const long t256 = bench_env("FD_GEMM_T256") ? atol(bench_env("FD_GEMM_T256")) : 100;
+        static const long t128 = bench_env("FD_GEMM_T128") ? atol(bench_env("FD_GEMM_T128")) : 80;
+        static const long maxsplit = bench_env("FD_GEMM_MAXSPLIT") ? atol(bench_env("FD_GEMM_MAXSPLIT")) : 8;
         if (d.N % 320 == 0) {
-            if (m256 * (d.N / 320) >= 200) return 256320;
-            if (m128 * (d.N / 320) >= 160) return 128320;
+            if (m256 * (d.N / 320) >= t256) return 256320;
+            if (m128 * (d.N / 320) >= t128) return 128320;
         }
         const bool can_split = d.workspace && (d.N & 3) == 0 && (d.ldc & 3) == 0 && d.act != FD_ACT_GEGLU && phs == 1;
         const long nk = (d.K + 63) / 64 + (d.K2 + 63) / 64;
         auto split_for = [&](long blocks, int tilecode) -> int {   // split K so ~256 blocks exist, >= 8 k-tiles each
             long split = blocks > 0 ? 256 / blocks : 1;
-            if (split > 8) split = 8;
+            if (split > maxsplit) split = maxsplit;
             while (split > 1 && (nk / split < 8 || (int64_t)split * d.M * d.N * 4 > d.workspace_bytes)) --split;
             return split > 1 ? (int)(split * 1000000 + tilecode) : 0;
         };
@@ -668,13 +675,15 @@ extern "C" int fd_gemm_tile(const fd_gemm_desc* dp) {
             const int c = split_for(m128 * (d.N / 320), 128320);
             if (c) return c;
         }
-        if (d.N % 160 == 0 && m128 * (d.N / 160) >= 160) return 128160;
+        static const long t160 = bench_env("FD_GEMM_T160") ? atol(bench_env("FD_GEMM_T160")) : 160;
+        if (d.N % 160 == 0 && m128 * (d.N / 160) >= t160) return 128160;
         // VAE decoder widths (256 / 512 channels at 256^2 / 512^2 pixels): 256x256 halves the A re-reads of the 256x128 tile
         static const bool no256 = bench_env("FD_GEMM_NO256256") != nullptr;
-        if (!no256 && d.N % 256 == 0 && m256 * (d.N / 256) >= 200) return 256256;
+        static const long tvae = bench_env("FD_GEMM_TVAE") ? atol(bench_env("FD_GEMM_TVAE")) : 200;
+        if (!no256 && d.N % 256 == 0 && m256 * (d.N / 256) >= tvae) return 256256;
         static const bool no512 = bench_env("FD_GEMM_NO512128") != nullptr;
         if (!no512 && d.N == 128 && ((d.M + 511) / 512) >= 400) return 512128;   // 128-channel layers at 512^2: the tallest tile that fits the LDS
-        if (d.N % 128 == 0 && m256 * (d.N / 128) >= 200) return 256128;
+        if (d.N % 128 == 0 && m256 * (d.N / 128) >= tvae) return 256128;
         // small-M, long-K (8x8 level): split K so that all 256 CUs get a block
         if (can_split && d.N % 160 == 0) {
             const int c = split_for(m128 * (d.N / 160), 128160);

@@ -46,13 +46,13 @@ __global__ __launch_bounds__(256) void lora_wgrad_partial(const f16* __restrict_
 // covers CGB column groups x RT = 256 / CGB row phases (CGB = 40: 320 columns, the U-Net's channel granule).  The RT partial sums are
 // combined through LDS in a fixed order.  Reads X at full line width instead of 2 bytes per lane.
 template <int RP, int CV, int CGB>
-__global__ __launch_bounds__(256) void lora_wgrad_partial_vec(const f16* __restrict__ X, int64_t ldx, const f16* __restrict__ T, int64_t ldt,
-                                                              float* __restrict__ partial, int M, int N, int rows_per_split) {
+__device__ __forceinline__ void lora_wgrad_partial_vec_body(const f16* __restrict__ X, int64_t ldx, const f16* __restrict__ T, int64_t ldt,
+                                                            float* __restrict__ partial, int M, int N, int rows_per_split, int bx, int by,
+                                                            float* red) {
     constexpr int RT = 256 / CGB;
-    __shared__ float red[(RT - 1) * CGB * (CV * RP + 1)];
     const int cgl = threadIdx.x % CGB, rt = threadIdx.x / CGB;
-    const int n0 = (blockIdx.x * CGB + cgl) * CV;
-    const int m0 = blockIdx.y * rows_per_split;
+    const int n0 = (bx * CGB + cgl) * CV;
+    const int m0 = by * rows_per_split;
     const int m1 = min(m0 + rows_per_split, M);
     float acc[CV][RP];
 #pragma unroll
@@ -111,9 +111,59 @@ __global__ __launch_bounds__(256) void lora_wgrad_partial_vec(const f16* __restr
                 float v = acc[c][r];
 #pragma unroll
                 for (int k = 0; k < RT - 1; ++k) v += red[(k * CGB + cgl) * (CV * RP + 1) + c * RP + r];
-                partial[((int64_t)blockIdx.y * N + n0 + c) * RP + r] = v;
+                partial[((int64_t)by * N + n0 + c) * RP + r] = v;
             }
     }
+}
+
+template <int RP, int CV, int CGB>
+__global__ __launch_bounds__(256) void lora_wgrad_partial_vec(const f16* __restrict__ X, int64_t ldx, const f16* __restrict__ T, int64_t ldt,
+                                                              float* __restrict__ partial, int M, int N, int rows_per_split) {
+    __shared__ float red[(256 / CGB - 1) * CGB * (CV * RP + 1)];
+    lora_wgrad_partial_vec_body<RP, CV, CGB>(X, ldx, T, ldt, partial, M, N, rows_per_split, blockIdx.x, blockIdx.y, red);
+}
+
+// ---- batched form: up to FD_WGRAD_MAX independent problems (the 16 LoRA weight gradients of one transformer block's backward) in ONE partial
+// launch and ONE final launch.  7808 + 7808 launches of ~10 + 7 us per training step were 3.7 % of it; the problems are far too small to fill the
+// chip one at a time.  Same arithmetic and the same fixed reduction order per problem as the single-problem kernels.
+struct WgradBatch {
+    const f16* X[FD_WGRAD_MAX];
+    const f16* T[FD_WGRAD_MAX];
+    float* G[FD_WGRAD_MAX];
+    int64_t ldx[FD_WGRAD_MAX], ldt[FD_WGRAD_MAX], sn[FD_WGRAD_MAX], sr[FD_WGRAD_MAX], poff[FD_WGRAD_MAX];
+    int M[FD_WGRAD_MAX], N[FD_WGRAD_MAX], R[FD_WGRAD_MAX], rows[FD_WGRAD_MAX], ncb[FD_WGRAD_MAX], nsplit[FD_WGRAD_MAX];
+    float scale[FD_WGRAD_MAX];
+    int bstart[FD_WGRAD_MAX + 1];      // first block of each problem in the partial launch
+    int ostart[FD_WGRAD_MAX + 1];      // first output element (n, r) of each problem in the final launch
+    int n;
+};
+
+template <int RP, int CV, int CGB>
+__global__ __launch_bounds__(256) void lora_wgrad_partial_multi(WgradBatch b, float* __restrict__ scratch) {
+    __shared__ float red[(256 / CGB - 1) * CGB * (CV * RP + 1)];
+    int p = 0;
+#pragma unroll 1
+    while (p + 1 < b.n && (int)blockIdx.x >= b.bstart[p + 1]) ++p;
+    const int local = blockIdx.x - b.bstart[p];
+    const int bx = local % b.ncb[p], by = local / b.ncb[p];
+    lora_wgrad_partial_vec_body<RP, CV, CGB>(b.X[p], b.ldx[p], b.T[p], b.ldt[p], scratch + b.poff[p], b.M[p], b.N[p], b.rows[p], bx, by, red);
+}
+
+__global__ __launch_bounds__(256) void lora_wgrad_final_multi(WgradBatch b, const float* __restrict__ scratch, int RP) {
+    const int o = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (o >= b.ostart[b.n]) return;
+    int p = 0;
+#pragma unroll 1
+    while (p + 1 < b.n && o >= b.ostart[p + 1]) ++p;
+    const int lo = o - b.ostart[p];
+    const int lane = threadIdx.x & 63;
+    const int R = b.R[p], N = b.N[p];
+    const int n = lo / R, r = lo % R;
+    const float* partial = scratch + b.poff[p];
+    float s = 0.f;
+    for (int k = lane; k < b.nsplit[p]; k += 64) s += partial[((int64_t)k * N + n) * RP + r];
+    s = wave_sum(s);
+    if (lane == 0) b.G[p][n * b.sn[p] + r * b.sr[p]] += b.scale[p] * s;
 }
 
 // one wave per output element (n, r): lanes stride over the splits in a fixed order, then a fixed-shape wave reduction
@@ -157,4 +207,52 @@ extern "C" int fd_lora_wgrad(const void* X, int64_t ldx, const void* T, int64_t 
     }
     hipLaunchKernelGGL(lora_wgrad_final, dim3((N * R + 3) / 4), dim3(256), 0, s, scratch, G, g_stride_n, g_stride_r, N, R, RP, nsplit, scale);
     return fd_check_launch("fd_lora_wgrad");
+}
+
+// Batched weight gradients: ``descs`` is a HOST array of n <= FD_WGRAD_MAX problems that share the padded rank RP (8 or 16) and satisfy the
+// vectorised kernel's alignment (N %% CV == 0, ldx %% CV == 0 with CV = 8 / 4); anything else is rejected (callers fall back to fd_lora_wgrad).
+extern "C" int fd_lora_wgrad_multi(const fd_wgrad_desc* descs, int n, float* scratch, int64_t scratch_elems, void* stream) {
+    FD_REQUIRE(n >= 1 && n <= FD_WGRAD_MAX, "fd_lora_wgrad_multi: 1..%d problems (got %d)", FD_WGRAD_MAX, n);
+    WgradBatch b;
+    b.n = n;
+    int RP = 0;
+    double work = 0;
+    for (int i = 0; i < n; ++i) {
+        const fd_wgrad_desc& d = descs[i];
+        FD_REQUIRE(d.M > 0 && d.N > 0 && d.R > 0 && d.R <= 16, "fd_lora_wgrad_multi: rank must be in 1..16");
+        const int rp = d.R <= 8 ? 8 : 16;
+        FD_REQUIRE(RP == 0 || rp == RP, "fd_lora_wgrad_multi: mixed padded ranks");
+        RP = rp;
+        const int cv = RP == 8 ? 8 : 4;
+        FD_REQUIRE((d.N % cv) == 0 && (d.ldx % cv) == 0 && d.ldt >= RP && (d.ldt & 7) == 0, "fd_lora_wgrad_multi: alignment (N, ldx %% %d; ldt)", cv);
+        work += (double)d.M * d.N;
+    }
+    const int cols_per_block = RP == 8 ? 320 : 160;
+    int64_t poff = 0;
+    int blocks = 0, outs = 0;
+    for (int i = 0; i < n; ++i) {
+        const fd_wgrad_desc& d = descs[i];
+        const int ncb = (d.N + cols_per_block - 1) / cols_per_block;
+        // ~1536 blocks over the whole batch, shared out by work; at least 64 rows per split
+        int nsplit = (int)(1536.0 * ((double)d.M * d.N / work) / ncb + 0.5);
+        if (nsplit < 1) nsplit = 1;
+        if (nsplit > (d.M + 63) / 64) nsplit = (d.M + 63) / 64;
+        int rows = (d.M + nsplit - 1) / nsplit;
+        rows = (rows + 5) / 6 * 6;
+        nsplit = (d.M + rows - 1) / rows;
+        b.X[i] = (const f16*)d.X; b.T[i] = (const f16*)d.T; b.G[i] = d.G;
+        b.ldx[i] = d.ldx; b.ldt[i] = d.ldt; b.sn[i] = d.g_stride_n; b.sr[i] = d.g_stride_r; b.poff[i] = poff;
+        b.M[i] = d.M; b.N[i] = d.N; b.R[i] = d.R; b.rows[i] = rows; b.ncb[i] = ncb; b.nsplit[i] = nsplit; b.scale[i] = d.scale;
+        b.bstart[i] = blocks; b.ostart[i] = outs;
+        blocks += ncb * nsplit;
+        outs += d.N * d.R;
+        poff += (int64_t)nsplit * d.N * RP;
+    }
+    b.bstart[n] = blocks; b.ostart[n] = outs;
+    FD_REQUIRE(poff <= scratch_elems, "fd_lora_wgrad_multi: scratch too small (%ld > %ld floats)", (long)poff, (long)scratch_elems);
+    hipStream_t s = (hipStream_t)stream;
+    if (RP == 8) hipLaunchKernelGGL((lora_wgrad_partial_multi<8, 8, 40>), dim3(blocks), dim3(256), 0, s, b, scratch);
+    else hipLaunchKernelGGL((lora_wgrad_partial_multi<16, 4, 40>), dim3(blocks), dim3(256), 0, s, b, scratch);
+    hipLaunchKernelGGL(lora_wgrad_final_multi, dim3((outs + 3) / 4), dim3(256), 0, s, b, (const float*)scratch, RP);
+    return fd_check_launch("fd_lora_wgrad_multi");
 }

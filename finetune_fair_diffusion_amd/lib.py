@@ -39,6 +39,13 @@ class GemmDesc(ctypes.Structure):
     ]
 
 
+class WgradDesc(ctypes.Structure):
+    """Mirror of ``fd_wgrad_desc`` (include/fairdiff_hip.h)."""
+    _fields_ = [("X", ctypes.c_void_p), ("ldx", ctypes.c_int64), ("T", ctypes.c_void_p), ("ldt", ctypes.c_int64),
+                ("G", ctypes.c_void_p), ("g_stride_n", ctypes.c_int64), ("g_stride_r", ctypes.c_int64),
+                ("M", ctypes.c_int32), ("N", ctypes.c_int32), ("R", ctypes.c_int32), ("scale", ctypes.c_float)]
+
+
 _CTYPE = {"int": ctypes.c_int, "int32_t": ctypes.c_int32, "int64_t": ctypes.c_int64, "float": ctypes.c_float}
 
 

@@ -515,10 +515,53 @@ def attn_fwd_fp8(q, k, v, B, H, T, d, scale=None, need_lse=False):
 
 
 # ----------------------------------------------------------------------------- LoRA / scheduler / optimizer
+_WGRAD_PENDING = None      # list of (X, T, G, sn, sr, R, scale) while a ``wgrad_batch()`` context is open
+_WGRAD_BATCHING = os.environ.get("FD_NO_WGRAD_BATCH") is None     # A/B switch: 0 -> every weight gradient is its own launch pair
+WGRAD_MAX = 16
+
+
 def lora_wgrad(X, T, G, sn, sr, R, scale=1.0):
+    """G[n*sn + r*sr] += scale * sum_m X[m,n] T[m,r].  Inside ``with wgrad_batch():`` the call is queued and executed with the other
+    queued problems in one partial + one final launch when the context closes (the operands are kept alive until then)."""
+    if _WGRAD_BATCHING and _WGRAD_PENDING is not None and R <= 16 and X.shape[1] % 8 == 0 and X.stride(0) % 8 == 0:
+        _WGRAD_PENDING.append((X, T, G, sn, sr, R, scale))
+        return
     M, N = X.shape
     sc = scratch(1 << 22, X.device)
     _call("fd_lora_wgrad", _p(X), X.stride(0), _p(T), T.stride(0), _p(G), sn, sr, M, N, R, scale, _p(sc), sc.numel(), _stream())
+
+
+class wgrad_batch:
+    """Collects the LoRA weight-gradient problems issued inside the block (``lora_wgrad`` calls) and runs them batched on exit:
+    problems of one padded rank go, up to 16 at a time, through ``fd_lora_wgrad_multi``."""
+
+    def __enter__(self):
+        global _WGRAD_PENDING
+        self.outer, _WGRAD_PENDING = _WGRAD_PENDING, []
+        return self
+
+    def __exit__(self, et, ev, tb):
+        global _WGRAD_PENDING
+        pend, _WGRAD_PENDING = _WGRAD_PENDING, self.outer
+        if et is None:
+            flush_wgrads(pend)
+        return False
+
+
+def flush_wgrads(pend):
+    by_rp = {}
+    for it in pend:
+        by_rp.setdefault(8 if it[5] <= 8 else 16, []).append(it)
+    for rp, items in by_rp.items():
+        for i in range(0, len(items), WGRAD_MAX):
+            chunk = items[i:i + WGRAD_MAX]
+            arr = (_lib.WgradDesc * len(chunk))()
+            for d, (X, T, G, sn, sr, R, scale) in zip(arr, chunk):
+                assert X.dtype == F16 and T.dtype == F16 and G.dtype == F32 and X.stride(1) == 1 and T.stride(1) == 1
+                d.X, d.ldx, d.T, d.ldt, d.G = X.data_ptr(), X.stride(0), T.data_ptr(), T.stride(0), G.data_ptr()
+                d.g_stride_n, d.g_stride_r, d.M, d.N, d.R, d.scale = sn, sr, X.shape[0], X.shape[1], R, scale
+            sc = scratch(1 << 22, chunk[0][0].device)
+            _call("fd_lora_wgrad_multi", ctypes.byref(arr), len(chunk), _p(sc), sc.numel(), _stream())
 
 
 def cfg_dpm_step(eps, guidance, lat, x0_prev, x0_out, alpha_t, sigma_t, c_x, c_d0, c_d1):

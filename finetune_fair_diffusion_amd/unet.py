@@ -162,7 +162,12 @@ class TransformerBlock:
     # -- backward ------------------------------------------------------------------------------
     def backward(self, d_out, B, H, W, c, gscale, need_dx=True):
         """d_out [B*HW, C] (B counts both halves of a paired forward).  ``need_dx=False``: nothing trainable upstream (first attention
-        of the U-Net), the gradient w.r.t. the block input is not formed."""
+        of the U-Net), the gradient w.r.t. the block input is not formed.  The block's 16 LoRA weight gradients are queued and run as
+        one batched launch pair at the end (``ops.wgrad_batch``)."""
+        with ops.wgrad_batch():
+            return self._backward(d_out, B, H, W, c, gscale, need_dx)
+
+    def _backward(self, d_out, B, H, W, c, gscale, need_dx=True):
         HW, C, h, d = H * W, self.C, self.heads, self.d
         l1, l2 = self.lora1, self.lora2
         pair = c.get("pair", False)

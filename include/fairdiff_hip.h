@@ -168,6 +168,19 @@ int fd_small_attn_bwd(const void* q, const void* k, const void* v, const float* 
 int fd_lora_wgrad(const void* X, int64_t ldx, const void* T, int64_t ldt, float* G, int64_t g_stride_n, int64_t g_stride_r,
                   int M, int N, int R, float scale, float* scratch, int64_t scratch_elems, void* stream);
 
+/* batched form: n <= FD_WGRAD_MAX independent problems (HOST array of descriptors) that share the padded rank (R <= 8, or 9..16) in one
+ * partial + one final launch -- the 16 LoRA weight gradients of one transformer block's backward.  Same arithmetic and fixed reduction order
+ * per problem as fd_lora_wgrad.  Requires N %% 8 == 0 and ldx %% 8 == 0 (R <= 8) or %% 4 (R <= 16). */
+#define FD_WGRAD_MAX 16
+typedef struct fd_wgrad_desc {
+    const void* X; int64_t ldx;          /* fp16 [M, N], row stride ldx */
+    const void* T; int64_t ldt;          /* fp16 [M, RP] (rank padded), row stride ldt */
+    float* G; int64_t g_stride_n, g_stride_r;   /* G[n * g_stride_n + r * g_stride_r] += scale * sum_m X[m,n] T[m,r] */
+    int32_t M, N, R;
+    float scale;
+} fd_wgrad_desc;
+int fd_lora_wgrad_multi(const fd_wgrad_desc* descs, int n, float* scratch, int64_t scratch_elems, void* stream);
+
 /* ---- scheduler / CFG (DPMSolverMultistepScheduler.step + CFG combine, 1-main-debias.py:1051-1056,1123-1131)
  * eps:[2N,4,HW] fp32 NCHW (uncond first); x0_prev/x0_out fp32; lat fp32 updated in place.
  * x0 = (lat - sigma*e)/alpha ; lat' = c_x*lat - c_d0*x0 - c_d1*(x0 - x0_prev)                        */

@@ -40,9 +40,10 @@ def test_gemm_plain(ops, dev, M, N, K):
     check(f"gemm {M}x{N}x{K}", c, a.float() @ b.float().t(), 2e-3)
 
 
-@pytest.mark.parametrize("M,N,K,tile", [(51300, 320, 1280, 256320), (20600, 320, 1288, 128320), (20500, 640, 1032, 128320), (1300, 2560, 1024, 128160),
+@pytest.mark.parametrize("M,N,K,tile", [(51300, 320, 1280, 256320), (20600, 320, 1288, 128320), (10000, 640, 1032, 128320), (20500, 640, 1032, 256320),
+                                          (7000, 480, 1024, 128160), (1300, 1280, 1024, 2128160),
                                           (51300, 128, 1096, 256128), (65536, 320, 320, 256320), (65536, 320, 256, 128064), (1024, 1280, 11520, 8128320), (1000, 320, 5120, 8128160),
-                                          (4096, 1280, 11520, 2128320),
+                                          (4096, 1280, 11520, 128320), (2048, 1280, 11520, 4128320),
                                           # banded tile order: B slab per 320-wide n-tile 1.3 MB -> bands of 2 n-tiles; 7 n-tiles -> bands 2,2,2,1
                                           (3000, 2240, 2048, 128320), (8200, 2240, 2048, 256320),
                                           (51300, 512, 1096, 256256), (26000, 256, 520, 256128), (205000, 128, 1160, 512128)])
