@@ -1,8 +1,8 @@
-"""rocprofv3 counter CSVs of scratch/prof_pmc_r02.sh -> profiles/r02_pmc_traffic.json (per kernel name as bench.py's roofline spells it).
-The three shapes of scratch/mb_pmc_r02.py all launch 256 workgroups, so launches are attributed to shapes by DISPATCH ORDER (the script runs
-the shapes one after the other, 2 * nset launches each)."""
+"""rocprofv3 counter CSVs of scratch/prof_pmc_r02.sh + the launch manifest of scratch/mb_pmc_r02.py -> profiles/r02_pmc_traffic.json, keyed by the
+kernel name bench.py's roofline reports.  Launches are attributed to shapes by DISPATCH ORDER (several shapes share a grid size)."""
 import csv, glob, json, os
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+man = json.load(open(os.path.join(R, "gpurun_out", "pmc_r02_manifest.json")))
 def load(pat, counter):
     rows = []
     for f in glob.glob(os.path.join(R, pat), recursive=True):
@@ -10,41 +10,35 @@ def load(pat, counter):
             if r["Counter_Name"] == counter:
                 rows.append((int(r["Dispatch_Id"]), r["Kernel_Name"], float(r["Counter_Value"])))
     return sorted(rows)
-fetch = load("gpurun_out/pmc_r02_fetch/**/*counter_collection.csv", "FETCH_SIZE")
-write = load("gpurun_out/pmc_r02_write/**/*counter_collection.csv", "WRITE_SIZE")
-shapes = [dict(level="32x32", B=16, H=32, C=640, split=1), dict(level="16x16", B=16, H=16, C=1280, split=2), dict(level="8x8", B=16, H=8, C=1280, split=8)]
-for s in shapes:
-    s["nlaunch"] = 2 * max(8, int(300e6 / (s["B"] * s["H"] ** 2 * s["C"] * 2 * 2)) + 1)
 def per_shape(rows):
-    """-> per shape (mean GEMM counter, mean reduce counter): walk the dispatches in order; a splitk_reduce_kernel belongs to the GEMM before it"""
-    gemm = [(d, v) for d, k, v in rows if "gemm_big_kernel<128, 320, 4, 4" in k]
-    red = {d: v for d, k, v in rows if "splitk_reduce_kernel" in k}
+    gemm = [(d, v) for d, k, v in rows if "gemm_big_kernel" in k or "gemm_glds_kernel" in k]
+    red = sorted((d, v) for d, k, v in rows if "splitk_reduce_kernel" in k)
     out, i = [], 0
-    for s in shapes:
-        part = gemm[i:i + s["nlaunch"]]
-        i += s["nlaunch"]
+    for s in man:
+        part = gemm[i:i + s["launches"]]
+        i += s["launches"]
         g = sum(v for _, v in part) / len(part)
         r = 0.0
-        if s["split"] > 1:
-            rv = [min((v for dd, v in red.items() if dd > d), default=0.0, key=None) if False else red.get(min((dd for dd in red if dd > d), default=-1), 0.0) for d, _ in part]
-            r = sum(rv) / len(rv)
+        if s["split"] > 1:      # the reduce kernel that directly follows each split GEMM
+            vals = []
+            for d, _ in part:
+                nxt = [v for dd, v in red if dd == d + 1]
+                vals.append(nxt[0] if nxt else 0.0)
+            r = sum(vals) / len(vals)
         out.append((g, r, len(part)))
     assert i == len(gemm), (i, len(gemm))
     return out
-F, Wt = per_shape(fetch), per_shape(write)
+F = per_shape(load("gpurun_out/pmc_r02_fetch/**/*counter_collection.csv", "FETCH_SIZE"))
+W = per_shape(load("gpurun_out/pmc_r02_write/**/*counter_collection.csv", "WRITE_SIZE"))
 out = {"corrections": "FETCH_SIZE (KB) doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B requests at 64 B); WRITE_SIZE (KB) as reported",
        "note": "FETCH_SIZE is tallied at the L2's fabric side: Infinity-Cache hits are included (upper bound on HBM bytes). Split-K launches: the fp32 "
                "partial slabs written by the GEMM and re-read by splitk_reduce_kernel are counted (both kernels' counters are added).",
+       "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on scratch/mb_pmc_r02.py; launches attributed to shapes by dispatch order",
        "kernels": {}}
-entry = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on scratch/mb_pmc_r02.py; launches attributed to shapes by dispatch order", "shapes": []}
-for s, (fg, fr, n), (wg, wr, _) in zip(shapes, F, Wt):
-    M, N, K = s["B"] * s["H"] ** 2, s["C"], 9 * s["C"]
-    alg = 2.0 * (M * s["C"] + N * K + M * N)
+for s, (fg, fr, n), (wg, wr, _) in zip(man, F, W):
     hbm = 2 * 1024 * (fg + fr) + 1024 * (wg + wr)
-    entry["shapes"].append(dict(level=s["level"], B=s["B"], H=s["H"], C=s["C"], split=s["split"], M=M, N=N, K=K, launches=n,
-                                fetch_size_kb_raw_gemm=fg, fetch_size_kb_raw_reduce=fr, write_size_kb_raw_gemm=wg, write_size_kb_raw_reduce=wr,
-                                hbm_bytes=hbm, algorithmic_bytes=alg, ratio=hbm / alg))
-out["kernels"]["gemm_big_kernel<128, 320, 4, 4, 1>"] = entry
+    e = dict(s, fetch_size_kb_raw_gemm=fg, fetch_size_kb_raw_reduce=fr, write_size_kb_raw_gemm=wg, write_size_kb_raw_reduce=wr, hbm_bytes=hbm,
+             ratio=hbm / s["algorithmic_bytes"])
+    out["kernels"].setdefault(s["kernel"], {"shapes": []})["shapes"].append(e)
+    print(s["kernel"], s["kind"], (s["M"], s["N"], s["K"]), "split", s["split"], "ratio %.2f" % e["ratio"], "MB %.1f" % (hbm / 1e6))
 json.dump(out, open(os.path.join(R, "profiles", "r02_pmc_traffic.json"), "w"), indent=1)
-for e in entry["shapes"]:
-    print({k: (round(v, 1) if isinstance(v, float) else v) for k, v in e.items()})
