@@ -6,7 +6,9 @@
 
 Same flags and defaults, same per-image noise seeding ``torch.manual_seed(random_seed + hash(prompt) + i)`` (:537, which
 in the reference, as here, depends on PYTHONHASHSEED), same skip-existing-files resume behaviour and output tree
-``save_dir/prompt_{i}/img_{j}.jpg``.  ``--load_prefix_embedding_from`` (exp-2's prefix tokens) is not built: it raises.
+``save_dir/prompt_{i}/img_{j}.jpg``.  ``--load_prefix_embedding_from`` (exp-2's learned prefix tokens, gen-images.py:272-343, :523-538): the
+``number_prefix_tokens`` placeholder tokens are prepended to every prompt and their embeddings replaced by the loaded ones
+(``prefix_tokens`` / ``generate_image(..., prefix=)``); the uncond branch follows ``StableDiffusionPipeline._encode_prompt`` (no padding mask).
 """
 import argparse
 import json
@@ -47,17 +49,37 @@ def to_uint8_hwc(images):
     return x.mul(255).to(torch.uint8).permute(0, 2, 3, 1).contiguous().cpu().numpy()
 
 
-def generate_image(tr, tokens, noises, num_denoising_steps=30):
-    """``generate_image`` of gen-images.py:112-175 on the trainer's no-grad rollout: tokens of ONE prompt (prompt ids/mask, uncond
-    ids/mask), noises [N,4,h,w] -> images [N,3,H,W] in [-1,1] (fp16)."""
-    enc = tr.encode_pair(tr.te, tokens)
+def prefix_tokens(tokens, n, vocab_size):
+    """The token tuple of ``"".join(prefix_tokens) + prompt`` (gen-images.py:524-526): n placeholder ids (``expand_tokenizer`` appends them
+    to the vocabulary: vocab_size .. vocab_size + n - 1) between BOS and the prompt's words; the uncond sequence is the pipeline's
+    ``[""]`` padded to the new length and -- unlike ``generate_image`` -- evaluated WITHOUT a padding mask
+    (``_encode_prompt``: ``attention_mask=None`` because SD-v1.5's text encoder config has no ``use_attention_mask``)."""
+    pid, pm, uid, um = tokens
+    ids = torch.cat([pid[:1], torch.arange(vocab_size, vocab_size + n, dtype=pid.dtype), pid[1:]])
+    L = ids.shape[0]
+    uids = torch.cat([uid[:1], uid[1:2].expand(L - 1)])
+    return ids, torch.ones(L, dtype=pm.dtype), uids, torch.ones(L, dtype=um.dtype)
+
+
+def load_prefix_embedding(path, n):
+    """``FairEmbeddings`` state dict (gen-images.py:537-538, ``strict=False``): rows 1..n of ``token_embedding.weight`` are the prefix vectors."""
+    sd = torch.load(path, map_location="cpu")
+    w = sd["token_embedding.weight"] if isinstance(sd, dict) and "token_embedding.weight" in sd else sd
+    if w.shape[0] != n + 1:
+        raise ValueError(f"{path}: token_embedding.weight has {w.shape[0]} rows, expected number_prefix_tokens + 1 = {n + 1}")
+    return w[1:].float()
+
+
+def generate_image(tr, tokens, noises, num_denoising_steps=30, prefix=None):
+    """``generate_image`` of gen-images.py:112-175 (``generate_image_w_prefix_embedding`` :273-343 with ``prefix`` [n, D]; ``tokens`` then come
+    from ``prefix_tokens``) on the trainer's no-grad rollout: tokens of ONE prompt (prompt ids/mask, uncond ids/mask), noises [N,4,h,w] ->
+    images [N,3,H,W] in [-1,1] (fp16)."""
+    enc = tr.encode_pair(tr.te, tokens, prefix=prefix)
     x, _, _ = tr.rollout(tr.unet, enc, noises.to(tr.device, torch.float32), num_denoising_steps)
     return tr.decode(x)
 
 
 def main(args, cfgs=None):
-    if args.load_prefix_embedding_from:
-        raise NotImplementedError("--load_prefix_embedding_from (exp-2 prefix-token tuning) is outside this build's scope")
     from .lib import WORKING_DTYPE
     if args.mixed_precision != WORKING_DTYPE:
         raise NotImplementedError(f"--mixed_precision {args.mixed_precision}: this process runs the {WORKING_DTYPE} library (fp16 and bf16 are "
@@ -84,6 +106,7 @@ def main(args, cfgs=None):
     tr, _ = build_trainer(targs, device, cfgs, state_dicts=state_dicts, frozen_copies=False)
     tok_dir = os.path.join(args.pretrained_model_name_or_path, "tokenizer")
     tokenizer = CLIPTokenizerAdapter(tok_dir) if os.path.isdir(tok_dir) else HashTokenizer(cfgs["clip"].vocab_size)
+    prefix = load_prefix_embedding(args.load_prefix_embedding_from, args.number_prefix_tokens) if args.load_prefix_embedding_from else None
     with open(args.prompts_path, "r") as f:
         test_prompts = json.load(f)["test_prompts"]
     lat = cfgs["unet"].sample_size
@@ -103,9 +126,11 @@ def main(args, cfgs=None):
             continue
         noises = torch.cat(noises)
         tokens = tokenizer(prompt)
+        if prefix is not None:
+            tokens = prefix_tokens(tokens, args.number_prefix_tokens, cfgs["clip"].vocab_size)
         for b in range(math.ceil(len(paths) / args.batch_size)):
             nb = noises[b * args.batch_size:(b + 1) * args.batch_size].to(device)
-            imgs = to_uint8_hwc(generate_image(tr, tokens, nb, args.num_denoising_steps))
+            imgs = to_uint8_hwc(generate_image(tr, tokens, nb, args.num_denoising_steps, prefix=prefix))
             for img, path in zip(imgs, paths[b * args.batch_size:(b + 1) * args.batch_size]):
                 Image.fromarray(img).save(path)
                 written.append(path)

@@ -194,12 +194,13 @@ class FairnessTrainer:
         return self._side[k]
 
     # ------------------------------------------------------------------ pieces
-    def encode_pair(self, te, tokens, record=False):
-        """tokens = (prompt_ids [L], prompt_mask [L], uncond_ids [L], uncond_mask [L]) -> enc [2,L,D] fp16, uncond first (:1035)."""
+    def encode_pair(self, te, tokens, record=False, prefix=None):
+        """tokens = (prompt_ids [L], prompt_mask [L], uncond_ids [L], uncond_mask [L]) -> enc [2,L,D] fp16, uncond first (:1035).
+        ``prefix`` [n, D]: learned prefix-token embeddings for positions 1..n of the PROMPT sequence (exp-2 consumer)."""
         pid, pm, uid, um = tokens
         ids = torch.stack([uid, pid]).to(self.device)
         mask = torch.stack([um, pm]).to(self.device)
-        return te.forward(ids, mask, record=record)[0]
+        return te.forward(ids, mask, record=record, prefix=None if prefix is None else (1, prefix))[0]
 
     def rollout_steps(self, unet, enc, noises, S, res, keep_inputs=False, record_prompt=False, keep_activations=False):
         """CFG denoising rollout (:1038-1056) as a generator: yields after the launches of each denoising step so that two rollouts (R1

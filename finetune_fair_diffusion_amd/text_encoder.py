@@ -62,14 +62,21 @@ class CLIPTextModel:
             self.refresh_lora()
 
     # ------------------------------------------------------------------ forward / backward
-    def forward(self, input_ids, attention_mask=None, record=False):
-        """input_ids [B,T] int64, attention_mask [B,T] (1 = keep).  Returns (last_hidden_state [B,T,D] fp16,)."""
+    def forward(self, input_ids, attention_mask=None, record=False, prefix=None):
+        """input_ids [B,T] int64, attention_mask [B,T] (1 = keep).  Returns (last_hidden_state [B,T,D] fp16,).
+        ``prefix`` = (row, vectors [n, D]): the token embeddings of positions 1..n of sequence ``row`` are replaced by ``vectors``
+        (exp-2's learned prefix tokens, ``FairEmbeddings.forward`` gen-images.py:72-90: fair token embedding + position embedding)."""
         cfg = self.config
         B, T = input_ids.shape
         D, H = cfg.hidden_size, cfg.num_attention_heads
         d = D // H
-        ids = input_ids.to(self.device)
-        x = (self.tok[ids] + self.pos[:T][None]).reshape(B * T, D).contiguous()  # embedding gather: plumbing
+        ids = input_ids.to(self.device).clamp(max=self.tok.shape[0] - 1)       # placeholder ids of prefix tokens lie beyond the vocabulary
+        te = self.tok[ids]
+        if prefix is not None:
+            row, vec = prefix
+            te = te.clone()
+            te[row, 1:1 + vec.shape[0]] = vec.to(self.device, te.dtype)
+        x = (te + self.pos[:T][None]).reshape(B * T, D).contiguous()  # embedding gather: plumbing
         kv = attention_mask.to(self.device, torch.int32).contiguous() if attention_mask is not None else None
         ctx = [] if record else None
         for L in self.layers:

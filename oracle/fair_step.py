@@ -258,6 +258,27 @@ def generate_image_no_gradient(tokens, noises, S, text_encoder, unet, vae, sched
     return vae.decode(latents.to(vae.dtype)).sample.clamp(-1, 1)
 
 
+@torch.no_grad()
+def generate_image_w_prefix_embedding(prompt_ids, noises, fair_ids, fair_table, eos_id, S, text_encoder, unet, vae, scheduler, guidance_scale=7.5):
+    """gen-images.py:273-343 restated: the prompt already carries the n prefix-token ids after BOS (``"".join(prefix_tokens) + prompt``,
+    :526); prompt embeddings through FairEmbeddings + text_model_forward WITH the (all-ones) attention mask; negative embeddings as
+    ``StableDiffusionPipeline._encode_prompt`` (diffusers 0.19.3) builds them: ``[""]`` padded to the prompt length with EOS, text encoder
+    called with ``attention_mask=None`` (SD-v1.5's config has no ``use_attention_mask``)."""
+    N, L = noises.shape[0], prompt_ids.shape[0]
+    pe = text_encoder(prompt_ids[None].repeat(N, 1), torch.ones(N, L, dtype=torch.long), fair=(fair_ids, fair_table))[0]
+    uids = torch.cat([prompt_ids[:1], torch.full((L - 1,), eos_id, dtype=prompt_ids.dtype)])
+    ne = text_encoder(uids[None].repeat(N, 1), None)[0]
+    emb = torch.cat([ne, pe])
+    scheduler.set_timesteps(S)
+    latents = noises
+    for t in scheduler.timesteps:
+        x = scheduler.scale_model_input(torch.cat([latents] * 2), t)
+        eps = unet(x, t, encoder_hidden_states=emb).sample.to(torch.float32)
+        eu, ec = eps.chunk(2)
+        latents = scheduler.step(eu + guidance_scale * (ec - eu), t, latents).prev_sample
+    return vae.decode(1 / vae.config.scaling_factor * latents).sample.clamp(-1, 1)
+
+
 def generate_image_w_gradient(tokens, noises, S, text_encoder, unet, vae, scheduler, guidance_scale=7.5, dtype=torch.float32,
                               trace=None):  # :1063-1136
     N = noises.shape[0]

@@ -114,11 +114,21 @@ class CLIPTextModel(nn.Module):
         self.config = cfg
         self.text_model = CLIPTextTransformer(cfg)
 
-    def forward(self, input_ids, attention_mask=None):
+    def forward(self, input_ids, attention_mask=None, fair=None):
+        """``fair`` = (fair token ids [n], fair embedding table [n+1, D]): exp-2's ``FairEmbeddings.forward`` (gen-images.py:72-90) followed by
+        ``text_model_forward`` (:190-271): positions whose id is a fair token get ``table[k+1] + position_embedding`` instead of the
+        (resized) vocabulary embedding."""
         tm = self.text_model
         B, T = input_ids.shape
         pos = torch.arange(T, device=input_ids.device)
-        x = tm.embeddings.token_embedding(input_ids) + tm.embeddings.position_embedding(pos)[None]
+        V = tm.embeddings.token_embedding.weight.shape[0]
+        x = tm.embeddings.token_embedding(input_ids.clamp(max=V - 1)) + tm.embeddings.position_embedding(pos)[None]
+        if fair is not None:
+            fair_ids, table = fair
+            x = x.clone()
+            for k, tid in enumerate(fair_ids.tolist()):
+                sel = input_ids == tid
+                x[sel] = (table[k + 1][None] + tm.embeddings.position_embedding(pos)[None].expand(B, T, -1)[sel]).to(x.dtype)
         neg = torch.finfo(x.dtype).min
         bias = torch.full((T, T), neg, dtype=x.dtype, device=x.device).triu(1)[None, None]
         if attention_mask is not None:

@@ -404,8 +404,15 @@ def test_generate_consumes_exported_lora(tmp_path):
     os.remove(tmp_path / "plain" / "prompt_1" / "img_1.jpg")
     again = generate.main(generate.parse_args(base + ["--save_dir", str(tmp_path / "plain")]), cfgs=TINY)
     assert [os.path.basename(p) for p in again] == ["img_1.jpg"]
-    with pytest.raises(NotImplementedError):
-        generate.main(generate.parse_args(base + ["--save_dir", str(tmp_path / "x"), "--load_prefix_embedding_from", "p.pth"]), cfgs=TINY)
+    # exp-2 consumer: learned prefix-token embeddings change the images; a file with the wrong number of rows is refused
+    pe = {"token_embedding.weight": torch.cat([torch.zeros(1, 64), torch.randn(5, 64, generator=torch.Generator().manual_seed(3))])}
+    torch.save(pe, tmp_path / "prefix.pth")
+    w2 = generate.main(generate.parse_args(base + ["--save_dir", str(tmp_path / "prefix"), "--load_prefix_embedding_from", str(tmp_path / "prefix.pth")]), cfgs=TINY)
+    c = np.asarray(Image.open(tmp_path / "prefix" / "prompt_0" / "img_0.jpg")).astype(np.float32)
+    assert len(w2) == 6 and np.abs(a - c).mean() > 0.0
+    with pytest.raises(ValueError):
+        generate.main(generate.parse_args(base + ["--save_dir", str(tmp_path / "x"), "--load_prefix_embedding_from", str(tmp_path / "prefix.pth"),
+                                                  "--number_prefix_tokens", "3"]), cfgs=TINY)
 
 
 # ------------------------------------------------------------------------------------------ image encoders of the regularisers
@@ -928,3 +935,26 @@ def test_full_step_smooth_head_pins_unet_chain_end_to_end(dev):
     assert err <= 1e-2
     check("smooth head: end-to-end unet LoRA gradient (max-norm)", got, refg, 3e-2)
     assert cos > 0.999
+
+
+def test_generate_image_with_prefix_embedding_matches_oracle(dev):
+    """exp-2 inference consumer (gen-images.py:272-343, :523-538): learned prefix tokens prepended to the prompt, their embeddings replaced
+    by ``FairEmbeddings`` rows, uncond branch as ``StableDiffusionPipeline._encode_prompt`` (no padding mask) -- vs the oracle restatement."""
+    from oracle import fair_step as fs
+    from finetune_fair_diffusion_amd import generate
+    from finetune_fair_diffusion_amd.step import FairnessTrainer
+    om = U.oracle_models(train_unet=False, train_te=False)
+    pm = U.product_models(om["sds"], dev, train_unet=False, train_te=False)
+    tr = FairnessTrainer(U.make_args(train_unet=False, train_text_encoder=False), pm["text_encoder"], pm["unet"], pm["vae"], pm["classifier"], pm["scheduler"],
+                         device=dev)
+    n, D, vocab = 4, 64, 1000
+    P = torch.randn(n, D, generator=torch.Generator().manual_seed(8)) * 0.5
+    tokens = generate.prefix_tokens(U.tiny_tokens(), n, vocab)
+    assert tokens[0].tolist()[:n + 2] == [vocab - 1, vocab, vocab + 1, vocab + 2, vocab + 3, 5] and tokens[2].tolist() == [vocab - 1] + [vocab - 2] * (len(tokens[0]) - 1)
+    noises = torch.randn(2, 4, 32, 32, generator=torch.Generator().manual_seed(1997))
+    ref = fs.generate_image_w_prefix_embedding(tokens[0], noises, torch.arange(vocab, vocab + n), torch.cat([torch.zeros(1, D), P]), vocab - 2, 10,
+                                               om["text_encoder"], om["unet"], om["vae"], om["scheduler"], 7.5)
+    img = generate.generate_image(tr, tokens, noises, 10, prefix=P)
+    check("generate_image with prefix embedding, S=10", img, ref, 3e-2)
+    plain = generate.generate_image(tr, U.tiny_tokens(), noises, 10)
+    assert float((plain.float() - img.float()).abs().max()) > 0.05      # the prefix really changes the image
