@@ -17,6 +17,10 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(fd_gemm_desc p, int ntm,
     __shared__ __attribute__((aligned(16))) f16 smem[OPS_HALFS > EPI_HALFS ? OPS_HALFS : EPI_HALFS];
     f16* As = smem;
     f16* Bs = smem + 2 * BM * 32;
+    // the zero page's address comes through the GOT: pinned in SGPRs once -- left to the compiler it is re-loaded (s_load + lgkmcnt(0)) in every
+    // k-tile, in front of the next tile's global_load_lds issue
+    const f16* zp = fd_zero_page;
+    asm volatile("" : "+s"(zp));
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, lg = lane >> 4;
@@ -80,14 +84,14 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(fd_gemm_desc p, int ntm,
                     iy >>= 1; ix >>= 1;
                     ok = ok && iy < p.H && ix < p.W;
                 }
-                const f16* src = ok ? A + (((int64_t)crow[i].b * p.H + iy) * p.W + ix) * p.lda + c0 + kchunk : fd_zero_page;
+                const f16* src = ok ? A + (((int64_t)crow[i].b * p.H + iy) * p.W + ix) * p.lda + c0 + kchunk : zp;
                 glds16(src, As + (buf * BM + (wave * AI + i) * 16) * 32);
             }
             const int kk = kt * 32 + kchunk;
 #pragma unroll
             for (int i = 0; i < BI; ++i) {
                 const int n = n0 + brow[i];
-                const f16* src = (n < p.N) ? B + (int64_t)n * p.ldb + kk : fd_zero_page;
+                const f16* src = (n < p.N) ? B + (int64_t)n * p.ldb + kk : zp;
                 glds16(src, Bs + (buf * BN + (wave * BI + i) * 16) * 32);
             }
         } else {
@@ -101,13 +105,13 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(fd_gemm_desc p, int ntm,
 #pragma unroll
             for (int i = 0; i < AI; ++i) {
                 const int m = m0 + arow[i];
-                const f16* src = (kok && m < p.M) ? Ap + (int64_t)m * la + kk : fd_zero_page;
+                const f16* src = (kok && m < p.M) ? Ap + (int64_t)m * la + kk : zp;
                 glds16(src, As + (buf * BM + (wave * AI + i) * 16) * 32);
             }
 #pragma unroll
             for (int i = 0; i < BI; ++i) {
                 const int n = n0 + brow[i];
-                const f16* src = (kok && n < p.N) ? Bp + (int64_t)n * lb + kk : fd_zero_page;
+                const f16* src = (kok && n < p.N) ? Bp + (int64_t)n * lb + kk : zp;
                 glds16(src, Bs + (buf * BN + (wave * BI + i) * 16) * 32);
             }
         }
@@ -183,6 +187,8 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_big_kernel(fd_gemm_desc p
     extern __shared__ __attribute__((aligned(16))) f16 smem[];
     f16* As = smem;                      // [2][BM][64]
     f16* Bs = smem + 2 * BM * 64;        // [2][BN][64]
+    const f16* zp = fd_zero_page;        // GOT load hoisted out of the main loop (see gemm_glds_kernel)
+    asm volatile("" : "+s"(zp));
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, lg = lane >> 4;
@@ -269,7 +275,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_big_kernel(fd_gemm_desc p
                     const int g = wave + i * NW;
                     if (g < NA && (part & 1)) {
                         const bool ok = (crow_yx[i] >> tap) & 1;
-                        const f16* src = ok ? A + (int64_t)(crow_b[i] + toff) : fd_zero_page;
+                        const f16* src = ok ? A + (int64_t)(crow_b[i] + toff) : zp;
                         glds16(src, As + (buf * BM + g * 8) * 64);
                     }
                 }
@@ -306,7 +312,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_big_kernel(fd_gemm_desc p
                         iy >>= 1; ix >>= 1;
                         ok = ok && iy < p.H && ix < p.W;
                     }
-                    const f16* src = ok ? A + (((int64_t)crow_b[i] * p.H + iy) * p.W + ix) * p.lda + c0 + kchunk : fd_zero_page;
+                    const f16* src = ok ? A + (((int64_t)crow_b[i] * p.H + iy) * p.W + ix) * p.lda + c0 + kchunk : zp;
                     glds16(src, As + (buf * BM + g * 8) * 64);
                 }
             }
@@ -316,7 +322,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_big_kernel(fd_gemm_desc p
                 const int g = wave + i * NW;
                 if (g < NB && (part & 2)) {
                     const int n = n0 + g * 8 + lrow;
-                    const f16* src = (n < p.N) ? B + (int64_t)n * p.ldb + kk : fd_zero_page;
+                    const f16* src = (n < p.N) ? B + (int64_t)n * p.ldb + kk : zp;
                     glds16(src, Bs + (buf * BN + g * 8) * 64);
                 }
             }
@@ -333,7 +339,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_big_kernel(fd_gemm_desc p
                 const int g = wave + i * NW;
                 if (g < NA && (part & 1)) {
                     const int m = m0 + g * 8 + lrow;
-                    const f16* src = (kok && m < p.M) ? Ap + (int64_t)m * la + kk : fd_zero_page;
+                    const f16* src = (kok && m < p.M) ? Ap + (int64_t)m * la + kk : zp;
                     glds16(src, As + (buf * BM + g * 8) * 64);
                 }
             }
@@ -342,7 +348,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_big_kernel(fd_gemm_desc p
                 const int g = wave + i * NW;
                 if (g < NB && (part & 2)) {
                     const int n = n0 + g * 8 + lrow;
-                    const f16* src = (kok && n < p.N) ? Bp + (int64_t)n * lb + kk : fd_zero_page;
+                    const f16* src = (kok && n < p.N) ? Bp + (int64_t)n * lb + kk : zp;
                     glds16(src, Bs + (buf * BN + g * 8) * 64);
                 }
             }

@@ -581,6 +581,7 @@ class FairnessTrainer:
                 # to ``bwd_streams`` HIP streams, each side stream accumulating its LoRA gradients into its own buffer, so that the many
                 # launches which cannot fill the chip alone overlap with a neighbouring timestep's.  Shared cross-attention dK/dV: fp32 atomics.
                 cur = torch.cuda.current_stream()
+                self.unet.prepare_backward()         # lazily built weight copies exist before any side stream can read them
                 nst = max(1, min(self.bwd_streams, S)) if self.concurrent_bwd else 1
                 sides = [self._side_stream(k) for k in range(1, nst)]
                 for k, side in enumerate(sides, 1):

@@ -349,6 +349,31 @@ class UNet2DConditionModel:
                 if lo is not None:
                     lo.refresh()
 
+    def prepare_backward(self):
+        """Materialise every lazily built backward operand (transposed / flipped weight copies) NOW, on the current stream.  The training
+        step deals the per-timestep backwards to several HIP streams; built lazily, a copy created by the first timestep on one stream
+        could be read by the next timestep on another stream before its transpose kernel has run."""
+        if getattr(self, "_bwd_ready", False):
+            return
+        for r in self.resnets:
+            r.conv1.wd, r.conv2.wd
+            if r.shortcut is not None:
+                r.shortcut.wT
+        for t in self.transformers:
+            for lin in (t.proj_in, t.proj_out, t.o1, t.q2, t.k2, t.v2, t.o2, t.ff2):
+                lin.wT
+            if t._ff1_wiT is None:
+                t._ff1_wiT = t.ff1_wi.t().contiguous()
+            if t._wqkvT is None:
+                t._wqkvT = t.wqkv.t().contiguous()
+        for blk in self.down:
+            if blk["down"] is not None:
+                blk["down"].wd
+        for blk in self.up:
+            if blk["up"] is not None:
+                blk["up"].wd, blk["up"].wd_up2p
+        self._bwd_ready = True
+
     def load_state_dict(self, sd, strict=False):
         """LoRA tensors by diffusers key (gen-images.py:520-521 calls exactly this with strict=False)."""
         if self.lora_bank is not None:

@@ -1,10 +1,11 @@
-"""A/B of the multi-block 128x320x32 kernels (gemm_mb.hip) against the current tile policy, on the step's shapes, with a correctness check.
+"""A/B of an experimental GEMM kernel family (now: gemm_p4.hip, FD_GEMM_P4=1; round 2 first used it for scratch/gemm_mb_experiment.hip) against the
+current tile policy, on the step's shapes, with a correctness check.
 Bench-hooks library; each arm in its own process (the switch is read once).  Usage: python scratch/mb_mb.py [arm]"""
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if len(sys.argv) > 1:
     if sys.argv[1] != "base":
-        os.environ["FD_GEMM_MB"] = sys.argv[1]
+        os.environ["FD_GEMM_P4"] = "1"
     os.environ["FAIRDIFF_LIB"] = os.path.join(ROOT, "finetune_fair_diffusion_amd", "libfairdiff_hip_bench.so")
     sys.path.insert(0, ROOT)
     import torch
@@ -46,10 +47,10 @@ if len(sys.argv) > 1:
         print(f"{sys.argv[1]:>5s}  gemm {M:6d}x{N:5d}x{K:5d} {act:6s} {us:8.1f} us {2.0 * M * N * (K + (8 if act == 'none' else 0)) / us / 1e6:8.1f} TF  err {err:.1e}")
 else:
     outs = {}
-    for arm in ("base", "1"):
+    for arm in ("base", "p4"):
         r = subprocess.run([sys.executable, os.path.abspath(__file__), arm], capture_output=True, text=True)
         outs[arm] = [l for l in r.stdout.splitlines() if l.strip()]
         if r.returncode:
             print(r.stderr[-1500:])
-    for a, b in zip(outs["base"], outs["1"]):
+    for a, b in zip(outs["base"], outs["p4"]):
         print(a); print(b)
