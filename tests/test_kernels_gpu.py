@@ -366,6 +366,38 @@ def test_lora_wgrad(ops, dev, M, N, R):
     check("lora wgrad [R,N]", G2, T[:, :R].float().t() @ X.float(), 1e-3)
 
 
+@pytest.mark.parametrize("R", [4, 12])
+def test_lora_wgrad_batched_equals_single_calls(ops, dev, R):
+    """fd_lora_wgrad_multi (the 16 weight gradients of a transformer block in one partial + one final launch) against the single-problem
+    path and fp32 torch: mixed M / N, strided X (column slices of a wider buffer) and both output layouts ([N,R] and [R,N])."""
+    RP = 8 if R <= 8 else 16
+    probs = []
+    g = 0
+    for (M, N, sl) in [(4096, 320, False), (4096, 320, True), (1000, 1280, False), (65536, 320, False), (26, 768, False), (2048, 640, True)] * 3:
+        g += 1
+        Xw = rnd(M, N * (3 if sl else 1), dev=dev, seed=10 + g)
+        X = Xw[:, N:2 * N] if sl else Xw
+        T = torch.zeros(M, RP, dtype=torch.float16, device=dev)
+        T[:, :R] = rnd(M, R, dev=dev, seed=50 + g)
+        probs.append((X, T, (g % 2 == 0)))
+    ref, single, batched = [], [], []
+    for X, T, trans in probs:
+        shape = (R, X.shape[1]) if trans else (X.shape[1], R)
+        r = 0.5 * (T[:, :R].float().t() @ X.float() if trans else X.float().t() @ T[:, :R].float()) + 1
+        ref.append(r)
+        single.append(torch.ones(shape, dtype=torch.float32, device=dev))
+        batched.append(torch.ones(shape, dtype=torch.float32, device=dev))
+    for (X, T, trans), G in zip(probs, single):
+        ops.lora_wgrad(X, T, G, *((1, X.shape[1]) if trans else (R, 1)), R, scale=0.5)
+    with ops.wgrad_batch():
+        for (X, T, trans), G in zip(probs, batched):
+            ops.lora_wgrad(X, T, G, *((1, X.shape[1]) if trans else (R, 1)), R, scale=0.5)
+        assert float(batched[0].sum()) == batched[0].numel()        # nothing ran yet: queued until the context closes
+    for i, (a, b, r) in enumerate(zip(single, batched, ref)):
+        check(f"wgrad single [{i}]", a, r, 1e-3)
+        check(f"wgrad batched [{i}]", b, r, 1e-3)
+
+
 def test_cfg_dpm_and_adamw(ops, dev):
     n = 2 * 4 * 64
     eps = rnd(2 * n, dev=dev, dtype=torch.float32, seed=1)
