@@ -25,10 +25,17 @@ __device__ __forceinline__ f32x16 zero16() {
 // row index inside a 32x32 C/D tile for accumulator register r of lane-half g
 __device__ __forceinline__ int crow(int r, int g) { return (r & 3) + 8 * (r >> 2) + 4 * g; }
 
-// the permuted-k A operand from a key-contiguous LDS tile [.][72]: keys base + 4g + {0..3} and base + 8 + 4g + {0..3}
+// Row stride (halfs) of the key-contiguous LDS tiles.  ds_read_b64 is serviced in two 32-lane groups over 64 banks: the 32 lanes of a
+// group read rows ql = 0..31 at one key offset, so the stride must put them on 32 distinct bank pairs.  68 halfs = 34 banks does
+// (even rows on banks 4m, odd rows on 4m + 34); the 72 of round 1 (36 banks) made rows r and r + 16 collide, 2 cycles -> 4 per read.
+#ifndef FD_ATTN_TS
+#define FD_ATTN_TS 68
+#endif
+constexpr int TS = FD_ATTN_TS;
+// the permuted-k A operand from a key-contiguous LDS tile [.][TS]: keys base + 4g + {0..3} and base + 8 + 4g + {0..3}
 __device__ __forceinline__ f16x8 read_perm(const f16* tile, int row, int base, int g) {
-    const f16x4 lo = *(const f16x4*)(tile + row * 72 + base + 4 * g);
-    const f16x4 hi = *(const f16x4*)(tile + row * 72 + base + 8 + 4 * g);
+    const f16x4 lo = *(const f16x4*)(tile + row * TS + base + 4 * g);
+    const f16x4 hi = *(const f16x4*)(tile + row * TS + base + 8 + 4 * g);
     return (f16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
 
@@ -106,7 +113,10 @@ __device__ __forceinline__ void store_cols(const TileRegs<D>& t, f16* dst) {
     for (int i = 0; i < NCH; ++i) {
         const int c = threadIdx.x + i * 256;
         const int r = c >> 3, cc = (c & 7) * 8;
-        if (c < N) *(f16x8*)(dst + r * 72 + cc) = t.r[i];
+        if (c < N) {   // rows are 8-byte aligned only (TS = 68): two 8-byte stores
+            *(f16x4*)(dst + r * TS + cc) = (f16x4){t.r[i][0], t.r[i][1], t.r[i][2], t.r[i][3]};
+            *(f16x4*)(dst + r * TS + cc + 4) = (f16x4){t.r[i][4], t.r[i][5], t.r[i][6], t.r[i][7]};
+        }
     }
 }
 // zero the padding that staging never touches: columns [D, DKP) of a row tile / rows [D, DV) of a column tile
@@ -116,19 +126,27 @@ __device__ __forceinline__ void zero_row_pad(f16* dst) {
 }
 template <int D, int DV>
 __device__ __forceinline__ void zero_col_pad(f16* dst) {
-    for (int c = threadIdx.x; c < (DV - D) * 72; c += 256) dst[D * 72 + c] = (f16)0;
+    for (int c = threadIdx.x; c < (DV - D) * TS; c += 256) dst[D * TS + c] = (f16)0;
 }
+
+// Occupancy targets (waves per SIMD, the second __launch_bounds__ argument).  Without one the register allocator spreads out to whatever
+// the 4-wave workgroup allows (512 per lane): round 1 shipped 184 (forward), 202 (dQ) and 310 (dK/dV) VGPR+AGPR at d = 40, i.e. 2 / 2 / 1
+// waves per SIMD, while reading only the arch-VGPR half of that number as "fits three".  The values below are the highest occupancy
+// each head-dim class reaches WITHOUT scratch (checked on the gfx950 ISA: .amdhsa_next_free_vgpr / private_segment_fixed_size).
+constexpr int fwd_waves(int D) { return D <= 64 ? 3 : D <= 128 ? 2 : 1; }
+constexpr int dq_waves(int D) { return D <= 40 ? 3 : D <= 128 ? 2 : 1; }
+constexpr int dkdv_waves(int D) { return D <= 64 ? 2 : 1; }
 
 // ================================================================================== forward
 template <int D>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const f16* __restrict__ Q, const f16* __restrict__ K, const f16* __restrict__ Vt,
+__global__ __launch_bounds__(256, fwd_waves(D)) void attn_fwd_kernel(const f16* __restrict__ Q, const f16* __restrict__ K, const f16* __restrict__ Vt,
                                                        f16* __restrict__ O, float* __restrict__ LSE, int H, int Tq, int Tk, int Tkp,
                                                        int Tkr, int kv_div, float scale, int ldq, int ldk) {
     constexpr int DK = (D + 15) / 16 * 16, DV = (D + 31) / 32 * 32, DKP = DK + 8;
     constexpr int NKS = DK / 16, NDV = DV / 32;
     extern __shared__ __attribute__((aligned(16))) f16 smem[];
     f16* Ks = smem;               // [64][DKP]
-    f16* Vts = smem + 64 * DKP;   // [DV][72]
+    f16* Vts = smem + 64 * DKP;   // [DV][TS]
 
     const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 128;
     const int bk = b / kv_div;
@@ -274,7 +292,7 @@ __global__ void attn_bwd_prep_kernel(const f16* O, const f16* dO, float* Dd, int
 
 // ================================================================================== dQ
 template <int D>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const f16* __restrict__ Q, const f16* __restrict__ K, const f16* __restrict__ V,
+__global__ __launch_bounds__(256, dq_waves(D)) void attn_bwd_dq_kernel(const f16* __restrict__ Q, const f16* __restrict__ K, const f16* __restrict__ V,
                                                           const f16* __restrict__ Kt, const f16* __restrict__ dO,
                                                           const float* __restrict__ LSE, float* __restrict__ Dd, f16* __restrict__ dQ,
                                                           const f16* __restrict__ O, int H, int Tq, int Tk, int Tkp, int Tkr, int kv_div,
@@ -284,7 +302,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const f16* __restrict_
     extern __shared__ __attribute__((aligned(16))) f16 smem[];
     f16* Ks = smem;                // [64][DKP]
     f16* Vs = Ks + 64 * DKP;       // [64][DKP]
-    f16* Kts = Vs + 64 * DKP;      // [DV][72]
+    f16* Kts = Vs + 64 * DKP;      // [DV][TS]
 
     const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 128;
     const int bk = b / kv_div;
@@ -405,7 +423,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const f16* __restrict_
 // ================================================================================== dK, dV
 // block = 128 keys (4 waves x 32), loops over 32-query tiles.  S[q][key] = Q.K^T with K,V rows in VGPRs.
 template <int D, bool ATOMIC>
-__global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const f16* __restrict__ Q, const f16* __restrict__ Qt, const f16* __restrict__ K,
+__global__ __launch_bounds__(256, dkdv_waves(D)) void attn_bwd_dkdv_kernel(const f16* __restrict__ Q, const f16* __restrict__ Qt, const f16* __restrict__ K,
                                                             const f16* __restrict__ V, const f16* __restrict__ dO,
                                                             const f16* __restrict__ dOt, const float* __restrict__ LSE,
                                                             const float* __restrict__ Dd, void* __restrict__ dKo, void* __restrict__ dVo,
@@ -415,9 +433,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const f16* __restric
     extern __shared__ __attribute__((aligned(16))) f16 smem[];
     f16* Qs = smem;                 // [64][DKP]
     f16* Gs = Qs + 64 * DKP;        // [64][DKP]  (dO rows)
-    f16* Qts = Gs + 64 * DKP;       // [DV][72]
-    f16* Gts = Qts + DV * 72;       // [DV][72]
-    float* lse_s = (float*)(Gts + DV * 72);  // [64]
+    f16* Qts = Gs + 64 * DKP;       // [DV][TS]
+    f16* Gts = Qts + DV * TS;       // [DV][TS]
+    float* lse_s = (float*)(Gts + DV * TS);  // [64]
     float* dd_s = lse_s + 64;                // [64]
 
     const int b = blockIdx.z, h = blockIdx.y, k0 = blockIdx.x * 128;
@@ -544,10 +562,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const f16* __restric
 }
 
 // ================================================================================== host side
-template <int D> static constexpr size_t fwd_lds() { return (size_t)(64 * (((D + 15) / 16 * 16) + 8) + ((D + 31) / 32 * 32) * 72) * 2; }
-template <int D> static constexpr size_t dq_lds() { return (size_t)(2 * 64 * (((D + 15) / 16 * 16) + 8) + ((D + 31) / 32 * 32) * 72) * 2; }
+template <int D> static constexpr size_t fwd_lds() { return (size_t)(64 * (((D + 15) / 16 * 16) + 8) + ((D + 31) / 32 * 32) * TS) * 2; }
+template <int D> static constexpr size_t dq_lds() { return (size_t)(2 * 64 * (((D + 15) / 16 * 16) + 8) + ((D + 31) / 32 * 32) * TS) * 2; }
 template <int D> static constexpr size_t dkdv_lds() {
-    return (size_t)(2 * 64 * (((D + 15) / 16 * 16) + 8) + 2 * ((D + 31) / 32 * 32) * 72) * 2 + 512;
+    return (size_t)(2 * 64 * (((D + 15) / 16 * 16) + 8) + 2 * ((D + 31) / 32 * 32) * TS) * 2 + 512;
 }
 
 #define FD_DISPATCH_D(d, CALL)                                                       \
