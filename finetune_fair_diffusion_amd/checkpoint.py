@@ -9,6 +9,7 @@ consumes exactly those four files.
 Here a checkpoint directory *is* the exported format plus one extra file:
 
     checkpoint-{step}/unet_lora.pth, unet_lora_EMA.pth, text_encoder_lora.pth, text_encoder_lora_EMA.pth
+    checkpoint-{step}/prefix_embedding.pth, prefix_embedding_EMA.pth      (exp-2 instead of the LoRA files)
     checkpoint-{step}/trainer_state.pth   Adam moments (flat fp32 per bank), optimiser / EMA / lr step counters, world size (rank 0 writes it)
     checkpoint-{step}/rng_rank{r}.pth     python / numpy / torch / OT-target RNG streams of rank r (every rank writes its own)
 
@@ -22,7 +23,11 @@ import shutil
 import numpy as np
 import torch
 
-BANK_FILES = {"unet": ("unet_lora.pth", "unet_lora_EMA.pth"), "text_encoder": ("text_encoder_lora.pth", "text_encoder_lora_EMA.pth")}
+BANK_FILES = {"unet": ("unet_lora.pth", "unet_lora_EMA.pth"), "text_encoder": ("text_encoder_lora.pth", "text_encoder_lora_EMA.pth"),
+              # exp-2 (exp-2-debias-gender-token/2-export-checkpoint.py:566-575): the FairEmbeddings state dict, live and EMA
+              "prefix_embedding": ("prefix_embedding.pth", "prefix_embedding_EMA.pth")}
+# entries of a FairEmbeddings state dict that are not trained (buffers of the frozen text encoder): written for gen-images.py, ignored on load
+PREFIX_FROZEN_KEYS = ("position_ids", "position_embedding.weight")
 
 
 def clean_checkpoint(ckpts_save_dir, name, checkpoints_total_limit):
@@ -46,14 +51,21 @@ def trainer_banks(trainer):
         out["unet"] = trainer.unet.lora_bank
     if getattr(trainer.args, "train_text_encoder", False):
         out["text_encoder"] = trainer.te.lora_bank
+    if getattr(trainer, "prefix", None) is not None:
+        out["prefix_embedding"] = trainer.prefix.bank
     return out
 
 
-def save_lora_files(banks, path):
-    """The four-file export (2-export-checkpoint.py:619-642): live and EMA weights by diffusers key, fp32 on CPU."""
+def save_lora_files(banks, path, prefix=None):
+    """The four-file export (2-export-checkpoint.py:619-642): live and EMA weights by diffusers key, fp32 on CPU.  ``prefix``: the
+    trainer's PrefixEmbedding (exp-2), whose files carry the full FairEmbeddings state dict."""
     os.makedirs(path, exist_ok=True)
     for which, bank in banks.items():
         live, ema = BANK_FILES[which]
+        if which == "prefix_embedding" and prefix is not None:
+            torch.save(prefix.state_dict(ema=False), os.path.join(path, live))
+            torch.save(prefix.state_dict(ema=True), os.path.join(path, ema))
+            continue
         torch.save(bank.state_dict(ema=False), os.path.join(path, live))
         torch.save(bank.state_dict(ema=True), os.path.join(path, ema))
 
@@ -64,7 +76,7 @@ def load_lora_files(banks, path, strict=True):
         live, ema = BANK_FILES[which]
         sd = torch.load(os.path.join(path, live), map_location="cpu")
         missing = [n for n in bank.names if n not in sd]
-        unexpected = [k for k in sd if k not in bank.offsets]
+        unexpected = [k for k in sd if k not in bank.offsets and not (which == "prefix_embedding" and k in PREFIX_FROZEN_KEYS)]
         if strict and (missing or unexpected):
             raise KeyError(f"{live}: missing {missing[:3]}... unexpected {unexpected[:3]}...")
         for n in bank.names:
@@ -94,7 +106,7 @@ def save_state(trainer, save_path, global_step, extra=None):
     rank, world = getattr(trainer, "rank", 0), getattr(trainer, "world", 1)
     banks = trainer_banks(trainer)
     if rank == 0:
-        save_lora_files(banks, save_path)
+        save_lora_files(banks, save_path, prefix=getattr(trainer, "prefix", None))
         st = dict(global_step=int(global_step), opt_step=int(trainer.opt_step), lr_step=int(getattr(trainer, "lr_step", 0)),
                   ema_steps=[e.optimization_step for e in trainer.ema], bank_order=list(banks.keys()),
                   exp_avg={k: b.exp_avg.detach().cpu() for k, b in banks.items()},

@@ -11,11 +11,12 @@ cannot be set from YAML and booleans follow Python's ``bool(value)`` -- plus the
   --lora_up_std          std of the LoRA ``up`` init; 0 (default) = zeros like the reference, non-zero only for synthetic experiments
 
 The multi-attribute experiments change a few flags and defaults (exp-3-debias-gender-race/1-main-debias.py:343-660,
-exp-4-debias-gender-race-age/...:343-672, exp-5-...:343-690): ``factor{1,2}`` split per attribute,
+exp-4-debias-gender-race-age/...:343-672, exp-5-...:343-690; exp-2-debias-gender-token/...:453-780 drops the two LoRA switches and adds
+``--train_num_tokens``): ``factor{1,2}`` split per attribute,
 ``face_gender[_race[_age]]_confidence_level``, bigger batches, three more prompt files in exp-5 -- ``EXPERIMENT_CLI``.
 
 Pinned by tests/golden/reference_cli.json and reference_cli_multi.json (defaults and every YAML overlay of
-exp-1/3/4/5, produced by running the reference's own parse_args).
+exp-1/2/3/4/5, produced by running the reference's own parse_args).
 """
 import argparse
 import os
@@ -30,6 +31,8 @@ _GR = dict(factor1_gender=0.2, factor1_race=0.6, factor2_gender=0.2, factor2_rac
 # experiment -> (changed defaults, removed flags, added float flags, added str flags)
 EXPERIMENT_CLI = {
     "exp-1": ({}, [], {}, {}),
+    # exp-2 (prefix-token tuning, exp-2-debias-gender-token/1-main-debias.py:453-780): no LoRA switches, one int flag (below)
+    "exp-2": ({}, ["train_text_encoder", "train_unet"], {}, {}),
     "exp-3": (dict(_MULTI, train_images_per_prompt_GPU=16, classifier_weight_path=_FF + "GenderRace4_09041216/epoch=9-step=3380_MobileNetLarge.pt"),
               ["factor1", "factor2", "face_gender_confidence_level"], dict(_GR, face_gender_race_confidence_level=0.8), {}),
     "exp-4": (dict(_MULTI, train_images_per_prompt_GPU=20, classifier_weight_path=_FF + "GenderRace4Age2_09151907/epoch=9-step=3380_MobileNetLarge.pt"),
@@ -58,6 +61,8 @@ def build_parser(experiment="exp-1"):
         p.add_argument("--" + k, type=float, default=v)
     for k, v in add_s.items():
         p.add_argument("--" + k, type=str, default=v)
+    if experiment == "exp-2":
+        p.add_argument("--train_num_tokens", type=int, default=5)       # number of tokens to finetune as prompt prefix (:479-484)
     # 1. experiment setting
     a("--proj_name", default="debias-SD", type=str)
     a("--pretrained_model_name_or_path", type=str, default="runwayml/stable-diffusion-v1-5")

@@ -57,6 +57,13 @@ def build_trainer(args, device, cfgs=SD15, seed=0, rank=0, world_size=1, experim
     test runs pass a non-zero std (the "one warm-up optimiser step" of SURVEY 8d) so that dL/d(down) is non-zero on the first step."""
     from .fairness import EXPERIMENT_ATTRS
     num_classes = EXPERIMENT_ATTRS[experiment][0]
+    train_prefix = experiment == "exp-2"          # prefix-token tuning: no LoRA anywhere, both networks frozen (exp-2 :946)
+    if not hasattr(args, "train_unet"):           # exp-2's CLI has neither switch
+        args.train_unet = False
+    if not hasattr(args, "train_text_encoder"):
+        args.train_text_encoder = False
+    if train_prefix and (args.train_unet or args.train_text_encoder):
+        raise ValueError("exp-2 trains the prefix embedding only")
     sds = dict(state_dicts or {})
     gen = lambda shapes, s, **k: W.synthetic_state_dict(shapes, seed=seed + s, **k)  # noqa: E731
     if "unet" not in sds:
@@ -68,7 +75,9 @@ def build_trainer(args, device, cfgs=SD15, seed=0, rank=0, world_size=1, experim
     if "clf" not in sds:
         sds["clf"] = gen(W.mobilenet_param_shapes(num_classes), 4, gain=classifier_gain)
     unet = UNet2DConditionModel(cfgs["unet"], sds["unet"], device)
-    eval_unet = UNet2DConditionModel(cfgs["unet"], sds["unet"], device) if (args.train_unet and frozen_copies) else None
+    # exp-2 runs R1 (debiased prompt) and R2 (plain prompt) through the SAME frozen weights; a second U-Net object (its own prompt K/V cache
+    # and recorded activations) lets the two rollouts run on two streams and R3 consume R1's forward, as in the LoRA experiments
+    eval_unet = UNet2DConditionModel(cfgs["unet"], sds["unet"], device) if ((args.train_unet or train_prefix) and frozen_copies) else None
     del sds["unet"]
     vae = AutoencoderKL(cfgs["vae"], sds["vae"], device)
     te = CLIPTextModel(cfgs["clip"], sds["clip"], device)
@@ -101,6 +110,13 @@ def build_trainer(args, device, cfgs=SD15, seed=0, rank=0, world_size=1, experim
                 dist.broadcast(m.lora_bank.flat, src=0)
                 m.lora_bank.ema.copy_(m.lora_bank.flat)
                 m.refresh_lora()
+    prefix = None
+    if train_prefix:
+        from .prefix import PrefixEmbedding
+        prefix = PrefixEmbedding(te, getattr(args, "train_num_tokens", 5), device, seed=seed + 13, state_dict=sds.get("prefix_embedding"))
+        if world_size > 1 or (os.environ.get("FD_FORCE_COLLECTIVES") is not None and _d.is_available() and _d.is_initialized()):
+            _d.broadcast(prefix.bank.flat, src=0)      # the resized embedding table is broadcast from rank 0 (:922)
+            prefix.bank.ema.copy_(prefix.bank.flat)
     clip_model = dino_model = None
     if regularisers and getattr(args, "weight_loss_img", 0) != 0:
         from .vit import VisionTransformer
@@ -122,5 +138,6 @@ def build_trainer(args, device, cfgs=SD15, seed=0, rank=0, world_size=1, experim
         face_db = sds.pop("face_db")
     sch = DPMSolverMultistepScheduler()
     tr = FairnessTrainer(args, te, unet, vae, clf, sch, eval_text_encoder=eval_te, eval_unet=eval_unet, experiment=experiment, rank=rank,
-                         world_size=world_size, device=device, clip_model=clip_model, dino_model=dino_model, face_net=face_net, face_db=face_db)
-    return tr, dict(clip_vision=clip_model, dino=dino_model, face_net=face_net, unet=unet, eval_unet=eval_unet, vae=vae, text_encoder=te, eval_text_encoder=eval_te, classifier=clf, scheduler=sch)
+                         world_size=world_size, device=device, clip_model=clip_model, dino_model=dino_model, face_net=face_net, face_db=face_db,
+                         prefix_embedding=prefix)
+    return tr, dict(prefix_embedding=prefix, clip_vision=clip_model, dino=dino_model, face_net=face_net, unet=unet, eval_unet=eval_unet, vae=vae, text_encoder=te, eval_text_encoder=eval_te, classifier=clf, scheduler=sch)

@@ -308,6 +308,7 @@ def generate_dynamic_targets_multi(probs_list, class_cdfs, num_samples_per_devic
 # per experiment: (factor1 flags, factor2 flags, confidence-level flag) of the regulariser terms, in attribute order
 EXPERIMENT_REG_FLAGS = {
     "exp-1": (["factor1"], ["factor2"], "face_gender_confidence_level"),
+    "exp-2": (["factor1"], ["factor2"], "face_gender_confidence_level"),
     "exp-3": (["factor1_gender", "factor1_race"], ["factor2_gender", "factor2_race"], "face_gender_race_confidence_level"),
     "exp-4": (["factor1_gender", "factor1_race", "factor1_age"], ["factor2_gender", "factor2_race", "factor2_age"], "face_gender_race_age_confidence_level"),
     "exp-5": (["factor1_gender", "factor1_race"], ["factor2_gender", "factor2_race"], "face_gender_race_confidence_level"),
@@ -316,6 +317,7 @@ EXPERIMENT_REG_FLAGS = {
 EXPERIMENT_ATTRS = {
     # name: (classifier logits, [(attribute, first logit column, width)], class CDF edges, exp-4 age asymmetry)
     "exp-1": (80, [("gender", 40, 2)], None, False),
+    "exp-2": (80, [("gender", 40, 2)], None, False),      # same classifier and binary targets as exp-1; what is trained differs (prefix.py)
     "exp-3": (6, [("gender", 0, 2), ("race", 2, 4)], [[0.5, 1.0], [0.25, 0.5, 0.75, 1.0]], False),
     "exp-4": (8, [("gender", 0, 2), ("race", 2, 4), ("age", 6, 2)], [[0.5, 1.0], [0.25, 0.5, 0.75, 1.0], [0.75, 1.0]], True),
     "exp-5": (6, [("gender", 0, 2), ("race", 2, 4)], [[0.5, 1.0], [0.25, 0.5, 0.75, 1.0]], False),

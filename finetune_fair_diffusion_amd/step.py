@@ -97,8 +97,9 @@ class EMAState:
 class FairnessTrainer:
     def __init__(self, args, text_encoder, unet, vae, classifier, scheduler, eval_text_encoder=None, eval_unet=None,
                  face_provider=None, experiment="exp-1", rank=0, world_size=1, device=None, clip_model=None, dino_model=None,
-                 face_net=None, face_db=None):
+                 face_net=None, face_db=None, prefix_embedding=None):
         self.args = args
+        self.prefix = prefix_embedding      # exp-2: trainable prompt-prefix vectors (prefix.PrefixEmbedding); every network stays frozen
         self.clip, self.dino = clip_model, dino_model
         self.use_img_loss = clip_model is not None and dino_model is not None and getattr(args, "weight_loss_img", 0) != 0
         if (clip_model is None) != (dino_model is None):
@@ -134,6 +135,10 @@ class FairnessTrainer:
             self.banks.append(unet.lora_bank)
         if getattr(args, "train_text_encoder", False):
             self.banks.append(text_encoder.lora_bank)
+        if self.prefix is not None:
+            if self.banks:
+                raise ValueError("exp-2 trains the prefix embedding only (1-main-debias.py:946): no LoRA banks next to it")
+            self.banks.append(self.prefix.bank)
         self.ema = [EMAState(args.EMA_decay) for _ in self.banks]
         self.opt_step = 0
         self.lr_step = 0      # lr_scheduler.step() count: advances every step, also when the update is skipped (:2023)
@@ -390,8 +395,11 @@ class FairnessTrainer:
                 dist.all_reduce(bank.grad, op=dist.ReduceOp.SUM)
 
     # ------------------------------------------------------------------ the step
-    def train_step(self, tokens, noises, S):
+    def train_step(self, tokens, noises, S, tokens_ori=None):
+        """``tokens``: the prompt the finetuned side sees (exp-2: ``prompt_debiaser(prompt)``, generate.prefix_tokens); ``tokens_ori``: the
+        prompt of the frozen original side R2 when it differs (exp-2 :1954: the plain prompt, no prefix embedding)."""
         args = self.args
+        tokens_ori = tokens if tokens_ori is None else tokens_ori
         dev = self.device
         B = noises.shape[0]
         noises = noises.to(dev, F32)
@@ -404,7 +412,10 @@ class FairnessTrainer:
         # ---- R1: images from the model being finetuned (:1786-1795)
         train_te = getattr(args, "train_text_encoder", False) and self.te.lora_bank is not None
         train_unet = getattr(args, "train_unet", False) and self.unet.lora_bank is not None
-        share = self.share_r1_r3 and vb >= B and self.eval_unet is not self.unet and (train_unet or train_te)
+        train_prefix = self.prefix is not None
+        pv = self.prefix.vectors() if train_prefix else None
+        rec_te = train_te or train_prefix
+        share = self.share_r1_r3 and vb >= B and self.eval_unet is not self.unet and (train_unet or train_te or train_prefix)
         shared = None
         # R1 (finetuned model) and R2 (frozen original, :1844-1858) are independent until the loss: with ``concurrent_r2`` their denoising
         # steps are enqueued in lockstep on two HIP streams, so the many launches that cannot fill 256 CUs on their own (16x16 / 8x8 levels,
@@ -416,10 +427,10 @@ class FairnessTrainer:
         if conc:
             side.wait_stream(cur)
             with torch.cuda.stream(side):
-                enc_ori = self.encode_pair(self.eval_te, tokens)
+                enc_ori = self.encode_pair(self.eval_te, tokens_ori)
                 g2 = self.rollout_steps(self.eval_unet, enc_ori, noises, S, r2)
         if share:
-            enc = self.encode_pair(self.te, tokens, record=train_te)
+            enc = self.encode_pair(self.te, tokens, record=rec_te, prefix=pv)
             r1 = {}
             g1 = self.rollout_steps(self.unet, enc, noises, S, r1, keep_inputs=True, record_prompt=True, keep_activations=self.keep_activations)
             for _ in g1:
@@ -431,7 +442,7 @@ class FairnessTrainer:
             images = self.decode(x_final, record=True)
             shared = (enc, inputs, ctxs)
         else:
-            enc = self.encode_pair(self.te, tokens)
+            enc = self.encode_pair(self.te, tokens, prefix=pv)
             lats = []
             for j in range(0, B, vb):
                 r1 = {}
@@ -459,7 +470,7 @@ class FairnessTrainer:
             images_ori.record_stream(cur)
         else:
             self._mark("R2_rollout")
-            enc_ori = self.encode_pair(self.eval_te, tokens) if self.eval_te is not self.te else enc
+            enc_ori = self.encode_pair(self.eval_te, tokens_ori) if (self.eval_te is not self.te or train_prefix or tokens_ori is not tokens) else enc
             lats = [self.rollout(self.eval_unet, enc_ori, noises[j:j + vb], S)[0] for j in range(0, B, vb)]
             self._mark("R2_vae")
             images_ori = torch.cat([self.decode(x) for x in lats])
@@ -484,7 +495,7 @@ class FairnessTrainer:
             (enc_g, inputs, ctxs), images_g, ind_g, boxes_g, per_g = shared, images, ind, boxes, per
         else:
             self._mark("R3_fwd_rollout")
-            enc_g = self.encode_pair(self.te, tokens, record=train_te)
+            enc_g = self.encode_pair(self.te, tokens, record=rec_te, prefix=pv)
             x_final, inputs, ctxs = self.rollout(self.unet, enc_g, noises, S, keep_inputs=True, record_prompt=True,
                                                  keep_activations=self.keep_activations)
             self._mark("R3_fwd_vae")
@@ -576,7 +587,7 @@ class FairnessTrainer:
             gscale = _pow2_scale(float(g.abs().max()) * float(abs(coefs).max()) * max(abs(gs), abs(1 - gs)), 64.0)
             out.update(g=g, coefs=coefs, gscale=gscale)
             self._mark("R3_bwd_unet")
-            if train_unet or train_te:
+            if train_unet or train_te or train_prefix:
                 # The S per-timestep backwards are independent (the U-Net input is detached at every step, :1115): they are dealt round-robin
                 # to ``bwd_streams`` HIP streams, each side stream accumulating its LoRA gradients into its own buffer, so that the many
                 # launches which cannot fill the chip alone overlap with a neighbouring timestep's.  Shared cross-attention dK/dV: fp32 atomics.
@@ -610,10 +621,13 @@ class FairnessTrainer:
                     cur.wait_stream(side)
                     for bank in self.banks:
                         bank.grad.add_(bank.grad_alt(k))
-                denc = self.unet.finish_prompt_backward(gscale, need_denc=train_te)
-                if train_te:
+                denc = self.unet.finish_prompt_backward(gscale, need_denc=rec_te)
+                if rec_te:
                     L = enc_g.shape[1]
-                    self.te.backward(denc.view(2, L, -1), gscale)
+                    dx0 = self.te.backward(denc.view(2, L, -1), gscale)
+                    if train_prefix:     # the prefix vectors sit at positions 1..n of the PROMPT row (row 1; row 0 is the uncond sequence)
+                        n = self.prefix.n
+                        self.prefix.bank.grad_view("token_embedding.weight")[1:].add_(dx0[1, 1:1 + n].float(), alpha=1.0 / gscale)
         else:
             self.vae._ctx = self.clf._ctx = None
         ctxs.clear()

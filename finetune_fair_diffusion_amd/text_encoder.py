@@ -109,7 +109,8 @@ class CLIPTextModel:
     __call__ = forward
 
     def backward(self, d_out, gscale):
-        """d_out: [B,T,D] fp16 = gscale * dL/d(last_hidden_state).  Accumulates the LoRA gradients."""
+        """d_out: [B,T,D] fp16 = gscale * dL/d(last_hidden_state).  Accumulates the LoRA gradients; returns gscale * dL/d(input embeddings)
+        [B,T,D] fp16 (token + position embedding sum: what exp-2's prefix vectors enter through)."""
         cfg, c = self.config, self._ctx
         B, T = c["B"], c["T"]
         D, H = cfg.hidden_size, cfg.num_attention_heads
@@ -128,3 +129,4 @@ class CLIPTextModel:
             dn1 = lora_linear_bwd(dv, s["n1"], s["tv"], L["v"], lo.get("v"), gscale, residual=dn1)
             dx = ops.layernorm_bwd(s["x"], dn1, L["ln1"].gamma, s["s1"], add=dh1)
         self._ctx = None
+        return dx.view(B, T, D)

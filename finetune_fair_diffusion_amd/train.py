@@ -1,6 +1,6 @@
 """Training driver: the loop of exp-1-debias-gender/1-main-debias.py ``main`` (:647-2070) around FairnessTrainer.
 
-    python -m finetune_fair_diffusion_amd.train [--experiment exp-1|exp-3|exp-4|exp-5] --config <yaml> [--synthetic]
+    python -m finetune_fair_diffusion_amd.train [--experiment exp-1|exp-2|exp-3|exp-4|exp-5] --config <yaml> [--synthetic]
     python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 -m finetune_fair_diffusion_amd.train ...
 
 Same flags, YAML overlay, seeding (``set_seed(seed, device_specific=True)`` :693, prompt order from
@@ -97,7 +97,7 @@ def main(argv=None, experiment=None, cfgs=None, log=None):
     if experiment is None:       # build addition: one driver for the reference's per-experiment scripts
         import argparse
         pre = argparse.ArgumentParser(add_help=False)
-        pre.add_argument("--experiment", default="exp-1", choices=["exp-1", "exp-3", "exp-4", "exp-5"])
+        pre.add_argument("--experiment", default="exp-1", choices=["exp-1", "exp-2", "exp-3", "exp-4", "exp-5"])
         ns, argv = pre.parse_known_args(argv)
         experiment = ns.experiment
     args = parse_args(argv, with_extras=True, experiment=experiment)
@@ -168,7 +168,15 @@ def main(argv=None, experiment=None, cfgs=None, log=None):
             if world > 1:
                 dist.broadcast_object_list(S, src=0)
             t0 = time.time()
-            out = trainer.train_step(tokenizer(prompt), noises, S[0])
+            toks = tokenizer(prompt)
+            if trainer.prefix is not None:
+                # exp-2 (:1846, :1895, :1954, :2001): the finetuned side sees "".join(prefix_tokens) + prompt with the pipeline's negative
+                # prompt (no padding mask); the original side sees the plain prompt, its empty prompt encoded without a mask as well
+                from .generate import prefix_tokens
+                out = trainer.train_step(prefix_tokens(toks, trainer.prefix.n, cfgs["clip"].vocab_size), noises, S[0],
+                                         tokens_ori=(toks[0], toks[1], toks[2], torch.ones_like(toks[3])))
+            else:
+                out = trainer.train_step(toks, noises, S[0])
             global_step += 1
             if rank == 0:
                 lf = out["loss_fair"]

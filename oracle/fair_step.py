@@ -239,11 +239,35 @@ def encode_prompts(text_encoder, prompt_ids, prompt_mask, uncond_ids, uncond_mas
     return torch.cat([ne, pe])
 
 
+def prefix_encoders(text_encoder, prompt_ids, fair_ids, fair_table, eos_id, plain_tokens):
+    """exp-2-debias-gender-token/1-main-debias.py:1049-1113 (= :1142-1210 for the gradient rollout): the two prompt encodings of a
+    prefix-tuning step as closures ``N -> [2N, L, D]`` (negative first).
+    * finetuned side (``which_prefix_embedding=prefix_embedding``, :1061-1086): ``prompt_ids`` already carries the n prefix-token ids after
+      BOS; FairEmbeddings + ``text_model_forward`` with the all-ones mask; negative embeddings as ``pipe._encode_prompt`` builds them
+      (``[""]`` padded to the prompt length, ``attention_mask=None``);
+    * original side (``which_prefix_embedding=None``, :1087-1112): the plain prompt with its mask, the empty prompt WITHOUT a mask (:1107-1110).
+    ``fair_table`` [n+1, D] may require grad: it is the only trained tensor (:946)."""
+    L = prompt_ids.shape[0]
+
+    def encode(N):
+        pe = text_encoder(prompt_ids[None].repeat(N, 1), torch.ones(N, L, dtype=torch.long), fair=(fair_ids, fair_table))[0]
+        uids = torch.cat([prompt_ids[:1], torch.full((L - 1,), eos_id, dtype=prompt_ids.dtype)])
+        ne = text_encoder(uids[None].repeat(N, 1), None)[0]
+        return torch.cat([ne, pe])
+
+    def encode_ori(N):
+        pid, pm, uid, _ = plain_tokens
+        pe = text_encoder(pid[None].repeat(N, 1), pm[None].repeat(N, 1))[0]
+        ne = text_encoder(uid[None].repeat(N, 1), None)[0]
+        return torch.cat([ne, pe])
+    return encode, encode_ori
+
+
 @torch.no_grad()
 def generate_image_no_gradient(tokens, noises, S, text_encoder, unet, vae, scheduler, guidance_scale=7.5, dtype=torch.float32,
-                               trace=None):  # :998-1061
+                               trace=None, encode=None):  # :998-1061
     N = noises.shape[0]
-    emb = encode_prompts(text_encoder, *tokens, N).to(dtype)
+    emb = (encode(N) if encode is not None else encode_prompts(text_encoder, *tokens, N)).to(dtype)
     scheduler.set_timesteps(S)
     latents = noises
     for i, t in enumerate(scheduler.timesteps):
@@ -280,9 +304,9 @@ def generate_image_w_prefix_embedding(prompt_ids, noises, fair_ids, fair_table, 
 
 
 def generate_image_w_gradient(tokens, noises, S, text_encoder, unet, vae, scheduler, guidance_scale=7.5, dtype=torch.float32,
-                              trace=None):  # :1063-1136
+                              trace=None, encode=None):  # :1063-1136
     N = noises.shape[0]
-    emb = encode_prompts(text_encoder, *tokens, N).to(dtype)
+    emb = (encode(N) if encode is not None else encode_prompts(text_encoder, *tokens, N)).to(dtype)
     scheduler.set_timesteps(S)
     coefs = grad_coefs(scheduler)
     latents = noises
@@ -332,7 +356,8 @@ def fairness_step(models, tokens, noises, S, cfg, world=None, attrs=None, target
     [M,512] database of FaceFeatsModel, :80-92) and cfg["weight_loss_face"] != 0.
 
     models: dict(text_encoder, unet, vae, classifier, scheduler, eval_text_encoder, eval_unet)
-    cfg: dict(train_GPU_batch_size, val_GPU_batch_size, uncertainty_threshold, factor2, guidance_scale, size_face, slice_fn)
+    cfg: dict(train_GPU_batch_size, val_GPU_batch_size, uncertainty_threshold, factor2, guidance_scale, size_face, slice_fn);
+         exp-2 adds ``encode`` / ``encode_ori`` (``prefix_encoders``): how the finetuned and the original side embed the prompt
     world: optional (rank, world_size, probs_all) -- when given, the dynamic targets use the
            gathered ``probs_all`` of every rank (:1805-1837).
     Returns dict with images, probs, targets, uncertainty, loss_fair (per image, -1 sentinel),
@@ -346,8 +371,9 @@ def fairness_step(models, tokens, noises, S, cfg, world=None, attrs=None, target
     with torch.no_grad():
         trace = []
         vb = cfg["val_GPU_batch_size"]
+        enc_fn, enc_ori_fn = cfg.get("encode"), cfg.get("encode_ori")
         images = torch.cat([generate_image_no_gradient(tokens, noises[j:j + vb], S, te, unet, vae, sch, gs,
-                                                       trace=trace if j == 0 else None) for j in range(0, B, vb)])
+                                                       trace=trace if j == 0 else None, encode=enc_fn) for j in range(0, B, vb)])
         ind, boxes, chips = faces(images)
         preds, probs, _ = get_face_gender(clf, chips, selector=ind, slice_fn=slice_fn)
         probs_all = probs if world is None else world[2]
@@ -356,7 +382,7 @@ def fairness_step(models, tokens, noises, S, cfg, world=None, attrs=None, target
         r = 0 if world is None else world[0]
         targets, unc = targets_all[B * r:B * (r + 1)], unc_all[B * r:B * (r + 1)]
         images_ori = torch.cat([generate_image_no_gradient(tokens, noises[j:j + vb], S, models["eval_text_encoder"],
-                                                           models["eval_unet"], vae, sch, gs) for j in range(0, B, vb)])
+                                                           models["eval_unet"], vae, sch, gs, encode=enc_ori_fn) for j in range(0, B, vb)])
         ind_o, boxes_o, chips_o = faces(images_ori)
         preds_o, probs_o, _ = get_face_gender(clf, chips_o, selector=ind_o, slice_fn=slice_fn)
         w_img = cfg.get("weight_loss_img", 0.0) if ("clip" in models and "dino" in models) else 0.0
@@ -377,7 +403,7 @@ def fairness_step(models, tokens, noises, S, cfg, world=None, attrs=None, target
     images_g = []
     for j in range(N_backward):
         idx = list(range(B))[j * tb:(j + 1) * tb]
-        img = generate_image_w_gradient(tokens, noises[idx], S, te, unet, vae, sch, gs)
+        img = generate_image_w_gradient(tokens, noises[idx], S, te, unet, vae, sch, gs, encode=enc_fn)
         ind_j, boxes_j, chips_j = faces(img)
         preds_j, probs_j, logits_j = get_face_gender(clf, chips_j, selector=ind_j, slice_fn=slice_fn)
         img_raw = img

@@ -132,7 +132,7 @@ def main():
 
     # CLI of the multi-attribute experiments (exp-3/4/5): defaults + every YAML config ----------
     multi = {}
-    for exp, d in [("exp-3", "exp-3-debias-gender-race"), ("exp-4", "exp-4-debias-gender-race-age"),
+    for exp, d in [("exp-2", "exp-2-debias-gender-token"), ("exp-3", "exp-3-debias-gender-race"), ("exp-4", "exp-4-debias-gender-race-age"),
                    ("exp-5", "exp-5-debias-gender-race-multi-concepts")]:
         pa = lift(["parse_args"], ref=f"/root/reference/{d}/1-main-debias.py")["parse_args"]
         e = dict(defaults=vars(pa([])))

@@ -308,11 +308,11 @@ def test_multi_attribute_targets_product_vs_oracle(exp):
 
 # ------------------------------------------------------------------------------------------ CLI of exp-3/4/5, lr schedule, checkpoints
 def test_cli_multi_attribute_experiments_match_reference(tmp_path):
-    """parse_args of exp-3/4/5 (defaults + every YAML overlay) against the reference's own parse_args output."""
+    """parse_args of exp-2/3/4/5 (defaults + every YAML overlay) against the reference's own parse_args output."""
     import yaml
     from finetune_fair_diffusion_amd.cli import parse_args
     gold = json.load(open(os.path.join(HERE, "golden", "reference_cli_multi.json")))
-    assert set(gold) == {"exp-3", "exp-4", "exp-5"}
+    assert set(gold) == {"exp-2", "exp-3", "exp-4", "exp-5"}
     for exp, cases in gold.items():
         assert vars(parse_args([], experiment=exp)) == cases["defaults"]
         for f, c in cases.items():
@@ -386,6 +386,43 @@ def _fake_trainer(seed):
     return t
 
 
+def test_prefix_embedding_checkpoint_files_are_fair_embeddings_state_dicts(tmp_path):
+    """exp-2: the trained table [n+1, D] (row 0 zero, rows 1..n initialised from existing vocabulary rows, exp-2 1-main-debias.py:86-146)
+    and its checkpoint files in the FairEmbeddings state-dict format of exp-2's 2-export-checkpoint.py:566-575."""
+    import types
+    from finetune_fair_diffusion_amd import checkpoint as ck, generate
+    from finetune_fair_diffusion_amd.prefix import PrefixEmbedding
+    from finetune_fair_diffusion_amd.step import EMAState
+    tok = torch.randn(50, 16, generator=torch.Generator().manual_seed(1)).half()
+    te = types.SimpleNamespace(tok=tok, pos=torch.randn(9, 16).half())
+    pe = PrefixEmbedding(te, 4, "cpu", seed=5)
+    assert pe.weight.shape == (5, 16) and float(pe.weight[0].abs().max()) == 0
+    for r in pe.weight[1:]:                                   # every prefix vector is a copy of one vocabulary row
+        assert any(torch.equal(r, v.float()) for v in tok)
+    assert torch.equal(PrefixEmbedding(te, 4, "cpu", seed=5).weight, pe.weight) and not torch.equal(PrefixEmbedding(te, 4, "cpu", seed=6).weight, pe.weight)
+    pe.bank.ema.mul_(0.5)
+    pe.bank.exp_avg.fill_(0.25)
+    tr = types.SimpleNamespace(args=types.SimpleNamespace(), prefix=pe, ema=[EMAState(0.996)], opt_step=3, lr_step=3,
+                               target_rng=torch.Generator().manual_seed(1), unet=None, te=None)
+    path = ck.save_state(tr, str(tmp_path / "checkpoint-3"), 3)
+    assert sorted(os.listdir(path)) == ["prefix_embedding.pth", "prefix_embedding_EMA.pth", "rng_rank0.pth", "trainer_state.pth"]
+    sd, sde = torch.load(os.path.join(path, "prefix_embedding.pth")), torch.load(os.path.join(path, "prefix_embedding_EMA.pth"))
+    assert sorted(sd) == ["position_embedding.weight", "position_ids", "token_embedding.weight"] and sd["position_ids"].shape == (1, 9)
+    assert torch.equal(sd["token_embedding.weight"], pe.weight) and torch.equal(sde["token_embedding.weight"], 0.5 * pe.weight)
+    assert torch.equal(generate.load_prefix_embedding(os.path.join(path, "prefix_embedding.pth"), 4), pe.vectors())
+    with pytest.raises(ValueError):
+        generate.load_prefix_embedding(os.path.join(path, "prefix_embedding.pth"), 5)
+    other = PrefixEmbedding(te, 4, "cpu", seed=9)
+    tr2 = types.SimpleNamespace(args=types.SimpleNamespace(), prefix=other, ema=[EMAState(0.996)], opt_step=0, lr_step=0,
+                                target_rng=torch.Generator().manual_seed(2), unet=None, te=None)
+    assert ck.load_state(tr2, path) == 3 and tr2.opt_step == 3
+    for buf in ("flat", "ema", "exp_avg", "exp_avg_sq"):
+        assert torch.equal(getattr(other.bank, buf), getattr(pe.bank, buf)), buf
+    # a LoRA checkpoint cannot be resumed as a prefix run
+    with pytest.raises((ValueError, FileNotFoundError, KeyError)):
+        ck.load_state(tr2, str(tmp_path / "nope"))
+
+
 def test_checkpoint_round_trip_export_and_rolling_cleanup(tmp_path):
     """Trainer state -> checkpoint_tmp-N -> fresh trainer; the four exported files are the reference's public format
     (2-export-checkpoint.py:619-642): fp32 CPU dict[str,Tensor] keyed by the diffusers LoRA names."""
@@ -412,7 +449,7 @@ def test_checkpoint_round_trip_export_and_rolling_cleanup(tmp_path):
     assert b.unet.refreshed == 1 and b.te.refreshed == 1
     # export = the four LoRA files only
     out, files = ck.export_checkpoint(path)
-    assert out.endswith("checkpoint_tmp-20_exported") and sorted(files) == sorted(f for v in ck.BANK_FILES.values() for f in v)
+    assert out.endswith("checkpoint_tmp-20_exported") and sorted(files) == sorted(f for k in ("unet", "text_encoder") for f in ck.BANK_FILES[k])
     with pytest.raises(ValueError):
         ck.export_checkpoint(os.path.join(d, "nope"))
     # files written by the reference (no trainer_state) load by key; wrong shapes are rejected

@@ -958,3 +958,102 @@ def test_generate_image_with_prefix_embedding_matches_oracle(dev):
     check("generate_image with prefix embedding, S=10", img, ref, 3e-2)
     plain = generate.generate_image(tr, U.tiny_tokens(), noises, 10)
     assert float((plain.float() - img.float()).abs().max()) > 0.05      # the prefix really changes the image
+
+
+# ------------------------------------------------------------------------------------------ exp-2: prefix-token tuning
+@pytest.mark.parametrize("schedule", ["shipped", "reference"])
+def test_exp2_prefix_token_training_step_vs_oracle(dev, schedule, monkeypatch):
+    """exp-2-debias-gender-token/1-main-debias.py:1846-2119: the only trained tensor is FairEmbeddings.token_embedding.weight [n+1, D]; R1/R3 see
+    ``"".join(prefix_tokens) + prompt`` through FairEmbeddings + the pipeline's negative prompt, R2 sees the plain prompt (:1954).  Images of
+    both sides, targets, loss and the gradient of the table vs the oracle's autograd -- in the shipped schedule (R3 consumes R1's forward,
+    two rollout streams, three backward streams) and in the reference's own (everything separate, one stream)."""
+    from oracle import fair_step as fs
+    from finetune_fair_diffusion_amd import generate
+    from finetune_fair_diffusion_amd.prefix import PrefixEmbedding
+    from finetune_fair_diffusion_amd.step import FairnessTrainer
+    from finetune_fair_diffusion_amd.unet import UNet2DConditionModel
+    if schedule == "reference":
+        for k in ("FD_NO_SHARE", "FD_NO_CONCURRENT_R2", "FD_NO_CONCURRENT_BWD"):
+            monkeypatch.setenv(k, "1")
+    om = U.oracle_models(train_unet=False, train_te=False)
+    pm = U.product_models(om["sds"], dev, train_unet=False, train_te=False)
+    eval_unet = UNet2DConditionModel(pm["unet"].config, om["sds"]["unet"], dev)     # same frozen weights, own prompt cache (factory does the same)
+    n, vocab = 3, 1000
+    prefix = PrefixEmbedding(pm["text_encoder"], n, dev, seed=3)
+    assert float(prefix.weight[0].abs().max()) == 0 and float(prefix.weight[1:].abs().min(dim=1).values.min()) >= 0 and prefix.weight.shape == (n + 1, 64)
+    table = torch.nn.Parameter(prefix.weight.detach().cpu().clone())
+    plain = U.tiny_tokens()
+    toks = generate.prefix_tokens(plain, n, vocab)
+    toks_ori = (plain[0], plain[1], plain[2], torch.ones_like(plain[3]))
+    enc, enc_ori = fs.prefix_encoders(om["text_encoder"], toks[0], torch.arange(vocab, vocab + n), table, vocab - 2, plain)
+    B, S = 4, 4
+    noises = torch.randn(B, 4, 32, 32, generator=torch.Generator().manual_seed(5991))
+    models_o = dict(text_encoder=om["text_encoder"], unet=om["unet"], vae=om["vae"], classifier=om["classifier"], scheduler=om["scheduler"],
+                    eval_text_encoder=om["text_encoder"], eval_unet=om["unet"])
+    ref = fs.fairness_step(models_o, None, noises, S, dict(train_GPU_batch_size=3, val_GPU_batch_size=8, uncertainty_threshold=0.2, factor2=0.2,
+                                                           size_face=64, encode=enc, encode_ori=enc_ori))
+    args = U.make_args(train_unet=False, train_text_encoder=False)
+    tr = FairnessTrainer(args, pm["text_encoder"], pm["unet"], pm["vae"], pm["classifier"], pm["scheduler"], eval_unet=eval_unet, experiment="exp-2",
+                         device=dev, prefix_embedding=prefix)
+    assert tr.banks == [prefix.bank] and tr.share_r1_r3 == (schedule == "shipped")
+    grads, apply = {}, tr.sync_and_update
+
+    def spy(N_backward, apply_=True):
+        grads[0] = prefix.bank.grad_view("token_embedding.weight").clone()
+        return apply(N_backward)
+    tr.sync_and_update = spy
+    w0 = prefix.weight.clone()
+    out = tr.train_step(toks, noises, S, tokens_ori=toks_ori)
+    check("exp-2 R1 images (prefix prompt)", out["images"], ref["images"], 3e-2)
+    check("exp-2 R2 images (plain prompt, unmasked negative prompt)", out["images_ori"], ref["images_ori"], 3e-2)
+    assert float((out["images"].float() - out["images_ori"].float()).abs().max()) > 0.02      # the prefix changes the image
+    assert out["targets"].tolist() == ref["targets"].tolist() and out["N_backward"] == ref["N_backward"] and out["grad_is_finite"]
+    check("exp-2 loss_fair", out["loss_fair"], ref["loss_fair"], 1e-2)
+    g, rg = grads[0].cpu(), table.grad
+    assert float(g[0].abs().max()) == 0 and float(rg[0].abs().max()) == 0        # row 0 ("not a prefix token") never receives gradient
+    cos = F.cosine_similarity(g[1:].flatten().double(), rg[1:].flatten().double(), dim=0)
+    print(f"[exp-2 {schedule}] cosine(prefix grad) = {float(cos):.5f}  |g|max = {float(rg.abs().max()):.3e}")
+    check("exp-2 gradient of the prefix table", g[1:], rg[1:], 3e-1)
+    assert cos > 0.97
+    # AdamW + EMA ran on the table: first step moves every trained entry by ~lr, row 0 stays exactly zero, EMA's first step copies
+    dw = (prefix.weight - w0).abs()
+    assert float(dw[0].max()) == 0 and 0 < float(dw[1:].max()) <= 1.2 * args.learning_rate
+    assert float((prefix.bank.ema - prefix.bank.flat).abs().max()) < 1e-6 and tr.opt_step == 1
+
+
+def test_exp2_train_loop_export_and_consumer(tmp_path, dev):
+    """exp-2 driver: ``train --experiment exp-2`` (debias-token.yaml keys), checkpoints carry ``prefix_embedding{,_EMA}.pth`` in the
+    FairEmbeddings state-dict format of exp-2's 2-export-checkpoint.py:566-575, which ``generate.load_prefix_embedding`` (gen-images.py:537)
+    and a resumed trainer read back bit for bit."""
+    from finetune_fair_diffusion_amd import checkpoint as ck, generate, train
+    from finetune_fair_diffusion_amd.cli import parse_args
+    from finetune_fair_diffusion_amd.factory import TINY, build_trainer
+    argv = ["--synthetic", "--train_num_tokens", "3", "--max_train_steps", "3", "--checkpointing_steps", "2", "--checkpointing_steps_long", "3",
+            "--checkpoints_total_limit", "2", "--num_denoising_steps", "3", "--train_images_per_prompt_GPU", "4", "--train_GPU_batch_size", "3",
+            "--val_GPU_batch_size", "4", "--learning_rate", "1e-4", "--output_dir", str(tmp_path / "run"), "--weight_loss_img", "0",
+            "--weight_loss_face", "0"]
+    logs = []
+    tr, nsteps = train.main(argv, experiment="exp-2", cfgs=TINY, log=logs.append)
+    recs = [json.loads(x) for x in logs]
+    assert nsteps == 3 and [r["step"] for r in recs] == [1, 2, 3] and all(r["grad_is_finite"] for r in recs)
+    assert tr.prefix is not None and tr.prefix.n == 3 and tr.unet.lora_bank is None and tr.te.lora_bank is None
+    cdir = tmp_path / "run" / "checkpoints"
+    assert sorted(os.listdir(cdir)) == ["checkpoint-3", "checkpoint_tmp-2"]
+    assert sorted(os.listdir(cdir / "checkpoint-3")) == ["prefix_embedding.pth", "prefix_embedding_EMA.pth", "rng_rank0.pth", "trainer_state.pth"]
+    sd = torch.load(cdir / "checkpoint-3" / "prefix_embedding.pth")
+    assert sorted(sd) == ["position_embedding.weight", "position_ids", "token_embedding.weight"] and sd["token_embedding.weight"].shape == (4, 64)
+    assert torch.equal(sd["token_embedding.weight"], tr.prefix.weight.cpu()) and float(sd["token_embedding.weight"][0].abs().max()) == 0
+    sd2 = torch.load(cdir / "checkpoint_tmp-2" / "prefix_embedding.pth")
+    assert not torch.equal(sd2["token_embedding.weight"][1:], sd["token_embedding.weight"][1:])        # the prefix moved between steps 2 and 3
+    # consumer side: gen-images.py --load_prefix_embedding_from
+    P = generate.load_prefix_embedding(str(cdir / "checkpoint-3" / "prefix_embedding.pth"), 3)
+    assert torch.equal(P, tr.prefix.vectors().cpu())
+    out, files = ck.export_checkpoint(str(cdir / "checkpoint-3"))
+    assert sorted(files) == ["prefix_embedding.pth", "prefix_embedding_EMA.pth"]
+    # resume: a fresh trainer restored from the step-2 checkpoint holds its weights, EMA, Adam moments and counters
+    args = parse_args(argv, with_extras=True, experiment="exp-2")
+    fresh, _ = build_trainer(args, dev, TINY, seed=args.seed, experiment="exp-2")
+    assert ck.load_state(fresh, str(cdir / "checkpoint_tmp-2")) == 2 and fresh.opt_step == 2
+    assert torch.equal(fresh.prefix.weight.cpu(), sd2["token_embedding.weight"])
+    ema2 = torch.load(cdir / "checkpoint_tmp-2" / "prefix_embedding_EMA.pth")["token_embedding.weight"]
+    assert torch.equal(fresh.prefix.vectors(ema=True).cpu(), ema2[1:]) and float(fresh.prefix.bank.exp_avg.abs().sum()) > 0
