@@ -6,7 +6,7 @@ cannot be set from YAML and booleans follow Python's ``bool(value)`` -- plus the
 
   --num_denoising_steps  fixed S instead of ``random.choices(range(19,24))`` (:1779)
   --synthetic            synthetic weights / token ids / face provider (no network, no data.zip)
-  --face_provider        detector seam: "synthetic" (default)
+  --face_provider        detector seam: "synthetic" (default) or "detector" (insightface + face_recognition, when installed)
   --num_classifier_logits  80 (exp-1) / 6 (exp-3,5) / 8 (exp-4)
   --lora_up_std          std of the LoRA ``up`` init; 0 (default) = zeros like the reference, non-zero only for synthetic experiments
 

@@ -45,7 +45,7 @@ def default_args(experiment="exp-1", **kw):
 
 
 def build_trainer(args, device, cfgs=SD15, seed=0, rank=0, world_size=1, experiment="exp-1", classifier_gain=1.4, state_dicts=None,
-                  frozen_copies=True, regularisers=False, lora_up_std=0.0):
+                  frozen_copies=True, regularisers=False, lora_up_std=0.0, face_provider=None):
     """Returns (trainer, models dict).  ``state_dicts`` may carry real weights by diffusers key
     (keys 'unet','vae','clip','clf','unet_lora','te_lora'); anything missing is synthetic.
     ``frozen_copies=False`` skips the original-model replicas of R2 (inference-only consumers such as generate.py).
@@ -139,5 +139,5 @@ def build_trainer(args, device, cfgs=SD15, seed=0, rank=0, world_size=1, experim
     sch = DPMSolverMultistepScheduler()
     tr = FairnessTrainer(args, te, unet, vae, clf, sch, eval_text_encoder=eval_te, eval_unet=eval_unet, experiment=experiment, rank=rank,
                          world_size=world_size, device=device, clip_model=clip_model, dino_model=dino_model, face_net=face_net, face_db=face_db,
-                         prefix_embedding=prefix)
+                         prefix_embedding=prefix, face_provider=face_provider)
     return tr, dict(prefix_embedding=prefix, clip_vision=clip_model, dino=dino_model, face_net=face_net, unet=unet, eval_unet=eval_unet, vae=vae, text_encoder=te, eval_text_encoder=eval_te, classifier=clf, scheduler=sch)

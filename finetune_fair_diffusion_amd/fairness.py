@@ -47,6 +47,86 @@ class SyntheticFaceProvider:
         return torch.tensor(pts, dtype=torch.float32)[None].repeat(N, 1, 1)
 
 
+class DetectorFaceProvider:
+    """The reference's detector seam behind the provider interface: ``get_face`` (:1192-1215) = insightface's ``FaceAnalysis`` first
+    (``get_face_app`` :1306-1353: BGR uint8 image in, largest face by the area of its box clipped to the image, ``expand_bbox(bbox, 0.5, 1)``,
+    the detector's 5 key points), and for the images it finds nothing in, face_recognition's CNN detector (``get_face_FR`` :1232-1293:
+    ``face_locations(model="cnn", number_of_times_to_upsample=0)`` in (top, right, bottom, left) order, ``expand_bbox(bbox, 1.1, 1)``, five
+    points derived from the 68-point "large" landmark model: eye means, last nose-bridge point, top-lip points 0 and 6).
+
+    ``face_app`` / ``face_recognition`` are the two detector objects (``insightface.app.FaceAnalysis`` instance with ``.get``, the
+    ``face_recognition`` module); ``from_installed()`` builds them the way the reference does (:936-945; the ONNX execution provider is the CPU one here --
+    onnxruntime has no CUDA provider on this platform).  Neither package ships with this
+    image: the adaptor is host-side glue, pinned in tests against the reference's own ``get_face`` on scripted detector outputs."""
+
+    def __init__(self, face_app=None, face_recognition=None, fill_value=-1):
+        if face_app is None and face_recognition is None:
+            raise ValueError("DetectorFaceProvider needs at least one detector (insightface FaceAnalysis and / or the face_recognition module)")
+        self.face_app, self.fr, self.fill = face_app, face_recognition, fill_value
+        self._seen = []          # results for the last few image batches, by object identity (boxes and landmarks come from one detector pass)
+
+    @classmethod
+    def from_installed(cls, det_size=(640, 640), ctx_id=0):
+        try:
+            from insightface.app import FaceAnalysis
+            import face_recognition
+        except ImportError as e:
+            raise ImportError("--face_provider detector needs the reference's detector side-car packages (insightface, face_recognition); "
+                              "neither is part of this build") from e
+        app = FaceAnalysis(name="buffalo_l", allowed_modules=["detection"], providers=["CPUExecutionProvider"])
+        app.prepare(ctx_id=ctx_id, det_size=det_size)
+        return cls(app, face_recognition)
+
+    @staticmethod
+    def _largest(boxes_xyxy, dim_max, dim_min=0):
+        """get_largest_face_app / get_largest_face_FR (:1217-1230, :1294-1304): first box of maximal clipped area (strict >, start at 0)."""
+        if len(boxes_xyxy) == 1:
+            return 0
+        area_max, idx_max = 0, 0
+        for i, b in enumerate(boxes_xyxy):
+            area = (min(b[2], dim_max) - max(b[0], dim_min)) * (min(b[3], dim_max) - max(b[1], dim_min))
+            if area > area_max:
+                area_max, idx_max = area, i
+        return idx_max
+
+    def detect(self, images):
+        """images [N,3,H,W] in [-1,1] -> (indicators [N] bool, boxes [N,4] int32, landmarks [N,5,2] float32), fill value where no face."""
+        for im, res in self._seen:
+            if im is images:
+                return res
+        x = ((images.detach().float() * 0.5 + 0.5) * 255).cpu().permute(0, 2, 3, 1).numpy().astype(np.uint8)
+        ind, boxes, lms = [], [], []
+        for img in x:
+            found = None
+            if self.face_app is not None:
+                faces = self.face_app.get(img[:, :, [2, 1, 0]])
+                if len(faces):
+                    f = faces[self._largest([fc["bbox"] for fc in faces], img.shape[0])]
+                    found = (expand_bbox(f["bbox"], 0.5, 1), np.asarray(f["kps"], dtype=np.float64))
+            if found is None and self.fr is not None:
+                locs = self.fr.face_locations(img, model="cnn", number_of_times_to_upsample=0)
+                if len(locs):
+                    xyxy = [np.array((l[-1],) + tuple(l[:-1])) for l in locs]                  # (top, right, bottom, left) -> (left, top, right, bottom)
+                    k = self._largest(xyxy, img.shape[0])
+                    lm = self.fr.face_landmarks(img, face_locations=[locs[k]], model="large")[0]
+                    pts = np.stack([np.array(lm["left_eye"]).mean(axis=0), np.array(lm["right_eye"]).mean(axis=0), np.array(lm["nose_bridge"][-1]),
+                                    np.array(lm["top_lip"][0]), np.array(lm["top_lip"][6])])
+                    found = (expand_bbox(xyxy[k], 1.1, 1), pts)
+            ind.append(found is not None)
+            boxes.append(found[0] if found else [self.fill] * 4)
+            lms.append(found[1] if found else np.full((5, 2), float(self.fill)))
+        res = (torch.tensor(ind, dtype=torch.bool), torch.tensor(boxes, dtype=torch.int32), torch.tensor(np.stack(lms), dtype=torch.float32))
+        self._seen = (self._seen + [(images, res)])[-3:]
+        return res
+
+    def __call__(self, images):
+        ind, boxes, _ = self.detect(images)
+        return ind, boxes
+
+    def landmarks(self, images):
+        return self.detect(images)[2]
+
+
 def umeyama_similarity(src, dst):
     """Least-squares similarity transform (Umeyama 1991) with scale, mapping ``src`` -> ``dst`` points [n,2]; what
     ``skimage.transform.SimilarityTransform().estimate(src, dst)`` stores in ``.params`` (:305-306).  Returns the 3x3 matrix."""

@@ -124,7 +124,13 @@ def main(argv=None, experiment=None, cfgs=None, log=None):
     if not args.synthetic:
         from .pretrained import load_pretrained
         state_dicts = load_pretrained(args, cfgs)
-    trainer, models = build_trainer(args, device, cfgs, seed=args.seed, rank=rank, world_size=world, experiment=experiment,
+    face_provider = None
+    if getattr(args, "face_provider", "synthetic") == "detector":       # the reference's insightface + face_recognition side-car (:936-945, :1192-1353)
+        from .fairness import DetectorFaceProvider
+        face_provider = DetectorFaceProvider.from_installed()
+    elif getattr(args, "face_provider", "synthetic") != "synthetic":
+        raise ValueError(f"--face_provider {args.face_provider}: 'synthetic' or 'detector'")
+    trainer, models = build_trainer(args, device, cfgs, seed=args.seed, rank=rank, world_size=world, experiment=experiment, face_provider=face_provider,
                                     state_dicts=state_dicts, regularisers=(args.weight_loss_img != 0 or args.weight_loss_face != 0),
                                     lora_up_std=getattr(args, "lora_up_std", 0.0))
     tok_dir = os.path.join(args.pretrained_model_name_or_path, "tokenizer")

@@ -364,7 +364,7 @@ def fairness_step(models, tokens, noises, S, cfg, world=None, attrs=None, target
     latents trace of R1, and N_backward; LoRA grads are left in the params' ``.grad``.
     """
     te, unet, vae, clf, sch = (models[k] for k in ("text_encoder", "unet", "vae", "classifier", "scheduler"))
-    faces = SyntheticFaceProvider(cfg.get("size_face", 224))
+    faces = cfg.get("face_provider") or SyntheticFaceProvider(cfg.get("size_face", 224))    # any get_face stand-in with the same returns
     gs, B = cfg.get("guidance_scale", 7.5), noises.shape[0]
     slice_fn = cfg.get("slice_fn")
     out = {}

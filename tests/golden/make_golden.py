@@ -211,5 +211,72 @@ def sfnet_golden():
     print("wrote sfnet20 golden:", tuple(y.shape), float(y.abs().max()))
 
 
+def face_provider_golden():
+    """The detector seam of the training step, ``get_face`` (:1192-1215) = ``get_face_app`` (insightface, :1306-1353) with ``get_face_FR``
+    (face_recognition's CNN detector, :1232-1293) for the images the first one misses, run on SCRIPTED detector outputs: the two detector
+    packages are test doubles that replay the detections listed in the fixture (neither package nor its weights exist here); everything
+    between detector output and the tensors the step consumes -- largest-face choice, box order, expand_bbox coefficients, the five
+    landmarks taken from the 68-point set, fill values -- is the reference's own code.  ``image_pipeline`` / ``crop_face`` outputs are not
+    part of this fixture (pinned elsewhere: test_face_alignment_*, crop goldens)."""
+    import types
+    ns = lift(["expand_bbox", "get_largest_face_app", "get_largest_face_FR", "get_face_app", "get_face_FR", "get_face"])
+    rng = np.random.default_rng(2024)
+    H = W = 96
+
+    def rand_box(big=False):
+        x0, y0 = rng.uniform(-6, 50, 2)
+        w, h = rng.uniform(20, 60 if big else 34, 2)
+        return [float(x0), float(y0), float(x0 + w), float(y0 + h)]
+
+    def rand_pts(n):
+        return [[float(a), float(b)] for a, b in rng.uniform(10, 86, (n, 2))]
+
+    cases = []
+    for c in range(6):
+        N = 5
+        app, fr = [], []
+        for i in range(N):
+            k = [1, 0, 3, 0, 2][(i + c) % 5]            # number of insightface detections for image i
+            app.append([dict(bbox=rand_box(j == 1), kps=rand_pts(5)) for j in range(k)])
+        for i in range(N):
+            k = [2, 0, 1, 3, 0][(i + 2 * c) % 5]        # face_recognition detections (asked only where insightface found none)
+            locs = []
+            for j in range(k):
+                b = rand_box(j == 0)
+                locs.append([int(b[1]), int(b[2]), int(b[3]), int(b[0])])            # (top, right, bottom, left)
+            lms = [dict(left_eye=rand_pts(6), right_eye=rand_pts(6), nose_bridge=rand_pts(4), top_lip=rand_pts(12)) for _ in locs]
+            fr.append(dict(locations=locs, landmarks=lms))
+        cases.append(dict(H=H, W=W, app=app, fr=fr))
+
+    out = []
+    for case in cases:
+        images = torch.zeros(len(case["app"]), 3, case["H"], case["W"])
+        app_q, fr_q = list(case["app"]), [f for f, a in zip(case["fr"], case["app"]) if len(a) == 0]
+        state = dict(fr_cur=None)
+
+        def app_get(img_bgr):
+            return [dict(bbox=np.array(d["bbox"]), kps=np.array(d["kps"])) for d in app_q.pop(0)]
+
+        def fr_locations(img, model, number_of_times_to_upsample):
+            assert model == "cnn" and number_of_times_to_upsample == 0
+            state["fr_cur"] = fr_q.pop(0)
+            return [tuple(l) for l in state["fr_cur"]["locations"]]
+
+        def fr_landmarks(img, face_locations, model):
+            assert model == "large" and len(face_locations) == 1
+            i = [tuple(l) for l in state["fr_cur"]["locations"]].index(tuple(face_locations[0]))
+            return [state["fr_cur"]["landmarks"][i]]
+        ns["face_app"] = types.SimpleNamespace(get=app_get)
+        ns["face_recognition"] = types.SimpleNamespace(face_locations=fr_locations, face_landmarks=fr_landmarks)
+        ns["args"] = types.SimpleNamespace(size_face=8, size_aligned_face=6)
+        ns["image_pipeline"] = lambda img, lm: torch.zeros(3, 6, 6)               # chips are not part of this fixture (torchvision / kornia /
+        ns["crop_face"] = lambda img, bbox, target_size, fill_value: torch.zeros(3, 8, 8)   # skimage are absent here)
+        ind, boxes, _, lms, _ = ns["get_face"](images, fill_value=-1)
+        out.append(dict(case, indicators=ind.tolist(), boxes=[[int(v) for v in b] for b in boxes.tolist()], landmarks=lms.tolist()))
+    json.dump(out, open(os.path.join(HERE, "reference_face_provider.json"), "w"))
+    print("wrote face-provider golden:", len(out), "cases;", sum(sum(c["indicators"]) for c in out), "faces of", sum(len(c["indicators"]) for c in out))
+
+
 if __name__ == "__main__":
     main()
+    face_provider_golden()

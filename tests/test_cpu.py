@@ -386,6 +386,48 @@ def _fake_trainer(seed):
     return t
 
 
+def test_detector_face_provider_matches_reference_get_face_on_scripted_detections():
+    """The adaptor behind the provider seam vs the reference's own get_face / get_face_app / get_face_FR (:1192-1353) replaying the same
+    scripted detector outputs (tests/golden/reference_face_provider.json, made by make_golden.face_provider_golden): which face wins, box
+    order and expansion, the five landmarks, fill values, and that face_recognition is consulted only where insightface found nothing."""
+    import types
+    from finetune_fair_diffusion_amd.fairness import DetectorFaceProvider
+    gold = json.load(open(os.path.join(HERE, "golden", "reference_face_provider.json")))
+    assert len(gold) == 6
+    n_fr_calls = 0
+    for case in gold:
+        N = len(case["app"])
+        images = torch.zeros(N, 3, case["H"], case["W"])
+        app_q = list(case["app"])
+        fr_q = [f for f, a in zip(case["fr"], case["app"]) if len(a) == 0]
+        state = {}
+
+        def app_get(img_bgr):
+            assert img_bgr.dtype == np.uint8 and img_bgr.shape == (case["H"], case["W"], 3)
+            return [dict(bbox=np.array(d["bbox"]), kps=np.array(d["kps"])) for d in app_q.pop(0)]
+
+        def fr_locations(img, model, number_of_times_to_upsample):
+            assert model == "cnn" and number_of_times_to_upsample == 0
+            state["cur"] = fr_q.pop(0)
+            return [tuple(l) for l in state["cur"]["locations"]]
+
+        def fr_landmarks(img, face_locations, model):
+            assert model == "large" and len(face_locations) == 1
+            return [state["cur"]["landmarks"][[tuple(l) for l in state["cur"]["locations"]].index(tuple(face_locations[0]))]]
+        prov = DetectorFaceProvider(types.SimpleNamespace(get=app_get), types.SimpleNamespace(face_locations=fr_locations, face_landmarks=fr_landmarks))
+        ind, boxes = prov(images)
+        lms = prov.landmarks(images)              # same images object: detectors are not run a second time
+        assert not app_q and not fr_q
+        n_fr_calls += sum(len(a) == 0 for a in case["app"])
+        assert ind.tolist() == case["indicators"] and boxes.dtype == torch.int32 and boxes.tolist() == case["boxes"]
+        assert torch.allclose(lms, torch.tensor(case["landmarks"]), atol=1e-4)
+    assert n_fr_calls > 0 and any(not all(c["indicators"]) for c in gold)
+    with pytest.raises(ValueError):
+        DetectorFaceProvider()
+    with pytest.raises(ImportError):
+        DetectorFaceProvider.from_installed()     # the detector packages are not part of this image
+
+
 def test_prefix_embedding_checkpoint_files_are_fair_embeddings_state_dicts(tmp_path):
     """exp-2: the trained table [n+1, D] (row 0 zero, rows 1..n initialised from existing vocabulary rows, exp-2 1-main-debias.py:86-146)
     and its checkpoint files in the FairEmbeddings state-dict format of exp-2's 2-export-checkpoint.py:566-575."""

@@ -1057,3 +1057,85 @@ def test_exp2_train_loop_export_and_consumer(tmp_path, dev):
     assert torch.equal(fresh.prefix.weight.cpu(), sd2["token_embedding.weight"])
     ema2 = torch.load(cdir / "checkpoint_tmp-2" / "prefix_embedding_EMA.pth")["token_embedding.weight"]
     assert torch.equal(fresh.prefix.vectors(ema=True).cpu(), ema2[1:]) and float(fresh.prefix.bank.exp_avg.abs().sum()) > 0
+
+
+def test_full_step_with_detector_provider_missing_face_and_fallback(dev):
+    """The real detector seam (fairness.DetectorFaceProvider = get_face :1192-1353) inside a training step, on scripted detections that
+    differ per image: image 0 an insightface hit, image 1 no face for either detector (-1 rows, -1 loss sentinel, no gradient), image 2
+    found only by the face_recognition fallback (box order + the wider expand_bbox(1.1)), image 3 two insightface faces (largest wins).
+    The oracle runs the same step with a stand-in that applies the oracle's own expand_bbox / crop_face to the same raw detections."""
+    import types
+    from oracle import fair_step as fs
+    from finetune_fair_diffusion_amd.fairness import DetectorFaceProvider
+    from finetune_fair_diffusion_amd.step import FairnessTrainer
+    om = U.oracle_models(train_unet=True, train_te=False, lora_up_std=0.05)
+    pm = U.product_models(om["sds"], dev, train_unet=True, train_te=False)
+    args = U.make_args(train_unet=True, train_text_encoder=False)
+    tokens, B, S = U.tiny_tokens(), 4, 3
+    noises = torch.randn(B, 4, 32, 32, generator=torch.Generator().manual_seed(11))
+    Himg = 32 * 8
+    app = [[dict(bbox=[60.0, 40.0, 170.0, 150.0], kps=[[0.0, 0.0]] * 5)], [], [],
+           [dict(bbox=[10.0, 10.0, 60.0, 70.0], kps=[[0.0, 0.0]] * 5), dict(bbox=[90.0, 70.0, 230.0, 200.0], kps=[[0.0, 0.0]] * 5)]]
+    fr = [None, [], [(50, 200, 190, 80)], None]                 # (top, right, bottom, left)
+    lm68 = dict(left_eye=[[1.0, 1.0]] * 6, right_eye=[[2.0, 2.0]] * 6, nose_bridge=[[3.0, 3.0]] * 4, top_lip=[[4.0, 4.0]] * 12)
+    pos = dict(app=0, fr=None)
+
+    def app_get(img):
+        i = pos["app"] % B
+        pos["app"] += 1
+        pos["fr"] = i
+        return [dict(bbox=np.array(d["bbox"]), kps=np.array(d["kps"])) for d in app[i]]
+    frm = types.SimpleNamespace(face_locations=lambda img, model, number_of_times_to_upsample: fr[pos["fr"]],
+                                face_landmarks=lambda img, face_locations, model: [lm68])
+    prov = DetectorFaceProvider(types.SimpleNamespace(get=app_get), frm)
+    raw = [([60.0, 40.0, 170.0, 150.0], 0.5), None, ([80, 50, 200, 190], 1.1), ([90.0, 70.0, 230.0, 200.0], 0.5)]
+
+    class OracleFaces:
+        """detections belong to batch positions: the two no-grad passes see the whole batch, the gradient pass sees it in micro-batches
+        of train_GPU_batch_size consecutive images (:1889-1893)"""
+        calls = off = 0
+
+        def __call__(self, images, fill_value=-1):
+            N = images.shape[0]
+            lo = 0
+            if self.calls >= 2:
+                lo, self.off = self.off, self.off + N
+            self.calls += 1
+            rw = raw[lo:lo + N]
+            ind = torch.tensor([r is not None for r in rw])
+            boxes = torch.tensor([fs.expand_bbox(np.array(r[0]), r[1], 1) if r is not None else [fill_value] * 4 for r in rw], dtype=torch.long)
+            chips = torch.stack([fs.crop_face(images[i], boxes[i].tolist(), [64, 64], fill_value) if ind[i] else torch.full((3, 64, 64), float(fill_value))
+                                 for i in range(N)])
+            return ind, boxes, chips
+    models_o = dict(text_encoder=om["text_encoder"], unet=om["unet"], vae=om["vae"], classifier=om["classifier"], scheduler=om["scheduler"],
+                    eval_text_encoder=om["text_encoder"], eval_unet=om["eval_unet"])
+    for p in om["lora_params"]:
+        p.grad = None
+    ref = fs.fairness_step(models_o, tokens, noises, S, dict(train_GPU_batch_size=3, val_GPU_batch_size=8, uncertainty_threshold=0.2, factor2=0.2,
+                                                             size_face=64, face_provider=OracleFaces()))
+    tr = FairnessTrainer(args, pm["text_encoder"], pm["unet"], pm["vae"], pm["classifier"], pm["scheduler"], eval_unet=pm["eval_unet"], device=dev,
+                         face_provider=prov)
+    grads, apply = {}, tr.sync_and_update
+
+    def spy(N_backward, apply_=True):
+        grads[0] = tr.banks[0].grad.clone()
+        return apply(N_backward)
+    tr.sync_and_update = spy
+    out = tr.train_step(tokens, noises, S)
+    assert out["images"].shape[-1] == Himg
+    check("detector step: R1 images", out["images"], ref["images"], 3e-2)
+    assert out["probs"][1].tolist() == [-1.0, -1.0] and ref["probs"][1].tolist() == [-1.0, -1.0]
+    check("detector step: probs", out["probs"], ref["probs"], 2e-2)
+    assert out["targets"].tolist() == ref["targets"].tolist() and out["targets"][1] == -1
+    # per-image CE = -log p[target]: a probability error of 1e-3 on a confidently wrong image (p ~ 0.03) is a 3e-2 loss error, so the
+    # band is relative to each loss value
+    print("loss_fair product", out["loss_fair"].tolist(), "oracle", ref["loss_fair"].tolist())
+    assert torch.allclose(out["loss_fair"].float(), ref["loss_fair"].float(), rtol=2e-2, atol=5e-3)
+    assert float(out["loss_fair"][1]) == -1.0
+    names = list(om["unet_lora_layers"].state_dict().keys())
+    refg = torch.cat([p.grad.flatten() for p in om["unet_lora_layers"].parameters()])
+    got = torch.cat([tr.banks[0].view(n, grads[0]).flatten() for n in names])
+    cos = F.cosine_similarity(got.cpu().double(), refg.double(), dim=0)
+    print("cosine(unet grads, detector provider) =", float(cos))
+    check("detector step: unet LoRA grad", got, refg, 3e-1)
+    assert cos > 0.97
