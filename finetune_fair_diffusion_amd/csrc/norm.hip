@@ -4,6 +4,14 @@
 
 #define GN_MAX_CHUNKS 64
 
+// A/B switches exist only in the bench-hooks build (make BENCH_HOOKS=1), as in gemm_device.h
+#ifdef FD_BENCH_HOOKS
+#include <cstdlib>
+static inline const char* bench_env(const char* name) { return getenv(name); }
+#else
+static inline const char* bench_env(const char*) { return nullptr; }
+#endif
+
 struct GNArgs {
     const f16* x1; const f16* x2; int C1, C2;
     const f16* dy;
@@ -207,6 +215,213 @@ static int gn_check(int C1, int C2, int groups) {
     return 0;
 }
 
+// ------------------------------------------------------------------ single-launch GroupNorm for the small feature maps
+// At the 32^2 / 16^2 / 8^2 levels a GroupNorm is 3-40 MB of traffic: the two-launch form above (reduce, then apply with the statistics
+// finalised in its prologue) spends most of its 22-45 us on launch and dependency latency, not on HBM.  Here one workgroup owns
+// (sample b, channel block): the smallest run of whole groups that is a multiple of 8 channels (40 channels = 1 group at C = 1280, 2 at 640;
+// 80 at 2560; 120 = 2 groups at 1920), reads its [HW, CB] slab ONCE into registers (forward) or streams it twice through L2 (backward),
+// reduces in a fixed order (per-thread channel sums -> LDS -> one wave per group -> shuffle tree: bit-reproducible, no atomics) and writes
+// the result.  Chosen by (C, HW, groups) only -- never by the batch size -- so a sample's result does not depend on what it is batched with.
+struct GNFused { int CB, VB, rpb, nv, ngb; };
+
+static bool gn_fused_geometry(int C, int HW, int G, int maxv, GNFused& f) {
+    static const bool off = bench_env("FD_GN_NOFUSED") != nullptr;        // A/B switch of the bench-hooks build
+    const int cg = C / G;
+    if (off || cg < 8) return false;
+    int CB = cg;
+    while (CB & 7) CB += cg;
+    if (C % CB || CB / cg > 4 || CB / 8 > 16) return false;
+    f.CB = CB; f.VB = CB / 8; f.rpb = 256 / f.VB; f.nv = (HW + f.rpb - 1) / f.rpb; f.ngb = CB / cg;
+    return f.nv <= maxv;
+}
+
+// the (at most two) groups of this block that the 8 channels starting at block-local channel ``lc`` belong to
+__device__ __forceinline__ void gn_vec_groups(int lc, int cg, int& ga, int& gb) { ga = lc / cg; gb = (lc + 7) / cg; }
+
+// sums the per-thread (A0, A1, B0, B1) group partials left in ``red`` into (sum0, sum1) of block-local group ``w`` -- called by wave w
+__device__ __forceinline__ void gn_group_total(const float* red, int w, int lane, int VB, int nact, int cg, float& t0, float& t1) {
+    t0 = t1 = 0.f;
+    for (int t = lane; t < nact; t += 64) {
+        int ga, gb;
+        gn_vec_groups((t % VB) * 8, cg, ga, gb);
+        if (ga == w) { t0 += red[t * 4]; t1 += red[t * 4 + 1]; }
+        if (gb == w && gb != ga) { t0 += red[t * 4 + 2]; t1 += red[t * 4 + 3]; }
+    }
+    t0 = wave_sum(t0);
+    t1 = wave_sum(t1);
+}
+
+template <int MAXV>
+__global__ __launch_bounds__(256) void gn_fused_fwd_kernel(GNArgs a, f16* y, float* stats_out, GNFused f) {
+    __shared__ float red[256 * 4];
+    __shared__ float st[8];
+    const int C = a.C1 + a.C2, cg = C / a.G;
+    const int b = blockIdx.y, cb0 = blockIdx.x * f.CB;
+    const int nact = f.VB * f.rpb;
+    const bool act = threadIdx.x < nact;
+    const int v = threadIdx.x % f.VB, rsub = threadIdx.x / f.VB;
+    const int lc = v * 8, c0 = cb0 + lc;
+    f16x8 xv[MAXV];
+    float s0[8], s1[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s0[j] = s1[j] = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int r = rsub + i * f.rpb;
+        if (act && i < f.nv && r < a.HW) {
+            xv[i] = gn_load(a, (int64_t)b * a.HW + r, c0);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float x = (float)xv[i][j];
+                s0[j] += x;
+                s1[j] += x * x;
+            }
+        }
+    }
+    int ga, gb;
+    gn_vec_groups(lc, cg, ga, gb);
+    float p[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const bool first = (lc + j) / cg == ga;
+        p[first ? 0 : 2] += s0[j];
+        p[first ? 1 : 3] += s1[j];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) red[threadIdx.x * 4 + k] = p[k];
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (wave < f.ngb) {
+        float t0, t1;
+        gn_group_total(red, wave, lane, f.VB, nact, cg, t0, t1);
+        if (lane == 0) {
+            const float n = (float)a.HW * (float)cg;
+            const float mu = t0 / n, rs = rsqrtf(fmaxf(t1 / n - mu * mu, 0.f) + a.eps);
+            st[wave * 2] = mu;
+            st[wave * 2 + 1] = rs;
+            if (stats_out) {
+                const int g = cb0 / cg + wave;
+                stats_out[(b * a.G + g) * 2] = mu;
+                stats_out[(b * a.G + g) * 2 + 1] = rs;
+            }
+        }
+    }
+    __syncthreads();
+    if (!act) return;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int g = (lc + j) / cg;
+        sc[j] = st[g * 2 + 1] * a.gamma[c0 + j];
+        sh[j] = a.beta[c0 + j] - st[g * 2] * sc[j];
+    }
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int r = rsub + i * f.rpb;
+        if (i < f.nv && r < a.HW) {
+            f16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float z = (float)xv[i][j] * sc[j] + sh[j];
+                if (a.silu) z = silu_f(z);
+                o[j] = (f16)z;
+            }
+            *(f16x8*)(y + ((int64_t)b * a.HW + r) * C + c0) = o;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void gn_fused_bwd_kernel(GNArgs a, const f16* add1, const f16* add2, f16* dx1, f16* dx2, GNFused f) {
+    __shared__ float red[256 * 4];
+    __shared__ float st[8];
+    const int C = a.C1 + a.C2, cg = C / a.G;
+    const int b = blockIdx.y, cb0 = blockIdx.x * f.CB;
+    const int nact = f.VB * f.rpb;
+    const bool act = threadIdx.x < nact;
+    const int v = threadIdx.x % f.VB, rsub = threadIdx.x / f.VB;
+    const int lc = v * 8, c0 = cb0 + lc;
+    float gm[8], bt[8], mu[8], rs[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int g = (c0 + j) / cg;
+        gm[j] = a.gamma[c0 + j];
+        bt[j] = a.beta[c0 + j];
+        mu[j] = a.mean_rstd[(b * a.G + g) * 2];
+        rs[j] = a.mean_rstd[(b * a.G + g) * 2 + 1];
+    }
+    float s0[8], s1[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s0[j] = s1[j] = 0.f;
+    if (act)
+        for (int r = rsub; r < a.HW; r += f.rpb) {
+            const int64_t pix = (int64_t)b * a.HW + r;
+            const f16x8 xv = gn_load(a, pix, c0);
+            const f16x8 dv = *(const f16x8*)(a.dy + pix * C + c0);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float xh = ((float)xv[j] - mu[j]) * rs[j];
+                float dz = (float)dv[j];
+                if (a.silu) dz *= silu_grad_f(xh * gm[j] + bt[j]);
+                const float t = dz * gm[j];
+                s0[j] += t;
+                s1[j] += t * xh;
+            }
+        }
+    int ga, gb;
+    gn_vec_groups(lc, cg, ga, gb);
+    float p[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const bool first = (lc + j) / cg == ga;
+        p[first ? 0 : 2] += s0[j];
+        p[first ? 1 : 3] += s1[j];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) red[threadIdx.x * 4 + k] = p[k];
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (wave < f.ngb) {
+        float t0, t1;
+        gn_group_total(red, wave, lane, f.VB, nact, cg, t0, t1);
+        if (lane == 0) {
+            const float n = (float)a.HW * (float)cg;
+            st[wave * 2] = t0 / n;
+            st[wave * 2 + 1] = t1 / n;
+        }
+    }
+    __syncthreads();
+    if (!act) return;
+    float m1[8], m2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int g = (lc + j) / cg;
+        m1[j] = st[g * 2];
+        m2[j] = st[g * 2 + 1];
+    }
+    const bool first = c0 < a.C1;
+    const int cc = first ? c0 : c0 - a.C1;
+    const int Cs = first ? a.C1 : a.C2;
+    f16* dxp = first ? dx1 : dx2;
+    const f16* addp = first ? add1 : add2;
+    if (!dxp) return;
+    for (int r = rsub; r < a.HW; r += f.rpb) {          // second sweep over the slab the workgroup has just read: served by L2
+        const int64_t pix = (int64_t)b * a.HW + r;
+        const f16x8 xv = gn_load(a, pix, c0);
+        const f16x8 dv = *(const f16x8*)(a.dy + pix * C + c0);
+        f16x8 av = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (addp) av = *(const f16x8*)(addp + pix * Cs + cc);
+        f16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float xh = ((float)xv[j] - mu[j]) * rs[j];
+            float dz = (float)dv[j];
+            if (a.silu) dz *= silu_grad_f(xh * gm[j] + bt[j]);
+            o[j] = (f16)(rs[j] * (dz * gm[j] - m1[j] - xh * m2[j]) + (float)av[j]);
+        }
+        *(f16x8*)(dxp + pix * Cs + cc) = o;
+    }
+}
+
 // GroupNorm forward: y = act(GN(x)); writes the (mean, rstd) it used to mean_rstd [B,groups,2] for the backward.
 // scratch: B * 64 * groups * 2 floats.
 extern "C" int fd_groupnorm_fwd(const void* x1, int C1, const void* x2, int C2, int B, int HW, int groups, float eps, const float* gamma,
@@ -218,6 +433,14 @@ extern "C" int fd_groupnorm_fwd(const void* x1, int C1, const void* x2, int C2, 
     int threads;
     FD_REQUIRE(gn_geometry(C1 + C2, HW, threads, a.rows_per_chunk, a.nchunks) == 0, "fd_groupnorm: C too large");
     hipStream_t s = (hipStream_t)stream;
+    GNFused f;
+    // measured, forward (reduce + apply -> one launch): 32x32x640 31 -> 21 us, 32x32x1280 44 -> 30, 16x16x1280 26 -> 16, 16x16x2560 38 -> 16, 8x8x1280 22 -> 15
+    if (gn_fused_geometry(C1 + C2, HW, groups, 24, f)) {
+        const dim3 grid((C1 + C2) / f.CB, B);
+        if (f.nv <= 8) hipLaunchKernelGGL(gn_fused_fwd_kernel<8>, grid, dim3(256), 0, s, a, (f16*)y, mean_rstd, f);
+        else hipLaunchKernelGGL(gn_fused_fwd_kernel<24>, grid, dim3(256), 0, s, a, (f16*)y, mean_rstd, f);
+        return fd_check_launch("fd_groupnorm_fwd");
+    }
     hipLaunchKernelGGL(gn_reduce_kernel<0>, dim3(a.nchunks, B), dim3(threads), threads * 16 * sizeof(float), s, a, scratch);
     const float n = (float)HW * (float)((C1 + C2) / groups);
     hipLaunchKernelGGL(gn_apply_kernel, dim3(a.nchunks, B), dim3(threads), 0, s, a, (f16*)y, (const float*)scratch, n, mean_rstd);
@@ -234,6 +457,14 @@ extern "C" int fd_groupnorm_bwd(const void* x1, int C1, const void* x2, int C2, 
     int threads;
     FD_REQUIRE(gn_geometry(C1 + C2, HW, threads, a.rows_per_chunk, a.nchunks) == 0, "fd_groupnorm: C too large");
     hipStream_t s = (hipStream_t)stream;
+    GNFused f;
+    // 16^2 and 8^2 only: at 32^2 (21 rows per thread, two sweeps) the single launch measured slower than the two-launch form
+    // (32x32x1280: 74 vs 58 us; 16x16x1280: 22 vs 31 us, 16x16x2560: 28 vs 56 us, 8x8x1280: 13 vs 25 us)
+    if (gn_fused_geometry(C1 + C2, HW, groups, 12, f)) {
+        hipLaunchKernelGGL(gn_fused_bwd_kernel, dim3((C1 + C2) / f.CB, B), dim3(256), 0, s, a, (const f16*)add1, (const f16*)add2, (f16*)dx1,
+                           (f16*)dx2, f);
+        return fd_check_launch("fd_groupnorm_bwd");
+    }
     hipLaunchKernelGGL(gn_reduce_kernel<1>, dim3(a.nchunks, B), dim3(threads), threads * 16 * sizeof(float), s, a, scratch);
     const float n = (float)HW * (float)((C1 + C2) / groups);
     hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(a.nchunks, B), dim3(threads), 0, s, a, (const float*)scratch, n, (const f16*)add1,

@@ -187,7 +187,12 @@ def test_conv3x3_modes(ops, dev, B, H, Cin, Cout):
         check("conv stride2 dgrad", _nchw(dx, B, Ho, Wo), xx.grad, 2e-3)
 
 
-@pytest.mark.parametrize("B,HW,C1,C2,silu", [(2, 256, 320, 0, True), (3, 64, 1280, 640, True), (2, 1024, 128, 0, False), (2, 100, 640, 320, False)])
+@pytest.mark.parametrize("B,HW,C1,C2,silu", [(2, 256, 320, 0, True), (3, 64, 1280, 640, True), (2, 1024, 128, 0, False), (2, 100, 640, 320, False),
+                                             # the U-Net's own small-map shapes (single-launch kernels: 32^2 keeps 21 row vectors per thread in registers)
+                                             (2, 1024, 640, 0, True), (2, 1024, 1280, 0, True), (1, 1024, 320, 0, False), (2, 256, 1280, 1280, True),
+                                             (2, 64, 1280, 1280, True), (2, 256, 1280, 640, True),
+                                             # ... and shapes that stay on the two-launch path (64^2; 1920 channels at 32^2: 61 vectors per thread)
+                                             (1, 4096, 320, 0, True), (1, 1024, 1280, 640, True)])
 def test_groupnorm(ops, dev, B, HW, C1, C2, silu):
     G, eps = 32, 1e-5
     x1 = rnd(B * HW, C1, dev=dev, seed=1) * 2 + 0.5
@@ -209,6 +214,30 @@ def test_groupnorm(ops, dev, B, HW, C1, C2, silu):
     check("groupnorm bwd dx1", dx1, gref[:, :C1] + add1.float(), 3e-3)
     if C2:
         check("groupnorm bwd dx2", dx2, gref[:, C1:], 3e-3)
+
+
+@pytest.mark.parametrize("HW,C1,C2", [(256, 1280, 0), (1024, 640, 0), (64, 1280, 1280), (4096, 320, 0)])
+def test_groupnorm_is_batch_invariant_and_reproducible(ops, dev, HW, C1, C2):
+    """A sample's GroupNorm (forward, statistics, backward) must not depend on what it is batched with -- the CFG prefix path evaluates N
+    samples where the duplicated batch has 2N, and R3 consumes R1's recorded forward -- nor vary from run to run (fixed reduction order)."""
+    G, B = 32, 3
+    C = C1 + C2
+    x1 = rnd(B * HW, C1, dev=dev, seed=1) * 2 + 0.5
+    x2 = (rnd(B * HW, C2, dev=dev, seed=2) - 0.3) if C2 else None
+    gamma = rnd(C, dev=dev, dtype=torch.float32, seed=3) * 0.2 + 1
+    beta = rnd(C, dev=dev, dtype=torch.float32, seed=4) * 0.2
+    dy = rnd(B * HW, C, dev=dev, seed=5)
+    y, st = ops.groupnorm(x1, x2, B, HW, G, 1e-5, gamma, beta, True)
+    dx1, dx2 = ops.groupnorm_bwd(x1, x2, dy, B, HW, G, st, gamma, beta, True)
+    y2, st2 = ops.groupnorm(x1, x2, B, HW, G, 1e-5, gamma, beta, True)
+    assert torch.equal(y, y2) and torch.equal(st, st2)
+    assert torch.equal(dx1, ops.groupnorm_bwd(x1, x2, dy, B, HW, G, st, gamma, beta, True)[0])
+    for b in range(B):
+        sl = slice(b * HW, (b + 1) * HW)
+        yb, stb = ops.groupnorm(x1[sl].contiguous(), x2[sl].contiguous() if C2 else None, 1, HW, G, 1e-5, gamma, beta, True)
+        assert torch.equal(yb, y[sl]) and torch.equal(stb[0], st[b])
+        d1, d2 = ops.groupnorm_bwd(x1[sl].contiguous(), x2[sl].contiguous() if C2 else None, dy[sl].contiguous(), 1, HW, G, stb, gamma, beta, True)
+        assert torch.equal(d1, dx1[sl]) and (not C2 or torch.equal(d2, dx2[sl]))
 
 
 @pytest.mark.parametrize("M,C", [(1000, 320), (333, 1280), (64, 768)])
