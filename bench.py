@@ -128,6 +128,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     phases_default = tr.phase_ms()
+    host_phases = tr.host_phase_ms()       # host enqueue time per phase of the last timed step (launch-bound check)
     tr.timers = None
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -164,6 +165,9 @@ def main():
     shared = bool(tr.share_r1_r3 and args.val_GPU_batch_size >= a.batch)
     f_exec = (6 if shared else 8) * a.S * F_UNET + (3 if shared else 4) * F_VAE
     line["config"]["phase_ms"] = {k: round(v, 1) for k, v in phases_default.items()}   # last timed step, shipped schedule (streams overlap phases)
+    # host time between the same marks: launches, host syncs, and time BLOCKED on a full stream queue (the host runs ~2600 C-ABI calls ahead of
+    # the device, scratch/prof_queue_depth.py; pure enqueue cost is ~105 ms per 20-step rollout, scratch/prof_host_rollout.py with FD_TINY=1)
+    line["config"]["host_ms_between_phase_marks"] = {k: round(v, 1) for k, v in host_phases.items()}
     line["config"].update(r3_consumes_r1_forward=shared, r1_r2_rollouts_on_two_streams=bool(tr.concurrent_r2), backward_timesteps_on_two_streams=bool(tr.concurrent_bwd), executed_flop_per_image=f_exec,
                           step_mfma_frac_executed=value / world * f_exec / MFMA_PEAK_F16)
 

@@ -157,7 +157,7 @@ class FairnessTrainer:
         self.share_r1_r3 = os.environ.get("FD_NO_SHARE") is None
         # per-phase wall-clock of the last step (HIP events on the launch stream; read with phase_ms()); None = off
         self.timers = None
-        self._marks = []
+        self._marks, self._host_marks = [], []
         # exp-3/4/5: run the Monte-Carlo OT solves on a worker thread underneath R2 (False = inline, like the reference)
         self.overlap_targets = os.environ.get("FD_NO_OT_OVERLAP") is None
         # R1 and R2 rollouts enqueued in lockstep on two HIP streams (FD_NO_CONCURRENT_R2=1: one after the other, as the reference does)
@@ -177,11 +177,20 @@ class FairnessTrainer:
         ev = torch.cuda.Event(enable_timing=True)
         ev.record()
         self._marks.append((name, ev))
+        self._host_marks.append((name, time.perf_counter()))
         if _ROCTX:
             if len(self._marks) > 1:
                 torch.cuda.nvtx.range_pop()
             if name != "end":
                 torch.cuda.nvtx.range_push(name)
+
+    def host_phase_ms(self):
+        """{phase: ms} the HOST spent between the phase marks of the last step: launch-enqueue time (plus whatever host syncs the phase
+        contains).  A phase whose host time equals its device time is launch-bound."""
+        out = {}
+        for (n0, t0), (_, t1) in zip(self._host_marks[:-1], self._host_marks[1:]):
+            out[n0] = out.get(n0, 0.0) + (t1 - t0) * 1e3
+        return out
 
     def phase_ms(self):
         """{phase: ms} of the last train_step (time from each mark to the next one), after a device sync."""
@@ -407,7 +416,7 @@ class FairnessTrainer:
         for bank in self.banks:
             bank.grad.zero_()
         vb = args.val_GPU_batch_size
-        self._marks = []
+        self._marks, self._host_marks = [], []
         self._mark("R1_rollout")
         # ---- R1: images from the model being finetuned (:1786-1795)
         train_te = getattr(args, "train_text_encoder", False) and self.te.lora_bank is not None

@@ -12,7 +12,7 @@ int fd_check_launch(const char*) { return hipGetLastError() == hipSuccess ? 0 : 
 enum { NO_EXP = 1, NO_PV = 2, NO_QK = 4, NO_GLOAD = 8, NO_STAGE = 16, NO_VREAD = 32, NO_MAX = 64 };
 
 template <int D, int MODE>
-__global__ __launch_bounds__(256) void attn_fwd_abl(const f16* __restrict__ Q, const f16* __restrict__ K, const f16* __restrict__ Vt,
+__global__ __launch_bounds__(256, 3) void attn_fwd_abl(const f16* __restrict__ Q, const f16* __restrict__ K, const f16* __restrict__ Vt,
                                                     f16* __restrict__ O, float* __restrict__ LSE, int H, int Tq, int Tk, int Tkp,
                                                     int Tkr, int kv_div, float scale, int ldq, int ldk) {
     constexpr int DK = (D + 15) / 16 * 16, DV = (D + 31) / 32 * 32, DKP = DK + 8;
