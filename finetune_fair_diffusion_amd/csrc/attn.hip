@@ -22,6 +22,27 @@ __device__ __forceinline__ f32x16 zero16() {
     for (int i = 0; i < 16; ++i) z[i] = 0.f;
     return z;
 }
+// Workgroup -> (batch, head, 128-row block).  Launches are 1-D; consecutive workgroup ids are dealt round-robin to the 8 XCDs, each with its
+// own 4 MB L2.  All row blocks of one (batch, head) re-read that head's K / V (0.66 MB at T = 4096, d = 40), so they are given ids that are
+// congruent mod 8: an XCD then holds the K / V of the few heads it is working on instead of every XCD holding every head's.
+__device__ __forceinline__ void attn_block_coords(int nblk, int H, int B, int& b, int& h, int& blk) {
+    const int L = blockIdx.x, NH = H * B;
+#ifndef FD_ATTN_NO_XCD_MAP
+    if ((NH & 7) == 0) {
+        const int xcd = L & 7, m = L >> 3;
+        blk = m % nblk;
+        const int hh = (m / nblk) * 8 + xcd;
+        b = hh / H;
+        h = hh - b * H;
+        return;
+    }
+#endif
+    blk = L % nblk;
+    const int hh = L / nblk;
+    b = hh / H;
+    h = hh - b * H;
+}
+
 // row index inside a 32x32 C/D tile for accumulator register r of lane-half g
 __device__ __forceinline__ int crow(int r, int g) { return (r & 3) + 8 * (r >> 2) + 4 * g; }
 
@@ -148,7 +169,9 @@ __global__ __launch_bounds__(256, fwd_waves(D)) void attn_fwd_kernel(const f16* 
     f16* Ks = smem;               // [64][DKP]
     f16* Vts = smem + 64 * DKP;   // [DV][TS]
 
-    const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 128;
+    int b, h, qblk;
+    attn_block_coords((Tq + 127) / 128, H, gridDim.x / (((Tq + 127) / 128) * H), b, h, qblk);
+    const int q0 = qblk * 128;
     const int bk = b / kv_div;
     const int C = H * D;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -304,7 +327,9 @@ __global__ __launch_bounds__(256, dq_waves(D)) void attn_bwd_dq_kernel(const f16
     f16* Vs = Ks + 64 * DKP;       // [64][DKP]
     f16* Kts = Vs + 64 * DKP;      // [DV][TS]
 
-    const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 128;
+    int b, h, qblk;
+    attn_block_coords((Tq + 127) / 128, H, gridDim.x / (((Tq + 127) / 128) * H), b, h, qblk);
+    const int q0 = qblk * 128;
     const int bk = b / kv_div;
     const int C = H * D;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -438,7 +463,9 @@ __global__ __launch_bounds__(256, dkdv_waves(D)) void attn_bwd_dkdv_kernel(const
     float* lse_s = (float*)(Gts + DV * TS);  // [64]
     float* dd_s = lse_s + 64;                // [64]
 
-    const int b = blockIdx.z, h = blockIdx.y, k0 = blockIdx.x * 128;
+    int b, h, kblk;
+    attn_block_coords((Tk + 127) / 128, H, gridDim.x / (((Tk + 127) / 128) * H), b, h, kblk);
+    const int k0 = kblk * 128;
     const int bk = b / kv_div;
     const int C = H * D;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -562,6 +589,7 @@ __global__ __launch_bounds__(256, dkdv_waves(D)) void attn_bwd_dkdv_kernel(const
 }
 
 // ================================================================================== host side
+
 template <int D> static constexpr size_t fwd_lds() { return (size_t)(64 * (((D + 15) / 16 * 16) + 8) + ((D + 31) / 32 * 32) * TS) * 2; }
 template <int D> static constexpr size_t dq_lds() { return (size_t)(2 * 64 * (((D + 15) / 16 * 16) + 8) + ((D + 31) / 32 * 32) * TS) * 2; }
 template <int D> static constexpr size_t dkdv_lds() {
@@ -596,7 +624,7 @@ extern "C" int fd_attn_fwd(const void* q, const void* k, const void* vt, void* o
     if (ldk <= 0) ldk = H * d;
     FD_REQUIRE((ldq & 7) == 0 && (ldk & 7) == 0, "fd_attn_fwd: row strides must be multiples of 8");
     FD_REQUIRE(B > 0 && H > 0 && Tq > 0 && Tk > 0 && Tkp >= Tk && (Tkp & 7) == 0 && Tkr >= Tk && kv_div >= 1, "fd_attn_fwd: bad shape");
-    dim3 grid((Tq + 127) / 128, H, B);
+    dim3 grid(((Tq + 127) / 128) * H * B);
 #define CALL(DD)                                                                                                                      \
     ALLOW_LDS(attn_fwd_kernel<DD>, fwd_lds<DD>());                                                                                    \
     hipLaunchKernelGGL(attn_fwd_kernel<DD>, grid, dim3(256), fwd_lds<DD>(), (hipStream_t)stream, (const f16*)q, (const f16*)k,        \
@@ -623,7 +651,7 @@ extern "C" int fd_attn_bwd_dq(const void* q, const void* k, const void* v, const
     if (lddq <= 0) lddq = H * d;
     FD_REQUIRE((ldq & 7) == 0 && (ldkv & 7) == 0 && (lddq & 3) == 0, "fd_attn_bwd_dq: row strides");
     FD_REQUIRE(B > 0 && H > 0 && Tq > 0 && Tk > 0 && Tkp >= Tk && (Tkp & 7) == 0 && Tkr >= Tk && kv_div >= 1, "fd_attn_bwd_dq: bad shape");
-    dim3 grid((Tq + 127) / 128, H, B);
+    dim3 grid(((Tq + 127) / 128) * H * B);
 #define CALL(DD)                                                                                                                      \
     ALLOW_LDS(attn_bwd_dq_kernel<DD>, dq_lds<DD>());                                                                                  \
     hipLaunchKernelGGL(attn_bwd_dq_kernel<DD>, grid, dim3(256), dq_lds<DD>(), (hipStream_t)stream, (const f16*)q, (const f16*)k,      \
@@ -641,7 +669,7 @@ extern "C" int fd_attn_bwd_dkdv(const void* q, const void* qt, const void* k, co
     if (lddkv <= 0) lddkv = H * d;
     FD_REQUIRE((ldq & 7) == 0 && (ldkv & 7) == 0 && (lddkv & 3) == 0, "fd_attn_bwd_dkdv: row strides");
     FD_REQUIRE(B > 0 && H > 0 && Tq > 0 && Tk > 0 && (Tq & 7) == 0 && Tkr >= Tk && kv_div >= 1, "fd_attn_bwd_dkdv: bad shape (Tq %% 8)");
-    dim3 grid((Tk + 127) / 128, H, B);
+    dim3 grid(((Tk + 127) / 128) * H * B);
 #define CALL(DD)                                                                                                                       \
     if (kv_div > 1) {                                                                                                                  \
         ALLOW_LDS((attn_bwd_dkdv_kernel<DD, true>), dkdv_lds<DD>());                                                                     \

@@ -4,11 +4,16 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <cmath>
 #include <vector>
 #include "../finetune_fair_diffusion_amd/csrc/attn.hip"
+#include "attn_fwd_glds_experiment.h"
 void fd_set_error(const char* fmt, ...) { va_list ap; va_start(ap, fmt); vfprintf(stderr, fmt, ap); va_end(ap); fputc('\n', stderr); }
 int fd_check_launch(const char*) { return hipGetLastError() == hipSuccess ? 0 : -1; }
 
+#ifndef GNW
+#define GNW 4
+#endif
 enum { NO_EXP = 1, NO_PV = 2, NO_QK = 4, NO_GLOAD = 8, NO_STAGE = 16, NO_VREAD = 32, NO_MAX = 64 };
 
 template <int D, int MODE>
@@ -20,7 +25,9 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_abl(const f16* __restrict__ Q
     extern __shared__ __attribute__((aligned(16))) f16 smem[];
     f16* Ks = smem;
     f16* Vts = smem + 64 * DKP;
-    const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 128;
+    int b, h, qblk;
+    attn_block_coords((Tq + 127) / 128, H, gridDim.x / (((Tq + 127) / 128) * H), b, h, qblk);
+    const int q0 = qblk * 128;
     const int bk = b / kv_div;
     const int C = H * D;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -161,7 +168,7 @@ static const int B = 16, H = 8, T = 4096, D = 40, C = H * D;
 
 template <int MODE>
 static void run(const char* name) {
-    dim3 grid((T + 127) / 128, H, B);
+    dim3 grid(((T + 127) / 128) * H * B);
     auto launch = [&]() {
         hipLaunchKernelGGL((attn_fwd_abl<D, MODE>), grid, dim3(256), fwd_lds<D>(), 0, q, q + C, vt, o, lse, H, T, T, T, T, 1, 0.158f, 3 * C, 3 * C);
     };
@@ -213,6 +220,37 @@ int main() {
         timeit("shipped fd_attn_bwd_dq", [&]() { fd_attn_bwd_dq(q, q + C, q + 2 * C, vt, o, lse, Dd, o, dqkv, B, H, T, T, T, T, D, 1, 0.158f, 3 * C, 3 * C, 3 * C, nullptr); });
         timeit("shipped fd_attn_bwd_dkdv", [&]() { fd_attn_bwd_dkdv(q, qt, q + C, q + 2 * C, o, dot_, lse, Dd, dqkv + C, dqkv + 2 * C, B, H, T, T, T, D, 1, 0.158f, 3 * C, 3 * C, 3 * C, nullptr); });
         timeit("shipped fd_attn_fwd (again)", [&]() { fd_attn_fwd(q, q + C, vt, o, lse, B, H, T, T, T, T, D, 1, 0.158f, 3 * C, 3 * C, nullptr); });
+    }
+    {   // register-staged kernel vs the direct-to-LDS pipeline: same inputs, compare O and LSE, time both
+        f16* o2; float* lse2;
+        hipMalloc(&o2, (size_t)B * T * C * 2); hipMalloc(&lse2, (size_t)B * H * T * 4);
+        dim3 grid(((T + 127) / 128) * H * B);
+        hipFuncSetAttribute((const void*)attn_fwd_glds_kernel<D, GNW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fwd_glds_lds<D>());
+        dim3 grid2(((T + 32 * GNW - 1) / (32 * GNW)) * H * B);
+        auto old_k = [&]() { hipLaunchKernelGGL((attn_fwd_kernel<D>), grid, dim3(256), fwd_lds<D>(), 0, q, q + C, vt, o, lse, H, T, T, T, T, 1, 0.158f, 3 * C, 3 * C); };
+        auto new_k = [&]() { hipLaunchKernelGGL((attn_fwd_glds_kernel<D, GNW>), grid2, dim3(64 * GNW), fwd_glds_lds<D>(), 0, q, q + C, vt, o2, lse2, H, T, T, T, T, 1, 0.158f, 3 * C, 3 * C); };
+        old_k(); new_k(); hipDeviceSynchronize();
+        printf("launch status: %s\n", hipGetErrorString(hipGetLastError()));
+        std::vector<f16> ho((size_t)B * T * C), ho2((size_t)B * T * C);
+        std::vector<float> hl((size_t)B * H * T), hl2((size_t)B * H * T);
+        hipMemcpy(ho.data(), o, ho.size() * 2, hipMemcpyDeviceToHost); hipMemcpy(ho2.data(), o2, ho2.size() * 2, hipMemcpyDeviceToHost);
+        hipMemcpy(hl.data(), lse, hl.size() * 4, hipMemcpyDeviceToHost); hipMemcpy(hl2.data(), lse2, hl2.size() * 4, hipMemcpyDeviceToHost);
+        double mo = 0, ml = 0, amax = 0; size_t nbad = 0;
+        for (size_t i = 0; i < ho.size(); ++i) { double a = (float)ho[i], b2 = (float)ho2[i]; if (!(b2 == b2)) ++nbad; mo = fmax(mo, fabs(a - b2)); amax = fmax(amax, fabs(a)); }
+        for (size_t i = 0; i < hl.size(); ++i) ml = fmax(ml, fabs((double)hl[i] - hl2[i]));
+        printf("glds vs staged: max|dO| = %.3e (max|O| = %.3f, NaNs %zu), max|dLSE| = %.3e\n", mo, amax, nbad, ml);
+        for (int rep = 0; rep < 2; ++rep) {
+            for (auto kn : {0, 1}) {
+                hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+                for (int i = 0; i < 3; ++i) { if (kn) new_k(); else old_k(); }
+                hipEventRecord(e0);
+                for (int i = 0; i < 20; ++i) { if (kn) new_k(); else old_k(); }
+                hipEventRecord(e1); hipEventSynchronize(e1);
+                float ms; hipEventElapsedTime(&ms, e0, e1);
+                const double us = ms * 1e3 / 20, fl = 4.0 * B * H * (double)T * T * D;
+                printf("%-44s %8.1f us  %7.1f TFLOP/s (useful)\n", kn ? "attn_fwd_glds_kernel (3-buffer direct-to-LDS)" : "attn_fwd_kernel (register-staged)", us, fl / us * 1e-6);
+            }
+        }
     }
     if (getenv("ABL") == nullptr) return 0;
     run<0>("full");
