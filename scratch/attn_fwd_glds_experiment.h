@@ -5,6 +5,8 @@
 // staged kernel attributes 27 % of its time to staging.  Ablating THIS kernel: without the in-loop loads 554 us, without the barrier 651 us:
 // the cost sits in delivering 10 KB per 64 keys per workgroup (2.7 GB per call, ~4.3 TB/s out of L2 / Infinity Cache into LDS), not in how it
 // is staged, and halving the re-reads with 256-query workgroups did not move it either (685 vs 719).  119 registers (4 waves / SIMD).
+// With a raw s_barrier instead of __syncthreads() (whose fence drains vmcnt(0), i.e. the tile that should stay in flight): 676 us (NW = 4),
+// 659 us (NW = 8) against 637 us for the register-staged kernel on the same box -- still behind.
 // 16 bytes per lane from global memory straight into LDS: lane l lands at (wave-uniform) lds_dst + 16 * l
 __device__ __forceinline__ void glds16(const f16* src, f16* lds_dst) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
@@ -101,7 +103,13 @@ __global__ __launch_bounds__(64 * NW, fwd_waves(D)) void attn_fwd_glds_kernel(co
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
 #ifndef FD_GLDS_ABL_NOBAR
-        __syncthreads();
+#ifdef FD_GLDS_SYNCTHREADS
+        __syncthreads();                                   // its fence waits vmcnt(0): drains the tile that should stay in flight
+#else
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                      // raw barrier: the counted vmcnt above is the only VM wait
+        asm volatile("" ::: "memory");
+#endif
 #endif
 #ifndef FD_GLDS_ABL_NOLOAD
         if (j + 2 < nt) issue(j + 2, (j + 2) % 3);
