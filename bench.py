@@ -52,7 +52,9 @@ def pmc_traffic(kernel, algorithmic_bytes_per_launch):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2)
+    # one step in ~10 runs 100-250 ms long on this pool (host-side, with or without the Python GC: profiles/r02_step_time_jitter.txt);
+    # four timed steps keep one such outlier from moving the line by more than ~3 %
+    ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=8, help="train_images_per_prompt_GPU")
     ap.add_argument("--S", type=int, default=20, help="denoising steps")
@@ -122,9 +124,11 @@ def main():
         one_step()
     tr.timers = True        # phase boundaries = HIP events on the launch stream (no host sync): recorded during the timed steps
     fence()
-    t0 = time.perf_counter()
+    step_t = [time.perf_counter()]
+    t0 = step_t[0]
     for _ in range(a.steps):
         out = one_step()
+        step_t.append(time.perf_counter())      # host time at the end of each step's enqueue + its own syncs (no extra sync added)
     fence()
     dt = time.perf_counter() - t0
     phases_default = tr.phase_ms()
@@ -168,6 +172,7 @@ def main():
     # host time between the same marks: launches, host syncs, and time BLOCKED on a full stream queue (the host runs ~2600 C-ABI calls ahead of
     # the device, scratch/prof_queue_depth.py; pure enqueue cost is ~105 ms per 20-step rollout, scratch/prof_host_rollout.py with FD_TINY=1)
     line["config"]["host_ms_between_phase_marks"] = {k: round(v, 1) for k, v in host_phases.items()}
+    line["config"]["host_ms_per_step"] = [round(1e3 * (b - a_), 1) for a_, b in zip(step_t[:-1], step_t[1:])]
     line["config"].update(r3_consumes_r1_forward=shared, r1_r2_rollouts_on_two_streams=bool(tr.concurrent_r2), backward_timesteps_on_two_streams=bool(tr.concurrent_bwd), executed_flop_per_image=f_exec,
                           step_mfma_frac_executed=value / world * f_exec / MFMA_PEAK_F16)
 
