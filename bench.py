@@ -176,14 +176,16 @@ def main():
     line["config"].update(r3_consumes_r1_forward=shared, r1_r2_rollouts_on_two_streams=bool(tr.concurrent_r2), backward_timesteps_on_two_streams=bool(tr.concurrent_bwd), executed_flop_per_image=f_exec,
                           step_mfma_frac_executed=value / world * f_exec / MFMA_PEAK_F16)
 
-    if rank == 0 and not a.no_roofline:
+    if not a.no_roofline:
         # roofline pass: one more identical step with per-launch HIP events on the GEMM/conv kernel family (keyed by the rocprof kernel
-        # name) and the per-phase HIP events of the trainer
-        ops.TIMER = ops.OpTimer()
-        tr.timers = True
+        # name) and the per-phase HIP events of the trainer.  EVERY rank runs the step (its collectives must be matched); rank 0 measures.
+        if rank == 0:
+            ops.TIMER = ops.OpTimer()
+            tr.timers = True
         conc, tr.concurrent_r2, concb, tr.concurrent_bwd = tr.concurrent_r2, False, tr.concurrent_bwd, False     # kernels timed in isolation on one stream
         one_step()
         tr.concurrent_r2, tr.concurrent_bwd = conc, concb
+    if rank == 0 and not a.no_roofline:
         summ = ops.TIMER.summary()
         if a.dump_shapes:
             with open(a.dump_shapes, "w") as f:
