@@ -369,6 +369,9 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_big_kernel(fd_gemm_desc p
     // (4 waves per SIMD already cover the LDS latency) do not move, and 512x128 spills 60 registers under the pinned order: they
     // keep the compiler-scheduled fragment loop
     constexpr bool PINNED = NW == 8;
+#ifndef FD_PD
+#define FD_PD 2        // depth of the streamed operand's register ring in the pinned loop (3 and 4 measured: see profiles/r02_gemm_ring_depth_ab.txt)
+#endif
 
     // split-K: blockIdx.y owns the k-tiles [kbeg, kend) and writes raw fp32 partials to the workspace
     const int nsplit = gridDim.y;
@@ -387,7 +390,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_big_kernel(fd_gemm_desc p
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 const uint32_t slot = (uint32_t)(((ks * 4 + lg) ^ fsw) * 16);
-                mma_k32<TM, TN, 2>(acc, a_base + slot, b_base + slot);
+                mma_k32<TM, TN, FD_PD>(acc, a_base + slot, b_base + slot);
             }
         } else {
             const f16* Ab = As + (buf * BM + wm * WTM) * 64 + frow;

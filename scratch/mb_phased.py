@@ -19,7 +19,7 @@ if len(sys.argv) > 1:
         b.record(); torch.cuda.synchronize()
         return a.elapsed_time(b) / n * 1e3
     g = torch.Generator(device="cuda").manual_seed(1)
-    for (B, H, Cin, Cout) in [(16, 64, 320, 320), (16, 64, 640, 320), (16, 32, 640, 640)]:
+    for (B, H, Cin, Cout) in [(16, 64, 320, 320), (16, 64, 640, 320), (16, 64, 960, 320), (8, 64, 320, 320)]:
         x = torch.randn(B * H * H, Cin, device=dev, generator=g).half(); w = (torch.randn(Cout, 9 * Cin, device=dev, generator=g) * 0.02).half(); bias = torch.randn(Cout, device=dev, generator=g)
         y, _, _ = ops.conv3x3(x, w, B, H, H, bias=bias)
         err = -1.0
