@@ -9,24 +9,46 @@ import sys
 
 
 def _preselect_working_dtype(argv):
+    """Same precedence as ``cli.parse_args`` and the reference (:625-642): the YAML overlay is applied LAST, so a ``mixed_precision`` key
+    in the ``--config`` file wins over the command-line flag.  Only the package's own entry points look at argv -- importing the package
+    from a host program (pytest, a notebook) never parses that program's arguments."""
     if "FD_DTYPE" in os.environ:
         return
     mp = None
-    for i, a in enumerate(argv):
-        if a == "--config" and i + 1 < len(argv) and os.path.exists(argv[i + 1]):
-            try:
-                import yaml
-                with open(argv[i + 1]) as f:
-                    mp = (yaml.safe_load(f) or {}).get("mixed_precision", mp)
-            except Exception:
-                pass
     for i, a in enumerate(argv):
         if a == "--mixed_precision" and i + 1 < len(argv):
             mp = argv[i + 1]
         elif a.startswith("--mixed_precision="):
             mp = a.split("=", 1)[1]
+    for i, a in enumerate(argv):
+        path = argv[i + 1] if (a == "--config" and i + 1 < len(argv)) else (a.split("=", 1)[1] if a.startswith("--config=") else None)
+        if path and os.path.exists(path):
+            try:
+                import yaml
+                with open(path) as f:
+                    mp = (yaml.safe_load(f) or {}).get("mixed_precision", mp)
+            except Exception:
+                pass
     if mp == "bf16":
         os.environ["FD_DTYPE"] = "bf16"
 
 
-_preselect_working_dtype(sys.argv)
+def _is_package_entry_point(argv):
+    """True when the process was started as ``python -m finetune_fair_diffusion_amd.train|generate ...`` (runpy leaves "-m" in argv[0] while
+    the package is being imported) or as one of those files directly."""
+    if not argv:
+        return False
+    if argv[0] == "-m":
+        try:
+            orig = sys.orig_argv
+        except AttributeError:      # Python < 3.10
+            return True
+        if "-m" in orig and orig.index("-m") + 1 < len(orig):
+            return orig[orig.index("-m") + 1].split(".")[0].replace("-", "_") == __name__.split(".")[0]
+        return False
+    base = os.path.basename(argv[0])
+    return base in ("train.py", "generate.py") and os.path.dirname(os.path.abspath(argv[0])) == os.path.dirname(os.path.abspath(__file__))
+
+
+if _is_package_entry_point(sys.argv):
+    _preselect_working_dtype(sys.argv)

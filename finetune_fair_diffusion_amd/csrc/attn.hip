@@ -663,7 +663,7 @@ extern "C" int fd_attn_bwd_dq(const void* q, const void* k, const void* v, const
 
 extern "C" int fd_attn_bwd_dkdv(const void* q, const void* qt, const void* k, const void* v, const void* d_o, const void* d_ot,
                                 const float* lse, const float* D, void* dk, void* dv, int B, int H, int Tq, int Tk, int Tkr, int d,
-                                int kv_div, float scale, int ldq, int ldkv, int lddkv, void* stream) {
+                                int kv_div, float scale, int ldq, int ldkv, int lddkv, int accumulate, void* stream) {
     if (ldq <= 0) ldq = H * d;
     if (ldkv <= 0) ldkv = H * d;
     if (lddkv <= 0) lddkv = H * d;
@@ -671,7 +671,7 @@ extern "C" int fd_attn_bwd_dkdv(const void* q, const void* qt, const void* k, co
     FD_REQUIRE(B > 0 && H > 0 && Tq > 0 && Tk > 0 && (Tq & 7) == 0 && Tkr >= Tk && kv_div >= 1, "fd_attn_bwd_dkdv: bad shape (Tq %% 8)");
     dim3 grid(((Tk + 127) / 128) * H * B);
 #define CALL(DD)                                                                                                                       \
-    if (kv_div > 1) {                                                                                                                  \
+    if (kv_div > 1 || accumulate) {                                                                                                    \
         ALLOW_LDS((attn_bwd_dkdv_kernel<DD, true>), dkdv_lds<DD>());                                                                     \
         hipLaunchKernelGGL((attn_bwd_dkdv_kernel<DD, true>), grid, dim3(256), dkdv_lds<DD>(), (hipStream_t)stream, (const f16*)q,      \
                            (const f16*)qt, (const f16*)k, (const f16*)v, (const f16*)d_o, (const f16*)d_ot, lse, D, dk, dv, H, Tq, Tk, \

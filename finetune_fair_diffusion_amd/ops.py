@@ -455,7 +455,8 @@ def attn_fwd(q, k, vt, B, H, Tq, Tk, d, kv_div=1, scale=None, need_lse=False, kv
 
 
 def attn_bwd(q, k, v, o, do, lse, B, H, Tq, Tk, d, kv_div=1, scale=None, kt=None, dk_acc=None, dv_acc=None, kv_rows=None, dqkv=None):
-    """Returns (dq, dk, dv).  With kv_div>1 (shared K/V) dk/dv are accumulated into the fp32 buffers dk_acc/dv_acc.
+    """Returns (dq, dk, dv).  With ``dk_acc`` / ``dv_acc`` (fp32 [Bk*Tk, C]; mandatory when kv_div > 1, i.e. shared K/V) dk/dv are ADDED
+    into those buffers with fp32 atomics -- safe for launches that run concurrently on different streams.
     q, k, v are 2-D and may be column slices of a wider buffer; with ``dqkv`` [M, 3*H*d] (self-attention, kv_div == 1) the three
     gradients are written as its column slices (returned as views), so that the projections' input gradient is ONE GEMM over K = 3*H*d."""
     scale = scale if scale is not None else d ** -0.5
@@ -474,10 +475,11 @@ def attn_bwd(q, k, v, o, do, lse, B, H, Tq, Tk, d, kv_div=1, scale=None, kt=None
     else:
         dq = torch.empty((q.shape[0], C), dtype=F16, device=q.device)
         lddkv = C
-        if kv_div > 1:
+        if dk_acc is not None:      # shared K/V (kv_div > 1) or a cross-step accumulator: fp32 buffers updated with atomics
             dk, dv = dk_acc, dv_acc
-            assert dk.dtype == F32 and dv.dtype == F32
+            assert dk.dtype == F32 and dv.dtype == F32 and dk.shape == (k.shape[0], C) and Tkr == Tk
         else:
+            assert kv_div == 1, "shared K/V (kv_div > 1) needs the fp32 accumulators dk_acc / dv_acc"
             mk = torch.empty if Tkr == Tk else torch.zeros
             dk, dv = mk((k.shape[0], C), dtype=F16, device=q.device), mk((k.shape[0], C), dtype=F16, device=q.device)
     _call("fd_attn_bwd_dq", _p(q), _p(k), _p(v), _p(kt), _p(_chk(do)), _p(lse), _p(Dd), _p(_chk(o)), _p(dq), B, H, Tq, Tk, Tkp, Tkr, d,
@@ -485,7 +487,7 @@ def attn_bwd(q, k, v, o, do, lse, B, H, Tq, Tk, d, kv_div=1, scale=None, kt=None
     qt = transpose_btc(q, B, Tq, C, Tq)
     dot = transpose_btc(do, B, Tq, C, Tq)
     _call("fd_attn_bwd_dkdv", _p(q), _p(qt), _p(k), _p(v), _p(do), _p(dot), _p(lse), _p(Dd), _p(dk), _p(dv), B, H, Tq, Tk, Tkr, d, kv_div, scale,
-          _rows(q), _rows(k), lddkv, _stream())
+          _rows(q), _rows(k), lddkv, int(dk_acc is not None), _stream())
     return dq, dk, dv
 
 

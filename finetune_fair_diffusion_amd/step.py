@@ -240,14 +240,34 @@ class FairnessTrainer:
                 unet._ctx = None
                 if i == 0:
                     per = _ctx_bytes(ctxs[0])
-                    free, _ = torch.cuda.mem_get_info()
-                    free += torch.cuda.memory_reserved() - torch.cuda.memory_allocated()
-                    budget = int(self.activation_mem_fraction * free / max(per, 1))
+                    budget = int(self.activation_mem_fraction * self._usable_free_bytes() / max(per, 1))
                     self.last_ctx_bytes, self.last_ctx_budget = per, budget
                 else:
                     budget -= 1
             self.sch.cfg_step(i, eps, gs, lat, state)
             yield i
+
+    def _usable_free_bytes(self):
+        """HBM the recording rollout (on the CURRENT stream) can still obtain without the allocator having to synchronise: what the driver
+        reports free plus the cached, unallocated blocks of the caching allocator -- minus the part of that cache which sits in the pools
+        of the side streams (R2 rollout, backward streams): a block freed on another stream is only handed to this one after an OOM-retry
+        ``free_cached_blocks`` + device sync, i.e. a stall in the middle of the step.  The side-stream share is estimated
+        from the allocator's per-stream segment snapshot."""
+        free, _ = torch.cuda.mem_get_info()
+        cached = torch.cuda.memory_reserved() - torch.cuda.memory_allocated()
+        cur = torch.cuda.current_stream().cuda_stream
+        n = getattr(self, "_snap_calls", 0)
+        self._snap_calls = n + 1
+        if n < 4 or n % 16 == 0:      # the pools settle after the warm-up steps: the (host-side, ms-scale) snapshot is refreshed rarely
+            other = 0
+            try:
+                for seg in torch.cuda.memory_snapshot():
+                    if seg.get("stream", cur) != cur:
+                        other += sum(b["size"] for b in seg.get("blocks", ()) if b.get("state") == "inactive")
+            except Exception:
+                other = cached // 2
+            self._other_stream_cache = other
+        return free + max(cached - self._other_stream_cache, 0)
 
     def rollout(self, unet, enc, noises, S, keep_inputs=False, record_prompt=False, keep_activations=False):
         """noises [N,4,h,w] fp32 on device.  Returns (x_final, [x_i], {i: ctx})."""
@@ -348,10 +368,15 @@ class FairnessTrainer:
             self._tgt["res"] = [generate_dynamic_targets(gathered[0], w_uncertainty=True)]
             return
 
+        st = self._tgt
+
         def work():
             t0 = time.perf_counter()
-            self._tgt["plan"] = mc_transport_plan(gathered, self.class_cdfs, 100, self.target_rng, self.age_asym)
-            self._tgt["solve_ms"] = 1e3 * (time.perf_counter() - t0)
+            try:
+                st["plan"] = mc_transport_plan(gathered, self.class_cdfs, 100, self.target_rng, self.age_asym)
+            except BaseException as e:      # re-raised on the main thread by finish_dynamic_targets (a dead worker would otherwise surface
+                st["error"] = e             # as KeyError('plan') here and as a collective timeout on the other ranks)
+            st["solve_ms"] = 1e3 * (time.perf_counter() - t0)
         if self.overlap_targets:
             th = threading.Thread(target=work, daemon=True)
             th.start()
@@ -367,6 +392,15 @@ class FairnessTrainer:
         if not st["single"]:
             if "thread" in st:
                 st["thread"].join()
+            failed = torch.tensor([1.0 if "error" in st else 0.0])
+            if self.collectives:            # every rank learns of a failed solve BEFORE the plan all-reduce, so all of them raise together
+                f = failed.to(self.device)
+                dist.all_reduce(f, op=dist.ReduceOp.MAX)
+                failed = f.cpu()
+            if float(failed) != 0:
+                self._tgt = None
+                raise RuntimeError("Monte-Carlo transport solve for the dynamic targets failed" +
+                                   (" on this rank" if "error" in st else " on another rank")) from st.get("error")
             idx, tp, sizes = st["plan"]
             if tp is not None and self.collectives:
                 t = tp.to(self.device)

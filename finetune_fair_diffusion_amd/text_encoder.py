@@ -70,12 +70,23 @@ class CLIPTextModel:
         B, T = input_ids.shape
         D, H = cfg.hidden_size, cfg.num_attention_heads
         d = D // H
-        ids = input_ids.to(self.device).clamp(max=self.tok.shape[0] - 1)       # placeholder ids of prefix tokens lie beyond the vocabulary
-        te = self.tok[ids]
+        vocab = self.tok.shape[0]
+        oov = input_ids >= vocab            # host tensor (token ids arrive from the tokenizer on the CPU): no device sync
         if prefix is not None:
+            # exp-2: the placeholder ids of the n prefix tokens lie beyond the vocabulary; they must sit exactly at positions 1..n of
+            # ``row`` (their embedding rows are overwritten below) -- any other out-of-vocabulary id is a corrupt input, not a placeholder
             row, vec = prefix
-            te = te.clone()
+            allowed = torch.zeros_like(oov)
+            allowed[row, 1:1 + vec.shape[0]] = True
+            if bool((oov & ~allowed).any()) or int(input_ids.min()) < 0:
+                raise ValueError("CLIPTextModel.forward: token id outside the vocabulary at a position that is not a prefix placeholder")
+            ids = input_ids.clamp(max=vocab - 1).to(self.device)
+            te = self.tok[ids].clone()
             te[row, 1:1 + vec.shape[0]] = vec.to(self.device, te.dtype)
+        else:
+            if bool(oov.any()) or int(input_ids.min()) < 0:
+                raise ValueError(f"CLIPTextModel.forward: token id outside the vocabulary of {vocab} entries")
+            te = self.tok[input_ids.to(self.device)]
         x = (te + self.pos[:T][None]).reshape(B * T, D).contiguous()  # embedding gather: plumbing
         kv = attention_mask.to(self.device, torch.int32).contiguous() if attention_mask is not None else None
         ctx = [] if record else None

@@ -105,14 +105,15 @@ def main(argv=None, experiment=None, cfgs=None, log=None):
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
-    if not torch.cuda.is_available():
-        raise RuntimeError("finetune_fair_diffusion_amd.train needs an MI355X (HIP device); there is no CPU path")
     from .lib import WORKING_DTYPE
     if args.mixed_precision not in ("fp16", "bf16"):
         raise NotImplementedError("--mixed_precision no (fp32 activations) is not built: the MFMA path computes in fp16 or bf16")
     if args.mixed_precision != WORKING_DTYPE:
         raise RuntimeError(f"--mixed_precision {args.mixed_precision} but this process was started with the {WORKING_DTYPE} library: the working "
-                           "dtype is fixed at import (set FD_DTYPE, or pass --mixed_precision on the command line of python -m ...train)")
+                           "dtype is fixed at import: set FD_DTYPE=%s in the environment (python -m finetune_fair_diffusion_amd.train reads --mixed_precision "
+                           "and the --config YAML by itself; the YAML value wins, as in the reference)" % args.mixed_precision)
+    if not torch.cuda.is_available():
+        raise RuntimeError("finetune_fair_diffusion_amd.train needs an MI355X (HIP device); there is no CPU path")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1 and not dist.is_initialized():

@@ -182,13 +182,10 @@ class TransformerBlock:
         do2 = lora_linear_bwd(dh2, c["o2"], c["to2"], self.o2, l2.out if l2 else None, gscale)
         cr = self.cross
         kv_div = B // cr["Bk"]
-        if kv_div > 1:
-            dq2, _, _ = ops.attn_bwd(c["q2"], cr["K"], cr["V"], c["o2"], do2, c["lse2"], B, h, HW, cr["L"], d, kv_div, kt=cr["Kt"],
-                                     dk_acc=cr["dK"], dv_acc=cr["dV"])
-        else:
-            dq2, dk2, dv2 = ops.attn_bwd(c["q2"], cr["K"], cr["V"], c["o2"], do2, c["lse2"], B, h, HW, cr["L"], d, 1, kt=cr["Kt"])
-            cr["dK"] += dk2.float()
-            cr["dV"] += dv2.float()
+        # dK/dV of every sample and every timestep add into ONE fp32 accumulator pair with atomics (also at kv_div == 1: the timesteps'
+        # backwards run on several HIP streams, step.py, and a plain read-modify-write of the shared buffer would lose updates)
+        dq2, _, _ = ops.attn_bwd(c["q2"], cr["K"], cr["V"], c["o2"], do2, c["lse2"], B, h, HW, cr["L"], d, kv_div, kt=cr["Kt"],
+                                 dk_acc=cr["dK"], dv_acc=cr["dV"])
         if pair:
             # the shared prefix received the gradient of both halves
             B = B // 2

@@ -140,10 +140,12 @@ int fd_attn_bwd_dq(const void* q, const void* k, const void* v, const void* kt, 
                    float* D, const void* o, void* dq, int B, int H, int Tq, int Tk, int Tkp, int Tkr, int d, int kv_div, float scale,
                    int ldq, int ldkv, int lddq, void* stream);
 /* dk,dv from (q, qt:[B,H*d,Tq], k, v, dO, dOt:[B,H*d,Tq], lse, D). When kv_div>1 the kv batch is shared by
- * kv_div consecutive samples; dk/dv are then fp32 [Bk,Tk,H*d] accumulated with atomics, else fp16. */
+ * kv_div consecutive samples; dk/dv are then fp32 [Bk,Tk,H*d] accumulated with atomics, else fp16 (overwritten).
+ * ``accumulate`` != 0 selects the fp32-atomic form at kv_div == 1 too: several launches -- timesteps of the truncated chain whose
+ * backwards run on different HIP streams -- may then add into one accumulator concurrently. */
 int fd_attn_bwd_dkdv(const void* q, const void* qt, const void* k, const void* v, const void* d_o, const void* d_ot,
                      const float* lse, const float* D, void* dk, void* dv, int B, int H, int Tq, int Tk, int Tkr, int d,
-                     int kv_div, float scale, int ldq, int ldkv, int lddkv, void* stream);
+                     int kv_div, float scale, int ldq, int ldkv, int lddkv, int accumulate, void* stream);
 
 /* ---- FP8 (OCP e4m3fn) self-attention forward: BASELINE configs[4] "bf16 + MFMA fp8 attention" (per-tile scaled QK^T / PV,
  * self-attention only).  Same reference op as fd_attn_fwd for the attn1 layers; the reference itself only ran fp16 (:401-405).

@@ -252,19 +252,32 @@ def test_library_exports_every_header_symbol():
 
 def test_working_dtype_preselection_from_the_reference_flag(tmp_path):
     """``--mixed_precision bf16`` (exp-1 main:401-405) or a --config YAML carrying it selects the bf16 library before the package binds its
-    dtype; an explicit FD_DTYPE wins."""
+    dtype, with ``parse_args``' precedence (the YAML overlay is applied last, :625-642); an explicit FD_DTYPE wins; a host program that
+    merely imports the package never has its own argv parsed."""
     import subprocess, sys
-    code = "from finetune_fair_diffusion_amd import lib; print(lib.WORKING_DTYPE, lib.LIB_PATH.rsplit('/', 1)[1])"
+    code = ("import sys, finetune_fair_diffusion_amd as P; P._preselect_working_dtype(sys.argv); "
+            "from finetune_fair_diffusion_amd import lib; print(lib.WORKING_DTYPE, lib.LIB_PATH.rsplit('/', 1)[1])")
     env = {k: v for k, v in os.environ.items() if k not in ("FD_DTYPE", "FAIRDIFF_LIB")}
-    run = lambda argv, e=env: subprocess.run([sys.executable, "-c", code] + argv, env=e, capture_output=True, text=True, cwd=os.path.dirname(HERE)).stdout.split()  # noqa: E731
+    run = lambda argv, e=env, c=code: subprocess.run([sys.executable, "-c", c] + argv, env=e, capture_output=True, text=True, cwd=os.path.dirname(HERE)).stdout.split()  # noqa: E731
     assert run([]) == ["fp16", "libfairdiff_hip.so"]
     assert run(["--mixed_precision", "bf16"]) == ["bf16", "libfairdiff_hip_bf16.so"]
     assert run(["--mixed_precision=bf16"])[0] == "bf16"
     y = tmp_path / "c.yaml"
     y.write_text("mixed_precision: bf16\nrank: 4\n")
     assert run(["--config", str(y)])[0] == "bf16"
-    assert run(["--config", str(y), "--mixed_precision", "fp16"])[0] == "fp16"
+    assert run(["--config", str(y), "--mixed_precision", "fp16"])[0] == "bf16"          # the YAML wins, as in parse_args
+    from finetune_fair_diffusion_amd.cli import parse_args
+    assert parse_args(["--config", str(y), "--mixed_precision", "fp16"]).mixed_precision == "bf16"
     assert run(["--mixed_precision", "bf16"], dict(env, FD_DTYPE="fp16"))[0] == "fp16"
+    # a plain import from a host program leaves that program's argv alone
+    plain = "from finetune_fair_diffusion_amd import lib; print(lib.WORKING_DTYPE)"
+    assert run(["--mixed_precision", "bf16"], env, plain) == ["fp16"]
+    # the package's own entry point does read it (python -m ...train): flag fp16 + YAML bf16 -> bf16 on both sides, so the driver gets past
+    # its dtype check and stops at the device check on a CPU-only box
+    if not torch.cuda.is_available():
+        r = subprocess.run([sys.executable, "-m", "finetune_fair_diffusion_amd.train", "--synthetic", "--config", str(y), "--mixed_precision", "fp16"],
+                           env=env, capture_output=True, text=True, cwd=os.path.dirname(HERE))
+        assert r.returncode != 0 and "needs an MI355X" in r.stderr and "was started with" not in r.stderr, r.stderr[-600:]
 
 
 def test_product_fails_loudly_without_library(monkeypatch):
