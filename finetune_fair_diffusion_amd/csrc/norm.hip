@@ -49,26 +49,44 @@ __global__ void gn_reduce_kernel(GNArgs a, float* partial /* [B,nchunks,G,2] */)
     }
     const int r0 = chunk * a.rows_per_chunk;
     const int r1 = min(r0 + a.rows_per_chunk, a.HW);
-    for (int r = r0 + rsub; r < r1; r += rpb) {
-        const int64_t pix = (int64_t)b * a.HW + r;
-        const f16x8 xv = gn_load(a, pix, c0);
-        if (MODE == 0) {
+    // GN_U rows per thread in flight: with one 16-byte load per loop trip a CU holds ~15 KB of requests, below what the HBM latency x
+    // bandwidth product needs (the two-launch kernels ran at ~2 TB/s); issuing the loads of GN_U rows before touching any of them
+    // multiplies the bytes in flight.  The accumulation order per thread (row by row) is unchanged: same bits as before.
+    constexpr int GN_U = 4;
+    for (int rb = r0 + rsub; rb < r1; rb += rpb * GN_U) {
+        f16x8 xs[GN_U], ds[GN_U];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float x = (float)xv[j];
-                s0[j] += x;
-                s1[j] += x * x;
+        for (int u = 0; u < GN_U; ++u) {
+            const int r = rb + u * rpb;
+            if (r < r1) {
+                const int64_t pix = (int64_t)b * a.HW + r;
+                xs[u] = gn_load(a, pix, c0);
+                if (MODE == 1) ds[u] = *(const f16x8*)(a.dy + pix * C + c0);
             }
-        } else {
-            const f16x8 dv = *(const f16x8*)(a.dy + pix * C + c0);
+        }
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float xh = ((float)xv[j] - mu[j]) * rs[j];
-                float dz = (float)dv[j];
-                if (a.silu) dz *= silu_grad_f(xh * gm[j] + bt[j]);
-                const float t = dz * gm[j];
-                s0[j] += t;
-                s1[j] += t * xh;
+        for (int u = 0; u < GN_U; ++u) {
+            const int r = rb + u * rpb;
+            if (r >= r1) break;
+            const f16x8 xv = xs[u];
+            if (MODE == 0) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float x = (float)xv[j];
+                    s0[j] += x;
+                    s1[j] += x * x;
+                }
+            } else {
+                const f16x8 dv = ds[u];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float xh = ((float)xv[j] - mu[j]) * rs[j];
+                    float dz = (float)dv[j];
+                    if (a.silu) dz *= silu_grad_f(xh * gm[j] + bt[j]);
+                    const float t = dz * gm[j];
+                    s0[j] += t;
+                    s1[j] += t * xh;
+                }
             }
         }
     }
@@ -138,17 +156,27 @@ __global__ void gn_apply_kernel(GNArgs a, f16* y, const float* partial, float n,
     }
     const int r0 = chunk * a.rows_per_chunk;
     const int r1 = min(r0 + a.rows_per_chunk, a.HW);
-    for (int r = r0 + rsub; r < r1; r += rpb) {
-        const int64_t pix = (int64_t)b * a.HW + r;
-        const f16x8 xv = gn_load(a, pix, c0);
-        f16x8 o;
+    constexpr int GN_U = 4;      // rows in flight per thread (see gn_reduce_kernel)
+    for (int rb = r0 + rsub; rb < r1; rb += rpb * GN_U) {
+        f16x8 xs[GN_U];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            float z = (float)xv[j] * sc[j] + sh[j];
-            if (a.silu) z = silu_f(z);
-            o[j] = (f16)z;
+        for (int u = 0; u < GN_U; ++u) {
+            const int r = rb + u * rpb;
+            if (r < r1) xs[u] = gn_load(a, (int64_t)b * a.HW + r, c0);
         }
-        *(f16x8*)(y + pix * C + c0) = o;
+#pragma unroll
+        for (int u = 0; u < GN_U; ++u) {
+            const int r = rb + u * rpb;
+            if (r >= r1) break;
+            f16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float z = (float)xs[u][j] * sc[j] + sh[j];
+                if (a.silu) z = silu_f(z);
+                o[j] = (f16)z;
+            }
+            *(f16x8*)(y + ((int64_t)b * a.HW + r) * C + c0) = o;
+        }
     }
 }
 
@@ -178,22 +206,35 @@ __global__ void gn_bwd_apply_kernel(GNArgs a, const float* partial, float n, con
     const f16* addp = first ? add1 : add2;
     const int r0 = chunk * a.rows_per_chunk;
     const int r1 = min(r0 + a.rows_per_chunk, a.HW);
-    for (int r = r0 + rsub; r < r1; r += rpb) {
-        const int64_t pix = (int64_t)b * a.HW + r;
-        const f16x8 xv = gn_load(a, pix, c0);
-        const f16x8 dv = *(const f16x8*)(a.dy + pix * C + c0);
-        f16x8 av = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (addp) av = *(const f16x8*)(addp + pix * Cs + cc);
-        f16x8 o;
+    constexpr int GN_U = 2;      // rows in flight per thread: three streams (x, dy, add) per row
+    for (int rb = r0 + rsub; rb < r1; rb += rpb * GN_U) {
+        f16x8 xs[GN_U], ds[GN_U], as[GN_U];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float xh = ((float)xv[j] - mu[j]) * rs[j];
-            float dz = (float)dv[j];
-            if (a.silu) dz *= silu_grad_f(xh * gm[j] + bt[j]);
-            const float d = rs[j] * (dz * gm[j] - m1[j] - xh * m2[j]) + (float)av[j];
-            o[j] = (f16)d;
+        for (int u = 0; u < GN_U; ++u) {
+            const int r = rb + u * rpb;
+            as[u] = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
+            if (r < r1) {
+                const int64_t pix = (int64_t)b * a.HW + r;
+                xs[u] = gn_load(a, pix, c0);
+                ds[u] = *(const f16x8*)(a.dy + pix * C + c0);
+                if (addp) as[u] = *(const f16x8*)(addp + pix * Cs + cc);
+            }
         }
-        if (dxp) *(f16x8*)(dxp + pix * Cs + cc) = o;
+#pragma unroll
+        for (int u = 0; u < GN_U; ++u) {
+            const int r = rb + u * rpb;
+            if (r >= r1) break;
+            f16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float xh = ((float)xs[u][j] - mu[j]) * rs[j];
+                float dz = (float)ds[u][j];
+                if (a.silu) dz *= silu_grad_f(xh * gm[j] + bt[j]);
+                const float d = rs[j] * (dz * gm[j] - m1[j] - xh * m2[j]) + (float)as[u][j];
+                o[j] = (f16)d;
+            }
+            if (dxp) *(f16x8*)(dxp + ((int64_t)b * a.HW + r) * Cs + cc) = o;
+        }
     }
 }
 

@@ -39,17 +39,163 @@ __global__ void conv_small_cin_kernel(const XT* x, int nchw, const float* w, con
         y[i] = (f16)apply_act(acc, act);
     }
 }
+// Fast path for the shapes on the hot path (U-Net conv_in 4 -> 320 and the data gradient of conv_out as a 4 -> 320 conv, both at 64^2 x 16
+// samples; VAE conv_in 4 -> 512; classifier stem 3 -> 16 stride 2): k = 3, Cin in {3, 4}, Cout % 8 == 0.  The kernel above spends one thread per
+// output ELEMENT (36 input + 36 weight loads for one 2-byte store: 344 us for 42 MB of output); here a thread owns 8 output channels of PX = 4
+// neighbouring output pixels: the 3 x (3*STRIDE + 3) x Cin input patch is loaded once into registers (the CG threads of a pixel group read the
+// same addresses: one transaction), the weights [9*Cin][Cout] sit in LDS (two 16-byte reads per tap feed 32 FMAs), the store is 16 bytes
+// per lane over whole 2*Cout-byte pixel rows.  Same summation order per output as the kernel above (bias, then ky, kx, ci).
+template <typename XT, int CIN, int STRIDE, bool NCHW, bool HAS_ACT>
+__global__ __launch_bounds__(256, 2) void conv_small_cin_fast_kernel(const XT* __restrict__ x, const float* __restrict__ w,
+                                                                   const float* __restrict__ bias, f16* __restrict__ y, int B, int H, int W, int Cout,
+                                                                   int Ho, int Wo, int act) {
+    constexpr int K = 3, PX = 4, COLS = (PX - 1) * STRIDE + K;
+    extern __shared__ __attribute__((aligned(16))) float wl[];   // [9*CIN][Cout]
+    for (int i = threadIdx.x; i < K * K * CIN * Cout / 4; i += 256) ((f32x4*)wl)[i] = ((const f32x4*)w)[i];
+    __syncthreads();
+    const int CG = Cout >> 3, slots = 256 / CG;
+    const int slot = threadIdx.x / CG, cg = threadIdx.x - slot * CG;
+    if (slot >= slots) return;
+    const int c0 = cg * 8;
+    const int qw = (Wo + PX - 1) / PX;
+    const int64_t nq = (int64_t)B * Ho * qw;
+    float bv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bv[j] = bias ? bias[c0 + j] : 0.f;
+#pragma unroll 1
+    for (int64_t q = (int64_t)blockIdx.x * slots + slot; q < nq; q += (int64_t)gridDim.x * slots) {
+        const int qx = (int)(q % qw);
+        int64_t p = q / qw;
+        const int oy = (int)(p % Ho);
+        const int b = (int)(p / Ho);
+        const int ox0 = qx * PX;
+        const int iy0 = oy * STRIDE - 1, ix0 = ox0 * STRIDE - 1;
+        float acc[PX][8];
+#pragma unroll
+        for (int px = 0; px < PX; ++px)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[px][j] = bv[j];
+        // the weight reads of a quad stay LDS reads next to their use: left visible as loop-invariant the compiler hoists all 288 weights
+        // into registers (395 VGPR+AGPR, one wave per SIMD -- or scratch under an occupancy target)
+        int wofs = c0;
+        asm volatile("" : "+v"(wofs));
+        // one input row (COLS x CIN values) live at a time, the next row's loads issued before this row's FMAs
+        float xr[COLS][CIN], xn[COLS][CIN];
+        const XT* xb = x + (int64_t)b * CIN * H * W;     // this image; everything below is 32-bit offsets from it
+        auto load_row = [&](int r, float (&dst)[COLS][CIN]) {
+            const int iy = iy0 + r;
+            const bool rok = iy >= 0 && iy < H;
+            const int rowoff = (rok ? iy : 0) * W;
+#pragma unroll
+            for (int c = 0; c < COLS; ++c) {
+                const int ix = ix0 + c;
+                const bool ok = rok && ix >= 0 && ix < W;
+                const int po = rowoff + (ok ? ix : 0);
+#pragma unroll
+                for (int ci = 0; ci < CIN; ++ci) {
+                    const float v = NCHW ? (float)xb[ci * H * W + po] : (float)xb[po * CIN + ci];
+                    dst[c][ci] = ok ? v : 0.f;
+                }
+            }
+        };
+        load_row(0, xr);
+#pragma unroll
+        for (int ky = 0; ky < K; ++ky) {
+            if (ky + 1 < K) load_row(ky + 1, xn);
+#pragma unroll
+            for (int kx = 0; kx < K; ++kx)
+#pragma unroll
+                for (int ci = 0; ci < CIN; ++ci) {
+                    const float* wp = wl + ((ky * K + kx) * CIN + ci) * Cout + wofs;
+                    const f32x4 w0 = *(const f32x4*)wp, w1 = *(const f32x4*)(wp + 4);
+#pragma unroll
+                    for (int px = 0; px < PX; ++px) {
+                        const float xv = xr[px * STRIDE + kx][ci];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            acc[px][j] += xv * w0[j];
+                            acc[px][4 + j] += xv * w1[j];
+                        }
+                    }
+                }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int c = 0; c < COLS; ++c)
+#pragma unroll
+                for (int ci = 0; ci < CIN; ++ci) xr[c][ci] = xn[c][ci];
+        }
+        // (the rolled loop below also keeps register allocation sane: an instantiation compiled WITHOUT it spilled 900 B per lane at
+        // 256 VGPRs against 120-156 VGPRs and no scratch with it, so there is only this one form; act == none skips it at run time)
+        if (HAS_ACT && act != FD_ACT_NONE) {
+#pragma unroll 1
+            for (int px = 0; px < PX; ++px)       // rolled: the generic activation switch is large, it must not be expanded 32 times
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[px][j] = apply_act(acc[px][j], act);
+        }
+#pragma unroll
+        for (int px = 0; px < PX; ++px) {
+            if (ox0 + px < Wo) {
+                f16x8 o;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = (f16)acc[px][j];
+                *(f16x8*)(y + (((int64_t)b * Ho + oy) * Wo + ox0 + px) * Cout + c0) = o;
+            }
+        }
+    }
+}
+
+template <typename XT, int CIN, int STRIDE, bool NCHW, bool HAS_ACT>
+static void launch_conv_small_fast_a(const void* x, const float* w, const float* bias, void* y, int B, int H, int W, int Cout, int Ho, int Wo,
+                                   int act, hipStream_t s) {
+    const size_t lds = (size_t)9 * CIN * Cout * sizeof(float);
+    static bool once = false;
+    if (!once) {
+        (void)hipFuncSetAttribute((const void*)conv_small_cin_fast_kernel<XT, CIN, STRIDE, NCHW, HAS_ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        once = true;
+    }
+    const int slots = 256 / (Cout / 8);
+    const int64_t nq = (int64_t)B * Ho * ((Wo + 3) / 4);
+    int64_t blocks = (nq + slots - 1) / slots;
+    if (blocks > 4096) blocks = 4096;         // each block first stages the weights: a few quads per slot amortise that
+    hipLaunchKernelGGL((conv_small_cin_fast_kernel<XT, CIN, STRIDE, NCHW, HAS_ACT>), dim3((unsigned)blocks), dim3(256), lds, s, (const XT*)x, w, bias, (f16*)y, B,
+                       H, W, Cout, Ho, Wo, act);
+}
+
+template <typename XT, int CIN, int STRIDE, bool NCHW>
+static void launch_conv_small_fast(const void* x, const float* w, const float* bias, void* y, int B, int H, int W, int Cout, int Ho, int Wo, int act,
+                                   hipStream_t s) {
+    launch_conv_small_fast_a<XT, CIN, STRIDE, NCHW, true>(x, w, bias, y, B, H, W, Cout, Ho, Wo, act, s);
+}
+
 extern "C" int fd_conv_small_cin(const void* x, int x_is_f32, int nchw, const float* w, const float* bias, void* y, int B, int H, int W, int Cin,
                                  int Cout, int ksize, int stride, int act, void* stream) {
     FD_REQUIRE(Cin >= 1 && Cin <= 8 && (ksize == 1 || ksize == 3) && (stride == 1 || stride == 2), "fd_conv_small_cin: Cin<=8, k in {1,3}");
     const int pad = (ksize - 1) / 2;
     const int Ho = (H + 2 * pad - ksize) / stride + 1, Wo = (W + 2 * pad - ksize) / stride + 1;
     const int64_t n = (int64_t)B * Ho * Wo * Cout;
+    hipStream_t s = (hipStream_t)stream;
+    if (ksize == 3 && (Cin == 3 || Cin == 4) && (Cout & 7) == 0 && Cout >= 16 && Cout <= 2048 && (size_t)9 * Cin * Cout * 4 <= 150 * 1024 &&
+        ((uintptr_t)w & 15) == 0 && (int64_t)B * Cin * H * W < (1LL << 31)) {
+#define FD_FAST(XT, CI, ST)                                                                                  \
+    do {                                                                                                     \
+        if (nchw) launch_conv_small_fast<XT, CI, ST, true>(x, w, bias, y, B, H, W, Cout, Ho, Wo, act, s);    \
+        else launch_conv_small_fast<XT, CI, ST, false>(x, w, bias, y, B, H, W, Cout, Ho, Wo, act, s);        \
+    } while (0)
+        if (x_is_f32) {
+            if (Cin == 4) { if (stride == 1) FD_FAST(float, 4, 1); else FD_FAST(float, 4, 2); }
+            else { if (stride == 1) FD_FAST(float, 3, 1); else FD_FAST(float, 3, 2); }
+        } else {
+            if (Cin == 4) { if (stride == 1) FD_FAST(f16, 4, 1); else FD_FAST(f16, 4, 2); }
+            else { if (stride == 1) FD_FAST(f16, 3, 1); else FD_FAST(f16, 3, 2); }
+        }
+#undef FD_FAST
+        return fd_check_launch("fd_conv_small_cin(fast)");
+    }
     if (x_is_f32)
-        hipLaunchKernelGGL(conv_small_cin_kernel<float>, grid1d(n), dim3(256), 0, (hipStream_t)stream, (const float*)x, nchw, w, bias, (f16*)y, B, H,
+        hipLaunchKernelGGL(conv_small_cin_kernel<float>, grid1d(n), dim3(256), 0, s, (const float*)x, nchw, w, bias, (f16*)y, B, H,
                            W, Cin, Cout, ksize, stride, Ho, Wo, act);
     else
-        hipLaunchKernelGGL(conv_small_cin_kernel<f16>, grid1d(n), dim3(256), 0, (hipStream_t)stream, (const f16*)x, nchw, w, bias, (f16*)y, B, H, W,
+        hipLaunchKernelGGL(conv_small_cin_kernel<f16>, grid1d(n), dim3(256), 0, s, (const f16*)x, nchw, w, bias, (f16*)y, B, H, W,
                            Cin, Cout, ksize, stride, Ho, Wo, act);
     return fd_check_launch("fd_conv_small_cin");
 }

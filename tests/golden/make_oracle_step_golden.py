@@ -1,0 +1,164 @@
+"""Golden vectors of the CPU oracle's SD-v1.5-SIZE runs ("latents after each scheduler step, loss_fair, LoRA grads of
+3 named tensors, dynamic targets / uncertainties ... committed as small fixtures and are what the MI355X run is checked against").
+
+CPU only.  ``latents`` (no-grad rollout, ~9 GB of host RAM, 2.5 min on 8 cores) runs in the build container; ``cfg0`` and ``smooth`` hold
+the oracle's autograd graph of the U-Net at SD-v1.5 size (more than the build container's 62 GB) and were generated on the host CPU of
+a GPU box with this same script (scratch/run_r03_a.sh copies the files back):
+
+    python tests/golden/make_oracle_step_golden.py [cfg0] [latents] [smooth]
+
+The inputs are fully synthetic and seeded (tests/util_models.py: weights.synthetic_state_dict seeds, factory.synthetic_tokens, CPU-drawn
+noise from torch.manual_seed(5991)), so the GPU box rebuilds the SAME product models from the same seeds and compares against the vectors
+stored here without re-running the oracle.  Test infrastructure only (like everything under oracle/): nothing in the product reads it.
+
+  oracle_sd15_cfg0_b2_s4_te_lora.npz   BASELINE configs[0]: exp-1, batch 2, 4 denoising steps, LoRA r=4 on the text encoder only --
+                                       the COMPLETE step (exp-1-debias-gender/1-main-debias.py:1746-2029): R1 latents after every
+                                       scheduler step (:1131), probabilities, dynamic targets + uncertainties (:1403-1447), loss_fair
+                                       (:1912-1916), three named text-encoder LoRA gradients, a seeded sample of the flat gradient
+  oracle_sd15_r1_latents_b1_s20.npz    BASELINE configs[1] rollout length: LoRA r=4 on the U-Net, batch 1, 20 steps -- the no-grad CFG
+                                       rollout (:1038-1056): latents after each of the 20 scheduler steps
+  oracle_sd15_smooth_head_b2_s2.npz    the complete step with U-Net LoRA and a classifier double WITHOUT discontinuities (two linear
+                                       layers + hardswish), batch 2, 2 steps: loss, probabilities, targets, three named U-Net LoRA
+                                       gradients, a seeded 65536-entry sample of the flat LoRA gradient and its norm (pins the backward
+                                       chain end to end at full size)
+"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import util_models as U  # noqa: E402
+from finetune_fair_diffusion_amd import factory  # noqa: E402  (synthetic_tokens only: host-side helper, no HIP)
+from oracle import fair_step as fs  # noqa: E402
+
+L = 13
+NOISE_SEED = 5991
+UNET_NAMED = ("down_blocks.0.attentions.0.transformer_blocks.0.attn1.processor.to_q_lora.up.weight",
+              "mid_block.attentions.0.transformer_blocks.0.attn2.processor.to_k_lora.down.weight",
+              "up_blocks.3.attentions.2.transformer_blocks.0.attn2.processor.to_out_lora.up.weight")
+SAMPLE_SEED, SAMPLE_N = 20260, 65536
+
+
+def smooth_head_weights(size_face=224, hidden=256, classes=80, seed=99):
+    """The classifier double of tests/test_engine_gpu.py::_SmoothHeadProduct at the SD-v1.5 face-chip size."""
+    g = torch.Generator().manual_seed(seed)
+    K = 3 * size_face * size_face
+    w1 = (torch.randn(hidden, K, generator=g) * (2.0 / K ** 0.5)).half().float()
+    b1 = torch.randn(hidden, generator=g) * 0.1
+    w2 = (torch.randn(classes, hidden, generator=g) * (2.0 / hidden ** 0.5)).half().float()
+    b2 = torch.randn(classes, generator=g) * 0.1
+    return w1, b1, w2, b2
+
+
+def smooth_head_module(w1, b1, w2, b2):
+    K, Hd, C = w1.shape[1], w1.shape[0], w2.shape[0]
+    m = torch.nn.Sequential(torch.nn.Flatten(), torch.nn.Linear(K, Hd), torch.nn.Hardswish(), torch.nn.Linear(Hd, C)).requires_grad_(False)
+    m[1].weight.copy_(w1); m[1].bias.copy_(b1); m[3].weight.copy_(w2); m[3].bias.copy_(b2)
+    return m
+
+
+def grad_sample_index(n):
+    return torch.randperm(n, generator=torch.Generator().manual_seed(SAMPLE_SEED))[:min(SAMPLE_N, n)]
+
+
+def unet_models():
+    return U.oracle_models(train_unet=True, train_te=False, lora_up_std=0.02, size="sd15", eval_copies=False)   # == tests/test_fullsize_gpu.py::full
+
+
+class Frozen:
+    """R2's frozen original U-Net (:1844-1858): the same module with its LoRA processors detached for the duration of a call."""
+
+    def __init__(self, unet):
+        self.u = unet
+
+    def __call__(self, *a, **k):
+        procs = dict(self.u.attn_processors)
+        self.u.set_attn_processor({n: None for n in procs})
+        try:
+            return self.u(*a, **k)
+        finally:
+            self.u.set_attn_processor(procs)
+
+
+def make_latents(om):
+    tokens = factory.synthetic_tokens(L, 49408)
+    noises = torch.randn(1, 4, 64, 64, generator=torch.Generator().manual_seed(NOISE_SEED))
+    trace = []
+    t0 = time.time()
+    with torch.no_grad():
+        img = fs.generate_image_no_gradient(tokens, noises, 20, om["text_encoder"], om["unet"], om["vae"], om["scheduler"], 7.5, trace=trace)
+    lat = torch.stack(trace)                # [20, 1, 4, 64, 64]
+    print(f"latents: 20-step rollout in {time.time() - t0:.0f} s; |x_final|max = {float(lat[-1].abs().max()):.3f}")
+    np.savez_compressed(os.path.join(HERE, "oracle_sd15_r1_latents_b1_s20.npz"), latents=lat.numpy().astype(np.float16),
+                        image_mean=np.float32(img.mean()), image_abs_mean=np.float32(img.abs().mean()),
+                        image_8x8=torch.nn.functional.avg_pool2d(img, 64).numpy().astype(np.float32))
+
+
+def make_smooth(om):
+    tokens = factory.synthetic_tokens(L, 49408)
+    B, S = 2, 2
+    noises = torch.randn(B, 4, 64, 64, generator=torch.Generator().manual_seed(NOISE_SEED))
+    head = smooth_head_module(*smooth_head_weights())
+    models = dict(text_encoder=om["text_encoder"], unet=om["unet"], vae=om["vae"], classifier=head, scheduler=om["scheduler"],
+                  eval_text_encoder=om["text_encoder"], eval_unet=Frozen(om["unet"]))
+    for p in om["lora_params"]:
+        p.grad = None
+    t0 = time.time()
+    ref = fs.fairness_step(models, tokens, noises, S, dict(train_GPU_batch_size=3, val_GPU_batch_size=8, uncertainty_threshold=0.7, factor2=0.2,
+                                                           size_face=224))
+    print(f"smooth head: full step B={B} S={S} in {time.time() - t0:.0f} s; targets {ref['targets'].tolist()} loss {ref['loss_fair'].tolist()}")
+    names = list(om["unet_lora_layers"].state_dict().keys())
+    flat = torch.cat([p.grad.flatten() for p in om["unet_lora_layers"].parameters()])
+    named = dict(zip(names, om["unet_lora_layers"].parameters()))
+    idx = grad_sample_index(flat.numel())
+    np.savez_compressed(os.path.join(HERE, "oracle_sd15_smooth_head_b2_s2.npz"),
+                        probs=ref["probs"].numpy(), targets=ref["targets"].numpy(), uncertainty=ref["uncertainty"].numpy(),
+                        loss_fair=ref["loss_fair"].numpy(), grad_norm=np.float64(flat.double().norm()), grad_sample=flat[idx].numpy(),
+                        grad_absmax=np.float32(flat.abs().max()),
+                        latents=torch.stack(ref["latents_trace"]).numpy().astype(np.float16),
+                        **{"grad::" + n: named[n].grad.numpy() for n in UNET_NAMED})
+
+
+def make_cfg0():
+    om = U.oracle_models(rank=4, train_unet=False, train_te=True, lora_up_std=0.01, size="sd15", eval_copies=True)
+    tokens = factory.synthetic_tokens(L, 49408)
+    B, S = 2, 4
+    noises = torch.randn(B, 4, 64, 64, generator=torch.Generator().manual_seed(NOISE_SEED))
+    models = dict(text_encoder=om["text_encoder"], unet=om["unet"], vae=om["vae"], classifier=om["classifier"], scheduler=om["scheduler"],
+                  eval_text_encoder=om["eval_text_encoder"], eval_unet=om["unet"])
+    for p in om["lora_params"]:
+        p.grad = None
+    t0 = time.time()
+    ref = fs.fairness_step(models, tokens, noises, S, dict(train_GPU_batch_size=3, val_GPU_batch_size=8, uncertainty_threshold=0.6, factor2=0.2,
+                                                           size_face=224))
+    print(f"cfg0: full step B={B} S={S} (TE LoRA) in {time.time() - t0:.0f} s; targets {ref['targets'].tolist()} loss {ref['loss_fair'].tolist()}")
+    names = list(om["te_lora_named"].keys())
+    flat = torch.cat([om["te_lora_named"][n].grad.flatten() for n in names])
+    pick = [names[0], names[len(names) // 2], names[-1]]
+    idx = grad_sample_index(flat.numel())
+    np.savez_compressed(os.path.join(HERE, "oracle_sd15_cfg0_b2_s4_te_lora.npz"),
+                        latents=torch.stack(ref["latents_trace"]).numpy().astype(np.float16),
+                        probs=ref["probs"].numpy(), probs_ori=ref["probs_ori"].numpy(), targets=ref["targets"].numpy(),
+                        uncertainty=ref["uncertainty"].numpy(), loss_fair=ref["loss_fair"].numpy(),
+                        grad_norm=np.float64(flat.double().norm()), grad_sample=flat[idx].numpy(), grad_absmax=np.float32(flat.abs().max()),
+                        named=np.array(pick), **{"grad::" + n: om["te_lora_named"][n].grad.numpy() for n in pick})
+
+
+if __name__ == "__main__":
+    what = sys.argv[1:] or ["cfg0", "latents", "smooth"]
+    torch.set_num_threads(min(os.cpu_count() or 1, 64))
+    if "cfg0" in what:
+        make_cfg0()
+    if "latents" in what or "smooth" in what:
+        om = unet_models()
+        if "latents" in what:
+            make_latents(om)
+        if "smooth" in what:
+            make_smooth(om)

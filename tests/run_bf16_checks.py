@@ -6,6 +6,9 @@ Bands (bf16 has 8 significand bits against fp16's 11, i.e. 8x the rounding step;
   tiny U-Net eps vs fp32 oracle   8e-2               (fp16: 2e-2);  LoRA gradients per family 2e-1 (fp16: 5e-2), cosine > 0.995
   SD-v1.5-size U-Net eps          8e-2, with FD_FP8_ATTN=1 (e4m3 self-attention at all four levels) 1.2e-1
   full tiny training step         images 1e-1, exact targets, loss_fair 5e-2, end-to-end gradient cosine > 0.8 (measured 0.87; ReLU / clamp mask flips)
+  exp-3 step on the d=40 model    (gender x race: 6-logit head, both sides on the oracle's OT targets; with FD_FP8_ATTN=1 every self-attention
+                                  forward of the 320-channel level runs on the e4m3 kernels)  images 1.5e-1 / RMS 4e-2, per-attribute
+                                  loss_fair 8e-2, end-to-end gradient cosine > 0.75
 """
 import math
 import os
@@ -152,6 +155,62 @@ def tiny_unet_and_step():
     assert cos > 0.8
 
 
+def exp3_step_d40():
+    """BASELINE configs[2] logic at configs[4] precision: one complete exp-3 step (exp-3-debias-gender-race/1-main-debias.py:2016-2146: 6-logit
+    head, loss = CE_gender + CE_race) in bf16 -- and, under FD_FP8_ATTN=1, with the e4m3 self-attention forward -- on a two-level U-Net with
+    SD-v1.5's head dims (40 / 80).  Both sides train on the ORACLE's OT targets, so the band is on arithmetic, not on target flips."""
+    from oracle import fair_step as fs
+    from finetune_fair_diffusion_amd.fairness import EXPERIMENT_ATTRS
+    from finetune_fair_diffusion_amd.step import FairnessTrainer
+    ncls, attrs, cdfs, asym = EXPERIMENT_ATTRS["exp-3"]
+    torch.set_num_threads(min(os.cpu_count() or 1, 64))
+    om = U.oracle_models(train_unet=True, train_te=False, lora_up_std=0.05, num_classes=ncls, size="d40")
+    for name in ("unet", "vae", "text_encoder", "classifier", "eval_unet"):
+        for p in om[name].parameters():
+            if not p.requires_grad:
+                p.data = p.data.to(BF).float()
+    sds = {k: ({n: (t.to(BF).float() if t.is_floating_point() and k in ("unet", "vae", "clip", "clf") else t) for n, t in sd.items()})
+           for k, sd in om["sds"].items()}
+    pm = U.product_models(sds, dev, train_unet=True, train_te=False, num_classes=ncls, size="d40")
+    thr = 0.7
+    args = U.make_args(train_unet=True, train_text_encoder=False, uncertainty_threshold=thr)
+    tokens = U.tiny_tokens()
+    B, S = 4, 3
+    noises = torch.randn(B, 4, 32, 32, generator=torch.Generator().manual_seed(17))
+    t0 = time.time()
+    tg_o, img_o, _ = U.oracle_multi_targets(om, tokens, noises, S, attrs, cdfs, asym, seed=4321, thr=thr)
+    assert sum(int((t != -1).sum()) for t in tg_o.values()) >= 3, tg_o
+    models_o = dict(text_encoder=om["text_encoder"], unet=om["unet"], vae=om["vae"], classifier=om["classifier"], scheduler=om["scheduler"])
+    for p in om["lora_params"]:
+        p.grad = None
+    ref = fs.fairness_step_multi(models_o, tokens, noises, S, dict(train_GPU_batch_size=3, size_face=64), attrs, tg_o)
+    print(f"oracle exp-3 step on the d=40 model: {time.time() - t0:.1f} s; targets", {k: v.tolist() for k, v in tg_o.items()})
+    tr = FairnessTrainer(args, pm["text_encoder"], pm["unet"], pm["vae"], pm["classifier"], pm["scheduler"], eval_unet=pm["eval_unet"],
+                         experiment="exp-3", device=dev)
+    tr.start_dynamic_targets = lambda per, Bn: None
+    tr.finish_dynamic_targets = lambda: [(tg_o[name].clone(), torch.zeros(B)) for name, _, _ in attrs]
+    grads, n8 = {}, [0]
+    tr.sync_and_update = lambda nb, apply=True: (grads.update({i: b.grad.clone() for i, b in enumerate(tr.banks)}), True)[1]
+    real8 = ops.attn_fwd_fp8
+    ops.attn_fwd_fp8 = lambda *a, **k: (n8.__setitem__(0, n8[0] + 1), real8(*a, **k))[1]
+    out = tr.train_step(tokens, noises, S)
+    ops.attn_fwd_fp8 = real8
+    print(f"e4m3 self-attention forwards in the step: {n8[0]}")
+    assert (n8[0] > 0) == FP8
+    check("exp-3 d40: R1 images", out["images"], img_o, 1.5e-1)
+    rms = float(((out["images"].float().cpu() - img_o) ** 2).mean().sqrt())
+    print(f"[exp-3 d40: R1 images] RMS err {rms:.3e} (band 4e-2)")
+    assert rms < 4e-2 and out["grad_is_finite"]
+    for name, _, _ in attrs:
+        check(f"exp-3 d40: loss_fair_{name}", out["loss_fair_by_attr"][name], ref["losses"][name], 8e-2)
+    names = list(om["unet_lora_layers"].state_dict().keys())
+    refg = torch.cat([p.grad.flatten() for p in om["unet_lora_layers"].parameters()])
+    got = torch.cat([tr.banks[0].view(n, grads[0]).flatten() for n in names])
+    cos = float(F.cosine_similarity(got.cpu().double(), refg.double(), dim=0))
+    print("cosine(exp-3 d40 unet grads) =", cos, " norm ratio =", float(got.norm().cpu() / refg.norm()))
+    assert cos > 0.75 and 0.6 < float(got.norm().cpu() / refg.norm()) < 1.6
+
+
 def sd15_unet():
     from oracle import fair_step as fs
     from finetune_fair_diffusion_amd import factory
@@ -191,4 +250,6 @@ if __name__ == "__main__":
         tiny_unet_and_step()
     if "sd15" in which:
         sd15_unet()
+    if "exp3" in which:
+        exp3_step_d40()
     print("BF16 CHECKS PASSED" + (" (fp8 attention on)" if FP8 else ""))

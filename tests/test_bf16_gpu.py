@@ -25,3 +25,8 @@ def test_bf16_kernels_unet_and_training_step(dev):
 
 def test_bf16_with_fp8_self_attention_in_the_sd15_unet(dev):
     _run({"FD_FP8_ATTN": "1"}, ["sd15"])
+
+
+def test_exp3_step_in_bf16_with_fp8_self_attention(dev):
+    """BASELINE configs[4] precision on a multi-attribute step: exp-3 logic, bf16 library, e4m3 self-attention forward."""
+    _run({"FD_FP8_ATTN": "1"}, ["exp3"])

@@ -746,25 +746,7 @@ def test_train_driver_runs_full_loss(tmp_path, experiment):
 
 
 # ------------------------------------------------------------------------------------------ BASELINE configs[2] / configs[3] at test size
-def _oracle_multi_targets(om, tokens, noises, S, attrs, cdfs, asym, seed, thr):
-    """The oracle's own R1 -> classifier -> Monte-Carlo OT (LP solver) targets (exp-3 :2016-2025, exp-4 :2157-2170)."""
-    from oracle import fair_step as fs
-    with torch.no_grad():
-        img = fs.generate_image_no_gradient(tokens, noises, S, om["text_encoder"], om["unet"], om["vae"], om["scheduler"])
-        ind, _, chips = fs.SyntheticFaceProvider(64)(img)
-        lo = om["classifier"](chips[ind])
-    probs = []
-    for _, c0, k in attrs:
-        p = torch.ones(noises.shape[0], k) * (-1)
-        p[ind] = torch.softmax(lo[:, c0:c0 + k], dim=-1)
-        probs.append(p)
-    res, tp = fs.generate_dynamic_targets_multi(probs, cdfs, 100, torch.Generator().manual_seed(seed), asym)
-    out = {}
-    for (name, _, _), (t, u) in zip(attrs, res):
-        t = t.clone()
-        t[u > thr] = -1
-        out[name] = t
-    return out, img, probs
+_oracle_multi_targets = U.oracle_multi_targets
 
 
 @pytest.mark.parametrize("experiment,mode", [("exp-3", "both"), ("exp-4", "unet")])
@@ -852,39 +834,7 @@ def test_generate_image_matches_oracle_at_30_steps(dev):
 
 
 # ------------------------------------------------------------------------------------------ smooth-head end-to-end chain
-class _SmoothHeadProduct:
-    """Test double with the classifier's contract (num_classes, forward(chips, record), backward(d_logits, gscale), _ctx) but NO
-    discontinuity: logits = W2 hardswish(W1 vec(chips) + b1) + b2, on the product's own kernels through the C-ABI (MFMA GEMMs,
-    fd_act_fwd/bwd).  With it the only non-smooth op left between the LoRA weights and the loss is images.clamp(-1, 1)."""
-
-    def __init__(self, w1, b1, w2, b2, dev):
-        self.w1, self.w2 = w1.to(dev).half().contiguous(), w2.to(dev).half().contiguous()
-        self.w1T, self.w2T = self.w1.t().contiguous(), self.w2.t().contiguous()
-        self.b1, self.b2 = b1.to(dev).float().contiguous(), b2.to(dev).float().contiguous()
-        self.num_classes, self._ctx = w2.shape[0], None
-
-    def forward(self, chips, record=False):
-        from finetune_fair_diffusion_amd import ops
-        n = chips.shape[0]
-        x = torch.zeros(((n + 7) // 8 * 8, self.w1.shape[1]), dtype=torch.float16, device=chips.device)
-        x[:n] = chips.reshape(n, -1)
-        z1 = ops.gemm(x, self.w1, bias=self.b1)
-        h = ops.act_fwd(z1, "hardswish")
-        logits = ops.gemm(h, self.w2, bias=self.b2, out_dtype=torch.float32)
-        if record:
-            self._ctx = dict(z1=z1, n=n, shape=chips.shape)
-        return logits[:n]
-
-    def backward(self, d_logits, gscale):
-        from finetune_fair_diffusion_amd import ops
-        c = self._ctx
-        d = torch.zeros((c["z1"].shape[0], self.num_classes), dtype=torch.float32, device=d_logits.device)
-        d[:c["n"]] = d_logits
-        dh = ops.gemm(ops.to_f16(d.contiguous(), gscale), self.w2T)
-        dz = ops.act_bwd(c["z1"], dh, "hardswish")
-        dx = ops.gemm(dz, self.w1T, out_dtype=torch.float32, alpha=1.0 / gscale)
-        self._ctx = None
-        return dx[:c["n"]].reshape(c["shape"]).contiguous()
+_SmoothHeadProduct = U.SmoothHeadProduct
 
 
 def test_full_step_smooth_head_pins_unet_chain_end_to_end(dev):

@@ -254,3 +254,223 @@ def test_sd15_zero_init_up_training_regime(full, dev, rank):
     # restore the fixture's r=4 LoRA for the other tests
     unet_o.set_attn_processor(dict(zip(keep[0].names, keep[0].layers)))
     unet_p.add_lora(4, om["sds"]["unet_lora"])
+
+
+# ------------------------------------------------------------------------------------------ committed oracle goldens (tests/golden/*.npz)
+# Produced in the build container by tests/golden/make_oracle_step_golden.py (CPU fp32 oracle, seeded synthetic inputs); the GPU box rebuilds
+# the SAME product models from the same seeds and checks against the stored vectors -- no oracle run at test time.
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _gold(name):
+    import numpy as np
+    path = os.path.join(GOLD, name)
+    assert os.path.exists(path), f"{path} missing: run tests/golden/make_oracle_step_golden.py in the build container"
+    return np.load(path, allow_pickle=False)
+
+
+def _rollout_latents(tr, unet, te, tokens, noises, S, dev):
+    """The per-step latents of the product's no-grad CFG rollout (:1038-1056; ``scheduler.step(...).prev_sample`` :1131)."""
+    enc = tr.encode_pair(te, tokens)
+    res, lats = {}, []
+    for _ in tr.rollout_steps(unet, enc, noises.to(dev), S, res):
+        lats.append(res["lat"].clone())
+    return torch.stack(lats).float().cpu()
+
+
+def _check_latents(name, got, ref, tol_first, tol_last):
+    """fp16 activations against the fp32 oracle, per scheduler step: the tolerance grows linearly from ``tol_first`` (one U-Net call) to
+    ``tol_last`` (the whole chain) of max|latents_i|."""
+    S = ref.shape[0]
+    worst = 0.0
+    for i in range(S):
+        tol = tol_first + (tol_last - tol_first) * i / max(S - 1, 1)
+        e = relerr(got[i], ref[i])
+        rms = float((got[i] - ref[i]).pow(2).mean().sqrt() / ref[i].pow(2).mean().sqrt())
+        print(f"[{name}] step {i:2d}: rel max err {e:.3e} (tol {tol:.1e})  rel RMS {rms:.3e}  max|ref| {float(ref[i].abs().max()):.3f}")
+        assert math.isfinite(e) and e <= tol, f"{name} step {i}: {e} > {tol}"
+        worst = max(worst, e)
+    return worst
+
+
+def test_sd15_r1_latents_per_step_vs_committed_golden(full, dev):
+    """(1a) BASELINE configs[1] rollout length: U-Net LoRA r=4, batch 1, S=20 -- the latents after EVERY scheduler step against the
+    committed oracle trace ("match the reference run's generated latents ... within fp16 tolerance")."""
+    from finetune_fair_diffusion_amd.step import FairnessTrainer
+    om, pm = full
+    g = _gold("oracle_sd15_r1_latents_b1_s20.npz")
+    ref = torch.from_numpy(g["latents"].astype("float32"))
+    args = U.make_args(train_unet=True, train_text_encoder=False, size_face=224)
+    tr = FairnessTrainer(args, pm["text_encoder"], pm["unet"], pm["vae"], pm["classifier"], pm["scheduler"], eval_unet=pm["eval_unet"], device=dev)
+    noises = torch.randn(1, 4, 64, 64, generator=torch.Generator().manual_seed(5991))
+    got = _rollout_latents(tr, pm["unet"], pm["text_encoder"], sd15_tokens(), noises, 20, dev)
+    assert got.shape == ref.shape == (20, 1, 4, 64, 64)
+    _check_latents("SD15 R1 latents B=1 S=20", got, ref, 5e-3, 2.5e-2)
+    img = tr.decode(got[-1].to(dev))
+    import numpy as np
+    pooled = F.avg_pool2d(img.float().cpu(), 64).numpy()
+    print("decoded image, 8x8 block means: max |diff| =", float(np.abs(pooled - g["image_8x8"]).max()))
+    assert np.abs(pooled - g["image_8x8"]).max() < 1e-2
+
+
+def test_sd15_cfg0_step_vs_committed_golden(dev):
+    """(1a) BASELINE configs[0] -- exp-1, batch 2, 4 denoising steps, LoRA r=4 on the text encoder only -- at SD-v1.5 size against the
+    committed oracle run: latents per step, probabilities, exact dynamic targets, uncertainties, loss_fair, three named text-encoder LoRA
+    gradients and a seeded sample of the whole flat gradient."""
+    from finetune_fair_diffusion_amd.step import FairnessTrainer
+    sys.path.insert(0, GOLD)
+    import make_oracle_step_golden as MG
+    g = _gold("oracle_sd15_cfg0_b2_s4_te_lora.npz")
+    sds = U.synthetic_sds(rank=4, train_unet=False, train_te=True, lora_up_std=0.01, size="sd15")
+    pm = U.product_models(sds, dev, train_unet=False, train_te=True, size="sd15", eval_copies=True)
+    args = U.make_args(train_unet=False, train_text_encoder=True, size_face=224, uncertainty_threshold=0.6)
+    tr = FairnessTrainer(args, pm["text_encoder"], pm["unet"], pm["vae"], pm["classifier"], pm["scheduler"],
+                         eval_text_encoder=pm["eval_text_encoder"], device=dev)
+    tokens = sd15_tokens()
+    B, S = 2, 4
+    noises = torch.randn(B, 4, 64, 64, generator=torch.Generator().manual_seed(MG.NOISE_SEED))
+    got = _rollout_latents(tr, pm["unet"], pm["text_encoder"], tokens, noises, S, dev)
+    _check_latents("SD15 cfg0 latents B=2 S=4", got, torch.from_numpy(g["latents"].astype("float32")), 5e-3, 1.2e-2)
+    grads = {}
+    tr.sync_and_update = lambda nb, apply=True: (grads.__setitem__(0, tr.banks[0].grad.clone()), True)[1]
+    out = tr.train_step(tokens, noises, S)
+    check("cfg0: probs", out["probs"], torch.from_numpy(g["probs"]), 2e-2)
+    check("cfg0: probs of the frozen original (R2)", out["probs_ori"], torch.from_numpy(g["probs_ori"]), 2e-2)
+    assert out["targets"].tolist() == g["targets"].tolist(), (out["targets"], g["targets"])
+    check("cfg0: uncertainty", out["uncertainty"], torch.from_numpy(g["uncertainty"]), 2e-2)
+    err = float((out["loss_fair"] - torch.from_numpy(g["loss_fair"])).abs().max())
+    print("cfg0: loss_fair product", out["loss_fair"].tolist(), "golden", g["loss_fair"].tolist(), " max |err| =", err)
+    assert err <= 5e-3
+    bank = tr.banks[0]
+    for n in [str(x) for x in g["named"]]:
+        ref = torch.from_numpy(g["grad::" + n])
+        gp = bank.view(n, grads[0])           # raw accumulated gradient on both sides (the 1 / N_backward is applied at the sync, :1998-2011)
+        cos = float(F.cosine_similarity(gp.flatten().cpu().double(), ref.flatten().double(), dim=0))
+        print(f"cfg0 grad {n}: cosine {cos:.5f}  norm ratio {float(gp.norm().cpu() / ref.norm()):.4f}")
+        assert cos > 0.97
+    names = list(bank.names)
+    flat = torch.cat([bank.view(n, grads[0]).flatten() for n in _te_names_in_oracle_order(bank, g)])
+    idx = MG.grad_sample_index(flat.numel())
+    sample, ref = flat[idx.to(dev)].cpu(), torch.from_numpy(g["grad_sample"])
+    cos = float(F.cosine_similarity(sample.double(), ref.double(), dim=0))
+    ratio = float(flat.double().norm().cpu() / float(g["grad_norm"]))
+    print(f"cfg0 flat TE-LoRA gradient: cosine over the seeded {len(idx)}-entry sample {cos:.5f}  norm ratio {ratio:.4f}  ({len(names)} tensors)")
+    assert cos > 0.97 and 0.8 < ratio < 1.25
+
+
+def _te_names_in_oracle_order(bank, g):
+    """The oracle flattens its text-encoder LoRA parameters in ``named_parameters()`` order; the product bank holds the same names."""
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from oracle import nn_clip
+    te = nn_clip.CLIPTextModel(nn_clip.CLIPTextConfig())
+    nn_clip.modify_text_encoder(te, 4)
+    names = [n for n, _ in te.named_parameters() if "lora_linear_layer" in n]
+    assert set(names) == set(bank.names), (len(names), len(bank.names))
+    return names
+
+
+def test_sd15_smooth_head_step_vs_committed_golden(full, dev):
+    """(1f) The complete step at SD-v1.5 size (B=2, S=2, U-Net LoRA r=4) with a classifier double that has NO discontinuity: the only
+    non-smooth op between the LoRA weights and the loss is images.clamp(-1, 1), so the end-to-end LoRA gradient pins the whole backward
+    chain (VAE backward, truncated DPM-Solver++ chain, 2 x 16 transformer / 22 ResNet backwards) against the oracle's autograd."""
+    from finetune_fair_diffusion_amd.step import FairnessTrainer
+    sys.path.insert(0, GOLD)
+    import make_oracle_step_golden as MG
+    om, pm = full
+    g = _gold("oracle_sd15_smooth_head_b2_s2.npz")
+    head = U.SmoothHeadProduct(*MG.smooth_head_weights(), dev)
+    args = U.make_args(train_unet=True, train_text_encoder=False, size_face=224, uncertainty_threshold=0.7)
+    tr = FairnessTrainer(args, pm["text_encoder"], pm["unet"], pm["vae"], head, pm["scheduler"], eval_unet=pm["eval_unet"], device=dev)
+    B, S = 2, 2
+    noises = torch.randn(B, 4, 64, 64, generator=torch.Generator().manual_seed(MG.NOISE_SEED))
+    grads = {}
+    tr.sync_and_update = lambda nb, apply=True: (grads.__setitem__(0, tr.banks[0].grad.clone()), True)[1]
+    out = tr.train_step(sd15_tokens(), noises, S)
+    assert out["targets"].tolist() == g["targets"].tolist() and int((g["targets"] != -1).sum()) >= 1, (out["targets"], g["targets"])
+    check("smooth head SD15: probs", out["probs"], torch.from_numpy(g["probs"]), 5e-3)
+    err = float((out["loss_fair"] - torch.from_numpy(g["loss_fair"])).abs().max())
+    print("smooth head SD15: loss_fair product", out["loss_fair"].tolist(), "golden", g["loss_fair"].tolist(), " max |err| =", err)
+    assert err <= 5e-3
+    bank = tr.banks[0]
+    names = list(om["unet_lora_layers"].state_dict().keys())
+    flat = torch.cat([bank.view(n, grads[0]).flatten() for n in names])
+    for n in MG.UNET_NAMED:
+        ref = torch.from_numpy(g["grad::" + n])
+        gp = bank.view(n, grads[0])
+        cos = float(F.cosine_similarity(gp.flatten().cpu().double(), ref.flatten().double(), dim=0))
+        print(f"smooth head SD15 grad {n}: cosine {cos:.5f}  rel max err {relerr(gp, ref):.3e}")
+        assert cos > 0.995
+    idx = MG.grad_sample_index(flat.numel())
+    sample, ref = flat[idx.to(dev)].cpu(), torch.from_numpy(g["grad_sample"])
+    cos = float(F.cosine_similarity(sample.double(), ref.double(), dim=0))
+    ratio = float(flat.double().norm().cpu() / float(g["grad_norm"]))
+    emax = float((sample - ref).abs().max() / float(g["grad_absmax"]))
+    print(f"smooth head SD15: end-to-end U-Net LoRA gradient, seeded {len(idx)}-entry sample: cosine {cos:.5f}  norm ratio {ratio:.4f}  max-norm err {emax:.3e}")
+    assert cos > 0.998 and 0.97 < ratio < 1.03 and emax < 4e-2
+
+
+# ------------------------------------------------------------------------------------------ schedule properties at the bench's own size (no oracle)
+def _bench_size_trainer(pm, dev):
+    from finetune_fair_diffusion_amd.step import FairnessTrainer
+    args = U.make_args(train_unet=True, train_text_encoder=False, size_face=224)
+    tr = FairnessTrainer(args, pm["text_encoder"], pm["unet"], pm["vae"], pm["classifier"], pm["scheduler"], eval_unet=pm["eval_unet"], device=dev)
+    grads = {}
+    tr.sync_and_update = lambda nb, apply=True: (grads.__setitem__(0, tr.banks[0].grad.clone()), True)[1]     # no optimiser step: runs stay comparable
+    return tr, grads
+
+
+def test_sd15_b8_s20_shipped_schedule_equals_reference_schedule(full, dev):
+    """(1c) BASELINE configs[1] (B=8, S=20, SD-v1.5 size): the shipped schedule -- R3 consuming R1's recorded forward, R1 || R2 on two HIP
+    streams, the 20 per-timestep backwards dealt to three streams with their own gradient buffers -- against the reference's own order
+    (R1, R2, R3-forward, R3-backward one after the other on ONE stream; FD_NO_SHARE + FD_NO_CONCURRENT_R2 + FD_NO_CONCURRENT_BWD).
+    Same kernels, so images must be BIT-equal and the LoRA gradient equal to fp32 summation-order rounding.  Races are size-dependent:
+    this is the size the bench times."""
+    om, pm = full
+    tr, grads = _bench_size_trainer(pm, dev)
+    noises = torch.randn(8, 4, 64, 64, generator=torch.Generator().manual_seed(77))
+    tokens = sd15_tokens()
+    assert tr.share_r1_r3 and tr.concurrent_r2 and tr.concurrent_bwd and tr.bwd_streams >= 3
+    t0 = time.time()
+    out_a = tr.train_step(tokens, noises, 20)
+    torch.cuda.synchronize()
+    ga = grads[0].clone()
+    print(f"shipped schedule: {time.time() - t0:.2f} s (first call, includes allocator growth); kept timesteps {1 + tr.last_ctx_budget}")
+    tr.share_r1_r3, tr.concurrent_r2, tr.concurrent_bwd = False, False, False
+    out_b = tr.train_step(tokens, noises, 20)
+    torch.cuda.synchronize()
+    gb = grads[0].clone()
+    assert torch.equal(out_a["images"], out_b["images"]) and torch.equal(out_a["images_ori"], out_b["images_ori"])
+    assert out_a["targets"].tolist() == out_b["targets"].tolist() and torch.equal(out_a["loss_fair"], out_b["loss_fair"])
+    assert float(ga.abs().max()) > 0
+    check("B=8 S=20: LoRA gradient, shipped schedule vs single-stream reference order", ga, gb, 2e-4)
+    # and the shipped schedule reproduces itself run to run (atomics and stream interleaving only reorder fp32 sums)
+    tr.share_r1_r3, tr.concurrent_r2, tr.concurrent_bwd = True, True, True
+    out_c = tr.train_step(tokens, noises, 20)
+    torch.cuda.synchronize()
+    assert torch.equal(out_a["images"], out_c["images"])
+    check("B=8 S=20: LoRA gradient, shipped schedule run twice", grads[0], ga, 2e-4)
+
+
+def test_sd15_b8_s50_mixed_keep_recompute_equals_all_recompute(full, dev):
+    """(1b) BASELINE configs[3]'s rollout length (S=50) at B=8, SD-v1.5 size: 50 recorded timesteps (7.8 GB each) do not fit in 288 GB, so the
+    step keeps as many as fit and recomputes the rest right before their backward (step.py rollout_steps / train_step; the reference's
+    gradient checkpointing :748).  The gradient of that MIXED schedule must equal the all-recompute gradient to fp32 rounding."""
+    om, pm = full
+    tr, grads = _bench_size_trainer(pm, dev)
+    noises = torch.randn(8, 4, 64, 64, generator=torch.Generator().manual_seed(78))
+    tokens = sd15_tokens()
+    S = 50
+    out_a = tr.train_step(tokens, noises, S)
+    torch.cuda.synchronize()
+    kept = min(S, 1 + max(tr.last_ctx_budget, 0))
+    ga = grads[0].clone()
+    print(f"S=50 B=8: {kept} of {S} timesteps kept in HBM ({tr.last_ctx_bytes / 2 ** 30:.2f} GiB each), {S - kept} recomputed; "
+          f"peak {torch.cuda.max_memory_allocated() / 2 ** 30:.0f} GiB")
+    assert 1 < kept < S, "the mixed keep / recompute schedule was not exercised"
+    tr.keep_activations = False
+    out_b = tr.train_step(tokens, noises, S)
+    torch.cuda.synchronize()
+    assert tr.keep_activations is False
+    assert torch.equal(out_a["images"], out_b["images"]) and out_a["targets"].tolist() == out_b["targets"].tolist()
+    assert float(ga.abs().max()) > 0 and out_a["grad_is_finite"]
+    check("B=8 S=50: LoRA gradient, mixed keep/recompute vs all-recompute", ga, grads[0], 2e-4)

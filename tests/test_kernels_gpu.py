@@ -475,6 +475,19 @@ def test_small_convs_and_classifier_pieces(ops, dev):
         ref.backward(g.float())
         dx = ops.conv_small_cin_bwd(_nhwc(g), wk, B, H, H, Cin, Cout, 3, stride)
         check(f"small conv bwd s{stride}", dx, xr.grad, 2e-3)
+    # the register-tiled fast path (k = 3, Cin in {3, 4}, Cout % 8 == 0) on the hot-path shapes: U-Net conv_in 4 -> 320 (fp16 NCHW latents),
+    # the classifier stem 3 -> 16, stride 2, hardswish, on an odd-sized image (partial quads, clipped rows and columns), and NHWC input
+    for (ci, co, hh, ww, st, act, nchw) in [(4, 320, 64, 64, 1, "none", True), (3, 16, 45, 37, 2, "hardswish", True), (4, 512, 18, 22, 1, "none", False)]:
+        xs = rnd(3, ci, hh, ww, dev=dev, seed=21)
+        ws = rnd(co, ci, 3, 3, dev=dev, dtype=torch.float32, scale=0.2, seed=22)
+        bs = rnd(co, dev=dev, dtype=torch.float32, seed=23)
+        wks = ws.permute(2, 3, 1, 0).reshape(9 * ci, co).contiguous()
+        ref = F.conv2d(xs.float(), ws, bs, stride=st, padding=1)
+        ref = F.hardswish(ref) if act == "hardswish" else ref
+        xin = xs if nchw else xs.permute(0, 2, 3, 1).contiguous()
+        y, Ho, Wo = ops.conv_small_cin(xin, wks, bs, 3, hh, ww, ci, co, 3, st, nchw=nchw, act=act)
+        assert (Ho, Wo) == tuple(ref.shape[2:])
+        check(f"small conv fast path {ci}->{co} {hh}x{ww} s{st} {act} {'nchw' if nchw else 'nhwc'}", _nchw(y, 3, Ho, Wo), ref, 2e-3)
     w1 = rnd(4, 4, 1, 1, dev=dev, dtype=torch.float32, seed=5)
     y, _, _ = ops.conv_small_cin(x.half(), w1.permute(2, 3, 1, 0).reshape(4, 4).contiguous(), None, B, H, H, 4, 4, 1)
     check("1x1 conv", _nchw(y, B, H, H), F.conv2d(x.half().float(), w1), 2e-3)
