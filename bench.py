@@ -254,17 +254,20 @@ def cpu_baseline(S, full=False):
     """SURVEY 8d / BASELINE.md 3: the oracle (fp32 PyTorch restatement of the reference's diffusers path, stock torch ops) timed on this
     box's host cores on a COMPLETE fairness step at SD-v1.5 size -- BASELINE configs[0]: exp-1, LoRA rank 4 on the text encoder only --
     i.e. R1 + R2 no-grad rollouts, R3 rollout with autograd, VAE, classifier, loss, backward.
-      default   bounded sample: B=1, S=1, one warm-up U-Net call + ONE timed step (tens of seconds; keeps the default bench within minutes)
-      --cpu_baseline_full   the full protocol: cfg1 size B=2, S=4, one warm-up step, median of 3 timed steps (~15 min); its result is
-                committed under profiles/ and quoted in DESIGN.md
-    ``value`` = images/s of the timed sample itself; the extrapolation to configs[1] (B=8, S=20) by algorithmic FLOPs is labelled as such."""
+      default   ``protocol: "bounded_sample"``: B=1, S=1, one un-timed warm-up STEP (thread pools, oneDNN primitive caches -- the same
+                warm-up the protocol prescribes) + ONE timed step (~40 s each on 64 threads); keeps the default bench within minutes
+      --cpu_baseline_full   ``protocol: "cfg1"``: the section-8(d) protocol itself: B=2, S=4, one warm-up step, median of 3 timed steps
+                (~11 min); its result is committed under profiles/ and quoted in DESIGN.md
+    ``value`` = images/s of the timed sample itself; the extrapolation to configs[1] (B=8, S=20) by algorithmic FLOPs is labelled as such.
+    Threads: FD_CPU_THREADS, default min(64, logical CPUs): on the pool's 2-socket 256-thread hosts the oracle's conv / matmul calls stop
+    scaling at one socket's physical cores and get slower beyond (profiles/r03_cpu_baseline_thread_scaling.txt)."""
     import statistics
     import torch
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import util_models as U
     from oracle import fair_step as fs
     ncpu = os.cpu_count() or 1
-    threads = min(ncpu, 64)
+    threads = int(os.environ.get("FD_CPU_THREADS", min(ncpu, 64)))
     torch.set_num_threads(threads)
     B, Sc, reps = (2, 4, 3) if full else (1, 1, 1)
     om = U.oracle_models(rank=4, train_unet=False, train_te=True, lora_up_std=0.01, size="sd15", eval_copies=True)
@@ -282,18 +285,15 @@ def cpu_baseline(S, full=False):
         fs.fairness_step(models, tokens, noises, Sc, cfg)
         return time.perf_counter() - t0
 
-    if full:
-        step()                                                     # warm-up step (thread pools, oneDNN primitive caches)
-    else:
-        with torch.no_grad():                                      # warm-up: one CFG-pair U-Net call
-            om["unet"](torch.randn(2, 4, 64, 64), torch.tensor(500), encoder_hidden_states=torch.randn(2, 13, 768))
+    warm = step()                                                  # warm-up step (thread pools, oneDNN primitive caches), never counted
     times = [step() for _ in range(reps)]
     dt = statistics.median(times)
     flop = B * f_img(Sc)
     return {"value": B / dt, "unit": "images/s", "cores": threads, "kind": "port", "host_cpu_count": ncpu, "cpu_model": cpu_model(),
-            "seconds_per_step": dt, "all_step_seconds": [round(t, 2) for t in times],
+            "protocol": "cfg1" if full else "bounded_sample",
+            "seconds_per_step": dt, "all_step_seconds": [round(t, 2) for t in times], "warmup_step_seconds": round(warm, 2),
             "sample": f"oracle fp32 full fairness step (R1+R2+R3 fwd/bwd, VAE, classifier, loss; exp-1, TE-LoRA r=4, SD-v1.5 512x512) at B={B}, S={Sc}: "
-                      f"{'median of 3 after one warm-up step' if full else 'one timed step after a U-Net warm-up call (bounded sample; --cpu_baseline_full runs cfg1 B=2,S=4, median of 3)'}; "
+                      f"{'SURVEY 8(d) protocol: median of 3 after one warm-up step' if full else 'BOUNDED SAMPLE, not the 8(d) protocol number: one timed step after one warm-up step (--cpu_baseline_full runs the protocol: cfg1 B=2, S=4, median of 3; committed under profiles/)'}; "
                       f"{threads} torch threads on {ncpu} logical CPUs ({cpu_model()})",
             "achieved_tflops": flop / dt / 1e12,
             "extrapolated_to_configs1_images_per_s": (flop / dt) / f_img(S),

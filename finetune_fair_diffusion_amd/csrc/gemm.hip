@@ -647,6 +647,25 @@ static int launch(const fd_gemm_desc& d, hipStream_t s) {
     return fd_check_launch("fd_gemm");
 }
 
+// gemm_pp.hip: the 8-wave 256x320 ping-pong kernel (BK = 32, four-stage ring, two wave groups half a k-step apart)
+bool fd_gemm_pp_eligible(const fd_gemm_desc& d);
+int fd_gemm_launch_pp(const fd_gemm_desc& d, hipStream_t s, bool prio);
+// which 256x320 problems the ping-pong kernel takes: bit 0 = stride-1 3x3 convolutions, bit 1 = dense GEMMs; bit 2 = s_setprio around its MFMA streams
+#ifndef FD_GEMM_PP_DEFAULT
+#define FD_GEMM_PP_DEFAULT 0
+#endif
+static int pp_mode() {
+#ifdef FD_BENCH_HOOKS
+    const char* e = getenv("FD_GEMM_PP");      // measurement build: re-read on every call so one process can A/B the variants
+    return e ? atoi(e) : FD_GEMM_PP_DEFAULT;
+#else
+    return FD_GEMM_PP_DEFAULT;
+#endif
+}
+static bool pp_takes(const fd_gemm_desc& d, int sel) {
+    return sel == 256320 && (pp_mode() & (d.conv ? 1 : 2)) && fd_gemm_pp_eligible(d);
+}
+
 // tile choice (BM*1000+BN): big tiles when the grid still fills 256 CUs a few times over
 extern "C" int fd_gemm_tile(const fd_gemm_desc* dp) {
     const fd_gemm_desc& d = *dp;
@@ -729,7 +748,8 @@ extern "C" int fd_gemm_kernel_name(const fd_gemm_desc* dp, char* buf, int n) {
         case 256128: wgm = 4; wgn = 2; break;
         default: fam = bm == 16 ? "gemm_skinny_kernel" : "gemm_glds_kernel"; break;
     }
-    if (wgm) snprintf(buf, n, "%s<%d, %d, %d, %d, %d>", fam, bm, bn, wgm, wgn, cv);
+    if (pp_takes(d, sel)) snprintf(buf, n, "(anonymous namespace)::gemm_pp_kernel<%d, %s>", d.conv ? 1 : 0, (pp_mode() & 4) ? "true" : "false");
+    else if (wgm) snprintf(buf, n, "%s<%d, %d, %d, %d, %d>", fam, bm, bn, wgm, wgn, cv);
     else if (bm == 16) snprintf(buf, n, "%s<%d, %d, 1>", fam, bn / 16, d.K >= 1280 ? 4 : d.K >= 640 ? 2 : 1);
     else snprintf(buf, n, "%s<%d, %d, %s>", fam, bm, bn, d.conv ? "true" : "false");
     return sel / 1000000;   // split-K factor (0 or 1 = none)
@@ -774,6 +794,7 @@ extern "C" int fd_gemm(const fd_gemm_desc* dp, void* stream) {
     if (sel >= 1000000) {
         return (sel % 1000000 == 128320) ? launch_big<128, 320, 4, 4>(d, s, sel / 1000000) : launch_big<128, 160, 4, 2>(d, s, sel / 1000000);
     }
+    if (pp_takes(d, sel)) return fd_gemm_launch_pp(d, s, (pp_mode() & 4) != 0);
     switch (sel) {
         case 16016: return launch_skinny<1>(d, s);
         case 16032: return launch_skinny<2>(d, s);

@@ -1,0 +1,290 @@
+// "Ping-pong" MFMA GEMM / stride-1 3x3 implicit-GEMM convolution for gfx950 (round 3): 256 x 320 tile, 8 waves, BK = 32, four-stage operand
+// ring with counted vmcnt, and the two halves of the workgroup running HALF A K-STEP APART.
+//
+// Why.  gemm_big_kernel<256, 320, 2, 4> (gemm.hip) keeps its eight waves in lockstep: every k-tile all of them drain vmcnt(0), meet at one
+// barrier, issue the next tile's global_load_lds and restart their fragment reads AT THE SAME TIME, so on each SIMD both resident waves do
+// their non-matrix work together and the matrix pipe idles meanwhile (profiles/r02_gemm_ablation.txt: conv 320 -> 320 @64^2 = 121 us full,
+// 94 us with MFMAs + fragment reads only, 66 us loads only; 44 % of wave-cycles parked on s_waitcnt / barriers,
+// profiles/r02_pmc_sq_wave_cycle_breakdown.txt).  Round 2 measured two coarser restructurings -- a four-stage ring with all waves in
+// lockstep, and two wave groups alternating "read everything" / "multiply everything" -- and both lost.  The guide's 8-phase GEMM gets its
+// speed from neither depth nor phase count but from the two waves of a SIMD being in DIFFERENT roles (MI355X_MICROARCH.md "Two waves per
+// SIMD"): one issues MFMAs while the other does its waits, DMA issue and first LDS reads.
+//
+// How.  Waves 0-3 (rows 0-127 of the tile, group G0) and waves 4-7 (rows 128-255, G1) sit pairwise on the four SIMDs (wave w and w + 4
+// share one).  Both groups run the pinned fragment-streaming loop of gemm_device.h (B resident, A two fragments ahead) over k-steps of 32,
+// but G0 crosses the workgroup barrier in the MIDDLE of its k-step (fragments already in flight: it goes straight on multiplying) while G1
+// crosses it at its k-step BOUNDARY (wait, DMA issue, restart of the fragment reads) -- and G0's own boundary falls in the middle of the
+// interval, where G1 is in mid-stream.  One barrier per k-step as in the lockstep ring, but at every moment one wave of each SIMD is in its
+// MFMA stream.
+//
+//   interval i (between barriers B_i and B_i+1):   G1:  issue L_i+3 | H1(i) H2(i)                        | wait vmcnt -> B_i+1
+//                                                  G0:  H2(i)       | issue L_i+3 | H1(i+1)              | wait vmcnt -> B_i+1
+//   L_s = the global_load_lds of k-step s into ring slot s & 3; H1 / H2 = first / second half of a k-step's MFMAs.
+//
+// Ring safety (4 slots).  Slot s & 3 is read by G0 from mid-interval s-1 to mid-interval s and by G1 during interval s.  L_s+3 overwrites the
+// slot of step s-1: G1 issues it after B_s (it finished step s-1 before arriving there; G0 finished it in interval s-1), G0 issues it after
+// its H2(s) (both groups are past B_s).  Every wave waits, in front of B_s, until only its L_s+2 are outstanding (counted vmcnt: 5 loads
+// per step for waves 0-3, 4 for waves 4-7 -- 36 sixteen-row groups per step), so once B_s is crossed ALL of step s+1's operands have
+// landed -- G0 starts reading them half an interval later, G1 a whole one.  LDS-DMA data is only ever read behind a counted vmcnt AND a
+// barrier every wave has passed.  Loads past the last k-step go from the zero page into a dump area, which keeps the counts uniform.
+// Raw s_barrier: __syncthreads() would fence with vmcnt(0) and drain the ring.
+//
+// Staging image, XOR slot permutation, zero page, swapped-operand v_mfma_f32_16x16x32 arrangement, second K-slab (LoRA rank update) and the
+// LDS-staged epilogues are those of the other GEMM kernels (gemm_device.h).
+#include "gemm_device.h"
+
+namespace {
+
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ void raw_barrier() { asm volatile("s_barrier" ::: "memory"); }
+
+// one k = 32 step of the 128 x 80 wave tile: B fragments resident, A fragments streamed PD ahead (mma_k32 of gemm_device.h), with a hook
+// that runs between the two halves of the step -- the point where the leading group crosses the workgroup barrier
+// PRIO: s_setprio(1) from the first to the last MFMA of the step -- with the two waves of a SIMD in different roles the arbiter has something
+// to decide (the wave in its MFMA stream outranks the one doing boundary work); in a lockstep loop it is a no-op
+template <int TM, int TN, int PD, int GS, bool PRIO, class MID>
+__device__ __forceinline__ void mma_k32_mid(f32x4 (&acc)[TM][TN], uint32_t a_addr, uint32_t b_addr, MID&& mid) {
+    static_assert(TN <= TM, "B resident");
+    constexpr int R = PD + 1;
+    f16x8 res[TN], ring[R];
+    static_for<0, TN>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        ds_read16<i * GS>(res[i], b_addr);
+    });
+    static_for<0, PD>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        ds_read16<i * GS>(ring[i % R], a_addr);
+    });
+    if (PRIO) __builtin_amdgcn_s_setprio(1);
+    static_for<0, TM>([&](auto ic) {
+        constexpr int s = decltype(ic)::value;
+        if constexpr (s + PD < TM) ds_read16<(s + PD) * GS>(ring[(s + PD) % R], a_addr);
+        constexpr int after = (TM - 1 - s) < PD ? (TM - 1 - s) : PD;
+        wait_lgkm<after>();
+        if constexpr (s == 0) {
+#pragma unroll
+            for (int r = 0; r < TN; ++r) tie(res[r]);
+        }
+        tie(ring[s % R]);
+#pragma unroll
+        for (int r = 0; r < TN; ++r) acc[s][r] = FD_MFMA_16x16x32(res[r], ring[s % R], acc[s][r]);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (s == TM / 2 - 1) {
+            mid();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    });
+    if (PRIO) __builtin_amdgcn_s_setprio(0);
+}
+
+constexpr int PP_BM = 256, PP_BN = 320, PP_NW = 8, PP_NST = 4;
+constexpr int PP_GROUP = 16 * 32;                       // halfs per 16-row group (16 rows x 64 bytes = 1 KB = one global_load_lds_dwordx4)
+constexpr int PP_NGA = PP_BM / 16, PP_NGB = PP_BN / 16; // 16 A groups + 20 B groups per k-step
+constexpr int PP_STAGE = (PP_NGA + PP_NGB) * PP_GROUP;  // 36 KB
+constexpr size_t PP_LDS = (size_t)(PP_NST * PP_STAGE + PP_NW * PP_GROUP) * sizeof(f16);   // ring + one dump group per wave = 152 KB
+
+template <int CONV, bool PRIO>
+__global__ __launch_bounds__(512) void gemm_pp_kernel(fd_gemm_desc p, int ntm, int ntn, int gn) {
+    constexpr int WTM = 128, WTN = 80, TM = 8, TN = 5;
+    extern __shared__ __attribute__((aligned(16))) f16 smem[];
+    const f16* zp = fd_zero_page;        // GOT load pinned in SGPRs (see gemm.hip)
+    asm volatile("" : "+s"(zp));
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, lg = lane >> 4;
+    const int wm = wave >> 2, wn = wave & 3;
+    const bool lead = wave < 4;          // G0: crosses the barriers in mid-step
+
+    int tile = xcd_remap(blockIdx.x, gridDim.x);
+    int mt, nt;
+    if (gn >= ntn) {
+        mt = tile / ntn;
+        nt = tile - mt * ntn;
+    } else {
+        const int per = ntm * gn, nbands = (ntn + gn - 1) / gn;
+        const int band = min(tile / per, nbands - 1);
+        const int r = tile - band * per;
+        const int w = band == nbands - 1 ? ntn - band * gn : gn;
+        mt = r / w;
+        nt = band * gn + (r - mt * w);
+    }
+    const int m0 = mt * PP_BM, n0 = nt * PP_BN;
+
+    const f16* A = (const f16*)p.A;
+    const f16* B = (const f16*)p.B;
+    const f16* A2 = (const f16*)p.A2;
+    const f16* B2 = (const f16*)p.B2;
+    const int nk1 = (p.K + 31) >> 5, nk2 = (p.K2 + 31) >> 5, nk = nk1 + nk2;
+
+    // this lane's slot in a 16-row group: row lane >> 2, 16-byte slot lane & 3 holding k-chunk (slot ^ G[row >> 2])  (gemm_glds_kernel's image)
+    const int lrow = lane >> 2;
+    const int kchunk = ((lane & 3) ^ swz_g(lane >> 4)) * 8;
+    // wave w stages groups w, w + 8, ... of the 36: two A groups (w, w + 8) and three (w < 4: w + 16, w + 24, w + 32) or two B groups
+    int a_off[2], a_mask[2];             // dense: row offset in elements (or -1); conv: centre-pixel offset + 9-bit tap mask
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = m0 + (wave + 8 * i) * 16 + lrow;
+        const bool valid = m < p.M;
+        if (CONV) {
+            const int hw = p.Ho * p.Wo;
+            const int mm = valid ? m : 0;
+            const int b = mm / hw;
+            const int r = mm - b * hw;
+            const int oy = r / p.Wo;
+            const int ox = r - oy * p.Wo;
+            int mask = 0;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int iy = oy + t / 3 - 1, ix = ox + t % 3 - 1;
+                if (valid && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) mask |= 1 << t;
+            }
+            a_off[i] = (int)(((int64_t)(b * p.H + oy) * p.W + ox) * p.lda) + kchunk;     // < 2^31 elements (checked by fd_gemm)
+            a_mask[i] = mask;
+        } else {
+            a_off[i] = valid ? m : -1;
+            a_mask[i] = 0;
+        }
+    }
+    int b_row[3];                        // B row index n (or -1)
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int n = n0 + (wave + 8 * i) * 16 + lrow;       // group 16 + wave + 8 i  <->  B rows (wave + 8 i) * 16 ..
+        b_row[i] = (n < p.N && (wave + 8 * i) < PP_NGB) ? n : -1;
+    }
+    f16* const dump = smem + PP_NST * PP_STAGE + wave * PP_GROUP;
+
+    // NL global_load_lds per call: 2 A groups + (NL - 2) B groups
+    auto issue = [&](int kt, auto nl_c) {
+        constexpr int NL = decltype(nl_c)::value;
+        if (kt >= nk) {                  // past the last k-step: keep the per-step load count uniform
+#pragma unroll
+            for (int i = 0; i < NL; ++i) glds16(zp, dump);
+            return;
+        }
+        f16* st = smem + (kt & 3) * PP_STAGE;
+        if (CONV) {
+            // k order = (32-channel chunk, tap): the 9 taps of a chunk re-read the same lines shifted by a pixel
+            const int cc = kt / 9;
+            const int tap = kt - cc * 9;
+            const int c0 = cc << 5;
+            const int ky = tap / 3, kx = tap - ky * 3;
+            const int toff = ((ky - 1) * p.W + (kx - 1)) * (int)p.lda + c0;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const f16* src = ((a_mask[i] >> tap) & 1) ? A + (int64_t)(a_off[i] + toff) : zp;
+                glds16(src, st + (wave + 8 * i) * PP_GROUP);
+            }
+            const int kk = tap * p.Cin + c0 + kchunk;
+#pragma unroll
+            for (int i = 0; i < NL - 2; ++i) {
+                const f16* src = b_row[i] >= 0 ? B + (int64_t)b_row[i] * p.ldb + kk : zp;
+                glds16(src, st + (PP_NGA + wave + 8 * i) * PP_GROUP);
+            }
+        } else {
+            const bool seg2 = kt >= nk1;
+            const f16* Ap = seg2 ? A2 : A;
+            const f16* Bp = seg2 ? B2 : B;
+            const int64_t la = seg2 ? p.lda2 : p.lda, lb = seg2 ? p.ldb2 : p.ldb;
+            const int Kseg = seg2 ? p.K2 : p.K;
+            const int kk = (seg2 ? kt - nk1 : kt) * 32 + kchunk;
+            const bool kok = kk < Kseg;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const f16* src = (kok && a_off[i] >= 0) ? Ap + (int64_t)a_off[i] * la + kk : zp;
+                glds16(src, st + (wave + 8 * i) * PP_GROUP);
+            }
+#pragma unroll
+            for (int i = 0; i < NL - 2; ++i) {
+                const f16* src = (kok && b_row[i] >= 0) ? Bp + (int64_t)b_row[i] * lb + kk : zp;
+                glds16(src, st + (PP_NGA + wave + 8 * i) * PP_GROUP);
+            }
+        }
+    };
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // fragment read offset inside a 16-row group: row l15, slot (lg ^ G[l15 >> 2])
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)smem;
+    const uint32_t frag = (uint32_t)(l15 * 32 + ((lg ^ swz_g(l15 >> 2)) * 8)) * 2;
+    const uint32_t a_frag = lds0 + (uint32_t)(wm * (WTM / 16) * PP_GROUP) * 2 + frag;
+    const uint32_t b_frag = lds0 + (uint32_t)((PP_NGA + wn * (WTN / 16)) * PP_GROUP) * 2 + frag;
+    constexpr uint32_t STAGE_B = PP_STAGE * 2, GROUP_B = PP_GROUP * 2;
+
+    if (lead) {
+        constexpr int NL = 5;
+        std::integral_constant<int, NL> nl;
+        issue(0, nl); issue(1, nl); issue(2, nl);
+        wait_vm<2 * NL>();               // L_0 landed
+        raw_barrier();                   // B_-1
+        for (int i = 0; i < nk; ++i) {
+            const uint32_t so = (uint32_t)(i & 3) * STAGE_B;
+            mma_k32_mid<TM, TN, 2, GROUP_B, PRIO>(acc, a_frag + so, b_frag + so, [&] {
+                wait_vm<NL>();           // this wave's L_i+1 landed (L_i+2 stays in flight)
+                raw_barrier();           // B_i, crossed in mid-step
+            });
+            issue(i + 3, nl);            // into the slot of step i-1: every wave is past B_i, i.e. done with it
+        }
+    } else {
+        constexpr int NL = 4;
+        std::integral_constant<int, NL> nl;
+        issue(0, nl); issue(1, nl); issue(2, nl);
+        wait_vm<2 * NL>();
+        raw_barrier();                   // B_-1
+        for (int i = 0; i < nk; ++i) {
+            wait_vm<NL>();
+            raw_barrier();               // B_i, crossed at the step boundary
+            issue(i + 3, nl);
+            const uint32_t so = (uint32_t)(i & 3) * STAGE_B;
+            mma_k32_mid<TM, TN, 2, GROUP_B, PRIO>(acc, a_frag + so, b_frag + so, [] {});
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // drain the pad loads before the ring is reused by the epilogue
+    __syncthreads();
+
+    const bool lds_epi = p.out_dtype == FD_OUT_F16 && (p.N & 7) == 0 && (p.ldc & 7) == 0 && (!p.residual || (p.ldr & 7) == 0) &&
+                         (!p.rowbias || (p.ld_rowbias & 3) == 0);
+    constexpr int TMC = TM / 2;          // 8 waves x 64 rows x 84 halfs = 84 KB of staging per pass
+    if (p.act == FD_ACT_GEGLU) {
+        gemm_epilogue_geglu_lds<TM, TN, TMC>(p, acc, smem + wave * (TMC * 16) * (WTN + 4), m0 + wm * WTM, n0 + wn * WTN, lane);
+    } else if (lds_epi) {
+        gemm_epilogue_lds<TM, TN, TMC>(p, acc, smem + wave * (TMC * 16) * (WTN + 4), m0 + wm * WTM, n0 + wn * WTN, lane, 0, 0);
+    } else {
+        gemm_epilogue<TM, TN>(p, acc, m0 + wm * WTM, n0 + wn * WTN, l15, lg, 0, 0);
+    }
+}
+
+}  // namespace
+
+bool fd_gemm_pp_eligible(const fd_gemm_desc& d) {
+    if (d.batch > 1 || (d.N % 320) != 0) return false;
+    if (d.conv) return d.conv_mode == FD_CONV_NORMAL && (d.Cin & 31) == 0 && d.K2 == 0;
+    return (d.K & 7) == 0;
+}
+
+template <int CONV, bool PRIO>
+static void launch_pp(const fd_gemm_desc& d, hipStream_t s, int ntm, int ntn, int gn) {
+    static std::once_flag once;
+    std::call_once(once, [] {
+        (void)hipFuncSetAttribute((const void*)gemm_pp_kernel<CONV, PRIO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PP_LDS);
+    });
+    hipLaunchKernelGGL((gemm_pp_kernel<CONV, PRIO>), dim3(ntm * ntn), dim3(512), PP_LDS, s, d, ntm, ntn, gn);
+}
+
+int fd_gemm_launch_pp(const fd_gemm_desc& d, hipStream_t s, bool prio) {
+    const int ntm = (d.M + PP_BM - 1) / PP_BM, ntn = d.N / PP_BN;
+    const long l2_budget = 3 * 1024 * 1024;
+    const long ktot = (long)d.K + d.K2;
+    long gnl = l2_budget / ((long)PP_BN * ktot * 2);
+    const int gn = (int)(gnl < 1 ? 1 : (gnl > ntn ? ntn : gnl));
+    if (d.conv) { if (prio) launch_pp<1, true>(d, s, ntm, ntn, gn); else launch_pp<1, false>(d, s, ntm, ntn, gn); }
+    else { if (prio) launch_pp<0, true>(d, s, ntm, ntn, gn); else launch_pp<0, false>(d, s, ntm, ntn, gn); }
+    return fd_check_launch("fd_gemm(pp)");
+}

@@ -181,13 +181,15 @@ def test_sd15_full_step_b2_s2(full, dev):
     check("SD15 step: R2 images", out["images_ori"], ref["images_ori"], 3e-2)
     check("SD15 step: probs", out["probs"], ref["probs"], 2e-2)
     assert out["targets"].tolist() == ref["targets"].tolist() and (ref["targets"] != -1).all(), (out["targets"], ref["targets"])
-    check("SD15 step: loss_fair", out["loss_fair"], ref["loss_fair"], 1e-2)
+    check("SD15 step: loss_fair", out["loss_fair"], ref["loss_fair"], 3e-3)       # measured 6.3e-4 .. 1.3e-3 (fp16 forward vs the fp32 oracle)
     names = list(om["unet_lora_layers"].state_dict().keys())
     refg = torch.cat([p.grad.flatten() for p in om["unet_lora_layers"].parameters()])
     got = torch.cat([tr.banks[0].view(n, grads[0]).flatten() for n in names])
     cos = float(F.cosine_similarity(got.cpu().double(), refg.double(), dim=0))
     print("cosine(SD15 step unet grads) =", cos, " norm ratio =", float(got.norm().cpu() / refg.norm()))
-    assert cos > 0.97 and 0.8 < float(got.norm().cpu() / refg.norm()) < 1.25
+    # ReLU / clamp mask flips of the random-weight MobileNetV3 bound this one (measured 0.980 .. 0.987, ratio 0.967 .. 0.999); the same step with
+    # a smooth head is pinned at cosine 0.9998 against the committed golden (test_sd15_smooth_head_step_vs_committed_golden)
+    assert cos > 0.975 and 0.93 < float(got.norm().cpu() / refg.norm()) < 1.07
 
 
 @pytest.mark.parametrize("rank", [4, 50])
@@ -305,7 +307,7 @@ def test_sd15_r1_latents_per_step_vs_committed_golden(full, dev):
     noises = torch.randn(1, 4, 64, 64, generator=torch.Generator().manual_seed(5991))
     got = _rollout_latents(tr, pm["unet"], pm["text_encoder"], sd15_tokens(), noises, 20, dev)
     assert got.shape == ref.shape == (20, 1, 4, 64, 64)
-    _check_latents("SD15 R1 latents B=1 S=20", got, ref, 5e-3, 2.5e-2)
+    _check_latents("SD15 R1 latents B=1 S=20", got, ref, 5e-3, 5e-3)       # measured 1.9e-3 .. 2.0e-3 at every one of the 20 steps
     img = tr.decode(got[-1].to(dev))
     import numpy as np
     pooled = F.avg_pool2d(img.float().cpu(), 64).numpy()
@@ -330,7 +332,7 @@ def test_sd15_cfg0_step_vs_committed_golden(dev):
     B, S = 2, 4
     noises = torch.randn(B, 4, 64, 64, generator=torch.Generator().manual_seed(MG.NOISE_SEED))
     got = _rollout_latents(tr, pm["unet"], pm["text_encoder"], tokens, noises, S, dev)
-    _check_latents("SD15 cfg0 latents B=2 S=4", got, torch.from_numpy(g["latents"].astype("float32")), 5e-3, 1.2e-2)
+    _check_latents("SD15 cfg0 latents B=2 S=4", got, torch.from_numpy(g["latents"].astype("float32")), 8e-3, 8e-3)     # measured 3.1e-3 .. 3.3e-3
     grads = {}
     tr.sync_and_update = lambda nb, apply=True: (grads.__setitem__(0, tr.banks[0].grad.clone()), True)[1]
     out = tr.train_step(tokens, noises, S)
@@ -340,7 +342,7 @@ def test_sd15_cfg0_step_vs_committed_golden(dev):
     check("cfg0: uncertainty", out["uncertainty"], torch.from_numpy(g["uncertainty"]), 2e-2)
     err = float((out["loss_fair"] - torch.from_numpy(g["loss_fair"])).abs().max())
     print("cfg0: loss_fair product", out["loss_fair"].tolist(), "golden", g["loss_fair"].tolist(), " max |err| =", err)
-    assert err <= 5e-3
+    assert err <= 2e-3                   # measured 6.8e-4 (north star: "loss ... within 1e-3")
     bank = tr.banks[0]
     for n in [str(x) for x in g["named"]]:
         ref = torch.from_numpy(g["grad::" + n])
@@ -390,7 +392,7 @@ def test_sd15_smooth_head_step_vs_committed_golden(full, dev):
     check("smooth head SD15: probs", out["probs"], torch.from_numpy(g["probs"]), 5e-3)
     err = float((out["loss_fair"] - torch.from_numpy(g["loss_fair"])).abs().max())
     print("smooth head SD15: loss_fair product", out["loss_fair"].tolist(), "golden", g["loss_fair"].tolist(), " max |err| =", err)
-    assert err <= 5e-3
+    assert err <= 2e-3                   # measured 6.7e-4
     bank = tr.banks[0]
     names = list(om["unet_lora_layers"].state_dict().keys())
     flat = torch.cat([bank.view(n, grads[0]).flatten() for n in names])
@@ -406,10 +408,30 @@ def test_sd15_smooth_head_step_vs_committed_golden(full, dev):
     ratio = float(flat.double().norm().cpu() / float(g["grad_norm"]))
     emax = float((sample - ref).abs().max() / float(g["grad_absmax"]))
     print(f"smooth head SD15: end-to-end U-Net LoRA gradient, seeded {len(idx)}-entry sample: cosine {cos:.5f}  norm ratio {ratio:.4f}  max-norm err {emax:.3e}")
-    assert cos > 0.998 and 0.97 < ratio < 1.03 and emax < 4e-2
+    assert cos > 0.9995 and 0.99 < ratio < 1.01 and emax < 2.5e-2      # measured 0.99985 / 0.9966 / 1.17e-2
 
 
 # ------------------------------------------------------------------------------------------ schedule properties at the bench's own size (no oracle)
+def _check_grad_equal_to_rounding(name, bank, ga, gb):
+    """Two schedules of the same step run the same kernels on the same data; what may differ is the ORDER of fp32 sums:
+      * every LoRA tensor but attn2.to_k / to_v: per-stream fp32 accumulation buffers summed in a different order -> fp32 rounding (2e-5 of
+        max |g|; measured ~1e-6);
+      * attn2.to_k / to_v (and whatever sits behind them: text-encoder LoRA, prefix vectors): their gradient passes through the shared
+        cross-attention dK / dV accumulators -- fp32 atomics from 8 samples x S timesteps x 3 streams, order free -- which are rounded to the
+        16-bit working dtype ONCE before the two small projection backwards (unet.finish_cross_backward): a sum that lands on the other side of
+        an fp16 rounding boundary moves that element by one ulp (4.9e-4 relative), hence 4e-3 of max |g| for these two families."""
+    kv = [n for n in bank.names if ".attn2.processor.to_k_lora." in n or ".attn2.processor.to_v_lora." in n]
+    rest = [n for n in bank.names if n not in set(kv)]
+    assert kv and rest
+    for fam, names, tol in (("all but attn2.to_k/to_v", rest, 2e-5), ("attn2.to_k/to_v (behind the fp16-rounded dK/dV accumulators)", kv, 4e-3)):
+        a = torch.cat([bank.view(n, ga).flatten() for n in names])
+        b = torch.cat([bank.view(n, gb).flatten() for n in names])
+        check(f"{name}: {fam}", a, b, tol)
+    cos = float(F.cosine_similarity(ga.double(), gb.double(), dim=0))
+    print(f"{name}: cosine over the whole flat gradient {cos:.9f}")
+    assert cos > 0.999999
+
+
 def _bench_size_trainer(pm, dev):
     from finetune_fair_diffusion_amd.step import FairnessTrainer
     args = U.make_args(train_unet=True, train_text_encoder=False, size_face=224)
@@ -442,13 +464,13 @@ def test_sd15_b8_s20_shipped_schedule_equals_reference_schedule(full, dev):
     assert torch.equal(out_a["images"], out_b["images"]) and torch.equal(out_a["images_ori"], out_b["images_ori"])
     assert out_a["targets"].tolist() == out_b["targets"].tolist() and torch.equal(out_a["loss_fair"], out_b["loss_fair"])
     assert float(ga.abs().max()) > 0
-    check("B=8 S=20: LoRA gradient, shipped schedule vs single-stream reference order", ga, gb, 2e-4)
+    _check_grad_equal_to_rounding("B=8 S=20, shipped schedule vs single-stream reference order", tr.banks[0], ga, gb)
     # and the shipped schedule reproduces itself run to run (atomics and stream interleaving only reorder fp32 sums)
     tr.share_r1_r3, tr.concurrent_r2, tr.concurrent_bwd = True, True, True
     out_c = tr.train_step(tokens, noises, 20)
     torch.cuda.synchronize()
     assert torch.equal(out_a["images"], out_c["images"])
-    check("B=8 S=20: LoRA gradient, shipped schedule run twice", grads[0], ga, 2e-4)
+    _check_grad_equal_to_rounding("B=8 S=20, shipped schedule run twice", tr.banks[0], grads[0], ga)
 
 
 def test_sd15_b8_s50_mixed_keep_recompute_equals_all_recompute(full, dev):
@@ -473,4 +495,4 @@ def test_sd15_b8_s50_mixed_keep_recompute_equals_all_recompute(full, dev):
     assert tr.keep_activations is False
     assert torch.equal(out_a["images"], out_b["images"]) and out_a["targets"].tolist() == out_b["targets"].tolist()
     assert float(ga.abs().max()) > 0 and out_a["grad_is_finite"]
-    check("B=8 S=50: LoRA gradient, mixed keep/recompute vs all-recompute", ga, grads[0], 2e-4)
+    _check_grad_equal_to_rounding("B=8 S=50, mixed keep/recompute vs all-recompute", tr.banks[0], ga, grads[0])
