@@ -501,6 +501,13 @@ __global__ void splitk_reduce_kernel(fd_gemm_desc p, int nsplit) {
     }
 }
 
+static int launch_splitk_reduce(const fd_gemm_desc& d, hipStream_t s, int nsplit) {
+    int64_t blocks = ((int64_t)d.M * d.N / 4 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, d, nsplit);
+    return fd_check_launch("fd_gemm(split-K reduce)");
+}
+
 template <int BM, int BN, int WGM, int WGN>
 static int launch_big(const fd_gemm_desc& d, hipStream_t s, int nsplit = 1) {
     const int ntm = (d.M + BM - 1) / BM, ntn = (d.N + BN - 1) / BN;
@@ -521,11 +528,7 @@ static int launch_big(const fd_gemm_desc& d, hipStream_t s, int nsplit = 1) {
         hipLaunchKernelGGL((gemm_big_kernel<BM, BN, WGM, WGN, 2>), dim3(ntm * ntn * nph, nsplit), dim3(WGM * WGN * 64), lds, s, d, ntm, ntn, gn);
     else if (d.conv) hipLaunchKernelGGL((gemm_big_kernel<BM, BN, WGM, WGN, 1>), dim3(ntm * ntn, nsplit), dim3(WGM * WGN * 64), lds, s, d, ntm, ntn, gn);
     else hipLaunchKernelGGL((gemm_big_kernel<BM, BN, WGM, WGN, 0>), dim3(ntm * ntn, nsplit), dim3(WGM * WGN * 64), lds, s, d, ntm, ntn, gn);
-    if (nsplit > 1) {
-        int64_t blocks = ((int64_t)d.M * d.N / 4 + 255) / 256;
-        if (blocks > 2048) blocks = 2048;
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, d, nsplit);
-    }
+    if (nsplit > 1) return launch_splitk_reduce(d, s, nsplit);
     return fd_check_launch("fd_gemm(big)");
 }
 
@@ -649,10 +652,15 @@ static int launch(const fd_gemm_desc& d, hipStream_t s) {
 
 // gemm_pp.hip: the 8-wave 256x320 ping-pong kernel (BK = 32, four-stage ring, two wave groups half a k-step apart)
 bool fd_gemm_pp_eligible(const fd_gemm_desc& d);
-int fd_gemm_launch_pp(const fd_gemm_desc& d, hipStream_t s, bool prio);
-// which 256x320 problems the ping-pong kernel takes: bit 0 = stride-1 3x3 convolutions, bit 1 = dense GEMMs; bit 2 = s_setprio around its MFMA streams
+int fd_gemm_launch_pp(const fd_gemm_desc& d, hipStream_t s, bool prio, int bm, int nsplit);
+// Which problems the ping-pong kernels take (bits): 1 = stride-1 3x3 convolutions on the 256x320 tile, 2 = every dense GEMM on it,
+// 4 = s_setprio around the MFMA streams, 8 = stride-1 convolutions on the 128x320 tile (split-K included), 16 = dense GEMMs on it,
+// 32 = dense 256x320 GEMMs with K <= 384 and N >= 2560 only (the FF1 projections of the 64^2 level).
+// Measured on the step's shapes (profiles/r03_gemm_pingpong_ab.txt): long-K convolutions +19..26 % (640 -> 320 @64^2: 252 -> 207 us,
+// 1280 -> 640 @32^2: 361 -> 287 us), FF1 @64^2 +9 %; the other dense shapes stay on the 16-wave lockstep kernel (4 waves per SIMD hide
+// more of a short K loop's latency than the role split returns: 65536x320x1280 65 vs 77 us).
 #ifndef FD_GEMM_PP_DEFAULT
-#define FD_GEMM_PP_DEFAULT 0
+#define FD_GEMM_PP_DEFAULT (1 | 4 | 32)
 #endif
 static int pp_mode() {
 #ifdef FD_BENCH_HOOKS
@@ -662,8 +670,17 @@ static int pp_mode() {
     return FD_GEMM_PP_DEFAULT;
 #endif
 }
-static bool pp_takes(const fd_gemm_desc& d, int sel) {
-    return sel == 256320 && (pp_mode() & (d.conv ? 1 : 2)) && fd_gemm_pp_eligible(d);
+// 0 = not taken, else the tile height (256 / 128)
+static int pp_takes(const fd_gemm_desc& d, int sel) {
+    const int t = sel % 1000000, split = sel / 1000000, m = pp_mode();
+    if (!m || !fd_gemm_pp_eligible(d)) return 0;
+    if (t == 256320 && split == 0) {
+        if (d.conv) return (m & 1) ? 256 : 0;
+        if ((m & 2) || ((m & 32) && d.K + d.K2 <= 384 && d.N >= 2560)) return 256;
+        return 0;
+    }
+    if (t == 128320) return (m & (d.conv ? 8 : 16)) ? 128 : 0;
+    return 0;
 }
 
 // tile choice (BM*1000+BN): big tiles when the grid still fills 256 CUs a few times over
@@ -748,7 +765,7 @@ extern "C" int fd_gemm_kernel_name(const fd_gemm_desc* dp, char* buf, int n) {
         case 256128: wgm = 4; wgn = 2; break;
         default: fam = bm == 16 ? "gemm_skinny_kernel" : "gemm_glds_kernel"; break;
     }
-    if (pp_takes(d, sel)) snprintf(buf, n, "(anonymous namespace)::gemm_pp_kernel<%d, %s>", d.conv ? 1 : 0, (pp_mode() & 4) ? "true" : "false");
+    if (pp_takes(d, sel)) snprintf(buf, n, "(anonymous namespace)::gemm_pp_kernel<%d, %d, %s>", pp_takes(d, sel), d.conv ? 1 : 0, (pp_mode() & 4) ? "true" : "false");
     else if (wgm) snprintf(buf, n, "%s<%d, %d, %d, %d, %d>", fam, bm, bn, wgm, wgn, cv);
     else if (bm == 16) snprintf(buf, n, "%s<%d, %d, 1>", fam, bn / 16, d.K >= 1280 ? 4 : d.K >= 640 ? 2 : 1);
     else snprintf(buf, n, "%s<%d, %d, %s>", fam, bm, bn, d.conv ? "true" : "false");
@@ -794,7 +811,12 @@ extern "C" int fd_gemm(const fd_gemm_desc* dp, void* stream) {
     if (sel >= 1000000) {
         return (sel % 1000000 == 128320) ? launch_big<128, 320, 4, 4>(d, s, sel / 1000000) : launch_big<128, 160, 4, 2>(d, s, sel / 1000000);
     }
-    if (pp_takes(d, sel)) return fd_gemm_launch_pp(d, s, (pp_mode() & 4) != 0);
+    if (const int bm = pp_takes(d, sel)) {
+        const int nsplit = sel >= 1000000 ? sel / 1000000 : 1;
+        const int rc = fd_gemm_launch_pp(d, s, (pp_mode() & 4) != 0, bm, nsplit);
+        if (rc != 0 || nsplit == 1) return rc;
+        return launch_splitk_reduce(d, s, nsplit);
+    }
     switch (sel) {
         case 16016: return launch_skinny<1>(d, s);
         case 16032: return launch_skinny<2>(d, s);

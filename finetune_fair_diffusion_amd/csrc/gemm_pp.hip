@@ -1,5 +1,5 @@
-// "Ping-pong" MFMA GEMM / stride-1 3x3 implicit-GEMM convolution for gfx950 (round 3): 256 x 320 tile, 8 waves, BK = 32, four-stage operand
-// ring with counted vmcnt, and the two halves of the workgroup running HALF A K-STEP APART.
+// "Ping-pong" MFMA GEMM / stride-1 3x3 implicit-GEMM convolution for gfx950 (round 3): 256 x 320 or 128 x 320 tile, 8 waves, BK = 32,
+// four-stage operand ring with counted vmcnt, and the two halves of the workgroup running HALF A K-STEP APART.
 //
 // Why.  gemm_big_kernel<256, 320, 2, 4> (gemm.hip) keeps its eight waves in lockstep: every k-tile all of them drain vmcnt(0), meet at one
 // barrier, issue the next tile's global_load_lds and restart their fragment reads AT THE SAME TIME, so on each SIMD both resident waves do
@@ -25,7 +25,7 @@
 // slot of step s-1: G1 issues it after B_s (it finished step s-1 before arriving there; G0 finished it in interval s-1), G0 issues it after
 // its H2(s) (both groups are past B_s).  Every wave waits, in front of B_s, until only its L_s+2 are outstanding (counted vmcnt: 5 loads
 // per step for waves 0-3, 4 for waves 4-7 -- 36 sixteen-row groups per step), so once B_s is crossed ALL of step s+1's operands have
-// landed -- G0 starts reading them half an interval later, G1 a whole one.  LDS-DMA data is only ever read behind a counted vmcnt AND a
+// landed -- G0 starts reading them half an interval later, G1 a whole one.  (128 x 320: 28 groups per step, 4 / 3 loads per wave.)  LDS-DMA data is only ever read behind a counted vmcnt AND a
 // barrier every wave has passed.  Loads past the last k-step go from the zero page into a dump area, which keeps the counts uniform.
 // Raw s_barrier: __syncthreads() would fence with vmcnt(0) and drain the ring.
 //
@@ -41,38 +41,42 @@ __device__ __forceinline__ void wait_vm() {
 }
 __device__ __forceinline__ void raw_barrier() { asm volatile("s_barrier" ::: "memory"); }
 
-// one k = 32 step of the 128 x 80 wave tile: B fragments resident, A fragments streamed PD ahead (mma_k32 of gemm_device.h), with a hook
-// that runs between the two halves of the step -- the point where the leading group crosses the workgroup barrier
+// one k = 32 step of a wave tile: the operand with fewer fragments resident, the other streamed PD ahead (mma_k32 of gemm_device.h), with
+// a hook that runs between the two halves of the step -- the point where the leading group crosses the workgroup barrier.
 // PRIO: s_setprio(1) from the first to the last MFMA of the step -- with the two waves of a SIMD in different roles the arbiter has something
 // to decide (the wave in its MFMA stream outranks the one doing boundary work); in a lockstep loop it is a no-op
 template <int TM, int TN, int PD, int GS, bool PRIO, class MID>
 __device__ __forceinline__ void mma_k32_mid(f32x4 (&acc)[TM][TN], uint32_t a_addr, uint32_t b_addr, MID&& mid) {
-    static_assert(TN <= TM, "B resident");
-    constexpr int R = PD + 1;
-    f16x8 res[TN], ring[R];
-    static_for<0, TN>([&](auto ic) {
+    constexpr bool BRES = TN <= TM;   // the operand with fewer fragments stays resident for the step
+    constexpr int NR = BRES ? TN : TM, NS = BRES ? TM : TN, R = PD + 1;
+    const uint32_t r_addr = BRES ? b_addr : a_addr, s_addr = BRES ? a_addr : b_addr;
+    f16x8 res[NR], ring[R];
+    static_for<0, NR>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
-        ds_read16<i * GS>(res[i], b_addr);
+        ds_read16<i * GS>(res[i], r_addr);
     });
     static_for<0, PD>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
-        ds_read16<i * GS>(ring[i % R], a_addr);
+        ds_read16<i * GS>(ring[i % R], s_addr);
     });
     if (PRIO) __builtin_amdgcn_s_setprio(1);
-    static_for<0, TM>([&](auto ic) {
+    static_for<0, NS>([&](auto ic) {
         constexpr int s = decltype(ic)::value;
-        if constexpr (s + PD < TM) ds_read16<(s + PD) * GS>(ring[(s + PD) % R], a_addr);
-        constexpr int after = (TM - 1 - s) < PD ? (TM - 1 - s) : PD;
+        if constexpr (s + PD < NS) ds_read16<(s + PD) * GS>(ring[(s + PD) % R], s_addr);
+        constexpr int after = (NS - 1 - s) < PD ? (NS - 1 - s) : PD;
         wait_lgkm<after>();
         if constexpr (s == 0) {
 #pragma unroll
-            for (int r = 0; r < TN; ++r) tie(res[r]);
+            for (int r = 0; r < NR; ++r) tie(res[r]);
         }
         tie(ring[s % R]);
 #pragma unroll
-        for (int r = 0; r < TN; ++r) acc[s][r] = FD_MFMA_16x16x32(res[r], ring[s % R], acc[s][r]);
+        for (int r = 0; r < NR; ++r) {
+            if constexpr (BRES) acc[s][r] = FD_MFMA_16x16x32(res[r], ring[s % R], acc[s][r]);
+            else acc[r][s] = FD_MFMA_16x16x32(ring[s % R], res[r], acc[r][s]);
+        }
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (s == TM / 2 - 1) {
+        if constexpr (s == NS / 2 - 1) {
             mid();
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -80,15 +84,17 @@ __device__ __forceinline__ void mma_k32_mid(f32x4 (&acc)[TM][TN], uint32_t a_add
     if (PRIO) __builtin_amdgcn_s_setprio(0);
 }
 
-constexpr int PP_BM = 256, PP_BN = 320, PP_NW = 8, PP_NST = 4;
+constexpr int PP_BN = 320, PP_NW = 8, PP_NST = 4;
 constexpr int PP_GROUP = 16 * 32;                       // halfs per 16-row group (16 rows x 64 bytes = 1 KB = one global_load_lds_dwordx4)
-constexpr int PP_NGA = PP_BM / 16, PP_NGB = PP_BN / 16; // 16 A groups + 20 B groups per k-step
-constexpr int PP_STAGE = (PP_NGA + PP_NGB) * PP_GROUP;  // 36 KB
-constexpr size_t PP_LDS = (size_t)(PP_NST * PP_STAGE + PP_NW * PP_GROUP) * sizeof(f16);   // ring + one dump group per wave = 152 KB
+constexpr int PP_NGB = PP_BN / 16;                      // 20 B groups per k-step
+template <int BM> constexpr int pp_stage() { return (BM / 16 + PP_NGB) * PP_GROUP; }      // 36 KB (BM = 256) / 28 KB (BM = 128)
+template <int BM> constexpr size_t pp_lds() { return (size_t)(PP_NST * pp_stage<BM>() + PP_NW * PP_GROUP) * sizeof(f16); }   // ring + a dump group per wave
 
-template <int CONV, bool PRIO>
+template <int BM, int CONV, bool PRIO>
 __global__ __launch_bounds__(512) void gemm_pp_kernel(fd_gemm_desc p, int ntm, int ntn, int gn) {
-    constexpr int WTM = 128, WTN = 80, TM = 8, TN = 5;
+    constexpr int WTM = BM / 2, WTN = 80, TM = WTM / 16, TN = 5;
+    constexpr int NGA = BM / 16, NAW = NGA / PP_NW;      // A groups per k-step, per wave (2 or 1)
+    constexpr int STAGE = pp_stage<BM>();
     extern __shared__ __attribute__((aligned(16))) f16 smem[];
     const f16* zp = fd_zero_page;        // GOT load pinned in SGPRs (see gemm.hip)
     asm volatile("" : "+s"(zp));
@@ -112,21 +118,25 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(fd_gemm_desc p, int ntm, i
         mt = r / w;
         nt = band * gn + (r - mt * w);
     }
-    const int m0 = mt * PP_BM, n0 = nt * PP_BN;
+    const int m0 = mt * BM, n0 = nt * PP_BN;
 
     const f16* A = (const f16*)p.A;
     const f16* B = (const f16*)p.B;
     const f16* A2 = (const f16*)p.A2;
     const f16* B2 = (const f16*)p.B2;
-    const int nk1 = (p.K + 31) >> 5, nk2 = (p.K2 + 31) >> 5, nk = nk1 + nk2;
+    const int nk1 = (p.K + 31) >> 5, nk2 = (p.K2 + 31) >> 5, nkt = nk1 + nk2;
+    // split-K: blockIdx.y owns the k-steps [kbeg, kend) and writes raw fp32 partials to the workspace
+    const int nsplit = gridDim.y;
+    const int kbeg = (int)((int64_t)nkt * blockIdx.y / nsplit), kend = (int)((int64_t)nkt * (blockIdx.y + 1) / nsplit);
+    const int nk = kend - kbeg;
 
     // this lane's slot in a 16-row group: row lane >> 2, 16-byte slot lane & 3 holding k-chunk (slot ^ G[row >> 2])  (gemm_glds_kernel's image)
     const int lrow = lane >> 2;
     const int kchunk = ((lane & 3) ^ swz_g(lane >> 4)) * 8;
-    // wave w stages groups w, w + 8, ... of the 36: two A groups (w, w + 8) and three (w < 4: w + 16, w + 24, w + 32) or two B groups
-    int a_off[2], a_mask[2];             // dense: row offset in elements (or -1); conv: centre-pixel offset + 9-bit tap mask
+    // wave w stages A groups w (+ 8) and B groups w, w + 8 (, w + 16 for w < 4): 5 / 4 loads per step at BM = 256, 4 / 3 at BM = 128
+    int a_off[NAW], a_mask[NAW];         // dense: row index (or -1); conv: centre-pixel offset + 9-bit tap mask
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < NAW; ++i) {
         const int m = m0 + (wave + 8 * i) * 16 + lrow;
         const bool valid = m < p.M;
         if (CONV) {
@@ -152,20 +162,21 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(fd_gemm_desc p, int ntm, i
     int b_row[3];                        // B row index n (or -1)
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-        const int n = n0 + (wave + 8 * i) * 16 + lrow;       // group 16 + wave + 8 i  <->  B rows (wave + 8 i) * 16 ..
+        const int n = n0 + (wave + 8 * i) * 16 + lrow;
         b_row[i] = (n < p.N && (wave + 8 * i) < PP_NGB) ? n : -1;
     }
-    f16* const dump = smem + PP_NST * PP_STAGE + wave * PP_GROUP;
+    f16* const dump = smem + PP_NST * STAGE + wave * PP_GROUP;
 
-    // NL global_load_lds per call: 2 A groups + (NL - 2) B groups
-    auto issue = [&](int kt, auto nl_c) {
+    // NL global_load_lds per call: NAW A groups + (NL - NAW) B groups, for local k-step j (global step kbeg + j) into ring slot j & 3
+    auto issue = [&](int j, auto nl_c) {
         constexpr int NL = decltype(nl_c)::value;
-        if (kt >= nk) {                  // past the last k-step: keep the per-step load count uniform
+        if (j >= nk) {                   // past the last k-step: keep the per-step load count uniform
 #pragma unroll
             for (int i = 0; i < NL; ++i) glds16(zp, dump);
             return;
         }
-        f16* st = smem + (kt & 3) * PP_STAGE;
+        const int kt = kbeg + j;
+        f16* st = smem + (j & 3) * STAGE;
         if (CONV) {
             // k order = (32-channel chunk, tap): the 9 taps of a chunk re-read the same lines shifted by a pixel
             const int cc = kt / 9;
@@ -174,15 +185,15 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(fd_gemm_desc p, int ntm, i
             const int ky = tap / 3, kx = tap - ky * 3;
             const int toff = ((ky - 1) * p.W + (kx - 1)) * (int)p.lda + c0;
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
+            for (int i = 0; i < NAW; ++i) {
                 const f16* src = ((a_mask[i] >> tap) & 1) ? A + (int64_t)(a_off[i] + toff) : zp;
                 glds16(src, st + (wave + 8 * i) * PP_GROUP);
             }
             const int kk = tap * p.Cin + c0 + kchunk;
 #pragma unroll
-            for (int i = 0; i < NL - 2; ++i) {
+            for (int i = 0; i < NL - NAW; ++i) {
                 const f16* src = b_row[i] >= 0 ? B + (int64_t)b_row[i] * p.ldb + kk : zp;
-                glds16(src, st + (PP_NGA + wave + 8 * i) * PP_GROUP);
+                glds16(src, st + (NGA + wave + 8 * i) * PP_GROUP);
             }
         } else {
             const bool seg2 = kt >= nk1;
@@ -193,14 +204,14 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(fd_gemm_desc p, int ntm, i
             const int kk = (seg2 ? kt - nk1 : kt) * 32 + kchunk;
             const bool kok = kk < Kseg;
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
+            for (int i = 0; i < NAW; ++i) {
                 const f16* src = (kok && a_off[i] >= 0) ? Ap + (int64_t)a_off[i] * la + kk : zp;
                 glds16(src, st + (wave + 8 * i) * PP_GROUP);
             }
 #pragma unroll
-            for (int i = 0; i < NL - 2; ++i) {
+            for (int i = 0; i < NL - NAW; ++i) {
                 const f16* src = (kok && b_row[i] >= 0) ? Bp + (int64_t)b_row[i] * lb + kk : zp;
-                glds16(src, st + (PP_NGA + wave + 8 * i) * PP_GROUP);
+                glds16(src, st + (NGA + wave + 8 * i) * PP_GROUP);
             }
         }
     };
@@ -215,11 +226,11 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(fd_gemm_desc p, int ntm, i
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)smem;
     const uint32_t frag = (uint32_t)(l15 * 32 + ((lg ^ swz_g(l15 >> 2)) * 8)) * 2;
     const uint32_t a_frag = lds0 + (uint32_t)(wm * (WTM / 16) * PP_GROUP) * 2 + frag;
-    const uint32_t b_frag = lds0 + (uint32_t)((PP_NGA + wn * (WTN / 16)) * PP_GROUP) * 2 + frag;
-    constexpr uint32_t STAGE_B = PP_STAGE * 2, GROUP_B = PP_GROUP * 2;
+    const uint32_t b_frag = lds0 + (uint32_t)((NGA + wn * (WTN / 16)) * PP_GROUP) * 2 + frag;
+    constexpr uint32_t STAGE_B = STAGE * 2, GROUP_B = PP_GROUP * 2;
 
     if (lead) {
-        constexpr int NL = 5;
+        constexpr int NL = NAW + 3;
         std::integral_constant<int, NL> nl;
         issue(0, nl); issue(1, nl); issue(2, nl);
         wait_vm<2 * NL>();               // L_0 landed
@@ -233,7 +244,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(fd_gemm_desc p, int ntm, i
             issue(i + 3, nl);            // into the slot of step i-1: every wave is past B_i, i.e. done with it
         }
     } else {
-        constexpr int NL = 4;
+        constexpr int NL = NAW + 2;
         std::integral_constant<int, NL> nl;
         issue(0, nl); issue(1, nl); issue(2, nl);
         wait_vm<2 * NL>();
@@ -246,12 +257,27 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(fd_gemm_desc p, int ntm, i
             mma_k32_mid<TM, TN, 2, GROUP_B, PRIO>(acc, a_frag + so, b_frag + so, [] {});
         }
     }
+    if (nsplit > 1) {                    // raw fp32 partials; splitk_reduce_kernel (gemm.hip) sums the slabs in a fixed order and applies the epilogue
+        float* ws = (float*)p.workspace + (int64_t)blockIdx.y * p.M * p.N;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = m0 + wm * WTM + i * 16 + l15;
+            if (m >= p.M) continue;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + wn * WTN + j * 16 + lg * 4;
+                if (n < p.N) *(f32x4*)(ws + (int64_t)m * p.N + n) = acc[i][j];
+            }
+        }
+        return;
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // drain the pad loads before the ring is reused by the epilogue
     __syncthreads();
 
     const bool lds_epi = p.out_dtype == FD_OUT_F16 && (p.N & 7) == 0 && (p.ldc & 7) == 0 && (!p.residual || (p.ldr & 7) == 0) &&
                          (!p.rowbias || (p.ld_rowbias & 3) == 0);
-    constexpr int TMC = TM / 2;          // 8 waves x 64 rows x 84 halfs = 84 KB of staging per pass
+    constexpr int TMC = BM == 256 ? TM / 2 : TM;             // 8 waves x 64 rows x 84 halfs = 84 KB of staging per pass
+    static_assert(PP_NW * TMC * 16 * (WTN + 4) <= PP_NST * STAGE, "epilogue staging does not fit the ring");
     if (p.act == FD_ACT_GEGLU) {
         gemm_epilogue_geglu_lds<TM, TN, TMC>(p, acc, smem + wave * (TMC * 16) * (WTN + 4), m0 + wm * WTM, n0 + wn * WTN, lane);
     } else if (lds_epi) {
@@ -259,6 +285,26 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(fd_gemm_desc p, int ntm, i
     } else {
         gemm_epilogue<TM, TN>(p, acc, m0 + wm * WTM, n0 + wn * WTN, l15, lg, 0, 0);
     }
+}
+
+template <int BM, int CONV, bool PRIO>
+void launch_pp(const fd_gemm_desc& d, hipStream_t s, int ntm, int ntn, int gn, int nsplit) {
+    static std::once_flag once;
+    std::call_once(once, [] {
+        (void)hipFuncSetAttribute((const void*)gemm_pp_kernel<BM, CONV, PRIO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pp_lds<BM>());
+    });
+    hipLaunchKernelGGL((gemm_pp_kernel<BM, CONV, PRIO>), dim3(ntm * ntn, nsplit), dim3(512), pp_lds<BM>(), s, d, ntm, ntn, gn);
+}
+
+template <int BM>
+void launch_pp_bm(const fd_gemm_desc& d, hipStream_t s, bool prio, int nsplit) {
+    const int ntm = (d.M + BM - 1) / BM, ntn = d.N / PP_BN;
+    const long l2_budget = 3 * 1024 * 1024;
+    const long ktot = ((long)d.K + d.K2) / nsplit;
+    long gnl = l2_budget / ((long)PP_BN * ktot * 2);
+    const int gn = (int)(gnl < 1 ? 1 : (gnl > ntn ? ntn : gnl));
+    if (d.conv) { if (prio) launch_pp<BM, 1, true>(d, s, ntm, ntn, gn, nsplit); else launch_pp<BM, 1, false>(d, s, ntm, ntn, gn, nsplit); }
+    else { if (prio) launch_pp<BM, 0, true>(d, s, ntm, ntn, gn, nsplit); else launch_pp<BM, 0, false>(d, s, ntm, ntn, gn, nsplit); }
 }
 
 }  // namespace
@@ -269,22 +315,9 @@ bool fd_gemm_pp_eligible(const fd_gemm_desc& d) {
     return (d.K & 7) == 0;
 }
 
-template <int CONV, bool PRIO>
-static void launch_pp(const fd_gemm_desc& d, hipStream_t s, int ntm, int ntn, int gn) {
-    static std::once_flag once;
-    std::call_once(once, [] {
-        (void)hipFuncSetAttribute((const void*)gemm_pp_kernel<CONV, PRIO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PP_LDS);
-    });
-    hipLaunchKernelGGL((gemm_pp_kernel<CONV, PRIO>), dim3(ntm * ntn), dim3(512), PP_LDS, s, d, ntm, ntn, gn);
-}
-
-int fd_gemm_launch_pp(const fd_gemm_desc& d, hipStream_t s, bool prio) {
-    const int ntm = (d.M + PP_BM - 1) / PP_BM, ntn = d.N / PP_BN;
-    const long l2_budget = 3 * 1024 * 1024;
-    const long ktot = (long)d.K + d.K2;
-    long gnl = l2_budget / ((long)PP_BN * ktot * 2);
-    const int gn = (int)(gnl < 1 ? 1 : (gnl > ntn ? ntn : gnl));
-    if (d.conv) { if (prio) launch_pp<1, true>(d, s, ntm, ntn, gn); else launch_pp<1, false>(d, s, ntm, ntn, gn); }
-    else { if (prio) launch_pp<0, true>(d, s, ntm, ntn, gn); else launch_pp<0, false>(d, s, ntm, ntn, gn); }
+// bm: 256 or 128 rows per tile; nsplit > 1: split-K partials into d.workspace (the caller launches the reduction)
+int fd_gemm_launch_pp(const fd_gemm_desc& d, hipStream_t s, bool prio, int bm, int nsplit) {
+    if (bm == 256) launch_pp_bm<256>(d, s, prio, nsplit);
+    else launch_pp_bm<128>(d, s, prio, nsplit);
     return fd_check_launch("fd_gemm(pp)");
 }

@@ -156,7 +156,8 @@ static void launch_conv_small_fast_a(const void* x, const float* w, const float*
     const int slots = 256 / (Cout / 8);
     const int64_t nq = (int64_t)B * Ho * ((Wo + 3) / 4);
     int64_t blocks = (nq + slots - 1) / slots;
-    if (blocks > 4096) blocks = 4096;         // each block first stages the weights: a few quads per slot amortise that
+    if (blocks > 512) blocks = 512;           // two workgroups per CU; each first stages the weights (46 KB at Cout = 320): with one pass of quads
+                                              // per workgroup that staging was most of the kernel (145 us for the U-Net conv_in at 1366 workgroups)
     hipLaunchKernelGGL((conv_small_cin_fast_kernel<XT, CIN, STRIDE, NCHW, HAS_ACT>), dim3((unsigned)blocks), dim3(256), lds, s, (const XT*)x, w, bias, (f16*)y, B,
                        H, W, Cout, Ho, Wo, act);
 }
@@ -419,29 +420,51 @@ __global__ void crop_resize_fwd_kernel(const f16* img, const int32_t* boxes, flo
         chips[i] = (f16)v;
     }
 }
-// dchips [B,3,S,S] fp32 -> dimg [B,3,H,W] fp32 (atomically accumulated; caller zeroes dimg)
+// dchips [B,3,S,S] fp32 -> dimg [B,3,H,W] fp32, ADDED to what dimg holds (the caller zeroes it or passes an accumulator).
+// Gather form, one thread per image pixel: the chip pixels whose bilinear footprint contains the pixel form a small contiguous range per
+// axis (the source coordinate is monotonic in the output index), visited in a fixed order -- the result is bit-reproducible.  The scatter
+// form with fp32 atomics this replaces made dL/d(image), and through the VAE backward's one fp16 rounding every LoRA gradient of the step,
+// vary from run to run at the fp16-ulp level (1e-3 of max |g| between two identical steps).
+__device__ __forceinline__ void bilinear_taps(int p, int in_size, int out_size, int& lo, int& hi) {
+    // output indices o whose two source taps can include source index p: src(o) in [p - 1, p + 1)  (+- 1 of slack, filtered exactly later)
+    const float r = (float)out_size / (float)in_size;
+    lo = (int)floorf(((float)p - 0.5f) * r - 0.5f) - 1;
+    hi = (int)ceilf(((float)p + 1.5f) * r - 0.5f) + 1;
+    if (lo < 0) lo = 0;
+    if (hi > out_size - 1) hi = out_size - 1;
+}
 __global__ void crop_resize_bwd_kernel(const float* dchips, const int32_t* boxes, float* dimg, int H, int W, int S, int64_t n) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const int ox = (int)(i % S);
-        int64_t p = i / S;
-        const int oy = (int)(p % S); p /= S;
+        const int xx = (int)(i % W);
+        int64_t p = i / W;
+        const int yy = (int)(p % H); p /= H;
         const int c = (int)(p % 3);
         const int b = (int)(p / 3);
         const int x0 = boxes[b * 4], y0 = boxes[b * 4 + 1], x1 = boxes[b * 4 + 2], y1 = boxes[b * 4 + 3];
-        int ya, yb, xa, xb;
-        float ly, lx;
-        bilinear_src(oy, y1 - y0, S, ya, yb, ly);
-        bilinear_src(ox, x1 - x0, S, xa, xb, lx);
-        float* ip = dimg + ((int64_t)b * 3 + c) * H * W;
-        const float g = dchips[i];
-        auto put = [&](int py, int px, float wgt) {
-            const int yy = y0 + py, xx = x0 + px;
-            if (yy >= 0 && yy < H && xx >= 0 && xx < W) atomicAdd(ip + (int64_t)yy * W + xx, g * wgt);
-        };
-        put(ya, xa, (1.f - ly) * (1.f - lx));
-        put(ya, xb, (1.f - ly) * lx);
-        put(yb, xa, ly * (1.f - lx));
-        put(yb, xb, ly * lx);
+        const int px = xx - x0, py = yy - y0;
+        if (px < 0 || py < 0 || px >= x1 - x0 || py >= y1 - y0) continue;
+        int oylo, oyhi, oxlo, oxhi;
+        bilinear_taps(py, y1 - y0, S, oylo, oyhi);
+        bilinear_taps(px, x1 - x0, S, oxlo, oxhi);
+        const float* gp = dchips + ((int64_t)b * 3 + c) * S * S;
+        float acc = 0.f;
+        for (int oy = oylo; oy <= oyhi; ++oy) {
+            int ya, yb;
+            float ly;
+            bilinear_src(oy, y1 - y0, S, ya, yb, ly);
+            const float wy = (ya == py ? 1.f - ly : 0.f) + (yb == py ? ly : 0.f);
+            if (wy == 0.f) continue;
+            float row = 0.f;
+            for (int ox = oxlo; ox <= oxhi; ++ox) {
+                int xa, xb;
+                float lx;
+                bilinear_src(ox, x1 - x0, S, xa, xb, lx);
+                const float wx = (xa == px ? 1.f - lx : 0.f) + (xb == px ? lx : 0.f);
+                row += wx * gp[(int64_t)oy * S + ox];
+            }
+            acc += wy * row;
+        }
+        dimg[i] += acc;
     }
 }
 extern "C" int fd_crop_resize_fwd(const void* img, const int32_t* boxes, float fill, void* chips, int B, int H, int W, int S, void* stream) {
@@ -450,7 +473,7 @@ extern "C" int fd_crop_resize_fwd(const void* img, const int32_t* boxes, float f
     return fd_check_launch("fd_crop_resize_fwd");
 }
 extern "C" int fd_crop_resize_bwd(const float* dchips, const int32_t* boxes, float* dimg, int B, int H, int W, int S, void* stream) {
-    const int64_t n = (int64_t)B * 3 * S * S;
+    const int64_t n = (int64_t)B * 3 * H * W;       // one thread per IMAGE pixel (gather)
     hipLaunchKernelGGL(crop_resize_bwd_kernel, grid1d(n), dim3(256), 0, (hipStream_t)stream, dchips, boxes, dimg, H, W, S, n);
     return fd_check_launch("fd_crop_resize_bwd");
 }

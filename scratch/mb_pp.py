@@ -1,6 +1,6 @@
 """A/B of the ping-pong 256x320 kernel (csrc/gemm_pp.hip) against the shipped lockstep kernels on the step's shapes, with a correctness check.
 Needs the bench-hooks library (make BENCH_HOOKS=1; FAIRDIFF_LIB=.../libfairdiff_hip_bench.so): FD_GEMM_PP is re-read on every call there.
-    FD_GEMM_PP: 0 shipped kernels, 1 conv -> pp, 2 dense -> pp, 3 both, +4 s_setprio"""
+    FD_GEMM_PP bits: 1 conv 256x320, 2 dense 256x320, 4 s_setprio, 8 conv 128x320 (split-K included), 16 dense 128x320 (gemm.hip pp_takes)"""
 import os
 import sys
 
@@ -32,14 +32,14 @@ def timeit(fn, n=20):
 
 def run(name, fn, flops):
     outs, ts = {}, {}
-    for mode in (0, 3, 7):
+    for mode in (0, 27, 31):
         os.environ["FD_GEMM_PP"] = str(mode)
         outs[mode] = fn().float()
         ts[mode] = timeit(fn)
     ref = outs[0]
-    e3 = float((outs[3] - ref).abs().max() / ref.abs().max())
-    e7 = float((outs[7] - ref).abs().max() / ref.abs().max())
-    print(f"{name:44s} shipped {ts[0]:7.1f} us ({flops / ts[0] / 1e6:6.0f} TF/s)  pp {ts[3]:7.1f} us ({flops / ts[3] / 1e6:6.0f})  pp+prio {ts[7]:7.1f} us ({flops / ts[7] / 1e6:6.0f})"
+    e3 = float((outs[27] - ref).abs().max() / ref.abs().max())
+    e7 = float((outs[31] - ref).abs().max() / ref.abs().max())
+    print(f"{name:44s} shipped {ts[0]:7.1f} us ({flops / ts[0] / 1e6:6.0f} TF/s)  pp {ts[27]:7.1f} us ({flops / ts[27] / 1e6:6.0f})  pp+prio {ts[31]:7.1f} us ({flops / ts[31] / 1e6:6.0f})"
           f"   max rel diff vs shipped {e3:.1e} / {e7:.1e}", flush=True)
     assert e3 < 2e-3 and e7 < 2e-3, name
 
@@ -66,6 +66,9 @@ if __name__ == "__main__":
     conv(3, 16, 352, 320, residual=True)
     gemm(4096 + 40, 320, 352)
     gemm(25600, 640, 320, residual=True, k2=8)
+    conv(2, 16, 1280, 1280)                 # 128x320 tile
+    conv(3, 8, 1280, 1280, residual=True)   # 128x320 tile, split-K
+    gemm(4096 + 24, 1280, 1280 + 32, residual=True)
     # the step's shapes (CFG batch 16)
     conv(16, 64, 320, 320)
     conv(16, 64, 320, 320, residual=True)
@@ -83,3 +86,14 @@ if __name__ == "__main__":
     gemm(16384, 5120, 640, act="geglu")
     gemm(16384, 640, 640, residual=True)
     gemm(16384, 1920, 640, k2=24)
+    # 16^2 / 8^2 levels: the 128x320 tile (8^2: split-K)
+    conv(16, 16, 1280, 1280)
+    conv(16, 16, 1280, 1280, residual=True)
+    conv(16, 16, 2560, 1280)
+    conv(16, 16, 1920, 1280)
+    conv(16, 8, 1280, 1280)
+    conv(16, 8, 2560, 1280)
+    gemm(4096, 1280, 5120, residual=True)
+    gemm(4096, 1280, 1280, residual=True)
+    gemm(4096, 10240, 1280, act="geglu")
+    gemm(4096, 3840, 1280, k2=24)
