@@ -654,13 +654,17 @@ static int launch(const fd_gemm_desc& d, hipStream_t s) {
 bool fd_gemm_pp_eligible(const fd_gemm_desc& d);
 int fd_gemm_launch_pp(const fd_gemm_desc& d, hipStream_t s, bool prio, int bm, int nsplit);
 // Which problems the ping-pong kernels take (bits): 1 = stride-1 3x3 convolutions on the 256x320 tile, 2 = every dense GEMM on it,
-// 4 = s_setprio around the MFMA streams, 8 = stride-1 convolutions on the 128x320 tile (split-K included), 16 = dense GEMMs on it,
-// 32 = dense 256x320 GEMMs with K <= 384 and N >= 2560 only (the FF1 projections of the 64^2 level).
-// Measured on the step's shapes (profiles/r03_gemm_pingpong_ab.txt): long-K convolutions +19..26 % (640 -> 320 @64^2: 252 -> 207 us,
-// 1280 -> 640 @32^2: 361 -> 287 us), FF1 @64^2 +9 %; the other dense shapes stay on the 16-wave lockstep kernel (4 waves per SIMD hide
-// more of a short K loop's latency than the role split returns: 65536x320x1280 65 vs 77 us).
+// 4 = s_setprio around the MFMA streams, 8 = stride-1 convolutions on the 128x320 tile, 16 = dense GEMMs on it, 32 = dense 256x320 GEMMs
+// with K <= 384 and N >= 2560 only (the FF1 projections of the 64^2 level), 64 = split-K launches of the 128x320 tile too.
+// Measured on the step's shapes against the lockstep kernels (profiles/r03_gemm_pingpong_ab_v2.txt, isolated launches, us):
+//   conv 640 -> 320 @64^2 250 -> 207, 960 -> 320 361 -> 296, 320 -> 320 122 -> 110; conv 1280 -> 640 @32^2 359 -> 288, 1920 -> 640 524 -> 415;
+//   conv 1280 -> 1280 @16^2 (128x320) 223 -> 191, 2560 -> 1280 429 -> 359 (+17..26 %); FF1 @64^2 206 -> 185 (+10 %);
+//   s_setprio is worth 3-9 % of that (it does nothing in a lockstep loop, as the guide says).
+// Left on the lockstep kernels: the other dense shapes (short K loops: four waves per SIMD hide more than the role split returns,
+// 65536x320x1280 65 vs 76 us; 128x320 dense within +-3 %) and the split-K launches of the 8^2 level (45 k-steps per slice: 54 vs 61 us).
+// Whole step, same box, bench-hooks library (profiles/r03_step_ab_pingpong.txt): 1497 ms without, 1453-1469 ms with.
 #ifndef FD_GEMM_PP_DEFAULT
-#define FD_GEMM_PP_DEFAULT (1 | 4 | 32)
+#define FD_GEMM_PP_DEFAULT (1 | 4 | 8 | 32)
 #endif
 static int pp_mode() {
 #ifdef FD_BENCH_HOOKS
@@ -679,7 +683,7 @@ static int pp_takes(const fd_gemm_desc& d, int sel) {
         if ((m & 2) || ((m & 32) && d.K + d.K2 <= 384 && d.N >= 2560)) return 256;
         return 0;
     }
-    if (t == 128320) return (m & (d.conv ? 8 : 16)) ? 128 : 0;
+    if (t == 128320 && (split == 0 || (m & 64))) return (m & (d.conv ? 8 : 16)) ? 128 : 0;
     return 0;
 }
 
@@ -765,7 +769,7 @@ extern "C" int fd_gemm_kernel_name(const fd_gemm_desc* dp, char* buf, int n) {
         case 256128: wgm = 4; wgn = 2; break;
         default: fam = bm == 16 ? "gemm_skinny_kernel" : "gemm_glds_kernel"; break;
     }
-    if (pp_takes(d, sel)) snprintf(buf, n, "(anonymous namespace)::gemm_pp_kernel<%d, %d, %s>", pp_takes(d, sel), d.conv ? 1 : 0, (pp_mode() & 4) ? "true" : "false");
+    if (pp_takes(d, sel)) snprintf(buf, n, "gemm_pp_kernel<%d, %d, %s>", pp_takes(d, sel), d.conv ? 1 : 0, (pp_mode() & 4) ? "true" : "false");
     else if (wgm) snprintf(buf, n, "%s<%d, %d, %d, %d, %d>", fam, bm, bn, wgm, wgn, cv);
     else if (bm == 16) snprintf(buf, n, "%s<%d, %d, 1>", fam, bn / 16, d.K >= 1280 ? 4 : d.K >= 640 ? 2 : 1);
     else snprintf(buf, n, "%s<%d, %d, %s>", fam, bm, bn, d.conv ? "true" : "false");

@@ -33,20 +33,18 @@
 // LDS-staged epilogues are those of the other GEMM kernels (gemm_device.h).
 #include "gemm_device.h"
 
-namespace {
-
 template <int N>
-__device__ __forceinline__ void wait_vm() {
+static __device__ __forceinline__ void wait_vm() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
-__device__ __forceinline__ void raw_barrier() { asm volatile("s_barrier" ::: "memory"); }
+static __device__ __forceinline__ void raw_barrier() { asm volatile("s_barrier" ::: "memory"); }
 
 // one k = 32 step of a wave tile: the operand with fewer fragments resident, the other streamed PD ahead (mma_k32 of gemm_device.h), with
 // a hook that runs between the two halves of the step -- the point where the leading group crosses the workgroup barrier.
 // PRIO: s_setprio(1) from the first to the last MFMA of the step -- with the two waves of a SIMD in different roles the arbiter has something
 // to decide (the wave in its MFMA stream outranks the one doing boundary work); in a lockstep loop it is a no-op
 template <int TM, int TN, int PD, int GS, bool PRIO, class MID>
-__device__ __forceinline__ void mma_k32_mid(f32x4 (&acc)[TM][TN], uint32_t a_addr, uint32_t b_addr, MID&& mid) {
+static __device__ __forceinline__ void mma_k32_mid(f32x4 (&acc)[TM][TN], uint32_t a_addr, uint32_t b_addr, MID&& mid) {
     constexpr bool BRES = TN <= TM;   // the operand with fewer fragments stays resident for the step
     constexpr int NR = BRES ? TN : TM, NS = BRES ? TM : TN, R = PD + 1;
     const uint32_t r_addr = BRES ? b_addr : a_addr, s_addr = BRES ? a_addr : b_addr;
@@ -288,7 +286,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(fd_gemm_desc p, int ntm, i
 }
 
 template <int BM, int CONV, bool PRIO>
-void launch_pp(const fd_gemm_desc& d, hipStream_t s, int ntm, int ntn, int gn, int nsplit) {
+static void launch_pp(const fd_gemm_desc& d, hipStream_t s, int ntm, int ntn, int gn, int nsplit) {
     static std::once_flag once;
     std::call_once(once, [] {
         (void)hipFuncSetAttribute((const void*)gemm_pp_kernel<BM, CONV, PRIO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pp_lds<BM>());
@@ -297,7 +295,7 @@ void launch_pp(const fd_gemm_desc& d, hipStream_t s, int ntm, int ntn, int gn, i
 }
 
 template <int BM>
-void launch_pp_bm(const fd_gemm_desc& d, hipStream_t s, bool prio, int nsplit) {
+static void launch_pp_bm(const fd_gemm_desc& d, hipStream_t s, bool prio, int nsplit) {
     const int ntm = (d.M + BM - 1) / BM, ntn = d.N / PP_BN;
     const long l2_budget = 3 * 1024 * 1024;
     const long ktot = ((long)d.K + d.K2) / nsplit;
@@ -306,8 +304,6 @@ void launch_pp_bm(const fd_gemm_desc& d, hipStream_t s, bool prio, int nsplit) {
     if (d.conv) { if (prio) launch_pp<BM, 1, true>(d, s, ntm, ntn, gn, nsplit); else launch_pp<BM, 1, false>(d, s, ntm, ntn, gn, nsplit); }
     else { if (prio) launch_pp<BM, 0, true>(d, s, ntm, ntn, gn, nsplit); else launch_pp<BM, 0, false>(d, s, ntm, ntn, gn, nsplit); }
 }
-
-}  // namespace
 
 bool fd_gemm_pp_eligible(const fd_gemm_desc& d) {
     if (d.batch > 1 || (d.N % 320) != 0) return false;

@@ -14,7 +14,7 @@ import util_models as U  # noqa: E402
 om = U.oracle_models(rank=4, train_unet=False, train_te=True, lora_up_std=0.01, size="sd15", eval_copies=False)
 x, enc = torch.randn(2, 4, 64, 64), torch.randn(2, 13, 768)
 print("logical CPUs:", os.cpu_count())
-for th in (32, 64, 128, os.cpu_count()):
+for th in (8, 16, 24, 32, 48, 64):     # 128 -> 9.6 s, 256 -> 150 s (first run of this probe, profiles/r03_cpu_baseline_thread_scaling.txt)
     torch.set_num_threads(th)
     with torch.no_grad():
         om["unet"](x, torch.tensor(500), encoder_hidden_states=enc)

@@ -3,7 +3,7 @@ db=sqlite3.connect(sys.argv[1]); cur=db.cursor()
 rows=cur.execute("select name, count(*), sum(end-start), avg(end-start), min(end-start), max(end-start) from kernels group by name order by 3 desc").fetchall()
 tot=sum(r[2] for r in rows)
 def short(n):
-    n=re.sub(r'\(.*','',n); n=n.replace('void ','')
+    n=n.replace('(anonymous namespace)::',''); n=re.sub(r'\(.*','',n); n=n.replace('void ','')
     return n[:100]
 print("total kernel ms", round(tot/1e6,1), "launches", sum(r[1] for r in rows))
 out=["name,calls,total_ms,avg_us,min_us,max_us,pct"]

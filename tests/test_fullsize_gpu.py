@@ -41,7 +41,7 @@ def sd15_tokens():
 
 @pytest.fixture(scope="module")
 def full(dev):
-    torch.set_num_threads(min(os.cpu_count() or 1, 64))
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))     # fastest on the pool's hosts (profiles/r03_cpu_baseline_thread_scaling.txt)
     t0 = time.time()
     om = U.oracle_models(train_unet=True, train_te=False, lora_up_std=0.02, size="sd15", eval_copies=False)
     pm = U.product_models(om["sds"], dev, train_unet=True, train_te=False, size="sd15", eval_copies=True)
