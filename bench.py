@@ -31,11 +31,11 @@ def f_img(S):
 
 def pmc_traffic(kernel, algorithmic_bytes_per_launch):
     """HBM-side bytes per launch of the dominant kernel from the committed PMC passes (FETCH_SIZE / WRITE_SIZE cannot be read from
-    inside a process; they are collected with rocprofv3 --pmc in separate runs on the kernel's own shapes, profiles/r02_pmc_traffic.json,
+    inside a process; they are collected with rocprofv3 --pmc in separate runs on the kernel's own shapes, profiles/r03_pmc_traffic.json,
     with the gfx950 corrections of MI355X_MICROARCH.md applied).  This run's per-launch figure = its mean ALGORITHMIC bytes per launch
     (exact, from every launch's M, N, K) x the measured traffic / algorithmic ratio of that kernel variant."""
     d = None
-    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", name)
         if os.path.exists(path):
             d = json.load(open(path))["kernels"].get(kernel)
@@ -259,16 +259,17 @@ def cpu_baseline(S, full=False):
       --cpu_baseline_full   ``protocol: "cfg1"``: the section-8(d) protocol itself: B=2, S=4, one warm-up step, median of 3 timed steps
                 (~11 min); its result is committed under profiles/ and quoted in DESIGN.md
     ``value`` = images/s of the timed sample itself; the extrapolation to configs[1] (B=8, S=20) by algorithmic FLOPs is labelled as such.
-    Threads: FD_CPU_THREADS, default min(32, logical CPUs) -- NOT os.cpu_count(): on the pool's 256-logical-CPU hosts the oracle's U-Net
-    forward takes 4.4 s on 32 torch threads, 6.2 s on 64, 9.6 s on 128 and 150 s on 256 (profiles/r03_cpu_baseline_thread_scaling.txt; the
-    boxes expose 256 logical CPUs but far fewer usable cores to the job): the fastest setting is the honest baseline."""
+    Threads: FD_CPU_THREADS, default min(16, logical CPUs) -- NOT os.cpu_count(): on the pool's 256-logical-CPU hosts the oracle's U-Net
+    forward takes 4.7 s on 8 torch threads, 3.7 s on 16, 4.3 s on 32, 6.1 s on 64, 9.6 s on 128 and 150 s on 256
+    (profiles/r03_cpu_baseline_thread_scaling.txt; the boxes expose 256 logical CPUs but far fewer usable cores to the job): the fastest
+    setting is the honest baseline."""
     import statistics
     import torch
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import util_models as U
     from oracle import fair_step as fs
     ncpu = os.cpu_count() or 1
-    threads = int(os.environ.get("FD_CPU_THREADS", min(ncpu, 32)))
+    threads = int(os.environ.get("FD_CPU_THREADS", min(ncpu, 16)))
     torch.set_num_threads(threads)
     B, Sc, reps = (2, 4, 3) if full else (1, 1, 1)
     om = U.oracle_models(rank=4, train_unet=False, train_te=True, lora_up_std=0.01, size="sd15", eval_copies=True)

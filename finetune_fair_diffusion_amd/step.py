@@ -258,7 +258,8 @@ class FairnessTrainer:
         cur = torch.cuda.current_stream().cuda_stream
         n = getattr(self, "_snap_calls", 0)
         self._snap_calls = n + 1
-        if n < 4 or n % 16 == 0:      # the pools settle after the warm-up steps: the (host-side, ms-scale) snapshot is refreshed rarely
+        if n < 2 or n % 256 == 0:     # the pools settle within two steps; the snapshot walks every block of the allocator (tens of ms of host
+                                      # time at 175 GB) right at the start of a step, where the device queue is empty: refreshed rarely
             other = 0
             try:
                 for seg in torch.cuda.memory_snapshot():
@@ -642,6 +643,8 @@ class FairnessTrainer:
                     for bank in self.banks:
                         bank.grad_alt(k).zero_()
                     side.wait_stream(cur)
+                # upstream gradient of the CFG pair eps = eps_u + gs (eps_c - eps_u): [(1 - gs) g ; gs g], built once; a timestep scales it
+                gpair = torch.cat([g * (1.0 - gs), g * gs])
                 for i in range(S):
                     k = i % nst
                     on_side = k > 0
@@ -656,8 +659,7 @@ class FairnessTrainer:
                             self.unet.forward_step(x if _CFG_PAIR else x.repeat(2, 1, 1, 1), i, record=True, pair=_CFG_PAIR)
                         for bank in self.banks:
                             bank.accum = bank.grad_alt(k) if on_side else bank.grad
-                        d = g * float(coefs[i] * gscale)
-                        self.unet.backward_step(torch.cat([d * (1.0 - gs), d * gs]), gscale)
+                        self.unet.backward_step(gpair * float(coefs[i] * gscale), gscale)
                 for bank in self.banks:
                     bank.accum = bank.grad
                 for k, side in enumerate(sides, 1):

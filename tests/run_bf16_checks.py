@@ -163,7 +163,7 @@ def exp3_step_d40():
     from finetune_fair_diffusion_amd.fairness import EXPERIMENT_ATTRS
     from finetune_fair_diffusion_amd.step import FairnessTrainer
     ncls, attrs, cdfs, asym = EXPERIMENT_ATTRS["exp-3"]
-    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    torch.set_num_threads(min(os.cpu_count() or 1, 16))
     om = U.oracle_models(train_unet=True, train_te=False, lora_up_std=0.05, num_classes=ncls, size="d40")
     for name in ("unet", "vae", "text_encoder", "classifier", "eval_unet"):
         for p in om[name].parameters():
@@ -214,7 +214,7 @@ def exp3_step_d40():
 def sd15_unet():
     from oracle import fair_step as fs
     from finetune_fair_diffusion_amd import factory
-    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    torch.set_num_threads(min(os.cpu_count() or 1, 16))
     om = U.oracle_models(train_unet=True, train_te=False, lora_up_std=0.02, size="sd15", eval_copies=False)
     for name in ("unet", "text_encoder"):
         for p in om[name].parameters():
