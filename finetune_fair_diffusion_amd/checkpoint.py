@@ -14,7 +14,8 @@ Here a checkpoint directory *is* the exported format plus one extra file:
     checkpoint-{step}/rng_rank{r}.pth     python / numpy / torch / OT-target RNG streams of rank r (every rank writes its own)
 
 so the reference's export step becomes a file copy (``export_checkpoint``), and files exported by the reference load
-back into the banks by key (``load_lora_files``).  Raw ``accelerate.save_state`` directories are not read.
+back into the banks by key (``load_lora_files``).  Raw ``accelerator.save_state`` directories of the reference are read by
+``accelerate_state.load_accelerate_state`` (``train --resume_from_checkpoint`` picks the reader by the directory's contents).
 """
 import os
 import random

@@ -159,7 +159,11 @@ def main(argv=None, experiment=None, cfgs=None, log=None):
                 print(f"Checkpoint '{args.resume_from_checkpoint}' does not exist. Starting a new training run.")
             args.resume_from_checkpoint = None
         else:
-            global_step = ckpt.load_state(trainer, args.resume_from_checkpoint, seed=args.seed)
+            from . import accelerate_state
+            if accelerate_state.is_accelerate_state_dir(args.resume_from_checkpoint):     # a directory written by the reference's accelerator.save_state (:2058)
+                global_step = accelerate_state.load_accelerate_state(trainer, args.resume_from_checkpoint)
+            else:
+                global_step = ckpt.load_state(trainer, args.resume_from_checkpoint, seed=args.seed)
             first_epoch, resume_step = global_step // steps_per_epoch, global_step % steps_per_epoch
     lat = cfgs["unet"].sample_size
     B = args.train_images_per_prompt_GPU

@@ -806,3 +806,123 @@ def test_oracle_clip_text_pinned_against_transformers():
     with torch.no_grad():
         c = mine(ids, None)[0]
     assert float((c[1, 2:] - b[1, 2:]).abs().max()) > 1e-3 and float((c[0] - b[0]).abs().max()) < 1e-6
+
+
+# ------------------------------------------------------------------ raw accelerator.save_state directories (VERDICT r2 missing 6)
+class _ProcLayers(torch.nn.Module):
+    """Stand-in for diffusers 0.19.3 ``AttnProcsLayers`` (1-main-debias.py:818): a ModuleList of LoRA attention processors whose state-dict
+    keys are renamed from ``layers.<i>`` to the processor names by a state-dict hook."""
+
+    def __init__(self, names, shapes):
+        super().__init__()
+        procs = []
+        for p in names:
+            m = torch.nn.Module()
+            for w in ("to_q", "to_k", "to_v", "to_out"):
+                lo = torch.nn.Module()
+                lo.down = torch.nn.Linear(shapes[f"{p}.{w}_lora.down.weight"][1], shapes[f"{p}.{w}_lora.down.weight"][0], bias=False)
+                lo.up = torch.nn.Linear(shapes[f"{p}.{w}_lora.up.weight"][1], shapes[f"{p}.{w}_lora.up.weight"][0], bias=False)
+                setattr(m, w + "_lora", lo)
+            procs.append(m)
+        self.layers = torch.nn.ModuleList(procs)
+        self.mapping = dict(enumerate(names))
+
+        def map_to(module, state_dict, *a, **k):
+            return {k_.replace(f"layers.{k_.split('.')[1]}", module.mapping[int(k_.split('.')[1])]): v for k_, v in state_dict.items()}
+        self._register_state_dict_hook(map_to)
+
+
+class _CustomModel(torch.nn.Module):
+    """The reference's text-encoder LoRA container (:856-872)."""
+
+    def __init__(self, d):
+        super().__init__()
+        self.params = torch.nn.ParameterList([d[n] for n in d])
+
+
+class _EMA:
+    """State-dict surface of diffusers ``EMAModel`` as accelerate's ``register_for_checkpointing`` uses it."""
+
+    def __init__(self, params, step):
+        self.shadow_params, self.optimization_step = [p.detach().clone() * 0.5 for p in params], step
+
+    def state_dict(self):
+        return dict(decay=0.996, min_decay=0.0, optimization_step=self.optimization_step, update_after_step=0, use_ema_warmup=False, inv_gamma=1.0,
+                    power=2 / 3, shadow_params=self.shadow_params)
+
+    def load_state_dict(self, sd):
+        self.shadow_params = sd["shadow_params"]
+
+
+def test_resume_from_a_raw_accelerate_save_state_directory(tmp_path):
+    """A directory written by REAL ``accelerate`` for the reference's object layout (:1648-1657, :2050-2068: CustomModel for the text-encoder LoRA,
+    AttnProcsLayers for the U-Net LoRA, AdamW over chain(unet, text-encoder) parameters, LambdaLR, two registered EMA models) restores by NAME
+    into the product's flat parameter banks: weights, Adam moments + step, lr position, EMA shadows, RNG streams, global step."""
+    import types
+    from accelerate import Accelerator
+    from finetune_fair_diffusion_amd import accelerate_state as AS, weights as W
+    from finetune_fair_diffusion_amd.layers import ParamBank
+    from finetune_fair_diffusion_amd.step import EMAState
+    ucfg = W.UNetConfig(block_out_channels=(32, 64), attention_head_dim=2, cross_attention_dim=16, down_block_types=("CrossAttnDownBlock2D", "DownBlock2D"),
+                        up_block_types=("UpBlock2D", "CrossAttnUpBlock2D"))
+    ccfg = W.CLIPTextConfig(vocab_size=100, hidden_size=16, intermediate_size=32, num_hidden_layers=2, num_attention_heads=2)
+    ushapes, tshapes = W.unet_lora_param_shapes(ucfg, 4), W.clip_lora_param_shapes(ccfg, 4)
+    un_order, te_order = AS.unet_reference_param_order(ucfg), AS.te_reference_param_order(2)
+    assert set(un_order) == set(ushapes) and set(te_order) == set(tshapes)
+    # the oracle's text encoder (pinned to transformers' key names elsewhere in this file) enumerates its LoRA tensors in exactly this order
+    from oracle import nn_clip
+    te_o = nn_clip.CLIPTextModel(nn_clip.CLIPTextConfig(vocab_size=100, hidden_size=16, intermediate_size=32, num_hidden_layers=2, num_attention_heads=2))
+    nn_clip.modify_text_encoder(te_o, 4)
+    assert [n for n, _ in te_o.named_parameters() if "lora_linear_layer" in n] == te_order
+    g = torch.Generator().manual_seed(0)
+    procs = []
+    for n in un_order:
+        p = n.rsplit(".", 3)[0]
+        if p not in procs:
+            procs.append(p)
+    unet_layers = _ProcLayers(procs, ushapes)
+    for p in unet_layers.parameters():
+        p.data = torch.randn(p.shape, generator=g)
+    assert list(unet_layers.state_dict().keys()) == un_order
+    te_dict = {n: torch.nn.Parameter(torch.randn(tshapes[n], generator=g)) for n in te_order}
+    te_model = _CustomModel(te_dict)
+    acc = Accelerator(cpu=True)
+    params = list(unet_layers.parameters()) + list(te_model.parameters())          # chain(unet, text encoder) (:891)
+    opt = torch.optim.AdamW(params, lr=5e-5)
+    sched = torch.optim.lr_scheduler.LambdaLR(opt, lambda s: 1.0)
+    opt, sched = acc.prepare(opt, sched)
+    te_ema, un_ema = _EMA(list(te_model.parameters()), 3), _EMA(list(unet_layers.parameters()), 3)
+    te_model = acc.prepare(te_model); acc.register_for_checkpointing(te_ema)
+    unet_layers = acc.prepare(unet_layers); acc.register_for_checkpointing(un_ema)
+    for _ in range(3):
+        for p in params:
+            p.grad = torch.randn(p.shape, generator=g)
+        opt.step(); sched.step()
+    torch.manual_seed(4242); expect_rand = None
+    d = str(tmp_path / "checkpoint_tmp-30")
+    acc.save_state(d)
+    expect_rand = torch.rand(3)           # what the reference would draw next after resuming
+    assert AS.is_accelerate_state_dir(d)
+    # the product side: flat banks on the CPU behind the trainer surface the reader touches
+    ub, tb = ParamBank(ushapes, torch.device("cpu")), ParamBank(tshapes, torch.device("cpu"))
+    stub = lambda **k: types.SimpleNamespace(**k)  # noqa: E731
+    tr = stub(args=stub(train_unet=True, train_text_encoder=True), prefix=None, rank=0,
+              unet=stub(lora_bank=ub, config=ucfg, refresh_lora=lambda: None), te=stub(lora_bank=tb, config=ccfg, refresh_lora=lambda: None),
+              banks=[ub, tb], ema=[EMAState(0.996), EMAState(0.996)], opt_step=0, lr_step=0)
+    torch.manual_seed(1)
+    step = AS.load_accelerate_state(tr, d)
+    assert step == 30 and tr.opt_step == 3 and tr.lr_step == 3 and [e.optimization_step for e in tr.ema] == [3, 3]
+    sd_u = unet_layers.state_dict()
+    opt_sd = opt.state_dict()
+    for i, n in enumerate(un_order):
+        assert torch.equal(ub.view(n), sd_u[n]) and torch.equal(ub.view(n, ub.ema), un_ema.shadow_params[i])
+        assert torch.equal(ub.view(n, ub.exp_avg), opt_sd["state"][i]["exp_avg"]) and torch.equal(ub.view(n, ub.exp_avg_sq), opt_sd["state"][i]["exp_avg_sq"])
+    for i, n in enumerate(te_order):
+        assert torch.equal(tb.view(n), te_dict[n].data) and torch.equal(tb.view(n, tb.ema), te_ema.shadow_params[i])
+        assert torch.equal(tb.view(n, tb.exp_avg), opt_sd["state"][len(un_order) + i]["exp_avg"])
+    assert torch.equal(torch.rand(3), expect_rand)          # the torch CPU stream continues where the checkpoint left it
+    # a run that trains something else is refused, not silently mis-mapped
+    tr2 = stub(args=stub(train_unet=True, train_text_encoder=False), prefix=None, rank=0, unet=tr.unet, te=stub(lora_bank=None, config=ccfg), banks=[ub],
+               ema=[EMAState(0.996)], opt_step=0, lr_step=0)
+    with pytest.raises(ValueError):
+        AS.load_accelerate_state(tr2, d)
