@@ -110,9 +110,16 @@ def main():
     hw = cfgs["unet"].sample_size
     torch.manual_seed(5991 + rank)  # set_seed(seed, device_specific=True) (:693): per-rank noise, drawn on the CPU (:1746-1749)
 
+    # The step is handed the NEXT step's inputs as well (the train loop knows them: prompt order and noise come from the host RNG, :1746-1749), so
+    # the frozen-model rollout R2 of step n+1 -- independent of step n's update -- can start underneath step n's tail (step.py r2_prefetch_steps).
+    # Every timed step still executes exactly one R2 rollout's worth of work: the steps it prefetches for its successor replace the ones its
+    # predecessor prefetched for it.  The noise tensors are drawn in the same RNG order as before (one draw per step), as host tensors.
+    nxt = [torch.randn([a.batch, 4, hw, hw], dtype=torch.float32)]
+
     def one_step():
-        noises = torch.randn([a.batch, 4, hw, hw], dtype=torch.float32)
-        return tr.train_step(tokens, noises.to(dev), a.S)
+        noises = nxt[0]
+        nxt[0] = torch.randn([a.batch, 4, hw, hw], dtype=torch.float32)
+        return tr.train_step(tokens, noises, a.S, next_step=dict(tokens_ori=tokens, noises=nxt[0], S=a.S))
 
     def fence():
         torch.cuda.synchronize()      # this rank's work is done before it enters the barrier ...
@@ -173,7 +180,7 @@ def main():
     # the device, scratch/prof_queue_depth.py; pure enqueue cost is ~105 ms per 20-step rollout, scratch/prof_host_rollout.py with FD_TINY=1)
     line["config"]["host_ms_between_phase_marks"] = {k: round(v, 1) for k, v in host_phases.items()}
     line["config"]["host_ms_per_step"] = [round(1e3 * (b - a_), 1) for a_, b in zip(step_t[:-1], step_t[1:])]
-    line["config"].update(r3_consumes_r1_forward=shared, r1_r2_rollouts_on_two_streams=bool(tr.concurrent_r2), backward_timesteps_on_two_streams=bool(tr.concurrent_bwd), executed_flop_per_image=f_exec,
+    line["config"].update(r2_steps_prefetched_under_previous_tail=int(tr.last_r2_prefetched), r3_consumes_r1_forward=shared, r1_r2_rollouts_on_two_streams=bool(tr.concurrent_r2), backward_timesteps_on_two_streams=bool(tr.concurrent_bwd), executed_flop_per_image=f_exec,
                           step_mfma_frac_executed=value / world * f_exec / MFMA_PEAK_F16)
 
     if not a.no_roofline:

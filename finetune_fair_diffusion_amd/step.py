@@ -166,6 +166,14 @@ class FairnessTrainer:
         self.concurrent_bwd = os.environ.get("FD_NO_CONCURRENT_BWD") is None
         self.bwd_streams = int(os.environ.get("FD_BWD_STREAMS", "3"))     # measured: 2 -> 1647, 3 -> 1589, 4 -> 1633 ms per step (run-to-run noise ~2 %)
         self._side = None
+        # R2 of the NEXT step does not depend on this step's update (frozen original models, its own noise and prompt): when the caller hands
+        # over the next step's inputs (``train_step(..., next_step=...)``) its first denoising steps are enqueued on the R2 stream as soon as
+        # this step's R2 has finished, i.e. underneath the VAE decode / classifier / loss / VAE backward tail, whose launches leave most of the
+        # chip idle (host syncs, small kernels).  Same kernels on the same inputs: results are bit-identical with and without it.
+        self.r2_prefetch_steps = int(os.environ.get("FD_R2_PREFETCH_STEPS", "6"))
+        self._r2_pre = None
+        self._sch_r2 = None
+        self.last_r2_prefetched = 0
         self.last_ot_ms = (0.0, 0.0)
         self._tgt = None
 
@@ -216,13 +224,14 @@ class FairnessTrainer:
         mask = torch.stack([um, pm]).to(self.device)
         return te.forward(ids, mask, record=record, prefix=None if prefix is None else (1, prefix))[0]
 
-    def rollout_steps(self, unet, enc, noises, S, res, keep_inputs=False, record_prompt=False, keep_activations=False):
+    def rollout_steps(self, unet, enc, noises, S, res, keep_inputs=False, record_prompt=False, keep_activations=False, sch=None):
         """CFG denoising rollout (:1038-1056) as a generator: yields after the launches of each denoising step so that two rollouts (R1
         on the current stream, R2 on the side stream) can be enqueued in lockstep; fills ``res`` = dict(lat, inputs, ctxs).
         With ``keep_activations`` the per-step backward contexts are kept for as many timesteps as fit in HBM
         (288 GB holds the whole 20-step chain at batch 8); the remaining steps are recomputed in the backward."""
-        self.sch.set_timesteps(S)
-        unet.prepare_timesteps(self.sch.timesteps)
+        sch = self.sch if sch is None else sch       # a prefetched R2 rollout of the NEXT step brings its own scheduler object (S may differ)
+        sch.set_timesteps(S)
+        unet.prepare_timesteps(sch.timesteps)
         unet.prepare_prompt(enc, record=record_prompt)
         lat = noises.clone()
         state, inputs, ctxs = {}, [], {}
@@ -244,7 +253,7 @@ class FairnessTrainer:
                     self.last_ctx_bytes, self.last_ctx_budget = per, budget
                 else:
                     budget -= 1
-            self.sch.cfg_step(i, eps, gs, lat, state)
+            sch.cfg_step(i, eps, gs, lat, state)
             yield i
 
     def _usable_free_bytes(self):
@@ -439,14 +448,26 @@ class FairnessTrainer:
                 dist.all_reduce(bank.grad, op=dist.ReduceOp.SUM)
 
     # ------------------------------------------------------------------ the step
-    def train_step(self, tokens, noises, S, tokens_ori=None):
+    def train_step(self, tokens, noises, S, tokens_ori=None, next_step=None):
         """``tokens``: the prompt the finetuned side sees (exp-2: ``prompt_debiaser(prompt)``, generate.prefix_tokens); ``tokens_ori``: the
-        prompt of the frozen original side R2 when it differs (exp-2 :1954: the plain prompt, no prefix embedding)."""
+        prompt of the frozen original side R2 when it differs (exp-2 :1954: the plain prompt, no prefix embedding).
+        ``next_step``: optional dict(tokens_ori=, noises=, S=) -- the inputs the NEXT call will receive (noises as a host tensor): the first
+        ``r2_prefetch_steps`` denoising steps of its R2 rollout are then enqueued underneath this step's tail."""
         args = self.args
         tokens_ori = tokens if tokens_ori is None else tokens_ori
         dev = self.device
         B = noises.shape[0]
-        noises = noises.to(dev, F32)
+        pre, self._r2_pre = self._r2_pre, None
+        if pre is not None and not (pre["S"] == S and not noises.is_cuda and pre["noises_host"].shape == noises.shape and
+                                    torch.equal(pre["noises_host"], noises.to(F32)) and
+                                    all(torch.equal(a, b) for a, b in zip(pre["tokens_ori"], tokens_ori))):
+            pre = None              # the caller changed its mind: the prefetched steps are dropped (their kernels were harmless)
+        if pre is not None:
+            torch.cuda.current_stream().wait_event(pre["ev_noise"])
+            noises = pre["noises_dev"]
+            noises.record_stream(torch.cuda.current_stream())
+        else:
+            noises = noises.to(dev, F32)
         out = {}
         for bank in self.banks:
             bank.grad.zero_()
@@ -466,9 +487,13 @@ class FairnessTrainer:
         # tail waves, latency-bound short-K GEMMs) overlap with the other rollout's work.  Same kernels, same results.
         conc = self.concurrent_r2 and vb >= B and self.eval_unet is not self.unet
         cur = torch.cuda.current_stream()
-        side = self._side_stream() if conc else None
+        side = self._side_stream("r2") if conc else None      # its own stream: the backward's side streams must not queue behind a prefetch
         r2 = {}
-        if conc:
+        self.last_r2_prefetched = 0
+        if conc and pre is not None:
+            g2, r2 = pre["gen"], pre["res"]                       # already ``pre["k"]`` denoising steps ahead
+            self.last_r2_prefetched = pre["k"]
+        elif conc:
             side.wait_stream(cur)
             with torch.cuda.stream(side):
                 enc_ori = self.encode_pair(self.eval_te, tokens_ori)
@@ -502,6 +527,27 @@ class FairnessTrainer:
                 for _ in g2:           # (nothing left when both rollouts have S steps)
                     pass
                 images_ori = self.decode(r2["lat"])
+            ev_r2 = torch.cuda.Event()
+            ev_r2.record(side)         # what the main stream waits for below: this step's R2, not a prefetch queued behind it
+            can_prefetch = (next_step is not None and self.r2_prefetch_steps > 0 and not next_step["noises"].is_cuda and
+                            next_step["noises"].shape[0] <= vb and not (train_te and self.eval_te is self.te))
+            if can_prefetch:
+                import copy
+                if self._sch_r2 is None:
+                    self._sch_r2 = copy.deepcopy(self.sch)
+                nt = next_step.get("tokens_ori")
+                k = min(self.r2_prefetch_steps, int(next_step["S"]))
+                with torch.cuda.stream(side):
+                    nh = next_step["noises"].to(F32)
+                    nd = nh.to(dev, non_blocking=False)
+                    ev_noise = torch.cuda.Event()
+                    ev_noise.record(side)
+                    r2n = {}
+                    g2n = self.rollout_steps(self.eval_unet, self.encode_pair(self.eval_te, nt), nd, int(next_step["S"]), r2n, sch=self._sch_r2)
+                    for _ in range(k):
+                        next(g2n, None)
+                self._r2_pre = dict(gen=g2n, res=r2n, k=k, S=int(next_step["S"]), noises_host=nh.clone(), noises_dev=nd, ev_noise=ev_noise,
+                                    tokens_ori=tuple(t.clone() for t in nt))
         self._mark("classify_targets")
         ind, boxes, per = self.classify(images, record=share)
         # ---- dynamic targets from the global batch (:1805-1837): gathered now, solved underneath R2, consumed by R3's loss
@@ -510,7 +556,7 @@ class FairnessTrainer:
         # ---- R2: images from the frozen original models (:1844-1858)
         if conc:
             self._mark("R2_tail_and_regularisers")
-            cur.wait_stream(side)              # everything downstream (classifier, feature encoders, loss) consumes images_ori on ``cur``
+            cur.wait_event(ev_r2)              # everything downstream (classifier, feature encoders, loss) consumes images_ori on ``cur``
             images_ori.record_stream(cur)
         else:
             self._mark("R2_rollout")

@@ -167,47 +167,70 @@ def main(argv=None, experiment=None, cfgs=None, log=None):
             first_epoch, resume_step = global_step // steps_per_epoch, global_step % steps_per_epoch
     lat = cfgs["unet"].sample_size
     B = args.train_images_per_prompt_GPU
-    for epoch in range(first_epoch, num_epochs):
-        for step, data_idx in enumerate(order[epoch]):
-            if args.resume_from_checkpoint and epoch == first_epoch and step < resume_step:
-                continue
-            if global_step >= args.max_train_steps:
-                break
-            prompt = prompts_train[data_idx]
-            noises = torch.randn([B, 4, lat, lat], dtype=torch.float32)          # CPU generator, differs by rank (:1746-1749)
-            S = [args.num_denoising_steps or random.choices(range(19, 24), k=1)[0]]
+    def draw(data_idx):
+        """The per-step host inputs in the reference's order (:1746-1749, :1779): prompt, CPU noise, number of denoising steps."""
+        prompt = prompts_train[data_idx]
+        noises = torch.randn([B, 4, lat, lat], dtype=torch.float32)          # CPU generator, differs by rank (:1746-1749)
+        S = [args.num_denoising_steps or random.choices(range(19, 24), k=1)[0]]
+        if world > 1:
+            dist.broadcast_object_list(S, src=0)
+        return prompt, noises, S[0]
+
+    def peek(data_idx):
+        """What ``draw`` WILL return for the next step, without consuming the generators: the draw is made on saved generator states that are
+        restored afterwards, so the run's random streams -- and the RNG state a checkpoint stores -- are exactly those of a loop without look-ahead."""
+        st = (random.getstate(), np.random.get_state(), torch.get_rng_state())
+        try:
+            return draw(data_idx)
+        finally:
+            random.setstate(st[0]); np.random.set_state(st[1]); torch.set_rng_state(st[2])
+
+    def r2_tokens(toks):
+        # exp-2 (:1954): the original side sees the plain prompt, its empty prompt encoded without a padding mask
+        return (toks[0], toks[1], toks[2], torch.ones_like(toks[3])) if trainer.prefix is not None else toks
+
+    plan = [(epoch, step, data_idx) for epoch in range(first_epoch, num_epochs) for step, data_idx in enumerate(order[epoch])
+            if not (args.resume_from_checkpoint and epoch == first_epoch and step < resume_step)]
+    for i, (epoch, step, data_idx) in enumerate(plan):
+        if global_step >= args.max_train_steps:
+            break
+        prompt, noises, S0 = draw(data_idx)
+        S = [S0]
+        t0 = time.time()
+        toks = tokenizer(prompt)
+        # the next step's inputs, so that its frozen-model rollout can start underneath this step's tail (step.py, r2_prefetch_steps)
+        nxt = None
+        if i + 1 < len(plan) and global_step + 1 < args.max_train_steps and os.environ.get("FD_NO_R2_PREFETCH") is None:
+            p_n, noises_n, S_n = peek(plan[i + 1][2])
+            nxt = dict(tokens_ori=r2_tokens(tokenizer(p_n)), noises=noises_n, S=S_n)
+        if trainer.prefix is not None:
+            # exp-2 (:1846, :1895, :1954, :2001): the finetuned side sees "".join(prefix_tokens) + prompt with the pipeline's negative
+            # prompt (no padding mask); the original side sees the plain prompt, its empty prompt encoded without a mask as well
+            from .generate import prefix_tokens
+            out = trainer.train_step(prefix_tokens(toks, trainer.prefix.n, cfgs["clip"].vocab_size), noises, S[0],
+                                     tokens_ori=r2_tokens(toks), next_step=nxt)
+        else:
+            out = trainer.train_step(toks, noises, S[0], next_step=nxt)
+        global_step += 1
+        if rank == 0:
+            lf = out["loss_fair"]
+            rec = dict(step=global_step, prompt=prompt, S=S[0], noise_checksum=float(noises.double().sum()), lr=trainer.last_lr, grad_is_finite=out["grad_is_finite"],
+                       loss_fair=float(lf[lf != -1].mean()) if bool((lf != -1).any()) else None,
+                       loss_CLIP=float(out["loss_CLIP"].mean()) if "loss_CLIP" in out else None,
+                       loss_DINO=float(out["loss_DINO"].mean()) if "loss_DINO" in out else None,
+                       loss_face=(float(out["loss_face"][out["loss_face"] != -1].mean()) if (out["loss_face"] != -1).any() else None) if "loss_face" in out else None,
+                       p_class1_mean=float(out["probs"][:, 1][out["probs"][:, 1] != -1].mean()) if bool((out["probs"] != -1).any()) else None,
+                       seconds=round(time.time() - t0, 3))
+            (log or print)(json.dumps(rec))
+        # checkpoints (:2050-2068): rank 0 cleans up and writes the shared state, every rank adds its own RNG streams
+        if global_step % args.checkpointing_steps == 0:
+            if rank == 0 and args.checkpoints_total_limit is not None:
+                ckpt.clean_checkpoint(ckpts_dir, "checkpoint_tmp", args.checkpoints_total_limit)
             if world > 1:
-                dist.broadcast_object_list(S, src=0)
-            t0 = time.time()
-            toks = tokenizer(prompt)
-            if trainer.prefix is not None:
-                # exp-2 (:1846, :1895, :1954, :2001): the finetuned side sees "".join(prefix_tokens) + prompt with the pipeline's negative
-                # prompt (no padding mask); the original side sees the plain prompt, its empty prompt encoded without a mask as well
-                from .generate import prefix_tokens
-                out = trainer.train_step(prefix_tokens(toks, trainer.prefix.n, cfgs["clip"].vocab_size), noises, S[0],
-                                         tokens_ori=(toks[0], toks[1], toks[2], torch.ones_like(toks[3])))
-            else:
-                out = trainer.train_step(toks, noises, S[0])
-            global_step += 1
-            if rank == 0:
-                lf = out["loss_fair"]
-                rec = dict(step=global_step, prompt=prompt, S=S[0], noise_checksum=float(noises.double().sum()), lr=trainer.last_lr, grad_is_finite=out["grad_is_finite"],
-                           loss_fair=float(lf[lf != -1].mean()) if bool((lf != -1).any()) else None,
-                           loss_CLIP=float(out["loss_CLIP"].mean()) if "loss_CLIP" in out else None,
-                           loss_DINO=float(out["loss_DINO"].mean()) if "loss_DINO" in out else None,
-                           loss_face=(float(out["loss_face"][out["loss_face"] != -1].mean()) if (out["loss_face"] != -1).any() else None) if "loss_face" in out else None,
-                           p_class1_mean=float(out["probs"][:, 1][out["probs"][:, 1] != -1].mean()) if bool((out["probs"] != -1).any()) else None,
-                           seconds=round(time.time() - t0, 3))
-                (log or print)(json.dumps(rec))
-            # checkpoints (:2050-2068): rank 0 cleans up and writes the shared state, every rank adds its own RNG streams
-            if global_step % args.checkpointing_steps == 0:
-                if rank == 0 and args.checkpoints_total_limit is not None:
-                    ckpt.clean_checkpoint(ckpts_dir, "checkpoint_tmp", args.checkpoints_total_limit)
-                if world > 1:
-                    dist.barrier()
-                ckpt.save_state(trainer, os.path.join(ckpts_dir, f"checkpoint_tmp-{global_step}"), global_step)
-            if global_step % args.checkpointing_steps_long == 0:
-                ckpt.save_state(trainer, os.path.join(ckpts_dir, f"checkpoint-{global_step}"), global_step)
+                dist.barrier()
+            ckpt.save_state(trainer, os.path.join(ckpts_dir, f"checkpoint_tmp-{global_step}"), global_step)
+        if global_step % args.checkpointing_steps_long == 0:
+            ckpt.save_state(trainer, os.path.join(ckpts_dir, f"checkpoint-{global_step}"), global_step)
     if world > 1:
         dist.barrier()
     return trainer, global_step
