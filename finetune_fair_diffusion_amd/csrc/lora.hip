@@ -256,3 +256,48 @@ extern "C" int fd_lora_wgrad_multi(const fd_wgrad_desc* descs, int n, float* scr
     hipLaunchKernelGGL(lora_wgrad_final_multi, dim3((outs + 3) / 4), dim3(256), 0, s, b, (const float*)scratch, RP);
     return fd_check_launch("fd_lora_wgrad_multi");
 }
+
+
+// ------------------------------------------------------------------ 16-bit operand copies of LoRA pairs after an optimiser step
+// 128 pairs x (zeros, two slice copies, two transposes) were ~1000 tiny torch launches per step (10 ms of host-bound time); here 16 pairs per launch.
+#define FD_REFRESH_MAX 16
+struct RefreshBatch { fd_lora_refresh_desc d[FD_REFRESH_MAX]; int n; };
+
+__global__ void lora_refresh_kernel(RefreshBatch b) {
+    const fd_lora_refresh_desc& p = b.d[blockIdx.y];
+    const int nd = p.rp * p.K, nu = p.N * p.rp;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nd + nu; i += gridDim.x * blockDim.x) {
+        if (i < nd) {
+            const int j = i / p.K, k = i - j * p.K;
+            const f16 v = (f16)(j < p.r ? p.down[(int64_t)j * p.K + k] : 0.f);
+            ((f16*)p.d16)[(int64_t)j * p.ld_d16 + k] = v;
+            ((f16*)p.dT16)[(int64_t)k * p.ld_dT16 + j] = v;
+        } else {
+            const int e = i - nd;
+            const int n = e / p.rp, j = e - n * p.rp;
+            const f16 v = (f16)(j < p.r ? p.up[(int64_t)n * p.r + j] * p.scale : 0.f);
+            ((f16*)p.u16)[(int64_t)n * p.ld_u16 + j] = v;
+            ((f16*)p.uT16)[(int64_t)j * p.ld_uT16 + n] = v;
+        }
+    }
+}
+
+extern "C" int fd_lora_refresh_multi(const fd_lora_refresh_desc* descs, int n, void* stream) {
+    FD_REQUIRE(descs && n > 0, "fd_lora_refresh_multi: no pairs");
+    for (int i0 = 0; i0 < n; i0 += FD_REFRESH_MAX) {
+        RefreshBatch b;
+        b.n = n - i0 < FD_REFRESH_MAX ? n - i0 : FD_REFRESH_MAX;
+        int64_t most = 0;
+        for (int i = 0; i < b.n; ++i) {
+            b.d[i] = descs[i0 + i];
+            const fd_lora_refresh_desc& p = b.d[i];
+            FD_REQUIRE(p.down && p.up && p.d16 && p.dT16 && p.u16 && p.uT16 && p.r > 0 && p.rp >= p.r && p.K > 0 && p.N > 0, "fd_lora_refresh_multi: bad pair %d", i0 + i);
+            const int64_t e = (int64_t)p.rp * (p.K + p.N);
+            most = e > most ? e : most;
+        }
+        int bx = (int)((most + 255) / 256);
+        if (bx > 64) bx = 64;
+        hipLaunchKernelGGL(lora_refresh_kernel, dim3(bx, b.n), dim3(256), 0, (hipStream_t)stream, b);
+    }
+    return fd_check_launch("fd_lora_refresh_multi");
+}

@@ -46,6 +46,14 @@ class WgradDesc(ctypes.Structure):
                 ("M", ctypes.c_int32), ("N", ctypes.c_int32), ("R", ctypes.c_int32), ("scale", ctypes.c_float)]
 
 
+class LoraRefreshDesc(ctypes.Structure):
+    """Mirror of ``fd_lora_refresh_desc`` (include/fairdiff_hip.h)."""
+    _fields_ = [("down", ctypes.c_void_p), ("up", ctypes.c_void_p), ("d16", ctypes.c_void_p), ("ld_d16", ctypes.c_int64),
+                ("dT16", ctypes.c_void_p), ("ld_dT16", ctypes.c_int64), ("u16", ctypes.c_void_p), ("ld_u16", ctypes.c_int64),
+                ("uT16", ctypes.c_void_p), ("ld_uT16", ctypes.c_int64), ("r", ctypes.c_int32), ("rp", ctypes.c_int32),
+                ("K", ctypes.c_int32), ("N", ctypes.c_int32), ("scale", ctypes.c_float)]
+
+
 _CTYPE = {"int": ctypes.c_int, "int32_t": ctypes.c_int32, "int64_t": ctypes.c_int64, "float": ctypes.c_float}
 
 

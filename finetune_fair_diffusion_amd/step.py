@@ -170,7 +170,7 @@ class FairnessTrainer:
         # over the next step's inputs (``train_step(..., next_step=...)``) its first denoising steps are enqueued on the R2 stream as soon as
         # this step's R2 has finished, i.e. underneath the VAE decode / classifier / loss / VAE backward tail, whose launches leave most of the
         # chip idle (host syncs, small kernels).  Same kernels on the same inputs: results are bit-identical with and without it.
-        self.r2_prefetch_steps = int(os.environ.get("FD_R2_PREFETCH_STEPS", "6"))
+        self.r2_prefetch_steps = int(os.environ.get("FD_R2_PREFETCH_STEPS", "8"))     # same-box A/B: 0 -> 1442-1448 ms, 6 -> 1431-1436, 8 -> 1429, 10 -> 1440
         self._r2_pre = None
         self._sch_r2 = None
         self.last_r2_prefetched = 0

@@ -52,9 +52,8 @@ class CLIPTextModel:
         return self.lora_bank
 
     def refresh_lora(self):
-        for L in self.layers:
-            for lo in L["lora"].values():
-                lo.refresh()
+        from .layers import refresh_pairs
+        refresh_pairs([lo for L in self.layers for lo in L["lora"].values()])
 
     def load_state_dict(self, sd, strict=False):
         if self.lora_bank is not None:

@@ -40,26 +40,38 @@ class LoRAAttnProcessor:
 
 
 class AttnLoRA:
-    """The four LoRALinearLayers of one LoRAAttnProcessor."""
+    """The four LoRALinearLayers of one LoRAAttnProcessor.  Self-attention (q, k, v project the same input): q, k, v run as ONE GEMM with stacked
+    weights [3C, C]; their LoRA rank updates ride it as one second K-slab -- t = n1 . down_qkv^T [M, 3rp] against the block-diagonal up matrix
+    [3C, 3rp] -- so the three pairs' 16-bit operand copies are views into four stacked buffers.  Cross-attention: k and v share ``down_kv16``."""
 
     def __init__(self, bank, name):
         self.q, self.k, self.v, self.out = (LoRAPair(bank, f"{name}.{p}_lora.down.weight", f"{name}.{p}_lora.up.weight")
                                             for p in ("to_q", "to_k", "to_v", "to_out"))
+        dev = bank.flat.device
+        rp = self.q.rp
+        if self.q.K == self.k.K:
+            C = self.q.N
+            self.down_qkv16 = torch.zeros((3 * rp, C), dtype=F16, device=dev)                                  # [3rp, C]
+            self.down_qkvT16 = torch.zeros((C, 3 * rp), dtype=F16, device=dev)                                 # [C, 3rp]
+            self.up_qkv16 = torch.zeros((3 * C, 3 * rp), dtype=F16, device=dev)                                # block diagonal; off-diagonal blocks stay 0
+            self.upT_qkv16 = torch.zeros((3 * rp, 3 * C), dtype=F16, device=dev)                               # [3rp, 3C]
+            for i, p in enumerate((self.q, self.k, self.v)):
+                p.place(self.down_qkv16[i * rp:(i + 1) * rp], self.down_qkvT16[:, i * rp:(i + 1) * rp],
+                        self.up_qkv16[i * C:(i + 1) * C, i * rp:(i + 1) * rp], self.upT_qkv16[i * rp:(i + 1) * rp, i * C:(i + 1) * C])
+            self.down_kv16 = self.down_qkv16[rp:]
+        else:
+            self.down_kv16 = torch.zeros((2 * rp, self.k.K), dtype=F16, device=dev)
+            self.q.place()
+            self.k.place(down16=self.down_kv16[:rp])
+            self.v.place(down16=self.down_kv16[rp:])
+        self.out.place()
+
+    def pairs(self):
+        return (self.q, self.k, self.v, self.out)
 
     def refresh(self):
-        for p in (self.q, self.k, self.v, self.out):
-            p.refresh()
-        # self-attention: q, k, v run as ONE GEMM with stacked weights [3C, C]; their LoRA rank updates ride it as one second K-slab:
-        # t = n1 . down_qkv^T [M, 3rp] against the block-diagonal up matrix [3C, 3rp]
-        if self.q.K == self.k.K:
-            self.down_qkv16 = torch.cat([self.q.down16, self.k.down16, self.v.down16], 0).contiguous()        # [3rp, C]
-            self.down_qkvT16 = self.down_qkv16.t().contiguous()                                                # [C, 3rp]
-            C, rp = self.q.N, self.q.rp
-            self.up_qkv16 = torch.zeros((3 * C, 3 * rp), dtype=F16, device=self.q.up16.device)
-            for i, p in enumerate((self.q, self.k, self.v)):
-                self.up_qkv16[i * C:(i + 1) * C, i * rp:(i + 1) * rp] = p.up16
-            self.upT_qkv16 = self.up_qkv16.t().contiguous()                                                    # [3rp, 3C]
-        self.down_kv16 = torch.cat([self.k.down16, self.v.down16], 0).contiguous()
+        from .layers import refresh_pairs
+        refresh_pairs(self.pairs())
 
 
 class TransformerBlock:
@@ -341,10 +353,8 @@ class UNet2DConditionModel:
         return self.lora_bank
 
     def refresh_lora(self):
-        for t in self.transformers:
-            for lo in (t.lora1, t.lora2):
-                if lo is not None:
-                    lo.refresh()
+        from .layers import refresh_pairs
+        refresh_pairs([p for t in self.transformers for lo in (t.lora1, t.lora2) if lo is not None for p in lo.pairs()])
 
     def prepare_backward(self):
         """Materialise every lazily built backward operand (transposed / flipped weight copies) NOW, on the current stream.  The training

@@ -183,6 +183,21 @@ typedef struct fd_wgrad_desc {
 } fd_wgrad_desc;
 int fd_lora_wgrad_multi(const fd_wgrad_desc* descs, int n, float* scratch, int64_t scratch_elems, void* stream);
 
+/* Operand copies of LoRA pairs after an optimiser step (1-main-debias.py:2016-2029 leaves fp32 parameters; the MFMA slabs want 16-bit, rank-padded,
+ * and transposed copies): for each pair  d16[j, k] = down[j, k] (rows j >= r zero),  dT16[k, j] = d16[j, k],  u16[n, j] = scale * up[n, j] (columns
+ * j >= r zero),  uT16[j, n] = u16[n, j].  The four outputs are written through row strides, so that several pairs can live inside one stacked
+ * buffer (the fused q/k/v projection of a self-attention layer).  Any number of pairs per call (chunked internally). */
+typedef struct fd_lora_refresh_desc {
+    const float* down; const float* up;            /* fp32 [r, K], [N, r] */
+    void* d16; int64_t ld_d16;                     /* 16-bit [rp, K] */
+    void* dT16; int64_t ld_dT16;                   /* 16-bit [K, rp] */
+    void* u16; int64_t ld_u16;                     /* 16-bit [N, rp] */
+    void* uT16; int64_t ld_uT16;                   /* 16-bit [rp, N] */
+    int32_t r, rp, K, N;
+    float scale;
+} fd_lora_refresh_desc;
+int fd_lora_refresh_multi(const fd_lora_refresh_desc* descs, int n, void* stream);
+
 /* ---- scheduler / CFG (DPMSolverMultistepScheduler.step + CFG combine, 1-main-debias.py:1051-1056,1123-1131)
  * eps:[2N,4,HW] fp32 NCHW (uncond first); x0_prev/x0_out fp32; lat fp32 updated in place.
  * x0 = (lat - sigma*e)/alpha ; lat' = c_x*lat - c_d0*x0 - c_d1*(x0 - x0_prev)                        */

@@ -1126,4 +1126,5 @@ def test_r2_prefetch_under_the_tail_is_bit_identical(dev):
         # later steps see parameters that went through one or two optimiser steps whose gradients are reproducible to rounding only (the fp32
         # atomics behind attn2.to_k / to_v): equal to fp16 noise, not to the bit
         assert float((a[0].float() - b[0].float()).abs().max()) <= 4e-3 and float((a[2] - b[2]).abs().max()) <= 1e-3, f"step {i}"
-        assert all(float((x - y).abs().max()) <= 1e-6 for x, y in zip(a[3], b[3])), f"parameters after step {i}"
+        # AdamW's first steps move every entry by ~lr * g / (|g| + eps): where g is at the atomics' noise level the two runs may step differently
+        assert all(float((x - y).abs().max()) <= 2.5e-4 for x, y in zip(a[3], b[3])), f"parameters after step {i}"
