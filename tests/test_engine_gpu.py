@@ -1094,8 +1094,10 @@ def test_full_step_with_detector_provider_missing_face_and_fallback(dev):
 def test_r2_prefetch_under_the_tail_is_bit_identical(dev):
     """The frozen-model rollout R2 of step n+1 (:1844-1858) does not depend on step n's update, so -- given the next step's host inputs -- its
     first denoising steps are enqueued underneath step n's tail (step.py ``r2_prefetch_steps``).  Same kernels on the same inputs: three
-    consecutive optimiser steps (different numbers of denoising steps, so the prefetch's own scheduler object is exercised) must give
-    bit-identical images, losses and parameters with and without it; a prefetch for inputs that then do not arrive is dropped harmlessly."""
+    consecutive steps (different numbers of denoising steps, so the prefetch's own scheduler object is exercised) must give bit-identical
+    R1 / R2 images, probabilities, targets and losses with and without it; a prefetch for inputs that then do not arrive is dropped harmlessly.
+    (The optimiser update is captured instead of applied: gradients are reproducible to rounding only -- the fp32 atomics behind attn2.to_k /
+    to_v -- and AdamW would turn that into parameter noise that has nothing to do with the prefetch.)"""
     from finetune_fair_diffusion_amd.step import FairnessTrainer
     sds = U.synthetic_sds(train_unet=True, train_te=True, lora_up_std=0.05)
     tokens = U.tiny_tokens()
@@ -1109,6 +1111,8 @@ def test_r2_prefetch_under_the_tail_is_bit_identical(dev):
         tr = FairnessTrainer(args, pm["text_encoder"], pm["unet"], pm["vae"], pm["classifier"], pm["scheduler"], eval_text_encoder=pm["eval_text_encoder"],
                              eval_unet=pm["eval_unet"], device=dev)
         tr.r2_prefetch_steps = 2
+        grads = []
+        tr.sync_and_update = lambda nb, apply=True: (grads.append([b.grad.clone() for b in tr.banks]), True)[1]
         outs, pre = [], []
         for i in range(3):
             nxt = dict(tokens_ori=tokens, noises=noises[i + 1], S=Ss[i + 1]) if mode == "prefetch" else None
@@ -1116,15 +1120,11 @@ def test_r2_prefetch_under_the_tail_is_bit_identical(dev):
                 nxt = dict(tokens_ori=tokens, noises=noises[4], S=Ss[2])       # announces inputs that will NOT arrive: must be dropped at step 2
             o = tr.train_step(tokens, noises[i], Ss[i], next_step=nxt)
             pre.append(tr.last_r2_prefetched)
-            outs.append((o["images"].clone(), o["images_ori"].clone(), o["loss_fair"].clone(), [b.flat.clone() for b in tr.banks]))
-        runs[mode] = (outs, pre)
+            outs.append((o["images"].clone(), o["images_ori"].clone(), o["loss_fair"].clone(), o["probs"].clone(), o["targets"].clone()))
+        runs[mode] = (outs, pre, grads)
     assert runs["plain"][1] == [0, 0, 0] and runs["prefetch"][1] == [0, 2, 0], runs["prefetch"][1]
     for i, (a, b) in enumerate(zip(runs["plain"][0], runs["prefetch"][0])):
-        assert torch.equal(a[1], b[1]), f"R2 images of step {i}"             # frozen models, same noise: exact, prefetched or not
-        if i == 0:
-            assert torch.equal(a[0], b[0]) and torch.equal(a[2], b[2])
-        # later steps see parameters that went through one or two optimiser steps whose gradients are reproducible to rounding only (the fp32
-        # atomics behind attn2.to_k / to_v): equal to fp16 noise, not to the bit
-        assert float((a[0].float() - b[0].float()).abs().max()) <= 4e-3 and float((a[2] - b[2]).abs().max()) <= 1e-3, f"step {i}"
-        # AdamW's first steps move every entry by ~lr * g / (|g| + eps): where g is at the atomics' noise level the two runs may step differently
-        assert all(float((x - y).abs().max()) <= 2.5e-4 for x, y in zip(a[3], b[3])), f"parameters after step {i}"
+        assert all(torch.equal(x, y) for x, y in zip(a, b)), f"step {i}"
+    for ga, gb in zip(runs["plain"][2], runs["prefetch"][2]):
+        for x, y in zip(ga, gb):
+            assert float((x - y).abs().max()) <= 4e-3 * float(x.abs().max())
