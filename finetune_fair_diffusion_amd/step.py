@@ -166,7 +166,6 @@ class FairnessTrainer:
         self.concurrent_bwd = os.environ.get("FD_NO_CONCURRENT_BWD") is None
         self.bwd_streams = int(os.environ.get("FD_BWD_STREAMS", "3"))     # measured: 2 -> 1647, 3 -> 1589, 4 -> 1633 ms per step (run-to-run noise ~2 %)
         self._side = None
-        self._amax_state, self._sync_scales = {}, os.environ.get("FD_SYNC_SCALES") is not None
         # R2 of the NEXT step does not depend on this step's update (frozen original models, its own noise and prompt): when the caller hands
         # over the next step's inputs (``train_step(..., next_step=...)``) its first denoising steps are enqueued on the R2 stream as soon as
         # this step's R2 has finished, i.e. underneath the VAE decode / classifier / loss / VAE backward tail, whose launches leave most of the
@@ -208,30 +207,6 @@ class FairnessTrainer:
         for (n0, e0), (_, e1) in zip(self._marks[:-1], self._marks[1:]):
             out[n0] = out.get(n0, 0.0) + e0.elapsed_time(e1)
         return out
-
-    def _amax(self, name, x):
-        """max |x| for a power-of-two gradient scale WITHOUT a host sync in the middle of the step: the value measured in the previous step is used
-        while this step's is copied to pinned host memory asynchronously for the next one.  Gradient magnitudes move slowly from step to step,
-        power-of-two scales are exact in the 16-bit formats away from the ends of their range, and the targets (1 or 64) leave 2^10 .. 2^16 of headroom:
-        a scale that lags by a few octaves gives the same bits; a jump beyond the headroom shows up as a non-finite gradient, which the guard
-        of :2002-2004 skips, and the next step has the fresh value.  First use of a name (or FD_SYNC_SCALES=1): measured synchronously --
-        every sync here used to drain the launch queue at a point where the chip has little queued behind it."""
-        cur = x.abs().max()
-        st = self._amax_state.get(name)
-        v = None
-        if st is not None and not self._sync_scales:
-            st[1].synchronize()
-            v = float(st[0])
-            if not (math.isfinite(v) and v > 0):
-                v = None
-        if v is None:
-            v = float(cur)
-        if st is None:
-            st = (torch.empty((), dtype=F32, pin_memory=True), torch.cuda.Event())
-            self._amax_state[name] = st
-        st[0].copy_(cur, non_blocking=True)
-        st[1].record()
-        return v
 
     def _side_stream(self, k=1):
         if self._side is None:
@@ -641,8 +616,8 @@ class FairnessTrainer:
             wi = (w * args.weight_loss_img * dyn).to(dev)
             loss_clip, de_c = feature_loss_and_grad(e_c, clip_ori, wi)
             loss_dino, de_d = feature_loss_and_grad(e_d, dino_ori, wi)
-            dsmall = self.clip.backward(de_c, _pow2_scale(self._amax("clip", de_c), 1.0))
-            self.dino.backward(de_d, _pow2_scale(self._amax("dino", de_d), 1.0), out=dsmall)
+            dsmall = self.clip.backward(de_c, _pow2_scale(float(de_c.abs().max()), 1.0))
+            self.dino.backward(de_d, _pow2_scale(float(de_d.abs().max()), 1.0), out=dsmall)
             d_img = ops.crop_resize_bwd(dsmall, fullbox, B, Himg, Wimg, args.img_size_small)
             # apply_grad_hook_face (:1904, :1584-1617) acts on this path only: the classifier saw the un-hooked images
             if len(tl) == 1:
@@ -675,7 +650,7 @@ class FairnessTrainer:
                 wf = (w[rows] * args.weight_loss_face).to(dev)
                 lf_rows, df = feature_loss_and_grad(feats, tgt, wf)
                 deferred.append(lambda lf_rows=lf_rows, rows=rows: loss_face.__setitem__(rows, lf_rows.float().cpu()))
-                dch = face_features_backward(self.face_net, fctx, df, _pow2_scale(self._amax("face", df), 1.0))
+                dch = face_features_backward(self.face_net, fctx, df, _pow2_scale(float(df.abs().max()), 1.0))
                 if d_img is None:
                     d_img = torch.zeros((B, 3, Himg, Wimg), dtype=F32, device=dev)
                 ops.warp_affine_bwd(dch.contiguous(), idx_f, A_f, d_img, args.size_aligned_face)   # un-hooked images (:1901)
@@ -695,12 +670,12 @@ class FairnessTrainer:
             else:
                 self.clf._ctx = None
             self._mark("R3_bwd_vae")
-            vscale = _pow2_scale(self._amax("d_img", d_img), 64.0)
+            vscale = _pow2_scale(float(d_img.abs().max()), 64.0)
             dz = self.vae.backward_images(d_img, vscale)
             g = dz * (1.0 / self.vae.config.scaling_factor)          # dL/dx_final  [B,4,h,w] fp32
             coefs = self.sch.grad_coefs() * self.sch.chain_coefs()   # hook (:1128) x scheduler recurrence (:1131)
             gs = args.guidance_scale
-            gscale = _pow2_scale(self._amax("g", g) * float(abs(coefs).max()) * max(abs(gs), abs(1 - gs)), 64.0)
+            gscale = _pow2_scale(float(g.abs().max()) * float(abs(coefs).max()) * max(abs(gs), abs(1 - gs)), 64.0)
             out.update(g=g, coefs=coefs, gscale=gscale)
             self._mark("R3_bwd_unet")
             if train_unet or train_te or train_prefix:
