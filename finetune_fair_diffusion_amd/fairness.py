@@ -298,11 +298,10 @@ def _cells(attr_sizes):
 
 
 @torch.no_grad()
-def mc_transport_plan(probs_list, class_cdfs, num_samples_per_device=100, generator=None, age_asymmetric=False):
-    """The rank-local, host-heavy half of the multi-attribute dynamic targets (exp-3 `:1488-1536`, exp-4 `:1517-1569`): for each of
-    ``num_samples_per_device`` Monte-Carlo draws of a balanced class assignment the faces are optimally transported onto the drawn
-    cell counts; returns (idx [n] bool of faces, summed plans [N, K] fp32, attribute sizes) -- or (idx, None, sizes) without faces.
-    It depends only on the gathered probabilities, so the step runs it on a worker thread underneath the R2 rollout."""
+def mc_transport_problem(probs_list, class_cdfs, num_samples_per_device=100, generator=None, age_asymmetric=False):
+    """The inputs of the Monte-Carlo transport solves (exp-3 `:1488-1536`, exp-4 `:1517-1569`): returns (idx [n] bool of faces, cost
+    matrix M [N, K] fp64 = distance of the probability vectors to the one-hot corners of each cell `:1514-1531`, counts [S, K] int64 =
+    drawn cell capacities per Monte-Carlo sample `:1492-1512`, attribute sizes) -- (idx, None, None, sizes) without faces."""
     n = probs_list[0].shape[0]
     sizes = [p.shape[1] for p in probs_list]
     idx = torch.ones(n, dtype=torch.bool)
@@ -310,7 +309,7 @@ def mc_transport_plan(probs_list, class_cdfs, num_samples_per_device=100, genera
         idx &= (p != -1).all(dim=-1)
     N = int(idx.sum())
     if N == 0:
-        return idx, None, sizes
+        return idx, None, None, sizes
     P = [p[idx].float().numpy() for p in probs_list]
     cells = _cells(sizes)
     K = len(cells)
@@ -337,11 +336,33 @@ def mc_transport_plan(probs_list, class_cdfs, num_samples_per_device=100, genera
                 d = d.copy(); d[:, 0] *= 2.0
             sq += (d ** 2).sum(axis=1)
         M[:, j] = np.sqrt(sq)
-    tp = np.zeros((N, K))
+    counts = np.zeros((num_samples_per_device, K), dtype=np.int64)
     for s in range(num_samples_per_device):
         cell_idx = sum(draws[a][s] * radix[a] for a in range(len(sizes)))
-        counts = np.bincount(cell_idx, minlength=K)
-        tp += _ot_assign(M, counts)
+        counts[s] = np.bincount(cell_idx, minlength=K)
+    return idx, M, counts, sizes
+
+
+@torch.no_grad()
+def mc_transport_plan(probs_list, class_cdfs, num_samples_per_device=100, generator=None, age_asymmetric=False, device=None):
+    """The rank-local half of the multi-attribute dynamic targets (exp-3 `:1488-1536`, exp-4 `:1517-1569`): for each of
+    ``num_samples_per_device`` Monte-Carlo draws of a balanced class assignment the faces are optimally transported onto the drawn
+    cell counts; returns (idx [n] bool of faces, summed plans [N, K] fp32, attribute sizes) -- or (idx, None, sizes) without faces.
+    It depends only on the gathered probabilities, so the step runs it on a worker thread underneath the R2 rollout.
+
+    ``device``: solve the draws on that GPU (``fd_ot_assign_sum``: one wave per draw, exact shortest-augmenting-path assignment in fp64;
+    the summed plan stays on the device for the all-reduce); None: the host solver (scipy's assignment -- what the CPU tests and the
+    ``FD_OT_HOST`` measurement switch use).  Both are exact: the plans are equal wherever the optimum is unique."""
+    idx, M, counts, sizes = mc_transport_problem(probs_list, class_cdfs, num_samples_per_device, generator, age_asymmetric)
+    if M is None:
+        return idx, None, sizes
+    if device is not None:
+        from . import ops
+        tp = ops.ot_assign_sum(torch.from_numpy(M).to(device), torch.from_numpy(counts.astype(np.int32)).to(device))
+        return idx, tp, sizes
+    tp = np.zeros(M.shape)
+    for s in range(counts.shape[0]):
+        tp += _ot_assign(M, counts[s])
     return idx, torch.tensor(tp, dtype=torch.float32), sizes
 
 
@@ -354,6 +375,7 @@ def targets_from_plan(idx, tp, sizes):
     if tp is None:
         return list(zip(out_t, out_u))
     cells = _cells(sizes)
+    tp = tp.cpu()
     tp = tp / tp[0, :].sum()
     for a in range(len(sizes)):
         marg = torch.zeros(tp.shape[0], sizes[a])
@@ -366,7 +388,7 @@ def targets_from_plan(idx, tp, sizes):
 
 @torch.no_grad()
 def generate_dynamic_targets_multi(probs_list, class_cdfs, num_samples_per_device=100, generator=None, allreduce=None,
-                                   age_asymmetric=False, return_plan=False):
+                                   age_asymmetric=False, return_plan=False, device=None):
     """Dynamic targets for several attributes at once (exp-3-debias-gender-race/1-main-debias.py:1459-1569,
     exp-4-debias-gender-race-age/1-main-debias.py:1477-1615).
 
@@ -374,14 +396,14 @@ def generate_dynamic_targets_multi(probs_list, class_cdfs, num_samples_per_devic
     edges used to turn a uniform draw into a class (gender [0.5, 1], race [.25,.5,.75,1], age [.75, 1]).
     The Monte-Carlo plans (``mc_transport_plan``) are summed (and all-reduced over ranks, ``allreduce`` callable),
     normalised, marginalised per attribute (``targets_from_plan``).  Returns [(targets [n] long, uncertainty [n])] per attribute
-    (plus the normalised plan with ``return_plan``).
+    (plus the normalised plan with ``return_plan``).  ``device``: run the transport solves on that GPU (see ``mc_transport_plan``).
     ``age_asymmetric``: exp-4's cost doubles the first age coordinate when the target is the second class (`exp-4:1551-1556`)."""
-    idx, tp, sizes = mc_transport_plan(probs_list, class_cdfs, num_samples_per_device, generator, age_asymmetric)
+    idx, tp, sizes = mc_transport_plan(probs_list, class_cdfs, num_samples_per_device, generator, age_asymmetric, device=device)
     if tp is not None and allreduce is not None:
         tp = allreduce(tp)
     res = targets_from_plan(idx, tp, sizes)
     if return_plan:
-        return res, (None if tp is None else tp / tp[0, :].sum())
+        return res, (None if tp is None else tp.cpu() / tp[0, :].sum().cpu())
     return res
 
 

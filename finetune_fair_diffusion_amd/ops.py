@@ -673,6 +673,19 @@ def rect_scale(dimg, rects, factors):
     return dimg
 
 
+def ot_assign_sum(cost, counts, plan=None, seats=False):
+    """Summed 0/1 transport plans of S capacity draws (exp-3 :1488-1536): cost [N,K] f64, counts [S,K] int32 (rows sum to N), both on the
+    device.  Returns plan [N,K] f32 (accumulated into ``plan`` when given) and, with ``seats``, the cell of every face per draw [S,N]."""
+    N, K = cost.shape
+    S = counts.shape[0]
+    assert counts.shape[1] == K
+    if plan is None:
+        plan = torch.zeros((N, K), dtype=F32, device=cost.device)
+    st = torch.empty((S, N), dtype=torch.int32, device=cost.device) if seats else None
+    _call("fd_ot_assign_sum", _p(_chk(cost, torch.float64)), _p(_chk(counts, torch.int32)), _p(_chk(plan, F32)), _p(st), N, K, S, _stream())
+    return (plan, st) if seats else plan
+
+
 # ----------------------------------------------------------------------------- text-encoder attention
 def small_attn_fwd(q, k, v, key_valid, B, H, T, d, scale, causal=True, save_p=False):
     o = torch.empty_like(q)

@@ -175,6 +175,9 @@ class FairnessTrainer:
         self._sch_r2 = None
         self.last_r2_prefetched = 0
         self.last_ot_ms = (0.0, 0.0)
+        # the Monte-Carlo transport solves of exp-3/4/5 run on the GPU (csrc/assign.hip); FD_OT_HOST=1: the host solver (measurement switch)
+        self.ot_on_device = os.environ.get("FD_OT_HOST") is None
+        self._ot_stream = torch.cuda.Stream(device=self.device)
         self._tgt = None
 
     # ------------------------------------------------------------------ per-phase timing (R1 / R2 / R3-fwd / R3-bwd / sync)
@@ -383,7 +386,12 @@ class FairnessTrainer:
         def work():
             t0 = time.perf_counter()
             try:
-                st["plan"] = mc_transport_plan(gathered, self.class_cdfs, 100, self.target_rng, self.age_asym)
+                if self.ot_on_device:       # fd_ot_assign_sum on a side stream of this thread; the summed plan stays in HBM for the all-reduce
+                    with torch.cuda.stream(self._ot_stream):
+                        st["plan"] = mc_transport_plan(gathered, self.class_cdfs, 100, self.target_rng, self.age_asym, device=self.device)
+                    self._ot_stream.synchronize()
+                else:
+                    st["plan"] = mc_transport_plan(gathered, self.class_cdfs, 100, self.target_rng, self.age_asym)
             except BaseException as e:      # re-raised on the main thread by finish_dynamic_targets (a dead worker would otherwise surface
                 st["error"] = e             # as KeyError('plan') here and as a collective timeout on the other ranks)
             st["solve_ms"] = 1e3 * (time.perf_counter() - t0)
@@ -412,10 +420,12 @@ class FairnessTrainer:
                 raise RuntimeError("Monte-Carlo transport solve for the dynamic targets failed" +
                                    (" on this rank" if "error" in st else " on another rank")) from st.get("error")
             idx, tp, sizes = st["plan"]
+            if tp is not None and tp.is_cuda:
+                tp.record_stream(torch.cuda.current_stream())
             if tp is not None and self.collectives:
                 t = tp.to(self.device)
                 dist.all_reduce(t, op=dist.ReduceOp.SUM)
-                tp = t.cpu()
+                tp = t
             st["res"] = targets_from_plan(idx, tp, sizes)
             self.last_ot_ms = (st.get("solve_ms", 0.0), 1e3 * (time.perf_counter() - t0))
         out = []

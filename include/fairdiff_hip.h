@@ -241,6 +241,13 @@ int fd_warp_affine_bwd(const float* dchips, const int32_t* src_index, const floa
 /* apply_grad_hook_face (:1584-1617) in the backward: dimg [B,3,H,W] fp32 *= factors[b] inside rects[b] = [x0,y0,x1,y1) */
 int fd_rect_scale(float* dimg, const int32_t* rects, const float* factors, int B, int H, int W, void* stream);
 
+/* ---- dynamic targets of the multi-attribute experiments: the Monte-Carlo transport solves (exp-3-debias-gender-race/1-main-debias.py:1488-1536
+ * ``ot.emd(ones(N), counts_s, M)`` for s < S; exp-4 :1517-1569).  N unit-mass faces onto K cells whose integer capacities counts[s, :]
+ * sum to N: an assignment problem on the capacity-replicated cost matrix, solved exactly (shortest augmenting paths, fp64) by one
+ * wave per draw.  cost [N,K] f64, counts [S,K] int32, plan [N,K] f32: plan += sum_s T_s (0/1 transport matrices; zero it first for a
+ * fresh sum); seats [S,N] int32 (cell of face i in draw s) or NULL.  N <= 1024. */
+int fd_ot_assign_sum(const double* cost, const int32_t* counts, float* plan, int32_t* seats, int N, int K, int S, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

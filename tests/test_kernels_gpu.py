@@ -572,3 +572,39 @@ def test_gemm_fused_geglu_with_pregate_output_and_interleaved_backward(ops, dev)
     d_il = ops.geglu_bwd_interleaved(aux, dy)
     d_ref = ops.geglu_bwd(proj, dy)
     assert torch.equal(d_il[:, 0::2], d_ref[:, :F]) and torch.equal(d_il[:, 1::2], d_ref[:, F:])
+
+
+@pytest.mark.parametrize("N,K,S", [(1, 8, 3), (5, 8, 20), (16, 8, 100), (64, 16, 100), (130, 16, 12), (64, 2, 10)])
+def test_ot_assign_device_solver_is_exact(ops, dev, N, K, S):
+    """fd_ot_assign_sum (exp-3 :1488-1536 ``ot.emd(ones(N), counts, M)`` per Monte-Carlo draw) against scipy's exact assignment on the
+    capacity-replicated matrix: every draw respects the capacities and reaches the optimal cost (1e-12 relative, fp64); with continuous
+    random costs the optimum is unique, so the summed plans are EQUAL.  The degenerate all-equal cost matrix must still give a feasible
+    optimum."""
+    import numpy as np
+    from scipy.optimize import linear_sum_assignment
+    rng = np.random.default_rng(1000 * N + K)
+    for degenerate in (False, True):
+        M = np.full((N, K), 0.75) if degenerate else np.sqrt(rng.random((N, K)) * 2.0)
+        counts = np.stack([np.bincount(rng.integers(0, K, N), minlength=K) for _ in range(S)]).astype(np.int32)
+        plan, seats = ops.ot_assign_sum(torch.from_numpy(M).to(dev), torch.from_numpy(counts).to(dev), seats=True)
+        torch.cuda.synchronize()
+        plan, seats = plan.cpu().numpy(), seats.cpu().numpy()
+        ref = np.zeros((N, K))
+        for s in range(S):
+            assert (np.bincount(seats[s], minlength=K) == counts[s]).all(), f"draw {s}: capacities violated"
+            cols = np.repeat(np.arange(K), counts[s])
+            r, c = linear_sum_assignment(M[:, cols])
+            opt = M[r, cols[c]].sum()
+            got = M[np.arange(N), seats[s]].sum()
+            assert abs(got - opt) <= 1e-12 * max(1.0, abs(opt)), f"draw {s}: cost {got} vs optimal {opt}"
+            ref[r, cols[c]] += 1.0
+        onehot = np.zeros((N, K))
+        for s in range(S):
+            onehot[np.arange(N), seats[s]] += 1.0
+        assert (plan == onehot).all(), "summed plan is not the sum of the per-draw seats"
+        assert plan.sum() == N * S
+        if not degenerate:
+            assert (plan == ref).all(), f"summed plan differs from the host solver in {(plan != ref).sum()} entries"
+    # accumulation into an existing plan
+    p2 = ops.ot_assign_sum(torch.from_numpy(M).to(dev), torch.from_numpy(counts).to(dev), plan=torch.from_numpy(plan).to(dev).float())
+    assert float(p2.sum()) == 2 * N * S
