@@ -653,6 +653,9 @@ static int launch(const fd_gemm_desc& d, hipStream_t s) {
 // gemm_pp.hip: the 8-wave 256x320 ping-pong kernel (BK = 32, four-stage ring, two wave groups half a k-step apart)
 bool fd_gemm_pp_eligible(const fd_gemm_desc& d);
 int fd_gemm_launch_pp(const fd_gemm_desc& d, hipStream_t s, bool prio, int bm, int nsplit);
+// gemm_pps.hip: the persistent form of the 128x320 ping-pong kernel for short-K dense projections (tiles streamed by <= 256 workgroups)
+bool fd_gemm_pps_eligible(const fd_gemm_desc& d);
+int fd_gemm_launch_pps(const fd_gemm_desc& d, hipStream_t s, int max_wg);
 // Which problems the ping-pong kernels take (bits): 1 = stride-1 3x3 convolutions on the 256x320 tile, 2 = every dense GEMM on it,
 // 4 = s_setprio around the MFMA streams, 8 = stride-1 convolutions on the 128x320 tile, 16 = dense GEMMs on it, 32 = dense 256x320 GEMMs
 // with K <= 384 and N >= 2560 only (the FF1 projections of the 64^2 level), 64 = split-K launches of the 128x320 tile too.
@@ -673,6 +676,14 @@ static int pp_mode() {
 #else
     return FD_GEMM_PP_DEFAULT;
 #endif
+}
+// bit 128: dense GEMMs with at least PPS_MIN 128-row tiles go to the persistent streaming kernel
+static bool pps_takes(const fd_gemm_desc& d, int sel) {
+    const int t = sel % 1000000, split = sel / 1000000;
+    if (!(pp_mode() & 128) || split != 0 || (t != 256320 && t != 128320) || !fd_gemm_pps_eligible(d)) return false;
+    static const long pps_min = bench_env("FD_GEMM_PPS_MIN") ? atol(bench_env("FD_GEMM_PPS_MIN")) : 512;
+    static const long pps_maxk = bench_env("FD_GEMM_PPS_MAXK") ? atol(bench_env("FD_GEMM_PPS_MAXK")) : 1 << 30;
+    return (long)((d.M + 127) / 128) * (d.N / 320) >= pps_min && d.K + d.K2 <= pps_maxk;
 }
 // 0 = not taken, else the tile height (256 / 128)
 static int pp_takes(const fd_gemm_desc& d, int sel) {
@@ -769,7 +780,8 @@ extern "C" int fd_gemm_kernel_name(const fd_gemm_desc* dp, char* buf, int n) {
         case 256128: wgm = 4; wgn = 2; break;
         default: fam = bm == 16 ? "gemm_skinny_kernel" : "gemm_glds_kernel"; break;
     }
-    if (pp_takes(d, sel)) snprintf(buf, n, "gemm_pp_kernel<%d, %d, %s>", pp_takes(d, sel), d.conv ? 1 : 0, (pp_mode() & 4) ? "true" : "false");
+    if (pps_takes(d, sel)) snprintf(buf, n, "gemm_pps_kernel<%d>", d.act == FD_ACT_GEGLU ? 1 : 0);
+    else if (pp_takes(d, sel)) snprintf(buf, n, "gemm_pp_kernel<%d, %d, %s>", pp_takes(d, sel), d.conv ? 1 : 0, (pp_mode() & 4) ? "true" : "false");
     else if (wgm) snprintf(buf, n, "%s<%d, %d, %d, %d, %d>", fam, bm, bn, wgm, wgn, cv);
     else if (bm == 16) snprintf(buf, n, "%s<%d, %d, 1>", fam, bn / 16, d.K >= 1280 ? 4 : d.K >= 640 ? 2 : 1);
     else snprintf(buf, n, "%s<%d, %d, %s>", fam, bm, bn, d.conv ? "true" : "false");
@@ -814,6 +826,10 @@ extern "C" int fd_gemm(const fd_gemm_desc* dp, void* stream) {
     }
     if (sel >= 1000000) {
         return (sel % 1000000 == 128320) ? launch_big<128, 320, 4, 4>(d, s, sel / 1000000) : launch_big<128, 160, 4, 2>(d, s, sel / 1000000);
+    }
+    if (pps_takes(d, sel)) {
+        static const int pps_wg = bench_env("FD_GEMM_PPS_WG") ? atoi(bench_env("FD_GEMM_PPS_WG")) : 256;
+        return fd_gemm_launch_pps(d, s, pps_wg);
     }
     if (const int bm = pp_takes(d, sel)) {
         const int nsplit = sel >= 1000000 ? sel / 1000000 : 1;
