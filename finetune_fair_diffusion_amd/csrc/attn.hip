@@ -60,6 +60,23 @@ __device__ __forceinline__ f16x8 read_perm(const f16* tile, int row, int base, i
     return (f16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
 
+// The same permuted-k A operand, but of a product whose A matrix is the TRANSPOSE of a row-major LDS tile [k][m] (row stride ``stride``
+// halfs, 8-byte aligned rows): gfx950's ds_read_b64_tr_b16.  A 16-lane group fetches one [4 k][16 m] block -- lane L of the group supplies
+// the address of row L / 4, columns 4 (L % 4) .. + 3 -- and lane c receives column c, i.e. A[m0 + c][k .. k + 3].  With it V (forward),
+// K (dQ) and Q / dO (dK, dV) are consumed in the layout the projections write them in: no transposed copies in HBM, no transposed tiles.
+// Columns past the tile's row only feed output rows >= D, which are never stored.
+typedef short fd_s16x4 __attribute__((__vector_size__(8)));
+__device__ __forceinline__ f16x8 read_tr(const f16* tile, int stride, int k0, int m0, int ml, int g) {
+    const f16* p = tile + (k0 + 4 * g + ((ml & 15) >> 2)) * stride + m0 + (ml & 16) + 4 * (ml & 3);
+    const fd_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) fd_s16x4*)p);
+    const fd_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) fd_s16x4*)(p + 8 * stride));
+    const f16x4 a = __builtin_bit_cast(f16x4, lo), b = __builtin_bit_cast(f16x4, hi);
+    return (f16x8){a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+}
+// row stride (halfs) of a tile that is only read with read_tr: the 32 lanes serviced together fetch 4 rows x 64 bytes, which sit on distinct
+// banks when the stride is 64 or 192 bytes modulo 256
+constexpr int tr_stride(int DV) { return DV % 128 == 32 || DV % 128 == 96 ? DV : (DV + 32) % 128 == 32 || (DV + 32) % 128 == 96 ? DV + 32 : DV + 64; }
+
 
 // ---- register-staged tiles with the load split from the LDS write (issue the next tile's global loads before
 // computing the current one, write them to LDS after the barrier): hides the HBM/L2 latency under the MFMAs.
@@ -156,18 +173,24 @@ __device__ __forceinline__ void zero_col_pad(f16* dst) {
 // each head-dim class reaches WITHOUT scratch (checked on the gfx950 ISA: .amdhsa_next_free_vgpr / private_segment_fixed_size).
 constexpr int fwd_waves(int D) { return D <= 64 ? 3 : D <= 128 ? 2 : 1; }
 constexpr int dq_waves(int D) { return D <= 40 ? 3 : D <= 128 ? 2 : 1; }
-constexpr int dkdv_waves(int D) { return D <= 64 ? 2 : 1; }
+#ifdef FD_DKDV_TR_W3      // measurement: the read_tr form of dK/dV at d = 40 squeezed to three waves per SIMD (168 registers + 124 B of scratch)
+constexpr int dkdv_waves(int D, bool QTR = false) { return (QTR && D == 40) ? 3 : D <= 64 ? 2 : 1; }
+#else
+constexpr int dkdv_waves(int D, bool QTR = false) { return D <= 64 ? 2 : 1; }
+#endif
 
 // ================================================================================== forward
-template <int D>
+// VTR: ``Vt`` points at V itself ([Bk, Tkr, .] rows of stride ldk, like K) and the PV operand comes from a row-major tile through read_tr
+template <int D, bool VTR>
 __global__ __launch_bounds__(256, fwd_waves(D)) void attn_fwd_kernel(const f16* __restrict__ Q, const f16* __restrict__ K, const f16* __restrict__ Vt,
                                                        f16* __restrict__ O, float* __restrict__ LSE, int H, int Tq, int Tk, int Tkp,
                                                        int Tkr, int kv_div, float scale, int ldq, int ldk) {
     constexpr int DK = (D + 15) / 16 * 16, DV = (D + 31) / 32 * 32, DKP = DK + 8;
     constexpr int NKS = DK / 16, NDV = DV / 32;
     extern __shared__ __attribute__((aligned(16))) f16 smem[];
+    constexpr int VP = tr_stride(DV);
     f16* Ks = smem;               // [64][DKP]
-    f16* Vts = smem + 64 * DKP;   // [DV][TS]
+    f16* Vts = smem + 64 * DKP;   // [DV][TS]   (VTR: [64][VP], keys x d)
 
     int b, h, qblk;
     attn_block_coords((Tq + 127) / 128, H, gridDim.x / (((Tq + 127) / 128) * H), b, h, qblk);
@@ -193,21 +216,24 @@ __global__ __launch_bounds__(256, fwd_waves(D)) void attn_fwd_kernel(const f16* 
     const float sl2 = scale * LOG2E;
 
     const f16* Kb = K + (int64_t)bk * Tkr * ldk + h * D;
-    const f16* Vtb = Vt + ((int64_t)bk * C + h * D) * Tkp;
+    const f16* Vtb = VTR ? Vt + (int64_t)bk * Tkr * ldk + h * D : Vt + ((int64_t)bk * C + h * D) * Tkp;
 
     TileRegs<D> kreg, vreg;
     TilePlan<D> kplan, vplan;
     plan_rows<D>(kplan, ldk);
-    plan_cols<D>(vplan, Tkp);
+    if (VTR) plan_rows<D>(vplan, ldk);
+    else plan_cols<D>(vplan, Tkp);
     zero_row_pad<D, DKP>(Ks);
-    zero_col_pad<D, DV>(Vts);
+    if (!VTR) zero_col_pad<D, DV>(Vts);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // Q fragments landed: no VM event may pend on them inside the loop
     load_rows<D>(kreg, Kb, ldk, 0, Tk);
-    load_cols<D>(vreg, Vtb, Tkp, 0, Tkp);
+    if (VTR) load_rows<D>(vreg, Vtb, ldk, 0, Tk);
+    else load_cols<D>(vreg, Vtb, Tkp, 0, Tkp);
     for (int k0 = 0; k0 < Tk; k0 += 64) {
         __syncthreads();
         store_rows<D, DKP>(kreg, Ks);
-        store_cols<D>(vreg, Vts);
+        if (VTR) store_rows<D, VP>(vreg, Vts);
+        else store_cols<D>(vreg, Vts);
         __syncthreads();
         f32x16 s[2];
 #pragma unroll
@@ -223,10 +249,11 @@ __global__ __launch_bounds__(256, fwd_waves(D)) void attn_fwd_kernel(const f16* 
         // compiler parks an s_waitcnt vmcnt(0) before the first MFMA and the whole load latency is exposed every tile)
         if (k0 + 128 <= Tk) {                 // next tile is an interior one: planned, unchecked loads
             load_planned<D>(kreg, Kb + (int64_t)(k0 + 64) * ldk, kplan);
-            load_planned<D>(vreg, Vtb + (k0 + 64), vplan);
+            load_planned<D>(vreg, VTR ? Vtb + (int64_t)(k0 + 64) * ldk : Vtb + (k0 + 64), vplan);
         } else if (k0 + 64 < Tk) {
             load_rows<D>(kreg, Kb, ldk, k0 + 64, Tk);
-            load_cols<D>(vreg, Vtb, Tkp, k0 + 64, Tkp);
+            if (VTR) load_rows<D>(vreg, Vtb, ldk, k0 + 64, Tk);
+            else load_cols<D>(vreg, Vtb, Tkp, k0 + 64, Tkp);
         }
         // online softmax on the raw scores: p = exp2(s*sl2 - m*sl2) is one FMA + one v_exp per element; the
         // key mask only exists in the last (partial) tile, a wave-uniform branch
@@ -270,7 +297,7 @@ __global__ __launch_bounds__(256, fwd_waves(D)) void attn_fwd_kernel(const f16* 
         for (int st = 0; st < 4; ++st)
 #pragma unroll
             for (int i = 0; i < NDV; ++i) {
-                const f16x8 vf = read_perm(Vts, i * 32 + ql, st * 16, g);
+                const f16x8 vf = VTR ? read_tr(Vts, VP, st * 16, i * 32, ql, g) : read_perm(Vts, i * 32 + ql, st * 16, g);
                 oacc[i] = mfma32(vf, pf[st], oacc[i]);
             }
     }
@@ -314,7 +341,8 @@ __global__ void attn_bwd_prep_kernel(const f16* O, const f16* dO, float* Dd, int
 }
 
 // ================================================================================== dQ
-template <int D>
+// KTR: no transposed K in HBM (Kt == nullptr); the dQ operand K^T comes from the row-major K tile through read_tr
+template <int D, bool KTR>
 __global__ __launch_bounds__(256, dq_waves(D)) void attn_bwd_dq_kernel(const f16* __restrict__ Q, const f16* __restrict__ K, const f16* __restrict__ V,
                                                           const f16* __restrict__ Kt, const f16* __restrict__ dO,
                                                           const float* __restrict__ LSE, float* __restrict__ Dd, f16* __restrict__ dQ,
@@ -373,28 +401,28 @@ __global__ __launch_bounds__(256, dq_waves(D)) void attn_bwd_dq_kernel(const f16
 
     const f16* Kb = K + (int64_t)bk * Tkr * ldkv + h * D;
     const f16* Vb = V + (int64_t)bk * Tkr * ldkv + h * D;
-    const f16* Ktb = Kt + ((int64_t)bk * C + h * D) * Tkp;
+    const f16* Ktb = KTR ? nullptr : Kt + ((int64_t)bk * C + h * D) * Tkp;
 
     constexpr bool PF = D <= 80;      // register prefetch where the register file has room
     TileRegs<D> kreg, vreg, ktreg;
     zero_row_pad<D, DKP>(Ks);
     zero_row_pad<D, DKP>(Vs);
-    zero_col_pad<D, DV>(Kts);
+    if (!KTR) zero_col_pad<D, DV>(Kts);
     if (PF) {
         load_rows<D>(kreg, Kb, ldkv, 0, Tk);
         load_rows<D>(vreg, Vb, ldkv, 0, Tk);
-        load_cols<D>(ktreg, Ktb, Tkp, 0, Tkp);
+        if (!KTR) load_cols<D>(ktreg, Ktb, Tkp, 0, Tkp);
     }
     for (int k0 = 0; k0 < Tk; k0 += 64) {
         __syncthreads();
         if (!PF) {
             load_rows<D>(kreg, Kb, ldkv, k0, Tk);
             load_rows<D>(vreg, Vb, ldkv, k0, Tk);
-            load_cols<D>(ktreg, Ktb, Tkp, k0, Tkp);
+            if (!KTR) load_cols<D>(ktreg, Ktb, Tkp, k0, Tkp);
         }
         store_rows<D, DKP>(kreg, Ks);
         store_rows<D, DKP>(vreg, Vs);
-        store_cols<D>(ktreg, Kts);
+        if (!KTR) store_cols<D>(ktreg, Kts);
         __syncthreads();
         f16x8 dsf[4];
 #pragma unroll
@@ -411,7 +439,7 @@ __global__ __launch_bounds__(256, dq_waves(D)) void attn_bwd_dq_kernel(const f16
             if (kt == 0 && PF && k0 + 64 < Tk) {
                 load_rows<D>(kreg, Kb, ldkv, k0 + 64, Tk);
                 load_rows<D>(vreg, Vb, ldkv, k0 + 64, Tk);
-                load_cols<D>(ktreg, Ktb, Tkp, k0 + 64, Tkp);
+                if (!KTR) load_cols<D>(ktreg, Ktb, Tkp, k0 + 64, Tkp);
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -424,7 +452,7 @@ __global__ __launch_bounds__(256, dq_waves(D)) void attn_bwd_dq_kernel(const f16
         for (int st = 0; st < 4; ++st)
 #pragma unroll
             for (int i = 0; i < NDV; ++i) {
-                const f16x8 kf = read_perm(Kts, i * 32 + ql, st * 16, g);
+                const f16x8 kf = KTR ? read_tr(Ks, DKP, st * 16, i * 32, ql, g) : read_perm(Kts, i * 32 + ql, st * 16, g);
                 acc[i] = mfma32(kf, dsf[st], acc[i]);
             }
     }
@@ -447,8 +475,9 @@ __global__ __launch_bounds__(256, dq_waves(D)) void attn_bwd_dq_kernel(const f16
 
 // ================================================================================== dK, dV
 // block = 128 keys (4 waves x 32), loops over 32-query tiles.  S[q][key] = Q.K^T with K,V rows in VGPRs.
-template <int D, bool ATOMIC>
-__global__ __launch_bounds__(256, dkdv_waves(D)) void attn_bwd_dkdv_kernel(const f16* __restrict__ Q, const f16* __restrict__ Qt, const f16* __restrict__ K,
+// QTR: no transposed Q / dO in HBM (Qt == dOt == nullptr); the dK / dV operands Q^T, dO^T come from the row-major tiles through read_tr
+template <int D, bool ATOMIC, bool QTR>
+__global__ __launch_bounds__(256, dkdv_waves(D, QTR)) void attn_bwd_dkdv_kernel(const f16* __restrict__ Q, const f16* __restrict__ Qt, const f16* __restrict__ K,
                                                             const f16* __restrict__ V, const f16* __restrict__ dO,
                                                             const f16* __restrict__ dOt, const float* __restrict__ LSE,
                                                             const float* __restrict__ Dd, void* __restrict__ dKo, void* __restrict__ dVo,
@@ -491,8 +520,8 @@ __global__ __launch_bounds__(256, dkdv_waves(D)) void attn_bwd_dkdv_kernel(const
 
     const f16* Qb = Q + (int64_t)b * Tq * ldq + h * D;
     const f16* Gb = dO + (int64_t)b * Tq * C + h * D;
-    const f16* Qtb = Qt + ((int64_t)b * C + h * D) * Tq;
-    const f16* Gtb = dOt + ((int64_t)b * C + h * D) * Tq;
+    const f16* Qtb = QTR ? nullptr : Qt + ((int64_t)b * C + h * D) * Tq;
+    const f16* Gtb = QTR ? nullptr : dOt + ((int64_t)b * C + h * D) * Tq;
     const float* Lb = LSE + ((int64_t)b * H + h) * Tq;
     const float* Db = Dd + ((int64_t)b * H + h) * Tq;
 
@@ -500,26 +529,34 @@ __global__ __launch_bounds__(256, dkdv_waves(D)) void attn_bwd_dkdv_kernel(const
     TileRegs<D> qreg, greg, qtreg, gtreg;
     zero_row_pad<D, DKP>(Qs);
     zero_row_pad<D, DKP>(Gs);
-    zero_col_pad<D, DV>(Qts);
-    zero_col_pad<D, DV>(Gts);
+    if (!QTR) {
+        zero_col_pad<D, DV>(Qts);
+        zero_col_pad<D, DV>(Gts);
+    }
     if (PF) {
         load_rows<D>(qreg, Qb, ldq, 0, Tq);
         load_rows<D>(greg, Gb, C, 0, Tq);
-        load_cols<D>(qtreg, Qtb, Tq, 0, Tq);
-        load_cols<D>(gtreg, Gtb, Tq, 0, Tq);
+        if (!QTR) {
+            load_cols<D>(qtreg, Qtb, Tq, 0, Tq);
+            load_cols<D>(gtreg, Gtb, Tq, 0, Tq);
+        }
     }
     for (int q0 = 0; q0 < Tq; q0 += 64) {
         __syncthreads();
         if (!PF) {
             load_rows<D>(qreg, Qb, ldq, q0, Tq);
             load_rows<D>(greg, Gb, C, q0, Tq);
-            load_cols<D>(qtreg, Qtb, Tq, q0, Tq);
-            load_cols<D>(gtreg, Gtb, Tq, q0, Tq);
+            if (!QTR) {
+                load_cols<D>(qtreg, Qtb, Tq, q0, Tq);
+                load_cols<D>(gtreg, Gtb, Tq, q0, Tq);
+            }
         }
         store_rows<D, DKP>(qreg, Qs);
         store_rows<D, DKP>(greg, Gs);
-        store_cols<D>(qtreg, Qts);
-        store_cols<D>(gtreg, Gts);
+        if (!QTR) {
+            store_cols<D>(qtreg, Qts);
+            store_cols<D>(gtreg, Gts);
+        }
         if (threadIdx.x < 64) {
             const int tq = q0 + threadIdx.x;
             lse_s[threadIdx.x] = tq < Tq ? Lb[tq] * LOG2E : INFINITY;
@@ -540,8 +577,10 @@ __global__ __launch_bounds__(256, dkdv_waves(D)) void attn_bwd_dkdv_kernel(const
             if (qt == 0 && PF && q0 + 64 < Tq) {       // prefetch behind the first MFMA group (see forward)
                 load_rows<D>(qreg, Qb, ldq, q0 + 64, Tq);
                 load_rows<D>(greg, Gb, C, q0 + 64, Tq);
-                load_cols<D>(qtreg, Qtb, Tq, q0 + 64, Tq);
-                load_cols<D>(gtreg, Gtb, Tq, q0 + 64, Tq);
+                if (!QTR) {
+                    load_cols<D>(qtreg, Qtb, Tq, q0 + 64, Tq);
+                    load_cols<D>(gtreg, Gtb, Tq, q0 + 64, Tq);
+                }
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -556,8 +595,8 @@ __global__ __launch_bounds__(256, dkdv_waves(D)) void attn_bwd_dkdv_kernel(const
         for (int st = 0; st < 4; ++st)
 #pragma unroll
             for (int i = 0; i < NDV; ++i) {
-                const f16x8 ga = read_perm(Gts, i * 32 + kl, st * 16, g);
-                const f16x8 qa = read_perm(Qts, i * 32 + kl, st * 16, g);
+                const f16x8 ga = QTR ? read_tr(Gs, DKP, st * 16, i * 32, kl, g) : read_perm(Gts, i * 32 + kl, st * 16, g);
+                const f16x8 qa = QTR ? read_tr(Qs, DKP, st * 16, i * 32, kl, g) : read_perm(Qts, i * 32 + kl, st * 16, g);
                 dv[i] = mfma32(ga, pf[st], dv[i]);
                 dk[i] = mfma32(qa, dsf[st], dk[i]);
             }
@@ -590,10 +629,17 @@ __global__ __launch_bounds__(256, dkdv_waves(D)) void attn_bwd_dkdv_kernel(const
 
 // ================================================================================== host side
 
-template <int D> static constexpr size_t fwd_lds() { return (size_t)(64 * (((D + 15) / 16 * 16) + 8) + ((D + 31) / 32 * 32) * TS) * 2; }
-template <int D> static constexpr size_t dq_lds() { return (size_t)(2 * 64 * (((D + 15) / 16 * 16) + 8) + ((D + 31) / 32 * 32) * TS) * 2; }
-template <int D> static constexpr size_t dkdv_lds() {
-    return (size_t)(2 * 64 * (((D + 15) / 16 * 16) + 8) + 2 * ((D + 31) / 32 * 32) * TS) * 2 + 512;
+template <int D, bool TR> static constexpr size_t fwd_lds() {
+    constexpr int DKP = (D + 15) / 16 * 16 + 8, DV = (D + 31) / 32 * 32;
+    return (size_t)(64 * DKP + (TR ? 64 * tr_stride(DV) : DV * TS)) * 2;
+}
+template <int D, bool TR> static constexpr size_t dq_lds() {
+    constexpr int DKP = (D + 15) / 16 * 16 + 8, DV = (D + 31) / 32 * 32;
+    return (size_t)(2 * 64 * DKP + (TR ? 64 : DV * TS)) * 2;      // TR: slack for the reads that run past the last row
+}
+template <int D, bool TR> static constexpr size_t dkdv_lds() {
+    constexpr int DKP = (D + 15) / 16 * 16 + 8, DV = (D + 31) / 32 * 32;
+    return (size_t)(2 * 64 * DKP + 2 * DV * TS) * 2 + 512;          // same carve-up for both forms (the TR form leaves the column tiles unused)
 }
 
 #define FD_DISPATCH_D(d, CALL)                                                       \
@@ -623,12 +669,19 @@ extern "C" int fd_attn_fwd(const void* q, const void* k, const void* vt, void* o
     if (ldq <= 0) ldq = H * d;
     if (ldk <= 0) ldk = H * d;
     FD_REQUIRE((ldq & 7) == 0 && (ldk & 7) == 0, "fd_attn_fwd: row strides must be multiples of 8");
-    FD_REQUIRE(B > 0 && H > 0 && Tq > 0 && Tk > 0 && Tkp >= Tk && (Tkp & 7) == 0 && Tkr >= Tk && kv_div >= 1, "fd_attn_fwd: bad shape");
+    const bool vtr = Tkp == 0;        // vt is V itself: rows of stride ldk, like k
+    FD_REQUIRE(B > 0 && H > 0 && Tq > 0 && Tk > 0 && (vtr || (Tkp >= Tk && (Tkp & 7) == 0)) && Tkr >= Tk && kv_div >= 1, "fd_attn_fwd: bad shape");
     dim3 grid(((Tq + 127) / 128) * H * B);
 #define CALL(DD)                                                                                                                      \
-    ALLOW_LDS(attn_fwd_kernel<DD>, fwd_lds<DD>());                                                                                    \
-    hipLaunchKernelGGL(attn_fwd_kernel<DD>, grid, dim3(256), fwd_lds<DD>(), (hipStream_t)stream, (const f16*)q, (const f16*)k,        \
-                       (const f16*)vt, (f16*)o, lse, H, Tq, Tk, Tkp, Tkr, kv_div, scale, ldq, ldk)
+    if (vtr) {                                                                                                                        \
+        ALLOW_LDS((attn_fwd_kernel<DD, true>), (fwd_lds<DD, true>()));                                                                \
+        hipLaunchKernelGGL((attn_fwd_kernel<DD, true>), grid, dim3(256), (fwd_lds<DD, true>()), (hipStream_t)stream, (const f16*)q,  \
+                           (const f16*)k, (const f16*)vt, (f16*)o, lse, H, Tq, Tk, Tkp, Tkr, kv_div, scale, ldq, ldk);                \
+    } else {                                                                                                                          \
+        ALLOW_LDS((attn_fwd_kernel<DD, false>), (fwd_lds<DD, false>()));                                                              \
+        hipLaunchKernelGGL((attn_fwd_kernel<DD, false>), grid, dim3(256), (fwd_lds<DD, false>()), (hipStream_t)stream, (const f16*)q, \
+                           (const f16*)k, (const f16*)vt, (f16*)o, lse, H, Tq, Tk, Tkp, Tkr, kv_div, scale, ldq, ldk);                \
+    }
     FD_DISPATCH_D(d, CALL)
 #undef CALL
     return fd_check_launch("fd_attn_fwd");
@@ -650,12 +703,21 @@ extern "C" int fd_attn_bwd_dq(const void* q, const void* k, const void* v, const
     if (ldkv <= 0) ldkv = H * d;
     if (lddq <= 0) lddq = H * d;
     FD_REQUIRE((ldq & 7) == 0 && (ldkv & 7) == 0 && (lddq & 3) == 0, "fd_attn_bwd_dq: row strides");
-    FD_REQUIRE(B > 0 && H > 0 && Tq > 0 && Tk > 0 && Tkp >= Tk && (Tkp & 7) == 0 && Tkr >= Tk && kv_div >= 1, "fd_attn_bwd_dq: bad shape");
+    const bool ktr = kt == nullptr;
+    FD_REQUIRE(B > 0 && H > 0 && Tq > 0 && Tk > 0 && (ktr || (Tkp >= Tk && (Tkp & 7) == 0)) && Tkr >= Tk && kv_div >= 1, "fd_attn_bwd_dq: bad shape");
     dim3 grid(((Tq + 127) / 128) * H * B);
 #define CALL(DD)                                                                                                                      \
-    ALLOW_LDS(attn_bwd_dq_kernel<DD>, dq_lds<DD>());                                                                                  \
-    hipLaunchKernelGGL(attn_bwd_dq_kernel<DD>, grid, dim3(256), dq_lds<DD>(), (hipStream_t)stream, (const f16*)q, (const f16*)k,      \
-                       (const f16*)v, (const f16*)kt, (const f16*)d_o, lse, D, (f16*)dq, (const f16*)o, H, Tq, Tk, Tkp, Tkr, kv_div, scale, ldq, ldkv, lddq)
+    if (ktr) {                                                                                                                        \
+        ALLOW_LDS((attn_bwd_dq_kernel<DD, true>), (dq_lds<DD, true>()));                                                              \
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<DD, true>), grid, dim3(256), (dq_lds<DD, true>()), (hipStream_t)stream, (const f16*)q, \
+                           (const f16*)k, (const f16*)v, (const f16*)kt, (const f16*)d_o, lse, D, (f16*)dq, (const f16*)o, H, Tq, Tk, \
+                           Tkp, Tkr, kv_div, scale, ldq, ldkv, lddq);                                                                 \
+    } else {                                                                                                                          \
+        ALLOW_LDS((attn_bwd_dq_kernel<DD, false>), (dq_lds<DD, false>()));                                                            \
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<DD, false>), grid, dim3(256), (dq_lds<DD, false>()), (hipStream_t)stream,              \
+                           (const f16*)q, (const f16*)k, (const f16*)v, (const f16*)kt, (const f16*)d_o, lse, D, (f16*)dq,            \
+                           (const f16*)o, H, Tq, Tk, Tkp, Tkr, kv_div, scale, ldq, ldkv, lddq);                                       \
+    }
     FD_DISPATCH_D(d, CALL)
 #undef CALL
     return fd_check_launch("fd_attn_bwd_dq");
@@ -668,21 +730,25 @@ extern "C" int fd_attn_bwd_dkdv(const void* q, const void* qt, const void* k, co
     if (ldkv <= 0) ldkv = H * d;
     if (lddkv <= 0) lddkv = H * d;
     FD_REQUIRE((ldq & 7) == 0 && (ldkv & 7) == 0 && (lddkv & 3) == 0, "fd_attn_bwd_dkdv: row strides");
-    FD_REQUIRE(B > 0 && H > 0 && Tq > 0 && Tk > 0 && (Tq & 7) == 0 && Tkr >= Tk && kv_div >= 1, "fd_attn_bwd_dkdv: bad shape (Tq %% 8)");
+    const bool qtr = qt == nullptr && d_ot == nullptr;
+    FD_REQUIRE(qtr || (qt && d_ot), "fd_attn_bwd_dkdv: qt and d_ot must both be given or both be NULL");
+    FD_REQUIRE(B > 0 && H > 0 && Tq > 0 && Tk > 0 && (qtr || (Tq & 7) == 0) && Tkr >= Tk && kv_div >= 1, "fd_attn_bwd_dkdv: bad shape (Tq %% 8)");
     dim3 grid(((Tk + 127) / 128) * H * B);
-#define CALL(DD)                                                                                                                       \
-    if (kv_div > 1 || accumulate) {                                                                                                    \
-        ALLOW_LDS((attn_bwd_dkdv_kernel<DD, true>), dkdv_lds<DD>());                                                                     \
-        hipLaunchKernelGGL((attn_bwd_dkdv_kernel<DD, true>), grid, dim3(256), dkdv_lds<DD>(), (hipStream_t)stream, (const f16*)q,      \
-                           (const f16*)qt, (const f16*)k, (const f16*)v, (const f16*)d_o, (const f16*)d_ot, lse, D, dk, dv, H, Tq, Tk, \
-                           Tkr, kv_div, scale, ldq, ldkv, lddkv);                                                                           \
-    } else {                                                                                                                           \
-        ALLOW_LDS((attn_bwd_dkdv_kernel<DD, false>), dkdv_lds<DD>());                                                                    \
-        hipLaunchKernelGGL((attn_bwd_dkdv_kernel<DD, false>), grid, dim3(256), dkdv_lds<DD>(), (hipStream_t)stream, (const f16*)q,     \
-                           (const f16*)qt, (const f16*)k, (const f16*)v, (const f16*)d_o, (const f16*)d_ot, lse, D, dk, dv, H, Tq, Tk, \
-                           Tkr, kv_div, scale, ldq, ldkv, lddkv);                                                                           \
+#define LAUNCH(DD, AT, TRQ)                                                                                                            \
+    {                                                                                                                                  \
+        ALLOW_LDS((attn_bwd_dkdv_kernel<DD, AT, TRQ>), (dkdv_lds<DD, TRQ>()));                                                         \
+        hipLaunchKernelGGL((attn_bwd_dkdv_kernel<DD, AT, TRQ>), grid, dim3(256), (dkdv_lds<DD, TRQ>()), (hipStream_t)stream,           \
+                           (const f16*)q, (const f16*)qt, (const f16*)k, (const f16*)v, (const f16*)d_o, (const f16*)d_ot, lse, D, dk, \
+                           dv, H, Tq, Tk, Tkr, kv_div, scale, ldq, ldkv, lddkv);                                                       \
+    }
+#define CALL(DD)                                                     \
+    if (kv_div > 1 || accumulate) {                                  \
+        if (qtr) LAUNCH(DD, true, true) else LAUNCH(DD, true, false) \
+    } else {                                                         \
+        if (qtr) LAUNCH(DD, false, true) else LAUNCH(DD, false, false) \
     }
     FD_DISPATCH_D(d, CALL)
 #undef CALL
+#undef LAUNCH
     return fd_check_launch("fd_attn_bwd_dkdv");
 }

@@ -442,19 +442,30 @@ def to_f32(x, scale=1.0):
 
 
 # ----------------------------------------------------------------------------- attention
-def attn_fwd(q, k, vt, B, H, Tq, Tk, d, kv_div=1, scale=None, need_lse=False, kv_rows=None):
-    """q [B*Tq, H*d], k [Bk*Tkr, H*d] (2-D; rows may be strided: column slices of a wider buffer), vt [Bk, H*d, Tkp].
+# The attention kernels consume V (forward), K (dQ) and Q / dO (dK, dV) in the row-major layout the projections write them in, through LDS
+# transpose reads (ds_read_b64_tr_b16).  FD_ATTN_NO_TR=1 restores the round-1/2 form with transposed copies made by fd_transpose_btc
+# (measurement switch; both forms are in the library).
+ATTN_TR = os.environ.get("FD_ATTN_NO_TR") is None
+
+
+def attn_fwd(q, k, vt, B, H, Tq, Tk, d, kv_div=1, scale=None, need_lse=False, kv_rows=None, v=None):
+    """q [B*Tq, H*d], k [Bk*Tkr, H*d] (2-D; rows may be strided: column slices of a wider buffer), and EITHER v (same shape and row
+    stride as k; read through LDS transpose reads) OR vt [Bk, H*d, Tkp] (the transposed copy).
     ``kv_rows``: rows per batch item of the k buffer when it is row-padded beyond the Tk keys (ViT token buffers)."""
-    Tkp = vt.shape[-1]
     Tkr = kv_rows or Tk
+    if v is not None:
+        assert vt is None and _rows(v) == _rows(k) and v.shape == k.shape
+        vp, Tkp = v, 0
+    else:
+        vp, Tkp = _chk(vt), vt.shape[-1]
     o = torch.empty((q.shape[0], H * d), dtype=F16, device=q.device)
     lse = torch.empty((B, H, Tq), dtype=F32, device=q.device) if need_lse else None
-    _call("fd_attn_fwd", _p(q), _p(k), _p(_chk(vt)), _p(o), _p(lse), B, H, Tq, Tk, Tkp, Tkr, d, kv_div,
+    _call("fd_attn_fwd", _p(q), _p(k), _p(vp), _p(o), _p(lse), B, H, Tq, Tk, Tkp, Tkr, d, kv_div,
           scale if scale is not None else d ** -0.5, _rows(q), _rows(k), _stream())
     return (o, lse) if need_lse else o
 
 
-def attn_bwd(q, k, v, o, do, lse, B, H, Tq, Tk, d, kv_div=1, scale=None, kt=None, dk_acc=None, dv_acc=None, kv_rows=None, dqkv=None):
+def attn_bwd(q, k, v, o, do, lse, B, H, Tq, Tk, d, kv_div=1, scale=None, kt=None, dk_acc=None, dv_acc=None, kv_rows=None, dqkv=None, tr=None):
     """Returns (dq, dk, dv).  With ``dk_acc`` / ``dv_acc`` (fp32 [Bk*Tk, C]; mandatory when kv_div > 1, i.e. shared K/V) dk/dv are ADDED
     into those buffers with fp32 atomics -- safe for launches that run concurrently on different streams.
     q, k, v are 2-D and may be column slices of a wider buffer; with ``dqkv`` [M, 3*H*d] (self-attention, kv_div == 1) the three
@@ -465,9 +476,13 @@ def attn_bwd(q, k, v, o, do, lse, B, H, Tq, Tk, d, kv_div=1, scale=None, kt=None
     assert _rows(k) == _rows(v)
     Dd = torch.empty((B, H, Tq), dtype=F32, device=q.device)     # D = rowsum(dO*O): produced inside the dq kernel, read by dk/dv
     Bk = B // kv_div
-    if kt is None:
-        kt = transpose_btc(k, Bk, Tkr, C)
-    Tkp = kt.shape[-1]
+    tr = ATTN_TR if tr is None else tr
+    if tr:
+        kt, Tkp = None, 0
+    else:
+        if kt is None:
+            kt = transpose_btc(k, Bk, Tkr, C)
+        Tkp = kt.shape[-1]
     if dqkv is not None:
         assert kv_div == 1 and dqkv.shape == (q.shape[0], 3 * C) and dqkv.is_contiguous() and Tkr == Tk and dqkv.dtype == F16
         dq, dk, dv = dqkv[:, :C], dqkv[:, C:2 * C], dqkv[:, 2 * C:]
@@ -484,8 +499,8 @@ def attn_bwd(q, k, v, o, do, lse, B, H, Tq, Tk, d, kv_div=1, scale=None, kt=None
             dk, dv = mk((k.shape[0], C), dtype=F16, device=q.device), mk((k.shape[0], C), dtype=F16, device=q.device)
     _call("fd_attn_bwd_dq", _p(q), _p(k), _p(v), _p(kt), _p(_chk(do)), _p(lse), _p(Dd), _p(_chk(o)), _p(dq), B, H, Tq, Tk, Tkp, Tkr, d,
           kv_div, scale, _rows(q), _rows(k), _rows(dq), _stream())
-    qt = transpose_btc(q, B, Tq, C, Tq)
-    dot = transpose_btc(do, B, Tq, C, Tq)
+    qt = None if tr else transpose_btc(q, B, Tq, C, Tq)
+    dot = None if tr else transpose_btc(do, B, Tq, C, Tq)
     _call("fd_attn_bwd_dkdv", _p(q), _p(qt), _p(k), _p(v), _p(do), _p(dot), _p(lse), _p(Dd), _p(dk), _p(dv), B, H, Tq, Tk, Tkr, d, kv_div, scale,
           _rows(q), _rows(k), lddkv, int(dk_acc is not None), _stream())
     return dq, dk, dv

@@ -101,7 +101,7 @@ class TransformerBlock:
 
     # -- cross-attention K/V for the rollout's prompt embeddings (timestep invariant) ------------
     def prepare_cross(self, enc, Bk, L, record):
-        """enc: [Bk*L, xdim] fp16.  Caches K [Bk*L,C], V, K^T, V^T ([Bk,C,Lp])."""
+        """enc: [Bk*L, xdim] fp16.  Caches K [Bk*L,C], V (and, with ops.ATTN_TR off, the transposed copies K^T, V^T [Bk,C,Lp])."""
         lo = self.lora2
         te = ops.gemm(enc, lo.down_kv16) if lo is not None else None
         rp = lo.k.rp if lo is not None else 0
@@ -110,9 +110,10 @@ class TransformerBlock:
             V = ops.gemm(enc, self.v2.w, a2=te[:, rp:], b2=lo.v.up16)
         else:
             K, V = ops.gemm(enc, self.k2.w), ops.gemm(enc, self.v2.w)
-        self.cross = dict(K=K, V=V, Vt=ops.transpose_btc(V, Bk, L, self.C), Bk=Bk, L=L, enc=enc, te=te)
+        self.cross = dict(K=K, V=V, Vt=None if ops.ATTN_TR else ops.transpose_btc(V, Bk, L, self.C), Kt=None, Bk=Bk, L=L, enc=enc, te=te)
         if record:
-            self.cross["Kt"] = ops.transpose_btc(K, Bk, L, self.C)
+            if not ops.ATTN_TR:
+                self.cross["Kt"] = ops.transpose_btc(K, Bk, L, self.C)
             self.cross["dK"] = torch.zeros((Bk * L, self.C), dtype=F32, device=enc.device)
             self.cross["dV"] = torch.zeros((Bk * L, self.C), dtype=F32, device=enc.device)
 
@@ -148,8 +149,10 @@ class TransformerBlock:
         if ops.fp8_attn_ok(HW, d):       # BASELINE configs[4]: e4m3 QK^T / PV in self-attention (the backward stays in the working dtype)
             o, lse = ops.attn_fwd_fp8(q, k, v, B, h, HW, d, need_lse=True)
         else:
-            vt = ops.transpose_btc(v, B, HW, C)
-            o, lse = ops.attn_fwd(q, k, vt, B, h, HW, HW, d, 1, need_lse=True)
+            if ops.ATTN_TR:
+                o, lse = ops.attn_fwd(q, k, None, B, h, HW, HW, d, 1, need_lse=True, v=v)
+            else:
+                o, lse = ops.attn_fwd(q, k, ops.transpose_btc(v, B, HW, C), B, h, HW, HW, d, 1, need_lse=True)
         h1, to1 = lora_linear_fwd(o, self.o1, l1.out if l1 else None, residual=h0)
         n2, ln2 = ops.layernorm(h1, self.ln2.gamma, self.ln2.beta, 1e-5, save_stats=True)
         l2 = self.lora2
@@ -158,7 +161,7 @@ class TransformerBlock:
         q2f, h1f, xf = (torch.cat([q2, q2]), torch.cat([h1, h1]), torch.cat([x, x])) if pair else (q2, h1, x)
         cr = self.cross
         kv_div = B2 // cr["Bk"]
-        o2, lse2 = ops.attn_fwd(q2f, cr["K"], cr["Vt"], B2, h, HW, cr["L"], d, kv_div, need_lse=True)
+        o2, lse2 = ops.attn_fwd(q2f, cr["K"], cr["Vt"], B2, h, HW, cr["L"], d, kv_div, need_lse=True, v=cr["V"] if cr["Vt"] is None else None)
         h2, to2 = lora_linear_fwd(o2, self.o2, l2.out if l2 else None, residual=h1f)
         n3, ln3 = ops.layernorm(h2, self.ln3.gamma, self.ln3.beta, 1e-5, save_stats=True)
         # bit-identical to projection + fd_geglu_fwd (both halves are rounded to fp16 before the gate)

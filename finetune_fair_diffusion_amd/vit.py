@@ -114,8 +114,10 @@ class VisionTransformer:
             q = ops.gemm(n1, L["q"].w, bias=L["q"].bias)
             k = ops.gemm(n1, L["k"].w, bias=L["k"].bias)
             v = ops.gemm(n1, L["v"].w, bias=L["v"].bias)
-            vt = ops.transpose_btc(v, N, Tp, D)
-            a, lse = ops.attn_fwd(q, k, vt, N, H, Tp, T, d, need_lse=True, kv_rows=Tp)
+            if ops.ATTN_TR:
+                a, lse = ops.attn_fwd(q, k, None, N, H, Tp, T, d, need_lse=True, kv_rows=Tp, v=v)
+            else:
+                a, lse = ops.attn_fwd(q, k, ops.transpose_btc(v, N, Tp, D), N, H, Tp, T, d, need_lse=True, kv_rows=Tp)
             h1 = ops.gemm(a, L["o"].w, bias=L["o"].bias, residual=x)
             n2, s2 = ops.layernorm(h1, L["ln2"].gamma, L["ln2"].beta, eps, save_stats=True)
             if record:

@@ -124,7 +124,8 @@ int fd_cast_f16_to_f32(const void* x, float* y, int64_t n, float scale, void* st
 
 /* ---- fused attention (diffusers Attention.get_attention_scores + bmm, LoRAAttnProcessor.__call__)
  * q:[B,Tq,H*d]  k:[Bk,Tkr,H*d] of which the first Tk rows are keys (Tkr>=Tk: row-padded token buffers of the ViTs)
- * vt:[Bk,H*d,Tkp] (V transposed, keys contiguous, Tkp>=Tk, Tkp%8==0)
+ * vt: with Tkp == 0, V ITSELF -- [Bk,Tkr,H*d] rows of stride ldk, exactly like k -- consumed through LDS transpose reads
+ *     (ds_read_b64_tr_b16; the shipped form); with Tkp > 0 a transposed copy [Bk,H*d,Tkp] (keys contiguous, Tkp>=Tk, Tkp%8==0).
  * sample b uses kv batch b / kv_div (cross-attention K/V are shared by each CFG half).
  * o:[B,Tq,H*d] fp16, lse:[B,H,Tq] fp32 (natural-log sum-exp of the scaled scores).
  * ldq / ldk (and ldkv, lddq, lddkv below): row strides in elements of q, k/v and of the dq, dk/dv outputs; 0 = H*d (contiguous).
@@ -134,12 +135,14 @@ int fd_attn_fwd(const void* q, const void* k, const void* vt, void* o, float* ls
                 int Tkp, int Tkr, int d, int kv_div, float scale, int ldq, int ldk, void* stream);
 /* D[b,h,t] = sum_j dO*O */
 int fd_attn_bwd_prep(const void* o, const void* d_o, float* D, int B, int H, int T, int d, void* stream);
-/* dq from (q, k, v, kt:[Bk,H*d,Tkp], dO, lse, D).  With o != NULL the kernel computes D = rowsum(dO*O) itself and WRITES it to D
+/* dq from (q, k, v, kt, dO, lse, D).  kt == NULL (the shipped form): K^T for the dS.K product comes from the row-major K tile through
+ * LDS transpose reads; else kt:[Bk,H*d,Tkp] is a transposed copy of k.  With o != NULL the kernel computes D = rowsum(dO*O) itself and WRITES it to D
  * for fd_attn_bwd_dkdv (fd_attn_bwd_prep is then not needed); with o == NULL it reads D. */
 int fd_attn_bwd_dq(const void* q, const void* k, const void* v, const void* kt, const void* d_o, const float* lse,
                    float* D, const void* o, void* dq, int B, int H, int Tq, int Tk, int Tkp, int Tkr, int d, int kv_div, float scale,
                    int ldq, int ldkv, int lddq, void* stream);
-/* dk,dv from (q, qt:[B,H*d,Tq], k, v, dO, dOt:[B,H*d,Tq], lse, D). When kv_div>1 the kv batch is shared by
+/* dk,dv from (q, qt, k, v, dO, dOt, lse, D).  qt == dOt == NULL (the shipped form): Q^T and dO^T come from the row-major q / dO tiles
+ * through LDS transpose reads (no Tq % 8 restriction); else qt, dOt:[B,H*d,Tq] are transposed copies.  When kv_div>1 the kv batch is shared by
  * kv_div consecutive samples; dk/dv are then fp32 [Bk,Tk,H*d] accumulated with atomics, else fp16 (overwritten).
  * ``accumulate`` != 0 selects the fp32-atomic form at kv_div == 1 too: several launches -- timesteps of the truncated chain whose
  * backwards run on different HIP streams -- may then add into one accumulator concurrently. */

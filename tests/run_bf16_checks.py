@@ -70,8 +70,7 @@ def kernels():
         return t.reshape(B, T, H, d).permute(0, 2, 1, 3)
     s = sp(qr) @ sp(kr).transpose(-1, -2) * d ** -0.5
     oref = (torch.softmax(s, -1) @ sp(vr)).permute(0, 2, 1, 3).reshape(B, T, C)
-    vt = ops.transpose_btc(v.reshape(B * T, C), B, T, C)
-    o, lse = ops.attn_fwd(q.reshape(B * T, C), k.reshape(B * T, C), vt, B, H, T, T, d, 1, need_lse=True)
+    o, lse = ops.attn_fwd(q.reshape(B * T, C), k.reshape(B * T, C), None, B, H, T, T, d, 1, need_lse=True, v=v.reshape(B * T, C))
     check("attention fwd d=40", o.reshape(B, T, C), oref, 2e-2)
     do = rnd(B, T, C, seed=14)
     oref.backward(do.float())

@@ -309,30 +309,48 @@ def _attn_ref(q, k, v, H, kv_div=1):
     return o.permute(0, 2, 1, 3).reshape(B, T, C), torch.logsumexp(s, -1)
 
 
+@pytest.mark.parametrize("tr", [True, False])
 @pytest.mark.parametrize("B,H,Tq,Tk,d,kv_div", [(2, 8, 1024, 1024, 40, 1), (2, 8, 256, 256, 80, 1), (2, 4, 256, 256, 160, 1),
                                                  (1, 2, 64, 64, 160, 1), (4, 8, 1024, 13, 40, 2), (2, 2, 200, 77, 64, 1),
-                                                 (2, 4, 64, 16, 32, 2), (1, 8, 4096, 4096, 40, 1)])
-def test_attention_fwd_bwd(ops, dev, B, H, Tq, Tk, d, kv_div):
+                                                 (2, 4, 64, 16, 32, 2), (1, 8, 4096, 4096, 40, 1), (2, 4, 100, 50, 16, 1), (1, 2, 130, 130, 128, 1)])
+def test_attention_fwd_bwd(ops, dev, B, H, Tq, Tk, d, kv_div, tr):
+    """tr = True: the shipped form -- V, K, Q, dO consumed row-major through LDS transpose reads (ds_read_b64_tr_b16); False: the form with
+    transposed copies made by fd_transpose_btc.  Same arithmetic, different operand delivery: the two must also be bit-identical."""
     C = H * d
     Bk = B // kv_div
     q, k, v = rnd(B, Tq, C, dev=dev, seed=1), rnd(Bk, Tk, C, dev=dev, seed=2), rnd(Bk, Tk, C, dev=dev, seed=3)
     qr, kr, vr = (t.float().requires_grad_(True) for t in (q, k, v))
     oref, lref = _attn_ref(qr, kr, vr, H, kv_div)
-    vt = ops.transpose_btc(v.reshape(Bk * Tk, C), Bk, Tk, C)
-    o, lse = ops.attn_fwd(q.reshape(B * Tq, C), k.reshape(Bk * Tk, C), vt, B, H, Tq, Tk, d, kv_div, need_lse=True)
+    q2, k2, v2 = q.reshape(B * Tq, C), k.reshape(Bk * Tk, C), v.reshape(Bk * Tk, C)
+
+    def fwd(form):
+        if form:
+            return ops.attn_fwd(q2, k2, None, B, H, Tq, Tk, d, kv_div, need_lse=True, v=v2)
+        return ops.attn_fwd(q2, k2, ops.transpose_btc(v2, Bk, Tk, C), B, H, Tq, Tk, d, kv_div, need_lse=True)
+    o, lse = fwd(tr)
     check("attn fwd", o.reshape(B, Tq, C), oref, 3e-3)
     check("attn lse", lse, lref, 1e-3)
-    if Tq % 8:
+    if tr:
+        o_other, lse_other = fwd(False)
+        assert torch.equal(o, o_other) and torch.equal(lse, lse_other), "transpose-read forward differs from the transposed-copy forward"
+    if Tq % 8 and not tr:
         return
     do = rnd(B, Tq, C, dev=dev, seed=4)
     oref.backward(do.float())
-    dk_acc = torch.zeros(Bk * Tk, C, dtype=torch.float32, device=dev) if kv_div > 1 else None
-    dv_acc = torch.zeros_like(dk_acc) if kv_div > 1 else None
-    dq, dk, dv = ops.attn_bwd(q.reshape(B * Tq, C), k.reshape(Bk * Tk, C), v.reshape(Bk * Tk, C), o, do.reshape(B * Tq, C), lse, B, H, Tq, Tk, d,
-                              kv_div, dk_acc=dk_acc, dv_acc=dv_acc)
+
+    def bwd(form):
+        dk_acc = torch.zeros(Bk * Tk, C, dtype=torch.float32, device=dev) if kv_div > 1 else None
+        dv_acc = torch.zeros_like(dk_acc) if kv_div > 1 else None
+        return ops.attn_bwd(q2, k2, v2, o, do.reshape(B * Tq, C), lse, B, H, Tq, Tk, d, kv_div, dk_acc=dk_acc, dv_acc=dv_acc, tr=form)
+    dq, dk, dv = bwd(tr)
     check("attn dq", dq.reshape(B, Tq, C), qr.grad, 5e-3)
     check("attn dk", dk.reshape(Bk, Tk, C), kr.grad, 5e-3)
     check("attn dv", dv.reshape(Bk, Tk, C), vr.grad, 5e-3)
+    if tr and Tq % 8 == 0:
+        dq2, dk2, dv2 = bwd(False)
+        assert torch.equal(dq, dq2), "transpose-read dQ differs"
+        if kv_div == 1:            # the shared-K/V form adds with fp32 atomics: order-dependent low bits
+            assert torch.equal(dk, dk2) and torch.equal(dv, dv2), "transpose-read dK / dV differ"
 
 
 @pytest.mark.parametrize("B,H,T,d", [(2, 8, 1024, 40), (2, 8, 256, 80), (1, 4, 64, 160)])
@@ -348,6 +366,8 @@ def test_attention_strided_qkv_slices(ops, dev, B, H, T, d):
     assert torch.equal(vt, ops.transpose_btc(vc, B, T, C))
     o, lse = ops.attn_fwd(q, k, vt, B, H, T, T, d, 1, need_lse=True)
     assert torch.equal(o, o_ref) and torch.equal(lse, lse_ref)
+    o_tr, lse_tr = ops.attn_fwd(q, k, None, B, H, T, T, d, 1, need_lse=True, v=v)      # the shipped form: v itself, row stride 3C
+    assert torch.equal(o_tr, o_ref) and torch.equal(lse_tr, lse_ref)
     do = rnd(B * T, C, dev=dev, seed=4)
     dq_r, dk_r, dv_r = ops.attn_bwd(qc, kc, vc, o_ref, do, lse_ref, B, H, T, T, d, 1)
     dqkv = torch.full((B * T, 3 * C), float("nan"), dtype=qkv.dtype, device=dev)
