@@ -564,6 +564,61 @@ __global__ __launch_bounds__(256, dkdv_waves(D, QTR)) void attn_bwd_dkdv_kernel(
         }
         __syncthreads();
         f16x8 pf[4], dsf[4];
+        // p and dS of keys past Tk are never zeroed: such a lane owns a key COLUMN of dK^T / dV^T that is never stored, and with its K / V
+        // fragments zero everything it computes stays finite
+        auto soft = [&](const f32x16& s, const f32x16& dp, int qt, int r) {
+            const int qi = qt * 32 + crow(r, g);
+            const float p = __builtin_amdgcn_exp2f(fmaf(s[r], sl2, -lse_s[qi]));
+            pf[qt * 2 + (r >> 3)][r & 7] = (f16)p;
+            dsf[qt * 2 + (r >> 3)][r & 7] = (f16)(p * (dp[r] - dd_s[qi]));   // scale applied to dK at the end
+        };
+        auto dvdk = [&](int st, int i) {
+            const f16x8 ga = QTR ? read_tr(Gs, DKP, st * 16, i * 32, kl, g) : read_perm(Gts, i * 32 + kl, st * 16, g);
+            const f16x8 qa = QTR ? read_tr(Qs, DKP, st * 16, i * 32, kl, g) : read_perm(Qts, i * 32 + kl, st * 16, g);
+            dv[i] = mfma32(ga, pf[st], dv[i]);
+            dk[i] = mfma32(qa, dsf[st], dk[i]);
+        };
+#ifdef FD_DKDV_PIPE
+        // measurement: both score tiles first, then the second tile's softmax interleaved with the first tile's dV / dK products
+        f32x16 s2[2], dp2[2];
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            s2[qt] = zero16(); dp2[qt] = zero16();
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                const f16x8 qa = *(const f16x8*)(Qs + (qt * 32 + kl) * DKP + ks * 16 + g * 8);
+                const f16x8 ga = *(const f16x8*)(Gs + (qt * 32 + kl) * DKP + ks * 16 + g * 8);
+                s2[qt] = mfma32(qa, kf[ks], s2[qt]);
+                dp2[qt] = mfma32(ga, vf[ks], dp2[qt]);
+            }
+        }
+        if (PF && q0 + 64 < Tq) {
+            load_rows<D>(qreg, Qb, ldq, q0 + 64, Tq);
+            load_rows<D>(greg, Gb, C, q0 + 64, Tq);
+            if (!QTR) {
+                load_cols<D>(qtreg, Qtb, Tq, q0 + 64, Tq);
+                load_cols<D>(gtreg, Gtb, Tq, q0 + 64, Tq);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) soft(s2[0], dp2[0], 0, r);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+#pragma unroll
+            for (int r = 4 * c; r < 4 * c + 4; ++r) soft(s2[1], dp2[1], 1, r);
+            if (NDV == 2) dvdk(c >> 1, c & 1);
+            else if (c < 2) {
+#pragma unroll
+                for (int i = 0; i < NDV; ++i) dvdk(c, i);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int st = 2; st < 4; ++st)
+#pragma unroll
+            for (int i = 0; i < NDV; ++i) dvdk(st, i);
+#else
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) {
             f32x16 s = zero16(), dp = zero16();
@@ -583,23 +638,13 @@ __global__ __launch_bounds__(256, dkdv_waves(D, QTR)) void attn_bwd_dkdv_kernel(
                 }
             }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int qi = qt * 32 + crow(r, g);
-                float p = __builtin_amdgcn_exp2f(fmaf(s[r], sl2, -lse_s[qi]));
-                if (!kvalid) p = 0.f;
-                pf[qt * 2 + (r >> 3)][r & 7] = (f16)p;
-                dsf[qt * 2 + (r >> 3)][r & 7] = (f16)(p * (dp[r] - dd_s[qi]));   // scale applied to dK at the end
-            }
+            for (int r = 0; r < 16; ++r) soft(s, dp, qt, r);
         }
 #pragma unroll
         for (int st = 0; st < 4; ++st)
 #pragma unroll
-            for (int i = 0; i < NDV; ++i) {
-                const f16x8 ga = QTR ? read_tr(Gs, DKP, st * 16, i * 32, kl, g) : read_perm(Gts, i * 32 + kl, st * 16, g);
-                const f16x8 qa = QTR ? read_tr(Qs, DKP, st * 16, i * 32, kl, g) : read_perm(Qts, i * 32 + kl, st * 16, g);
-                dv[i] = mfma32(ga, pf[st], dv[i]);
-                dk[i] = mfma32(qa, dsf[st], dk[i]);
-            }
+            for (int i = 0; i < NDV; ++i) dvdk(st, i);
+#endif
     }
     if (kvalid) {
         const int64_t off = ((int64_t)bk * Tkr + key) * lddkv + h * D;

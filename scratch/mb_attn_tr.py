@@ -33,14 +33,14 @@ def case(B, H, T, d, Tk=None, kv_div=1):
     k = torch.randn(Bk * Tk, C, generator=g).to(dev).half()
     v = torch.randn(Bk * Tk, C, generator=g).to(dev).half()
     do = torch.randn(B * T, C, generator=g).to(dev).half()
-    vt = ops.transpose_btc(v, Bk, Tk, C)
+    vt = ops.transpose_btc(v, Bk, Tk, C, (Tk + 7) // 8 * 8)
     o, lse = ops.attn_fwd(q, k, vt, B, H, T, Tk, d, kv_div, need_lse=True)
     acc = (torch.zeros(Bk * Tk, C, device=dev), torch.zeros(Bk * Tk, C, device=dev)) if kv_div > 1 else (None, None)
     fl = 4.0 * B * H * T * Tk * d
-    t_tr = timeit(lambda: ops.transpose_btc(v, Bk, Tk, C))
+    t_tr = timeit(lambda: ops.transpose_btc(v, Bk, Tk, C, (Tk + 7) // 8 * 8))
     f0 = timeit(lambda: ops.attn_fwd(q, k, vt, B, H, T, Tk, d, kv_div, need_lse=True))
     f1 = timeit(lambda: ops.attn_fwd(q, k, None, B, H, T, Tk, d, kv_div, need_lse=True, v=v))
-    b0 = timeit(lambda: ops.attn_bwd(q, k, v, o, do, lse, B, H, T, Tk, d, kv_div, dk_acc=acc[0], dv_acc=acc[1], tr=False))
+    b0 = timeit(lambda: ops.attn_bwd(q, k, v, o, do, lse, B, H, T, Tk, d, kv_div, dk_acc=acc[0], dv_acc=acc[1], tr=False)) if T % 8 == 0 else float("nan")
     b1 = timeit(lambda: ops.attn_bwd(q, k, v, o, do, lse, B, H, T, Tk, d, kv_div, dk_acc=acc[0], dv_acc=acc[1], tr=True))
     print(f"B{B} H{H} T{T}x{Tk} d{d} kv_div{kv_div}: fwd copies {f0:7.1f} us (+{t_tr:5.1f} transpose)  tr {f1:7.1f} us ({fl / f1 / 1e6:5.0f} TF/s)"
           f"   bwd copies (3 transposes incl.) {b0:7.1f} us  tr {b1:7.1f} us ({2.5 * fl / b1 / 1e6:5.0f} TF/s)", flush=True)
