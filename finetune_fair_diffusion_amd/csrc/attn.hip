@@ -441,10 +441,15 @@ __global__ __launch_bounds__(256, dq_waves(D)) void attn_bwd_dq_kernel(const f16
                 load_rows<D>(vreg, Vb, ldkv, k0 + 64, Tk);
                 if (!KTR) load_cols<D>(ktreg, Ktb, Tkp, k0 + 64, Tkp);
             }
+            if (k0 + 64 > Tk) {                  // the key mask only exists in the last (partial) tile: a wave-uniform branch
+                asm volatile("" ::: "memory");   // keeps it a real branch (if-converted it is ~110 VALU -- as many as the softmax itself -- on every tile)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (k0 + kt * 32 + crow(r, g) >= Tk) s[r] = -INFINITY;
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                float p = __builtin_amdgcn_exp2f(fmaf(s[r], sl2, -lse2));
-                if (k0 + 64 > Tk && k0 + kt * 32 + crow(r, g) >= Tk) p = 0.f;
+                const float p = __builtin_amdgcn_exp2f(fmaf(s[r], sl2, -lse2));
                 dsf[kt * 2 + (r >> 3)][r & 7] = (f16)(p * (dp[r] - dd));   // the softmax scale is applied once to the accumulator
             }
         }
