@@ -232,7 +232,8 @@ def main():
         dist.barrier()
     if a.experiment != "exp-1":
         line["config"]["experiment"] = a.experiment
-        line["config"]["ot_host_solve_ms"], line["config"]["ot_exposed_wait_ms"] = [round(v, 2) for v in tr.last_ot_ms]
+        line["config"]["ot_solver"] = "device (fd_ot_assign_sum)" if tr.ot_on_device else "host (scipy assignment)"
+        line["config"]["ot_solve_ms"], line["config"]["ot_exposed_wait_ms"] = [round(v, 2) for v in tr.last_ot_ms]
     if a.force_collectives:
         line["config"]["collectives"] = "RCCL process group of world size %d: probability all-gather + flat LoRA-gradient all-reduce executed" % world
 
