@@ -388,7 +388,10 @@ class FairnessTrainer:
             try:
                 if self.ot_on_device:       # fd_ot_assign_sum on a side stream of this thread; the summed plan stays in HBM for the all-reduce
                     with torch.cuda.stream(self._ot_stream):
-                        st["plan"] = mc_transport_plan(gathered, self.class_cdfs, 100, self.target_rng, self.age_asym, device=self.device)
+                        idx, tp, sizes = mc_transport_plan(gathered, self.class_cdfs, 100, self.target_rng, self.age_asym, device=self.device)
+                        if tp is not None and not self.collectives:
+                            tp = tp.cpu()           # read back on THIS stream: a copy on the launch stream would wait for the queued rollout
+                        st["plan"] = (idx, tp, sizes)
                     self._ot_stream.synchronize()
                 else:
                     st["plan"] = mc_transport_plan(gathered, self.class_cdfs, 100, self.target_rng, self.age_asym)

@@ -1128,3 +1128,35 @@ def test_r2_prefetch_under_the_tail_is_bit_identical(dev):
     for ga, gb in zip(runs["plain"][2], runs["prefetch"][2]):
         for x, y in zip(ga, gb):
             assert float((x - y).abs().max()) <= 4e-3 * float(x.abs().max())
+
+
+def test_single_image_step_concurrent_backward_streams_equal_one_stream(dev, monkeypatch):
+    """with ONE image per prompt and GPU the CFG batch is 2 and every sample has its own prompt row (``kv_div == 1``), the
+    case in which the shared cross-attention dK / dV accumulators used to be updated with plain read-modify-writes from three backward
+    streams at once.  They go through the fp32-atomic kernel on every path now: a B = 1, S = 4 step with the text-encoder AND U-Net LoRA
+    trained (the text-encoder gradient exists only through dK / dV) must give the same gradients with the timesteps' backwards on three
+    streams as on one -- images and losses bit-equal, gradients to fp32-atomic rounding."""
+    from finetune_fair_diffusion_amd.step import FairnessTrainer
+    sds = U.synthetic_sds(train_unet=True, train_te=True, lora_up_std=0.05)
+    tokens = U.tiny_tokens()
+    noises = torch.randn(1, 4, 32, 32, generator=torch.Generator().manual_seed(77))
+    res = {}
+    for mode in ("three_streams", "one_stream"):
+        if mode == "one_stream":
+            monkeypatch.setenv("FD_NO_CONCURRENT_BWD", "1")
+        pm = U.product_models(sds, dev, train_unet=True, train_te=True)
+        args = U.make_args(train_unet=True, train_text_encoder=True, uncertainty_threshold=1.1)
+        tr = FairnessTrainer(args, pm["text_encoder"], pm["unet"], pm["vae"], pm["classifier"], pm["scheduler"], eval_text_encoder=pm["eval_text_encoder"],
+                             eval_unet=pm["eval_unet"], device=dev)
+        grads = []
+        tr.sync_and_update = lambda nb, apply=True: (grads.append([b.grad.clone() for b in tr.banks]), True)[1]
+        o = tr.train_step(tokens, noises, 4)
+        assert o["N_backward"] == 1 and len(grads) == 1, "the single image must have a target (raise uncertainty_threshold otherwise)"
+        res[mode] = (o["images"].clone(), o["loss_fair"].clone(), grads[0])
+    a, b = res["three_streams"], res["one_stream"]
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    for x, y in zip(a[2], b[2]):
+        assert float(x.abs().max()) > 0
+        err = float((x - y).abs().max()) / float(y.abs().max())
+        print(f"[B=1 three streams vs one] bank of {x.numel()} entries: rel max err {err:.2e}")
+        assert err <= 2e-3
