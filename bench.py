@@ -76,6 +76,7 @@ def main():
     os.environ["FD_DTYPE"] = a.dtype          # fixed before the package is imported (selects libfairdiff_hip[_bf16].so)
     if a.fp8_attn:
         os.environ["FD_FP8_ATTN"] = "1"
+    import finetune_fair_diffusion_amd  # noqa: F401  (first: its __init__ puts GPU_MAX_HW_QUEUES=8 in the environment, which HIP reads when the device is initialised)
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -167,6 +168,7 @@ def main():
                    "loss_face_mean": float(out["loss_face"][out["loss_face"] != -1].mean()) if "loss_face" in out and (out["loss_face"] != -1).any() else None,
                    "grad_is_finite": bool(out["grad_is_finite"]),
                    "peak_hbm_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
+                   "hip_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "4 (runtime default)"),
                    "r3_activation_gb_per_timestep": round(tr.last_ctx_bytes / 2 ** 30, 2),
                    "r3_timesteps_kept_in_hbm": min(a.S, 1 + max(tr.last_ctx_budget, 0)) if tr.keep_activations else 0},
     }

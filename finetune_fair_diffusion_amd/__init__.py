@@ -50,5 +50,12 @@ def _is_package_entry_point(argv):
     return base in ("train.py", "generate.py") and os.path.dirname(os.path.abspath(argv[0])) == os.path.dirname(os.path.abspath(__file__))
 
 
+# HIP maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and streams that share one serialise.  The step keeps up to seven
+# streams busy (launch, frozen-model rollout, two more backward streams, the OT solver's, RCCL's internal one, torch's copy streams): with 4
+# queues the R2 prefetch and -- at world size > 1 -- every collective queued behind another stream's kernels (same box, bench.py: 1427-1431 ms
+# with 4 queues, 1382-1399 with 8, 1383 with 16; with the step's collectives on: 1614 vs 1421 ms, profiles/r03_step_ab_hw_queues.txt).  The
+# runtime reads the variable when it initialises the device, so it must be in the environment before the first HIP call; an explicit setting wins.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 if _is_package_entry_point(sys.argv):
     _preselect_working_dtype(sys.argv)
