@@ -3,7 +3,7 @@
 
 CPU only.  ``latents`` (no-grad rollout, ~9 GB of host RAM, 2.5 min on 8 cores) runs in the build container; ``cfg0`` and ``smooth`` hold
 the oracle's autograd graph of the U-Net at SD-v1.5 size (more than the build container's 62 GB) and were generated on the host CPU of
-a GPU box with this same script (scratch/run_r03_a.sh copies the files back):
+a GPU box with this same script (scratch/r03_passes.sh a copies the files back):
 
     python tests/golden/make_oracle_step_golden.py [cfg0] [latents] [smooth]
 
