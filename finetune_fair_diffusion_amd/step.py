@@ -81,6 +81,19 @@ def _pow2_scale(amax, target):
     return float(2.0 ** round(math.log2(target / amax)))
 
 
+_NO_PINNED_H2D = os.environ.get("FD_NO_PINNED_H2D") is not None
+_FINE_MARKS = os.environ.get("FD_FINE_MARKS") is not None
+
+
+def _h2d(t, dev):
+    """Small host tensor -> device WITHOUT draining the launch stream: staged through pinned memory (torch's caching host allocator) and
+    copied non-blocking.  ``t.to(dev)`` from pageable memory makes hipMemcpyAsync wait until the stream has run dry -- in the loss phase
+    of the step (nine such copies between the five read-backs) that kept the host from ever running ahead of the device."""
+    if _NO_PINNED_H2D:          # measurement switch (FD_NO_PINNED_H2D=1): the old pageable copies
+        return t.to(dev).contiguous()
+    return t.contiguous().pin_memory().to(dev, non_blocking=True)
+
+
 class EMAState:
     """diffusers ``EMAModel`` decay schedule (no warm-up flag): decay_n = min(decay, (1+n)/(10+n)), first step copies."""
 
@@ -195,6 +208,11 @@ class FairnessTrainer:
             if name != "end":
                 torch.cuda.nvtx.range_push(name)
 
+    def _fine(self, name):
+        """Sub-phase mark, only with FD_FINE_MARKS=1 (diagnosis of the host-bound tail; the bench line then carries the extra keys)."""
+        if _FINE_MARKS:
+            self._mark(name)
+
     def host_phase_ms(self):
         """{phase: ms} the HOST spent between the phase marks of the last step: launch-enqueue time (plus whatever host syncs the phase
         contains).  A phase whose host time equals its device time is launch-bound."""
@@ -303,14 +321,14 @@ class FairnessTrainer:
         logits = None
         logits_dev = None
         if len(sel):
-            chips = ops.crop_resize(images[sel.to(images.device)].contiguous() if len(sel) != N else images, boxes[sel].to(self.device).contiguous(), -1.0, S)
+            chips = ops.crop_resize(images[_h2d(sel, images.device)].contiguous() if len(sel) != N else images, _h2d(boxes[sel], self.device), -1.0, S)
             logits_dev = self.clf.forward(chips, record=record).float()
             logits = logits_dev.cpu()
         if self.collectives:
             # exchange point 1 stays on the device: [N, sum k] probabilities (-1 rows = no face) for ONE all-gather of all attributes
             pd = torch.full((N, sum(k for _, _, k in self.attrs)), -1.0, dtype=F32, device=self.device)
             if logits_dev is not None:
-                pd[sel.to(self.device)] = torch.cat([torch.softmax(logits_dev[:, c0:c0 + k], dim=-1) for _, c0, k in self.attrs], dim=1)
+                pd[_h2d(sel, self.device)] = torch.cat([torch.softmax(logits_dev[:, c0:c0 + k], dim=-1) for _, c0, k in self.attrs], dim=1)
             self._probs_dev = pd
         for name, c0, k in self.attrs:
             probs = torch.full((N, k), -1.0)
@@ -345,8 +363,8 @@ class FairnessTrainer:
         lms = self.faces.landmarks(images)
         sel = ind.nonzero().view(-1).tolist()
         A = np.stack([alignment_sampling_matrix(lms[i].numpy(), H, W, crop) for i in sel]) if sel else np.zeros((0, 6))
-        A = torch.tensor(A, dtype=F32, device=self.device).contiguous()
-        idx = torch.tensor(sel, dtype=torch.int32, device=self.device)
+        A = _h2d(torch.tensor(A, dtype=F32), self.device)
+        idx = _h2d(torch.tensor(sel, dtype=torch.int32), self.device)
         return ops.warp_affine(images, idx, A, crop), idx, A
 
     def nearest_face_feats(self, query):
@@ -621,23 +639,27 @@ class FairnessTrainer:
             # image-semantics term (:1904-1910, :1931-1932): w_i = (1/n_j) * weight_loss_img * dynamic_weight_i
             small, fullbox = self.resize_small(images_g)
             e_c, e_d = self.image_features(small, record=True)
+            self._fine("L_a_clip_dino_fwd_enqueued")
             tl, pl = [t for t, _ in tgt], [a["preds"] for a in per_o]
             if len(tl) == 1:
                 dyn = gen_dynamic_weights(ind_g, targets, per_o[0]["preds"], factor=self.factors1[0])
             else:
                 dyn = gen_dynamic_weights_multi(ind_g, tl, pl, self.factors1)
-            wi = (w * args.weight_loss_img * dyn).to(dev)
+            wi = _h2d(w * args.weight_loss_img * dyn, dev)
             loss_clip, de_c = feature_loss_and_grad(e_c, clip_ori, wi)
             loss_dino, de_d = feature_loss_and_grad(e_d, dino_ori, wi)
-            dsmall = self.clip.backward(de_c, _pow2_scale(float(de_c.abs().max()), 1.0))
-            self.dino.backward(de_d, _pow2_scale(float(de_d.abs().max()), 1.0), out=dsmall)
+            am = torch.stack([de_c.abs().max(), de_d.abs().max()]).float().cpu()        # ONE read-back for both scales
+            self._fine("L_b_after_amax_readback")
+            dsmall = self.clip.backward(de_c, _pow2_scale(float(am[0]), 1.0))
+            self.dino.backward(de_d, _pow2_scale(float(am[1]), 1.0), out=dsmall)
             d_img = ops.crop_resize_bwd(dsmall, fullbox, B, Himg, Wimg, args.img_size_small)
             # apply_grad_hook_face (:1904, :1584-1617) acts on this path only: the classifier saw the un-hooked images
             if len(tl) == 1:
                 rects, facs = face_grad_factors(boxes_g, boxes_o, targets, per_o[0]["preds"], self.factors2[0], Himg, Wimg)
             else:
                 rects, facs = face_grad_factors_multi(boxes_g, boxes_o, tl, pl, self.factors2, Himg, Wimg)
-            ops.rect_scale(d_img, rects.to(dev).contiguous(), facs.to(dev).contiguous())
+            ops.rect_scale(d_img, _h2d(rects, dev), _h2d(facs, dev))
+            self._fine("L_c_clip_dino_bwd_enqueued")
             # (the per-image regulariser values are only reported: they are read back at the end of the step, not here)
             deferred.append(lambda lc=loss_clip, ld=loss_dino: out.update(
                 loss_CLIP=lc.float().cpu(), loss_DINO=ld.float().cpu(), dynamic_weights=dyn,
@@ -658,9 +680,9 @@ class FairnessTrainer:
                 feats, fctx = face_features(self.face_net, chips_f, record=True)
                 fn = F.normalize(feats, dim=-1)
                 tgt = self.nearest_face_feats(fn)
-                use_ori = from_ori[rows].to(dev)
-                tgt = torch.where(use_ori[:, None], face_ori[rows.to(dev)], tgt)
-                wf = (w[rows] * args.weight_loss_face).to(dev)
+                use_ori = _h2d(from_ori[rows], dev)
+                tgt = torch.where(use_ori[:, None], face_ori[_h2d(rows, dev)], tgt)
+                wf = _h2d(w[rows] * args.weight_loss_face, dev)
                 lf_rows, df = feature_loss_and_grad(feats, tgt, wf)
                 deferred.append(lambda lf_rows=lf_rows, rows=rows: loss_face.__setitem__(rows, lf_rows.float().cpu()))
                 dch = face_features_backward(self.face_net, fctx, df, _pow2_scale(float(df.abs().max()), 1.0))
@@ -668,17 +690,18 @@ class FairnessTrainer:
                     d_img = torch.zeros((B, 3, Himg, Wimg), dtype=F32, device=dev)
                 ops.warp_affine_bwd(dch.contiguous(), idx_f, A_f, d_img, args.size_aligned_face)   # un-hooked images (:1901)
             deferred.append(lambda: out.update(loss_face=loss_face, loss=out.get("loss", sum(loss_by_attr.values())) + args.weight_loss_face * loss_face))
+            self._fine("L_d_face_branch_done")
         if (len(sel) and float(dlog_full.abs().sum()) > 0) or d_img is not None:
             if len(sel) and float(dlog_full.abs().sum()) > 0:
                 dlog = dlog_full[sel]
-                dchips = self.clf.backward(dlog.to(dev), self.clf_gscale)
+                dchips = self.clf.backward(_h2d(dlog, dev), self.clf_gscale)
                 full = dchips
                 if len(sel) != B:
                     full = torch.zeros((B,) + tuple(dchips.shape[1:]), dtype=F32, device=dev)
-                    full[sel.to(dev)] = dchips
+                    full[_h2d(sel, dev)] = dchips
                 bx = boxes_g.clone()
                 bx[~ind_g] = 0
-                d_fair = ops.crop_resize_bwd(full.contiguous(), bx.to(dev).contiguous(), B, Himg, Wimg, args.size_face)
+                d_fair = ops.crop_resize_bwd(full.contiguous(), _h2d(bx, dev), B, Himg, Wimg, args.size_face)
                 d_img = d_fair if d_img is None else d_img.add_(d_fair)
             else:
                 self.clf._ctx = None

@@ -344,13 +344,26 @@ t)
   cat $O/kernel_stats_top.txt | cut -c1-160
   ;;
 u)
-  # round-3 GPU pass U: 20-step bench (the driver's usual step count) as a soak of the final stream setup, then the 8(d) CPU-baseline protocol.
+  # round-3 GPU pass U: small host -> device copies of the loss phase through pinned memory (non-blocking) vs pageable (FD_NO_PINNED_H2D=1); engine tests.
   O=gpurun_out/r03u
+  mkdir -p $O
+  one() { python -c "import sys,json; d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print('$1', round(d['value'],3), 'img/s', round(d['ms_per_step'],1), 'ms', d['config']['phase_ms'], d['config']['host_ms_between_phase_marks'])"; }
+  for m in pinned pageable pinned pageable; do
+    if [ $m = pageable ]; then export FD_NO_PINNED_H2D=1; else unset FD_NO_PINNED_H2D; fi
+    timeout 600 python bench.py --steps 8 --warmup 2 --no_cpu_baseline --no_roofline 2>/dev/null | one "H2D=$m" | tee -a $O/step_ab.txt
+  done
+  unset FD_NO_PINNED_H2D
+  timeout 1500 python -m pytest tests/test_engine_gpu.py -m gpu -q -x 2>&1 | tail -4 > $O/pytest_engine.log
+  cat $O/pytest_engine.log
+  ;;
+v)
+  # round-3 GPU pass V: 20-step bench (the driver's usual step count) as a soak of the final stream setup, then the 8(d) CPU-baseline protocol.
+  O=gpurun_out/r03v
   mkdir -p $O
   timeout 900 python bench.py --steps 20 --warmup 3 > $O/bench_20.json 2> $O/bench_20.err
   python -c "import sys,json; d=json.loads([l for l in open('$O/bench_20.json') if l.startswith('{')][-1]); print(round(d['value'],3), 'img/s', round(d['ms_per_step'],1), 'ms', d['config']['host_ms_per_step'], d['config']['peak_hbm_gb'])"
   timeout 2400 python bench.py --steps 20 --warmup 2 --cpu_baseline_full --no_roofline > $O/bench_cpu_full.json 2> $O/bench_cpu_full.err
   python -c "import sys,json; d=json.loads([l for l in open('$O/bench_cpu_full.json') if l.startswith('{')][-1]); print(round(d['value'],3), 'img/s', d['cpu_baseline'])"
   ;;
-*) echo "usage: $0 <a..u>"; exit 2;;
+*) echo "usage: $0 <a..v>"; exit 2;;
 esac
