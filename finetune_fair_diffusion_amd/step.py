@@ -83,6 +83,7 @@ def _pow2_scale(amax, target):
 
 _NO_PINNED_H2D = os.environ.get("FD_NO_PINNED_H2D") is not None
 _FINE_MARKS = os.environ.get("FD_FINE_MARKS") is not None
+_NO_TAIL_REORDER = os.environ.get("FD_NO_TAIL_REORDER") is not None      # measurement switch: the tail in its old order
 
 
 def _h2d(t, dev):
@@ -310,20 +311,24 @@ class FairnessTrainer:
     def decode(self, lat, record=False):
         return self.vae.decode_images(lat * (1.0 / self.vae.config.scaling_factor), record=record)
 
-    def classify(self, images, record=False):
-        """get_face + get_face_gender[_race[_age]] (:1794-1795; exp-3 :1387-1457; exp-4 :1378-1475).
-        Returns indicators, boxes and per attribute (preds [N], probs [N,k] (-1 filled), logits [N,k])."""
+    def classify_begin(self, images, record=False):
+        """First half of ``classify``: face boxes from the provider, crop + resize, classifier forward -- everything ENQUEUED, nothing read
+        back, so that the caller can enqueue more device work that does not need the logits before it blocks in ``classify_end``."""
         N = images.shape[0]
         ind, boxes = self.faces(images)
-        S = self.args.size_face
-        per = []
         sel = ind.nonzero().view(-1)
-        logits = None
         logits_dev = None
         if len(sel):
-            chips = ops.crop_resize(images[_h2d(sel, images.device)].contiguous() if len(sel) != N else images, _h2d(boxes[sel], self.device), -1.0, S)
+            chips = ops.crop_resize(images[_h2d(sel, images.device)].contiguous() if len(sel) != N else images, _h2d(boxes[sel], self.device), -1.0,
+                                    self.args.size_face)
             logits_dev = self.clf.forward(chips, record=record).float()
-            logits = logits_dev.cpu()
+        return dict(N=N, ind=ind, boxes=boxes, sel=sel, logits_dev=logits_dev)
+
+    def classify_end(self, h):
+        """Second half: the read-back of the logits (a host sync with the launch stream) and the per-attribute host tensors."""
+        N, ind, boxes, sel, logits_dev = h["N"], h["ind"], h["boxes"], h["sel"], h["logits_dev"]
+        per = []
+        logits = logits_dev.cpu() if logits_dev is not None else None
         if self.collectives:
             # exchange point 1 stays on the device: [N, sum k] probabilities (-1 rows = no face) for ONE all-gather of all attributes
             pd = torch.full((N, sum(k for _, _, k in self.attrs)), -1.0, dtype=F32, device=self.device)
@@ -342,6 +347,11 @@ class FairnessTrainer:
                 preds[sel] = p.max(dim=-1).indices
             per.append(dict(name=name, preds=preds, probs=probs, logits=la_full))
         return ind, boxes, per
+
+    def classify(self, images, record=False):
+        """get_face + get_face_gender[_race[_age]] (:1794-1795; exp-3 :1387-1457; exp-4 :1378-1475).
+        Returns indicators, boxes and per attribute (preds [N], probs [N,k] (-1 filled), logits [N,k])."""
+        return self.classify_end(self.classify_begin(images, record=record))
 
     def resize_small(self, images):
         """``transforms.Resize(img_size_small)`` (:1860, :1905): bilinear, no antialias == the crop kernel on the full-image box."""
@@ -580,7 +590,15 @@ class FairnessTrainer:
                 self._r2_pre = dict(gen=g2n, res=r2n, k=k, S=int(next_step["S"]), noises_host=nh.clone(), noises_dev=nd, ev_noise=ev_noise,
                                     tokens_ori=tuple(t.clone() for t in nt))
         self._mark("classify_targets")
-        ind, boxes, per = self.classify(images, record=share)
+        # The host still runs ahead of the device here (it finished enqueueing the rollout early): everything that needs only R1's images is
+        # enqueued BEFORE the first read-back of the tail -- the classifier and, when R3 consumes R1's forward, the recorded CLIP / DINO forward
+        # of the loss's image-semantics term -- so that it runs back to back with the decode instead of host-paced after the sync.
+        h_g = self.classify_begin(images, record=share)
+        pre_g = None
+        if share and self.use_img_loss and not _NO_TAIL_REORDER:
+            small_g, fullbox_g = self.resize_small(images)
+            pre_g = (fullbox_g,) + tuple(self.image_features(small_g, record=True))
+        ind, boxes, per = self.classify_end(h_g)
         # ---- dynamic targets from the global batch (:1805-1837): gathered now, solved underneath R2, consumed by R3's loss
         self.start_dynamic_targets(per, B)
         out.update(images=images, probs=per[0]["probs"], preds=per[0]["preds"])
@@ -596,17 +614,22 @@ class FairnessTrainer:
             self._mark("R2_vae")
             images_ori = torch.cat([self.decode(x) for x in lats])
             self._mark("R2_classify_regularisers")
-        ind_o, boxes_o, per_o = self.classify(images_ori)
-        out.update(images_ori=images_ori, preds_ori=per_o[0]["preds"], probs_ori=per_o[0]["probs"])
+        h_o = self.classify_begin(images_ori)
+        if _NO_TAIL_REORDER:
+            ind_o, boxes_o, per_o = self.classify_end(h_o)
+        ind_o = h_o["ind"]
         if self.use_img_loss:                                                    # :1860-1862
-            e_c, e_d = self.image_features(self.resize_small(images_ori)[0])
-            clip_ori, dino_ori = F.normalize(e_c, dim=-1), F.normalize(e_d, dim=-1)
+            e_co, e_do = self.image_features(self.resize_small(images_ori)[0])
+            clip_ori, dino_ori = F.normalize(e_co, dim=-1), F.normalize(e_do, dim=-1)
         if self.use_face_loss:                                                   # :1870
             from .sfnet import face_features
             ch_o, idx_o, _ = self.aligned_faces(images_ori, ind_o)
             face_ori = torch.zeros((B, 512), dtype=F32, device=dev)
             if len(idx_o):
                 face_ori[idx_o.long()] = F.normalize(face_features(self.face_net, ch_o)[0], dim=-1)
+        if not _NO_TAIL_REORDER:                 # the read-back of R2's logits comes after its feature encoders have been enqueued
+            ind_o, boxes_o, per_o = self.classify_end(h_o)
+        out.update(images_ori=images_ori, preds_ori=per_o[0]["preds"], probs_ori=per_o[0]["probs"])
         tgt = self.finish_dynamic_targets()
         targets = tgt[0][0]
         out.update(targets=targets, uncertainty=tgt[0][1], targets_by_attr={a["name"]: t for a, (t, _) in zip(per, tgt)})
@@ -637,8 +660,11 @@ class FairnessTrainer:
         deferred = []          # host read-backs of reported values: executed once the whole backward has been enqueued
         if self.use_img_loss:
             # image-semantics term (:1904-1910, :1931-1932): w_i = (1/n_j) * weight_loss_img * dynamic_weight_i
-            small, fullbox = self.resize_small(images_g)
-            e_c, e_d = self.image_features(small, record=True)
+            if share and pre_g is not None:
+                fullbox, e_c, e_d = pre_g            # enqueued ahead of the tail's first read-back (see classify_targets above)
+            else:
+                small, fullbox = self.resize_small(images_g)
+                e_c, e_d = self.image_features(small, record=True)
             self._fine("L_a_clip_dino_fwd_enqueued")
             tl, pl = [t for t, _ in tgt], [a["preds"] for a in per_o]
             if len(tl) == 1:

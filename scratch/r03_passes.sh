@@ -365,5 +365,22 @@ v)
   timeout 2400 python bench.py --steps 20 --warmup 2 --cpu_baseline_full --no_roofline > $O/bench_cpu_full.json 2> $O/bench_cpu_full.err
   python -c "import sys,json; d=json.loads([l for l in open('$O/bench_cpu_full.json') if l.startswith('{')][-1]); print(round(d['value'],3), 'img/s', d['cpu_baseline'])"
   ;;
-*) echo "usage: $0 <a..v>"; exit 2;;
+w)
+  # round-3 GPU pass W: the tail's enqueues reordered (classifier + recorded CLIP / DINO forward of R1's images before the first read-back; R2's feature
+  # encoders before its logits' read-back) vs the old order (FD_NO_TAIL_REORDER=1); engine + full-size step tests; one run with fine phase marks.
+  O=gpurun_out/r03w
+  mkdir -p $O
+  timeout 1500 python -m pytest tests/test_engine_gpu.py -m gpu -q -x 2>&1 | tail -4 > $O/pytest_engine.log
+  cat $O/pytest_engine.log
+  one() { python -c "import sys,json; d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print('$1', round(d['value'],3), 'img/s', round(d['ms_per_step'],1), 'ms', d['config']['phase_ms'], d['config']['host_ms_between_phase_marks'])"; }
+  for m in reorder old reorder old reorder old; do
+    if [ $m = old ]; then export FD_NO_TAIL_REORDER=1; else unset FD_NO_TAIL_REORDER; fi
+    timeout 600 python bench.py --steps 8 --warmup 2 --no_cpu_baseline --no_roofline 2>/dev/null | one "TAIL=$m" | tee -a $O/step_ab.txt
+  done
+  unset FD_NO_TAIL_REORDER
+  FD_FINE_MARKS=1 timeout 600 python bench.py --steps 6 --warmup 2 --no_cpu_baseline --no_roofline 2>/dev/null | one "FINE" | tee -a $O/fine_marks.txt
+  timeout 1700 python -m pytest tests/test_fullsize_gpu.py -m gpu -q -x -k "full_step or golden" 2>&1 | tail -4 > $O/pytest_fullsize.log
+  cat $O/pytest_fullsize.log
+  ;;
+*) echo "usage: $0 <a..w>"; exit 2;;
 esac
