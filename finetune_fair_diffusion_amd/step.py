@@ -83,7 +83,10 @@ def _pow2_scale(amax, target):
 
 _NO_PINNED_H2D = os.environ.get("FD_NO_PINNED_H2D") is not None
 _FINE_MARKS = os.environ.get("FD_FINE_MARKS") is not None
-_NO_TAIL_REORDER = os.environ.get("FD_NO_TAIL_REORDER") is not None      # measurement switch: the tail in its old order
+# FD_TAIL_REORDER=1 (measurement): enqueue the recorded CLIP / DINO forward of R1's images and R2's feature encoders AHEAD of the logits' read-backs.
+# Measured slower (1409-1424 vs 1378-1402 ms, profiles/r03_step_ab_tail_reorder_rejected.txt): the work it moves in front of the first read-back
+# delays everything behind it by its full device time, while in the old order it hides behind the host-paced loss phase.
+_NO_TAIL_REORDER = os.environ.get("FD_TAIL_REORDER") is None
 
 
 def _h2d(t, dev):
@@ -590,9 +593,7 @@ class FairnessTrainer:
                 self._r2_pre = dict(gen=g2n, res=r2n, k=k, S=int(next_step["S"]), noises_host=nh.clone(), noises_dev=nd, ev_noise=ev_noise,
                                     tokens_ori=tuple(t.clone() for t in nt))
         self._mark("classify_targets")
-        # The host still runs ahead of the device here (it finished enqueueing the rollout early): everything that needs only R1's images is
-        # enqueued BEFORE the first read-back of the tail -- the classifier and, when R3 consumes R1's forward, the recorded CLIP / DINO forward
-        # of the loss's image-semantics term -- so that it runs back to back with the decode instead of host-paced after the sync.
+        # (FD_TAIL_REORDER=1 enqueues the recorded CLIP / DINO forward of the loss here, ahead of the tail's first read-back: measured slower)
         h_g = self.classify_begin(images, record=share)
         pre_g = None
         if share and self.use_img_loss and not _NO_TAIL_REORDER:
@@ -703,15 +704,21 @@ class FairnessTrainer:
             rows = has.nonzero().view(-1)
             if len(rows):
                 chips_f, idx_f, A_f = self.aligned_faces(images_g, has)
+                self._fine("L_c1_aligned_faces")
                 feats, fctx = face_features(self.face_net, chips_f, record=True)
+                self._fine("L_c2_sfnet_fwd_enqueued")
                 fn = F.normalize(feats, dim=-1)
                 tgt = self.nearest_face_feats(fn)
                 use_ori = _h2d(from_ori[rows], dev)
                 tgt = torch.where(use_ori[:, None], face_ori[_h2d(rows, dev)], tgt)
                 wf = _h2d(w[rows] * args.weight_loss_face, dev)
                 lf_rows, df = feature_loss_and_grad(feats, tgt, wf)
+                self._fine("L_c3_nearest_and_loss_enqueued")
                 deferred.append(lambda lf_rows=lf_rows, rows=rows: loss_face.__setitem__(rows, lf_rows.float().cpu()))
-                dch = face_features_backward(self.face_net, fctx, df, _pow2_scale(float(df.abs().max()), 1.0))
+                dfmax = float(df.abs().max())
+                self._fine("L_c4_df_amax_readback")
+                dch = face_features_backward(self.face_net, fctx, df, _pow2_scale(dfmax, 1.0))
+                self._fine("L_c5_sfnet_bwd_enqueued")
                 if d_img is None:
                     d_img = torch.zeros((B, 3, Himg, Wimg), dtype=F32, device=dev)
                 ops.warp_affine_bwd(dch.contiguous(), idx_f, A_f, d_img, args.size_aligned_face)   # un-hooked images (:1901)

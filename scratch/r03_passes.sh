@@ -382,5 +382,13 @@ w)
   timeout 1700 python -m pytest tests/test_fullsize_gpu.py -m gpu -q -x -k "full_step or golden" 2>&1 | tail -4 > $O/pytest_fullsize.log
   cat $O/pytest_fullsize.log
   ;;
-*) echo "usage: $0 <a..w>"; exit 2;;
+x)
+  # round-3 GPU pass X: fine phase marks inside the face-realism branch of the loss (shipped tail order), twice.
+  O=gpurun_out/r03x
+  mkdir -p $O
+  one() { python -c "import sys,json; d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print('$1', round(d['value'],3), 'img/s', round(d['ms_per_step'],1), 'ms', d['config']['phase_ms'], d['config']['host_ms_between_phase_marks'])"; }
+  FD_FINE_MARKS=1 timeout 600 python bench.py --steps 6 --warmup 2 --no_cpu_baseline --no_roofline 2>/dev/null | one "FINE" | tee -a $O/fine_marks.txt
+  FD_FINE_MARKS=1 timeout 600 python bench.py --steps 6 --warmup 2 --no_cpu_baseline --no_roofline 2>/dev/null | one "FINE" | tee -a $O/fine_marks.txt
+  ;;
+*) echo "usage: $0 <a..x>"; exit 2;;
 esac
