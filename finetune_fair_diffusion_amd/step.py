@@ -83,6 +83,7 @@ def _pow2_scale(amax, target):
 
 _NO_PINNED_H2D = os.environ.get("FD_NO_PINNED_H2D") is not None
 _FINE_MARKS = os.environ.get("FD_FINE_MARKS") is not None
+_MAIN_PRIORITY = int(os.environ.get("FD_MAIN_PRIORITY", "0"))
 # FD_TAIL_REORDER=1 (measurement): enqueue the recorded CLIP / DINO forward of R1's images and R2's feature encoders AHEAD of the logits' read-backs.
 # Measured slower (1409-1424 vs 1378-1402 ms, profiles/r03_step_ab_tail_reorder_rejected.txt): the work it moves in front of the first read-back
 # delays everything behind it by its full device time, while in the old order it hides behind the host-paced loss phase.
@@ -237,7 +238,9 @@ class FairnessTrainer:
         if self._side is None:
             self._side = {}
         if k not in self._side:
-            self._side[k] = torch.cuda.Stream(device=self.device)
+            # FD_R2_PRIORITY (measurement): HIP priority of the frozen-model rollout's stream (-1 high, 0 normal, 1 low where the runtime has it)
+            prio = int(os.environ.get("FD_R2_PRIORITY", "0")) if k == "r2" else 0
+            self._side[k] = torch.cuda.Stream(device=self.device, priority=prio) if prio else torch.cuda.Stream(device=self.device)
         return self._side[k]
 
     # ------------------------------------------------------------------ pieces
@@ -493,6 +496,21 @@ class FairnessTrainer:
 
     # ------------------------------------------------------------------ the step
     def train_step(self, tokens, noises, S, tokens_ori=None, next_step=None):
+        """One training step (``_train_step`` below).  With FD_MAIN_PRIORITY=-1 (measurement) the whole step is launched from a HIGH-priority stream
+        instead of the caller's current one, so that the critical path's many small tail kernels are dispatched ahead of the frozen-model
+        rollout's (normal-priority) kernels they share the chip with."""
+        if _MAIN_PRIORITY == 0:
+            return self._train_step(tokens, noises, S, tokens_ori, next_step)
+        if getattr(self, "_main_stream", None) is None:
+            self._main_stream = torch.cuda.Stream(device=self.device, priority=_MAIN_PRIORITY)
+        caller = torch.cuda.current_stream()
+        self._main_stream.wait_stream(caller)
+        with torch.cuda.stream(self._main_stream):
+            out = self._train_step(tokens, noises, S, tokens_ori, next_step)
+        caller.wait_stream(self._main_stream)
+        return out
+
+    def _train_step(self, tokens, noises, S, tokens_ori=None, next_step=None):
         """``tokens``: the prompt the finetuned side sees (exp-2: ``prompt_debiaser(prompt)``, generate.prefix_tokens); ``tokens_ori``: the
         prompt of the frozen original side R2 when it differs (exp-2 :1954: the plain prompt, no prefix embedding).
         ``next_step``: optional dict(tokens_ori=, noises=, S=) -- the inputs the NEXT call will receive (noises as a host tensor): the first

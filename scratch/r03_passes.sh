@@ -390,5 +390,44 @@ x)
   FD_FINE_MARKS=1 timeout 600 python bench.py --steps 6 --warmup 2 --no_cpu_baseline --no_roofline 2>/dev/null | one "FINE" | tee -a $O/fine_marks.txt
   FD_FINE_MARKS=1 timeout 600 python bench.py --steps 6 --warmup 2 --no_cpu_baseline --no_roofline 2>/dev/null | one "FINE" | tee -a $O/fine_marks.txt
   ;;
-*) echo "usage: $0 <a..x>"; exit 2;;
+y)
+  # round-3 GPU pass Y: host profile of the recorded CLIP / DINO forward (scratch/diag_recorded_features.py).
+  O=gpurun_out/r03y
+  mkdir -p $O
+  timeout 900 python scratch/diag_recorded_features.py > $O/diag.txt 2>&1
+  tail -80 $O/diag.txt | cut -c1-200
+  ;;
+z)
+  # round-3 GPU pass Z: HIP stream priority of the frozen-model rollout (R2 + prefetch) stream: does a low-priority prefetch stop slowing the tail's small kernels?
+  O=gpurun_out/r03z
+  mkdir -p $O
+  python -c "import torch; print('priority range (least, greatest):', torch.cuda.Stream.priority_range())" 2>&1 | tail -1 | tee $O/priority_range.txt
+  one() { python -c "import sys,json; d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print('$1', round(d['value'],3), 'img/s', round(d['ms_per_step'],1), 'ms', d['config']['phase_ms'])"; }
+  for pr in 0 1 -1 0 1 -1; do
+    FD_R2_PRIORITY=$pr timeout 600 python bench.py --steps 8 --warmup 2 --no_cpu_baseline --no_roofline 2>$O/err_$pr.txt | one "R2_PRIORITY=$pr" | tee -a $O/step_ab.txt
+  done
+  tail -3 $O/err_1.txt
+  ;;
+A)
+  # round-3 GPU pass AA: the whole step launched from a high-priority stream (FD_MAIN_PRIORITY=-1) vs the default stream; engine tests under it.
+  O=gpurun_out/r03aa
+  mkdir -p $O
+  one() { python -c "import sys,json; d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print('$1', round(d['value'],3), 'img/s', round(d['ms_per_step'],1), 'ms', d['config']['phase_ms'])"; }
+  for pr in 0 -1 0 -1 0 -1; do
+    FD_MAIN_PRIORITY=$pr timeout 600 python bench.py --steps 8 --warmup 2 --no_cpu_baseline --no_roofline 2>$O/err.txt | one "MAIN_PRIORITY=$pr" | tee -a $O/step_ab.txt
+  done
+  tail -3 $O/err.txt
+  FD_MAIN_PRIORITY=-1 timeout 1500 python -m pytest tests/test_engine_gpu.py -m gpu -q -x 2>&1 | tail -4 > $O/pytest_engine.log
+  cat $O/pytest_engine.log
+  ;;
+B)
+  # round-3 GPU pass BB: final full -m gpu suite and the driver's smoke() on the final tree.
+  O=gpurun_out/r03bb
+  mkdir -p $O
+  timeout 1700 python -m pytest tests -m gpu -q -x 2>&1 | tail -6 > $O/pytest_gpu.log
+  cat $O/pytest_gpu.log
+  timeout 600 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1
+  tail -3 $O/smoke.log
+  ;;
+*) echo "usage: $0 <a..z, A, B>"; exit 2;;
 esac
