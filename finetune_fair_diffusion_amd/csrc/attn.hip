@@ -53,6 +53,11 @@ __device__ __forceinline__ int crow(int r, int g) { return (r & 3) + 8 * (r >> 2
 #define FD_ATTN_TS 68
 #endif
 constexpr int TS = FD_ATTN_TS;
+// Row padding (halfs) of the backward kernels' row-major Q / dO / K / V tiles, read both as 16-byte fragments and through read_tr.
+// Measurement knob (make BENCH_HOOKS=1 EXTRA_DEFS=-DFD_ATTN_BWD_PAD=n): 8 is the shipped value.
+#ifndef FD_ATTN_BWD_PAD
+#define FD_ATTN_BWD_PAD 8
+#endif
 // the permuted-k A operand from a key-contiguous LDS tile [.][TS]: keys base + 4g + {0..3} and base + 8 + 4g + {0..3}
 __device__ __forceinline__ f16x8 read_perm(const f16* tile, int row, int base, int g) {
     const f16x4 lo = *(const f16x4*)(tile + row * TS + base + 4 * g);
@@ -225,6 +230,22 @@ __global__ __launch_bounds__(256, fwd_waves(D)) void attn_fwd_kernel(const f16* 
     else plan_cols<D>(vplan, Tkp);
     zero_row_pad<D, DKP>(Ks);
     if (!VTR) zero_col_pad<D, DV>(Vts);
+    // Head dims with a spare padded output row (40, 80, 16): "V column D" is a column of ones, so row D of O^T accumulates sum_k p -- the softmax
+    // denominator comes out of the P.V MFMAs (with the same rescaling as O) instead of 32 VALU adds and a shuffle per tile; it is the sum of
+    // the fp16-rounded probabilities the numerator is built from.
+#ifdef FD_ATTN_NO_ONES
+    constexpr bool ONES = false;
+#else
+    constexpr bool ONES = D < DV;
+#endif
+    if (ONES) {
+        if (VTR) {
+            for (int r = threadIdx.x; r < 64; r += 256) Vts[r * VP + D] = (f16)1.f;
+        } else {
+            __syncthreads();                           // behind zero_col_pad's writes of the same row
+            for (int c = threadIdx.x; c < TS; c += 256) Vts[D * TS + c] = (f16)1.f;
+        }
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // Q fragments landed: no VM event may pend on them inside the loop
     load_rows<D>(kreg, Kb, ldk, 0, Tk);
     if (VTR) load_rows<D>(vreg, Vtb, ldk, 0, Tk);
@@ -281,11 +302,13 @@ __global__ __launch_bounds__(256, fwd_waves(D)) void attn_fwd_kernel(const f16* 
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float p = __builtin_amdgcn_exp2f(fmaf(s[kt][r], sl2, nm));
-                rs += p;
+                if (!ONES) rs += p;
                 pf[kt * 2 + (r >> 3)][r & 7] = (f16)p;
             }
-        rs += __shfl_xor(rs, 32, 64);
-        l_run = l_run * alpha + rs;
+        if (!ONES) {
+            rs += __shfl_xor(rs, 32, 64);
+            l_run = l_run * alpha + rs;
+        }
         if (__any(m_new != m_run)) {                   // rescale O only when some row's max moved
 #pragma unroll
             for (int i = 0; i < NDV; ++i)
@@ -300,6 +323,10 @@ __global__ __launch_bounds__(256, fwd_waves(D)) void attn_fwd_kernel(const f16* 
                 const f16x8 vf = VTR ? read_tr(Vts, VP, st * 16, i * 32, ql, g) : read_perm(Vts, i * 32 + ql, st * 16, g);
                 oacc[i] = mfma32(vf, pf[st], oacc[i]);
             }
+    }
+    if (ONES) {                                        // row D of O^T: lane-half GL, register RL of tile D / 32 (crow), for this lane's query column
+        constexpr int LOC = D % 32, GL = (LOC >> 2) & 1, RL = (LOC & 3) + 4 * (LOC >> 3);
+        l_run = __shfl(oacc[D / 32][RL], ql + 32 * GL, 64);
     }
     if (tvalid) {
         const float inv = 1.f / l_run;
@@ -348,7 +375,7 @@ __global__ __launch_bounds__(256, dq_waves(D)) void attn_bwd_dq_kernel(const f16
                                                           const float* __restrict__ LSE, float* __restrict__ Dd, f16* __restrict__ dQ,
                                                           const f16* __restrict__ O, int H, int Tq, int Tk, int Tkp, int Tkr, int kv_div,
                                                           float scale, int ldq, int ldkv, int lddq) {
-    constexpr int DK = (D + 15) / 16 * 16, DV = (D + 31) / 32 * 32, DKP = DK + 8;
+    constexpr int DK = (D + 15) / 16 * 16, DV = (D + 31) / 32 * 32, DKP = DK + FD_ATTN_BWD_PAD;
     constexpr int NKS = DK / 16, NDV = DV / 32;
     extern __shared__ __attribute__((aligned(16))) f16 smem[];
     f16* Ks = smem;                // [64][DKP]
@@ -487,7 +514,7 @@ __global__ __launch_bounds__(256, dkdv_waves(D, QTR)) void attn_bwd_dkdv_kernel(
                                                             const f16* __restrict__ dOt, const float* __restrict__ LSE,
                                                             const float* __restrict__ Dd, void* __restrict__ dKo, void* __restrict__ dVo,
                                                             int H, int Tq, int Tk, int Tkr, int kv_div, float scale, int ldq, int ldkv, int lddkv) {
-    constexpr int DK = (D + 15) / 16 * 16, DV = (D + 31) / 32 * 32, DKP = DK + 8;
+    constexpr int DK = (D + 15) / 16 * 16, DV = (D + 31) / 32 * 32, DKP = DK + FD_ATTN_BWD_PAD;
     constexpr int NKS = DK / 16, NDV = DV / 32;
     extern __shared__ __attribute__((aligned(16))) f16 smem[];
     f16* Qs = smem;                 // [64][DKP]
@@ -684,11 +711,11 @@ template <int D, bool TR> static constexpr size_t fwd_lds() {
     return (size_t)(64 * DKP + (TR ? 64 * tr_stride(DV) : DV * TS)) * 2;
 }
 template <int D, bool TR> static constexpr size_t dq_lds() {
-    constexpr int DKP = (D + 15) / 16 * 16 + 8, DV = (D + 31) / 32 * 32;
+    constexpr int DKP = (D + 15) / 16 * 16 + FD_ATTN_BWD_PAD, DV = (D + 31) / 32 * 32;
     return (size_t)(2 * 64 * DKP + (TR ? 64 : DV * TS)) * 2;      // TR: slack for the reads that run past the last row
 }
 template <int D, bool TR> static constexpr size_t dkdv_lds() {
-    constexpr int DKP = (D + 15) / 16 * 16 + 8, DV = (D + 31) / 32 * 32;
+    constexpr int DKP = (D + 15) / 16 * 16 + FD_ATTN_BWD_PAD, DV = (D + 31) / 32 * 32;
     return (size_t)(2 * 64 * DKP + 2 * DV * TS) * 2 + 512;          // same carve-up for both forms (the TR form leaves the column tiles unused)
 }
 

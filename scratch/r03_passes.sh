@@ -429,5 +429,43 @@ B)
   timeout 600 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1
   tail -3 $O/smoke.log
   ;;
-*) echo "usage: $0 <a..z, A, B>"; exit 2;;
+C)
+  # round-3 GPU pass CC: row padding of the backward attention kernels' row-major tiles (read as 16-byte fragments AND through transpose reads):
+  # shipped 8 halfs vs 16 / 24 / 40 (bench-hooks libraries built with -DFD_ATTN_BWD_PAD=n).
+  O=gpurun_out/r03cc
+  mkdir -p $O
+  for pad in 8 16 24 40 8; do
+    if [ $pad = 8 ]; then unset FAIRDIFF_LIB; else export FAIRDIFF_LIB=$PWD/finetune_fair_diffusion_amd/libfairdiff_hip_bench_pad$pad.so; fi
+    echo "# pad $pad" | tee -a $O/mb_attn_pad.txt
+    timeout 600 python scratch/mb_attn_tr.py 2>&1 | grep "^B" | cut -c1-250 | tee -a $O/mb_attn_pad.txt
+  done
+  ;;
+D)
+  # round-3 GPU pass DD: forward attention with the softmax denominator taken from a ones column of V (row D of the P.V accumulator) vs summed on the
+  # VALU (bench-hooks library built with -DFD_ATTN_NO_ONES); parity of both forms; isolated forward A/B; engine tests.
+  O=gpurun_out/r03dd
+  mkdir -p $O
+  timeout 900 python -m pytest tests/test_kernels_gpu.py -m gpu -q -x -k "attention" 2>&1 | tail -3 > $O/pytest_attn.log
+  cat $O/pytest_attn.log
+  for m in ones valu ones valu; do
+    if [ $m = ones ]; then unset FAIRDIFF_LIB; else export FAIRDIFF_LIB=$PWD/finetune_fair_diffusion_amd/libfairdiff_hip_bench.so; fi
+    echo "# $m" | tee -a $O/mb_attn_ones.txt
+    timeout 600 python scratch/mb_attn_tr.py 2>&1 | grep "^B" | cut -c1-110 | tee -a $O/mb_attn_ones.txt
+  done
+  unset FAIRDIFF_LIB
+  timeout 1500 python -m pytest tests/test_engine_gpu.py tests/test_bf16_gpu.py -m gpu -q -x 2>&1 | tail -3 > $O/pytest_engine.log
+  cat $O/pytest_engine.log
+  ;;
+E)
+  # round-3 GPU pass EE: last full -m gpu suite, smoke() and default bench line on the final tree (after the forward-attention denominator change).
+  O=gpurun_out/r03ee
+  mkdir -p $O
+  timeout 1700 python -m pytest tests -m gpu -q -x 2>&1 | tail -6 > $O/pytest_gpu.log
+  cat $O/pytest_gpu.log
+  timeout 600 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1
+  tail -2 $O/smoke.log
+  timeout 900 python bench.py > $O/bench.json 2> $O/bench.err
+  python -c "import sys,json; d=json.loads([l for l in open('$O/bench.json') if l.startswith('{')][-1]); print(round(d['value'],3), 'img/s', round(d['ms_per_step'],1), 'ms', d['roofline']['frac'])"
+  ;;
+*) echo "usage: $0 <a..z, A..E>"; exit 2;;
 esac
