@@ -91,9 +91,10 @@ _NO_TAIL_REORDER = os.environ.get("FD_TAIL_REORDER") is None
 
 
 def _h2d(t, dev):
-    """Small host tensor -> device WITHOUT draining the launch stream: staged through pinned memory (torch's caching host allocator) and
-    copied non-blocking.  ``t.to(dev)`` from pageable memory makes hipMemcpyAsync wait until the stream has run dry -- in the loss phase
-    of the step (nine such copies between the five read-backs) that kept the host from ever running ahead of the device."""
+    """Small host tensor -> device without a blocking copy: staged through pinned memory (torch's caching host allocator) and copied
+    non-blocking; ``t.to(dev)`` from pageable memory is a synchronous hipMemcpy behind everything queued on the launch stream.  The loss
+    phase has nine such copies between its read-backs (loss phase 62-78 -> 55-58 ms; the whole step within noise,
+    profiles/r03_step_ab_pinned_h2d.txt)."""
     if _NO_PINNED_H2D:          # measurement switch (FD_NO_PINNED_H2D=1): the old pageable copies
         return t.to(dev).contiguous()
     return t.contiguous().pin_memory().to(dev, non_blocking=True)

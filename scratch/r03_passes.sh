@@ -467,5 +467,16 @@ E)
   timeout 900 python bench.py > $O/bench.json 2> $O/bench.err
   python -c "import sys,json; d=json.loads([l for l in open('$O/bench.json') if l.startswith('{')][-1]); print(round(d['value'],3), 'img/s', round(d['ms_per_step'],1), 'ms', d['roofline']['frac'])"
   ;;
-*) echo "usage: $0 <a..z, A..E>"; exit 2;;
+F)
+  # round-3 GPU pass FF: rocprofv3 kernel trace of the final tree (3-step bench) -> profiles/r03_bench_step_kernel_stats_v7_final.csv
+  O=gpurun_out/r03ff
+  mkdir -p $O
+  R=$PWD
+  cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/prof_ff -o r03ff -- python $R/bench.py --steps 2 --warmup 1 --no_cpu_baseline --no_roofline > $R/$O/bench_prof.json 2> $R/$O/bench_prof.err
+  cd $R
+  DB=$(find /tmp/prof_ff -name "*.db" | head -1)
+  python scratch/profsum.py $DB $O/kernel_stats.csv 40 > $O/kernel_stats_top.txt
+  cat $O/kernel_stats_top.txt | cut -c1-160
+  ;;
+*) echo "usage: $0 <a..z, A..F>"; exit 2;;
 esac
