@@ -513,103 +513,140 @@ extern "C" int fd_groupnorm_bwd(const void* x1, int C1, const void* x2, int C2, 
     return fd_check_launch("fd_groupnorm_bwd");
 }
 
-// ------------------------------------------------------------------ LayerNorm: one wave per row
-template <bool BWD>
+// ------------------------------------------------------------------ LayerNorm: a wave owns R consecutive rows
+// A row of C = 320 channels is 40 sixteen-byte vectors: one row per wave left 24 lanes idle, ONE load in flight per lane, and re-read gamma / beta
+// (64 B per lane, four times the row data) for every row.  Here a wave issues the loads of R rows before it touches any of them (R x the bytes in
+// flight) and keeps gamma / beta in registers across them.  The arithmetic of a row is unchanged -- lane-local sums over its own vectors, then
+// the wave shuffle tree -- so the statistics are bit-identical to the one-row form (outputs too at C = 320; at wider C a few fp16 outputs move by
+// one ulp with the compiler's FMA contraction).  32768 x 320: forward 41.8 -> 17.4 us, backward 26.4 -> 18.3 us; 16384 x 640: 41.9 -> 17.5 / 26.5 -> 21.6
+// (profiles/r03_layernorm_rows_per_wave_ab.txt).  MAXV: vectors per lane (C <= 512 * MAXV).
+template <bool BWD, int MAXV, int R>
 __global__ __launch_bounds__(256) void layernorm_kernel(const f16* x, const f16* dy, const float* gamma, const float* beta,
                                                         const f16* add, f16* out, float* mean_rstd, int M, int C, float eps) {
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= M) return;
+    const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
+    if (row0 >= M) return;
     const int V = C >> 3;
-    constexpr int MAXV = 4;  // C <= 2048
-    f16x8 xv[MAXV], dv[MAXV];
-    float s0 = 0.f, s1 = 0.f;
-    if (!BWD) {
+    float gm[MAXV][8], bt[MAXV][8];
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int v = lane + i * 64;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            gm[i][j] = v < V ? gamma[v * 8 + j] : 0.f;
+            bt[i][j] = (!BWD && v < V) ? beta[v * 8 + j] : 0.f;
+        }
+    }
+    f16x8 xv[R][MAXV], dv[BWD ? R : 1][MAXV];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
 #pragma unroll
         for (int i = 0; i < MAXV; ++i) {
             const int v = lane + i * 64;
-            if (v < V) {
-                xv[i] = *(const f16x8*)(x + (int64_t)row * C + v * 8);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) s0 += (float)xv[i][j];
+            if (row0 + r < M && v < V) {
+                xv[r][i] = *(const f16x8*)(x + (int64_t)(row0 + r) * C + v * 8);
+                if (BWD) dv[r][i] = *(const f16x8*)(dy + (int64_t)(row0 + r) * C + v * 8);
             }
         }
-        const float mean = wave_sum(s0) / C;
 #pragma unroll
-        for (int i = 0; i < MAXV; ++i) {
-            const int v = lane + i * 64;
-            if (v < V) {
+    for (int r = 0; r < R; ++r) {
+        const int row = row0 + r;
+        if (row >= M) break;
+        float s0 = 0.f, s1 = 0.f;
+        if (!BWD) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float d = (float)xv[i][j] - mean;
-                    s1 += d * d;
+            for (int i = 0; i < MAXV; ++i) {
+                const int v = lane + i * 64;
+                if (v < V) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) s0 += (float)xv[r][i][j];
                 }
             }
-        }
-        const float rstd = rsqrtf(wave_sum(s1) / C + eps);
-        if (mean_rstd && lane == 0) {
-            mean_rstd[row * 2] = mean;
-            mean_rstd[row * 2 + 1] = rstd;
-        }
+            const float mean = wave_sum(s0) / C;
 #pragma unroll
-        for (int i = 0; i < MAXV; ++i) {
-            const int v = lane + i * 64;
-            if (v < V) {
-                f16x8 o;
+            for (int i = 0; i < MAXV; ++i) {
+                const int v = lane + i * 64;
+                if (v < V) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j)
-                    o[j] = (f16)(((float)xv[i][j] - mean) * rstd * gamma[v * 8 + j] + beta[v * 8 + j]);
-                *(f16x8*)(out + (int64_t)row * C + v * 8) = o;
-            }
-        }
-    } else {
-        const float mean = mean_rstd[row * 2], rstd = mean_rstd[row * 2 + 1];
-#pragma unroll
-        for (int i = 0; i < MAXV; ++i) {
-            const int v = lane + i * 64;
-            if (v < V) {
-                xv[i] = *(const f16x8*)(x + (int64_t)row * C + v * 8);
-                dv[i] = *(const f16x8*)(dy + (int64_t)row * C + v * 8);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float t = (float)dv[i][j] * gamma[v * 8 + j];
-                    s0 += t;
-                    s1 += t * ((float)xv[i][j] - mean) * rstd;
+                    for (int j = 0; j < 8; ++j) {
+                        const float d = (float)xv[r][i][j] - mean;
+                        s1 += d * d;
+                    }
                 }
             }
-        }
-        const float m1 = wave_sum(s0) / C, m2 = wave_sum(s1) / C;
+            const float rstd = rsqrtf(wave_sum(s1) / C + eps);
+            if (mean_rstd && lane == 0) {
+                mean_rstd[row * 2] = mean;
+                mean_rstd[row * 2 + 1] = rstd;
+            }
 #pragma unroll
-        for (int i = 0; i < MAXV; ++i) {
-            const int v = lane + i * 64;
-            if (v < V) {
-                f16x8 av = {0, 0, 0, 0, 0, 0, 0, 0};
-                if (add) av = *(const f16x8*)(add + (int64_t)row * C + v * 8);
-                f16x8 o;
+            for (int i = 0; i < MAXV; ++i) {
+                const int v = lane + i * 64;
+                if (v < V) {
+                    f16x8 o;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float xh = ((float)xv[i][j] - mean) * rstd;
-                    const float t = (float)dv[i][j] * gamma[v * 8 + j];
-                    o[j] = (f16)(rstd * (t - m1 - xh * m2) + (float)av[j]);
+                    for (int j = 0; j < 8; ++j) o[j] = (f16)(((float)xv[r][i][j] - mean) * rstd * gm[i][j] + bt[i][j]);
+                    *(f16x8*)(out + (int64_t)row * C + v * 8) = o;
                 }
-                *(f16x8*)(out + (int64_t)row * C + v * 8) = o;
+            }
+        } else {
+            const float mean = mean_rstd[row * 2], rstd = mean_rstd[row * 2 + 1];
+#pragma unroll
+            for (int i = 0; i < MAXV; ++i) {
+                const int v = lane + i * 64;
+                if (v < V) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float t = (float)dv[r][i][j] * gm[i][j];
+                        s0 += t;
+                        s1 += t * ((float)xv[r][i][j] - mean) * rstd;
+                    }
+                }
+            }
+            const float m1 = wave_sum(s0) / C, m2 = wave_sum(s1) / C;
+#pragma unroll
+            for (int i = 0; i < MAXV; ++i) {
+                const int v = lane + i * 64;
+                if (v < V) {
+                    f16x8 av = {0, 0, 0, 0, 0, 0, 0, 0};
+                    if (add) av = *(const f16x8*)(add + (int64_t)row * C + v * 8);
+                    f16x8 o;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float xh = ((float)xv[r][i][j] - mean) * rstd;
+                        const float t = (float)dv[r][i][j] * gm[i][j];
+                        o[j] = (f16)(rstd * (t - m1 - xh * m2) + (float)av[j]);
+                    }
+                    *(f16x8*)(out + (int64_t)row * C + v * 8) = o;
+                }
             }
         }
     }
 }
 
+template <bool BWD>
+static void launch_layernorm(hipStream_t s, const f16* x, const f16* dy, const float* gamma, const float* beta, const f16* add, f16* out,
+                             float* mean_rstd, int M, int C, float eps) {
+#ifdef FD_LN_ONE_ROW      // measurement: the one-row-per-wave form
+    constexpr int R1 = 1, R2 = 1, R4 = 1;
+#else
+    constexpr int R1 = 4, R2 = 4, R4 = 2;
+#endif
+    if (C <= 512) hipLaunchKernelGGL((layernorm_kernel<BWD, 1, R1>), dim3((M + 4 * R1 - 1) / (4 * R1)), dim3(256), 0, s, x, dy, gamma, beta, add, out, mean_rstd, M, C, eps);
+    else if (C <= 1024) hipLaunchKernelGGL((layernorm_kernel<BWD, 2, R2>), dim3((M + 4 * R2 - 1) / (4 * R2)), dim3(256), 0, s, x, dy, gamma, beta, add, out, mean_rstd, M, C, eps);
+    else hipLaunchKernelGGL((layernorm_kernel<BWD, 4, R4>), dim3((M + 4 * R4 - 1) / (4 * R4)), dim3(256), 0, s, x, dy, gamma, beta, add, out, mean_rstd, M, C, eps);
+}
+
 extern "C" int fd_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean_rstd, int M, int C,
                                 float eps, void* stream) {
     FD_REQUIRE((C & 7) == 0 && C <= 2048 && M > 0, "fd_layernorm_fwd: C=%d must be a multiple of 8 and <= 2048", C);
-    hipLaunchKernelGGL(layernorm_kernel<false>, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const f16*)x, (const f16*)nullptr,
-                       gamma, beta, (const f16*)nullptr, (f16*)y, mean_rstd, M, C, eps);
+    launch_layernorm<false>((hipStream_t)stream, (const f16*)x, (const f16*)nullptr, gamma, beta, (const f16*)nullptr, (f16*)y, mean_rstd, M, C, eps);
     return fd_check_launch("fd_layernorm_fwd");
 }
 
 extern "C" int fd_layernorm_bwd(const void* x, const void* dy, const float* gamma, const float* mean_rstd, const void* add, void* dx,
                                 int M, int C, void* stream) {
     FD_REQUIRE((C & 7) == 0 && C <= 2048 && M > 0 && mean_rstd, "fd_layernorm_bwd: bad args");
-    hipLaunchKernelGGL(layernorm_kernel<true>, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const f16*)x, (const f16*)dy, gamma,
-                       (const float*)nullptr, (const f16*)add, (f16*)dx, (float*)mean_rstd, M, C, 0.f);
+    launch_layernorm<true>((hipStream_t)stream, (const f16*)x, (const f16*)dy, gamma, (const float*)nullptr, (const f16*)add, (f16*)dx, (float*)mean_rstd, M, C, 0.f);
     return fd_check_launch("fd_layernorm_bwd");
 }

@@ -478,5 +478,28 @@ F)
   python scratch/profsum.py $DB $O/kernel_stats.csv 40 > $O/kernel_stats_top.txt
   cat $O/kernel_stats_top.txt | cut -c1-160
   ;;
-*) echo "usage: $0 <a..z, A..F>"; exit 2;;
+G)
+  # round-3 GPU pass GG: LayerNorm with R rows per wave and gamma / beta in registers (product library) vs one row per wave (bench-hooks library built
+  # with -DFD_LN_ONE_ROW): timing and output checksums (bit-identity), kernel tests.
+  O=gpurun_out/r03gg
+  mkdir -p $O
+  echo "# shipped (R rows per wave)" | tee $O/mb_ln.txt
+  timeout 300 python scratch/mb_ln.py 2>&1 | grep "^LN" | tee -a $O/mb_ln.txt
+  echo "# one row per wave" | tee -a $O/mb_ln.txt
+  FAIRDIFF_LIB=$PWD/finetune_fair_diffusion_amd/libfairdiff_hip_bench.so timeout 300 python scratch/mb_ln.py 2>&1 | grep "^LN" | tee -a $O/mb_ln.txt
+  timeout 900 python -m pytest tests/test_kernels_gpu.py -m gpu -q -x 2>&1 | tail -3 > $O/pytest_kernels.log
+  cat $O/pytest_kernels.log
+  ;;
+H)
+  # round-3 GPU pass HH: full -m gpu suite, smoke and two bench runs after the LayerNorm change.
+  O=gpurun_out/r03hh
+  mkdir -p $O
+  timeout 1700 python -m pytest tests -m gpu -q -x 2>&1 | tail -6 > $O/pytest_gpu.log
+  cat $O/pytest_gpu.log
+  timeout 600 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1
+  tail -2 $O/smoke.log
+  timeout 900 python bench.py > $O/bench.json 2> $O/bench.err
+  python -c "import sys,json; d=json.loads([l for l in open('$O/bench.json') if l.startswith('{')][-1]); print(round(d['value'],3), 'img/s', round(d['ms_per_step'],1), 'ms', d['roofline']['frac'], d['config']['phase_ms'])"
+  ;;
+*) echo "usage: $0 <a..z, A..H>"; exit 2;;
 esac
