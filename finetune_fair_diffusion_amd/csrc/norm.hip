@@ -518,8 +518,8 @@ extern "C" int fd_groupnorm_bwd(const void* x1, int C1, const void* x2, int C2, 
 // (64 B per lane, four times the row data) for every row.  Here a wave issues the loads of R rows before it touches any of them (R x the bytes in
 // flight) and keeps gamma / beta in registers across them.  The arithmetic of a row is unchanged -- lane-local sums over its own vectors, then
 // the wave shuffle tree -- so the statistics are bit-identical to the one-row form (outputs too at C = 320; at wider C a few fp16 outputs move by
-// one ulp with the compiler's FMA contraction).  32768 x 320: forward 41.8 -> 17.4 us, backward 26.4 -> 18.3 us; 16384 x 640: 41.9 -> 17.5 / 26.5 -> 21.6
-// (profiles/r03_layernorm_rows_per_wave_ab.txt).  MAXV: vectors per lane (C <= 512 * MAXV).
+// one ulp with the compiler's FMA contraction).  32768 x 320: forward 41.8 -> 17.4 us (backward, if it were multi-row too: 26.4 -> 18.3 us);
+// 16384 x 640: 41.9 -> 17.5 (profiles/r03_layernorm_rows_per_wave_ab.txt).  MAXV: vectors per lane (C <= 512 * MAXV).
 template <bool BWD, int MAXV, int R>
 __global__ __launch_bounds__(256) void layernorm_kernel(const f16* x, const f16* dy, const float* gamma, const float* beta,
                                                         const f16* add, f16* out, float* mean_rstd, int M, int C, float eps) {
@@ -627,10 +627,20 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const f16* x, const f16*
 template <bool BWD>
 static void launch_layernorm(hipStream_t s, const f16* x, const f16* dy, const float* gamma, const float* beta, const f16* add, f16* out,
                              float* mean_rstd, int M, int C, float eps) {
-#ifdef FD_LN_ONE_ROW      // measurement: the one-row-per-wave form
+#if defined(FD_LN_ONE_ROW)      // measurement: the one-row-per-wave form
     constexpr int R1 = 1, R2 = 1, R4 = 1;
-#else
+#elif defined(FD_LN_FWD_ONE_ROW)
+    constexpr int R1 = BWD ? 4 : 1, R2 = BWD ? 4 : 1, R4 = BWD ? 2 : 1;
+#elif defined(FD_LN_BWD_ONE_ROW)
+    constexpr int R1 = BWD ? 1 : 4, R2 = BWD ? 1 : 4, R4 = BWD ? 1 : 2;
+#elif defined(FD_LN_BWD_MULTI_ROW)   // measurement only, see below
     constexpr int R1 = 4, R2 = 4, R4 = 2;
+#else
+    // Shipped: the FORWARD owns 4 / 4 / 2 rows per wave; the backward stays at one.  With a multi-row backward the B = 8 / S = 20 schedule test
+    // (three backward streams vs one) differs by 3e-4 run to run although the kernel is bit-identical to the one-row form in isolation, on one
+    // stream, and under row shifts / doubling (scratch/diag_ln_rowpos.py); forward multi-row + backward one-row passes bit-exactly.  Not
+    // understood yet (profiles/r03_layernorm_rows_per_wave_ab.txt); the backward's gain (26 -> 18 us at 32768 x 320) is left on the table.
+    constexpr int R1 = BWD ? 1 : 4, R2 = BWD ? 1 : 4, R4 = BWD ? 1 : 2;
 #endif
     if (C <= 512) hipLaunchKernelGGL((layernorm_kernel<BWD, 1, R1>), dim3((M + 4 * R1 - 1) / (4 * R1)), dim3(256), 0, s, x, dy, gamma, beta, add, out, mean_rstd, M, C, eps);
     else if (C <= 1024) hipLaunchKernelGGL((layernorm_kernel<BWD, 2, R2>), dim3((M + 4 * R2 - 1) / (4 * R2)), dim3(256), 0, s, x, dy, gamma, beta, add, out, mean_rstd, M, C, eps);

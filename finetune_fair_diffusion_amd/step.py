@@ -774,12 +774,15 @@ class FairnessTrainer:
                 self.unet.prepare_backward()         # lazily built weight copies exist before any side stream can read them
                 nst = max(1, min(self.bwd_streams, S)) if self.concurrent_bwd else 1
                 sides = [self._side_stream(k) for k in range(1, nst)]
+                # upstream gradient of the CFG pair eps = eps_u + gs (eps_c - eps_u): [(1 - gs) g ; gs g], built once; a timestep scales it.
+                # Built on the launch stream BEFORE the side streams take their dependency on it: enqueued after ``wait_stream`` (as it was for
+                # most of round 3) the side streams' first timesteps could read it while its ``cat`` was still running -- a race that showed
+                # as a 4e-4 schedule-to-schedule gradient difference (once as NaN) whenever kernel timing shifted.
+                gpair = torch.cat([g * (1.0 - gs), g * gs])
                 for k, side in enumerate(sides, 1):
                     for bank in self.banks:
                         bank.grad_alt(k).zero_()
                     side.wait_stream(cur)
-                # upstream gradient of the CFG pair eps = eps_u + gs (eps_c - eps_u): [(1 - gs) g ; gs g], built once; a timestep scales it
-                gpair = torch.cat([g * (1.0 - gs), g * gs])
                 for i in range(S):
                     k = i % nst
                     on_side = k > 0

@@ -501,5 +501,46 @@ H)
   timeout 900 python bench.py > $O/bench.json 2> $O/bench.err
   python -c "import sys,json; d=json.loads([l for l in open('$O/bench.json') if l.startswith('{')][-1]); print(round(d['value'],3), 'img/s', round(d['ms_per_step'],1), 'ms', d['roofline']['frac'], d['config']['phase_ms'])"
   ;;
-*) echo "usage: $0 <a..z, A..H>"; exit 2;;
+I)
+  # round-3 GPU pass II: the B = 8 / S = 20 schedule test alone, with its output (it failed once in pass HH).
+  O=gpurun_out/r03ii
+  mkdir -p $O
+  timeout 900 python -m pytest tests/test_fullsize_gpu.py -m gpu -q -x -s -k "shipped_schedule_equals_reference" 2>&1 | grep -v amdgpu.ids | tail -40 > $O/pytest_sched.log
+  cat $O/pytest_sched.log | cut -c1-300
+  ;;
+J)
+  # round-3 GPU pass JJ: row-position dependence of the LayerNorm kernel (scratch/diag_ln_rowpos.py).
+  O=gpurun_out/r03jj
+  mkdir -p $O
+  timeout 300 python scratch/diag_ln_rowpos.py 2>&1 | grep -v amdgpu.ids | tee $O/diag.txt
+  ;;
+K)
+  # round-3 GPU pass KK: the schedule test with the one-row-per-wave LayerNorm (bench-hooks library built with -DFD_LN_ONE_ROW) and with the shipped one, twice each.
+  O=gpurun_out/r03kk
+  mkdir -p $O
+  for m in onerow shipped onerow shipped; do
+    if [ $m = onerow ]; then export FAIRDIFF_LIB=$PWD/finetune_fair_diffusion_amd/libfairdiff_hip_bench.so; else unset FAIRDIFF_LIB; fi
+    echo "# $m" | tee -a $O/sched.txt
+    timeout 600 python -m pytest tests/test_fullsize_gpu.py -m gpu -q -x -s -k "shipped_schedule_equals_reference" 2>&1 | grep -E "rel max err|passed|failed" | cut -c1-200 | tee -a $O/sched.txt
+  done
+  ;;
+L)
+  # round-3 GPU pass LL: which half of the multi-row LayerNorm breaks the schedule test: forward one-row / backward multi-row, and the reverse.
+  O=gpurun_out/r03ll
+  mkdir -p $O
+  for m in fwd1 bwd1; do
+    export FAIRDIFF_LIB=$PWD/finetune_fair_diffusion_amd/libfairdiff_hip_bench_$m.so
+    echo "# $m" | tee -a $O/sched.txt
+    timeout 600 python -m pytest tests/test_fullsize_gpu.py -m gpu -q -x -s -k "shipped_schedule_equals_reference" 2>&1 | grep -E "rel max err|passed|failed" | cut -c1-200 | tee -a $O/sched.txt
+  done
+  ;;
+M)
+  # round-3 GPU pass MM: after moving the CFG-pair upstream gradient in front of the side streams' wait: the schedule test (shipped multi-row LayerNorm), 3 times.
+  O=gpurun_out/r03mm
+  mkdir -p $O
+  for m in 1 2 3; do
+    timeout 600 python -m pytest tests/test_fullsize_gpu.py -m gpu -q -x -s -k "shipped_schedule_equals_reference" 2>&1 | grep -E "rel max err|passed|failed" | cut -c1-200 | tee -a $O/sched.txt
+  done
+  ;;
+*) echo "usage: $0 <a..z, A..M>"; exit 2;;
 esac
