@@ -548,6 +548,23 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const f16* x, const f16*
                 if (BWD) dv[r][i] = *(const f16x8*)(dy + (int64_t)(row0 + r) * C + v * 8);
             }
         }
+#ifdef FD_LN_BWD_PRELOAD      // diagnosis: every input of every row is read before the first row is stored
+    f16x8 avp[BWD ? R : 1][MAXV];
+    float mp[BWD ? R : 1], rp[BWD ? R : 1];
+    if (BWD) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            mp[r] = rp[r] = 0.f;
+            if (row0 + r < M) { mp[r] = mean_rstd[(row0 + r) * 2]; rp[r] = mean_rstd[(row0 + r) * 2 + 1]; }
+#pragma unroll
+            for (int i = 0; i < MAXV; ++i) {
+                const int v = lane + i * 64;
+                avp[r][i] = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
+                if (add && row0 + r < M && v < V) avp[r][i] = *(const f16x8*)(add + (int64_t)(row0 + r) * C + v * 8);
+            }
+        }
+    }
+#endif
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int row = row0 + r;
@@ -590,7 +607,11 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const f16* x, const f16*
                 }
             }
         } else {
+#ifdef FD_LN_BWD_PRELOAD
+            const float mean = mp[r], rstd = rp[r];
+#else
             const float mean = mean_rstd[row * 2], rstd = mean_rstd[row * 2 + 1];
+#endif
 #pragma unroll
             for (int i = 0; i < MAXV; ++i) {
                 const int v = lane + i * 64;
@@ -608,8 +629,12 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const f16* x, const f16*
             for (int i = 0; i < MAXV; ++i) {
                 const int v = lane + i * 64;
                 if (v < V) {
+#ifdef FD_LN_BWD_PRELOAD
+                    const f16x8 av = avp[r][i];
+#else
                     f16x8 av = {0, 0, 0, 0, 0, 0, 0, 0};
                     if (add) av = *(const f16x8*)(add + (int64_t)row * C + v * 8);
+#endif
                     f16x8 o;
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {

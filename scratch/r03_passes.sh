@@ -542,5 +542,12 @@ M)
     timeout 600 python -m pytest tests/test_fullsize_gpu.py -m gpu -q -x -s -k "shipped_schedule_equals_reference" 2>&1 | grep -E "rel max err|passed|failed" | cut -c1-200 | tee -a $O/sched.txt
   done
   ;;
-*) echo "usage: $0 <a..z, A..M>"; exit 2;;
+N)
+  # round-3 GPU pass NN: multi-row LayerNorm backward with every input of every row read BEFORE the first store (-DFD_LN_BWD_MULTI_ROW -DFD_LN_BWD_PRELOAD): the schedule test.
+  O=gpurun_out/r03nn
+  mkdir -p $O
+  export FAIRDIFF_LIB=$PWD/finetune_fair_diffusion_amd/libfairdiff_hip_bench.so
+  timeout 600 python -m pytest tests/test_fullsize_gpu.py -m gpu -q -x -s -k "shipped_schedule_equals_reference" 2>&1 | grep -E "rel max err|passed|failed" | cut -c1-200 | tee -a $O/sched.txt
+  ;;
+*) echo "usage: $0 <a..z, A..N>"; exit 2;;
 esac
