@@ -549,5 +549,12 @@ N)
   export FAIRDIFF_LIB=$PWD/finetune_fair_diffusion_amd/libfairdiff_hip_bench.so
   timeout 600 python -m pytest tests/test_fullsize_gpu.py -m gpu -q -x -s -k "shipped_schedule_equals_reference" 2>&1 | grep -E "rel max err|passed|failed" | cut -c1-200 | tee -a $O/sched.txt
   ;;
-*) echo "usage: $0 <a..z, A..N>"; exit 2;;
+O)
+  # round-3 GPU pass OO: last check of the rebuilt libraries: smoke() and the kernel tests.
+  O=gpurun_out/r03oo
+  mkdir -p $O
+  timeout 600 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2 | tee $O/smoke.log
+  timeout 600 python -m pytest tests/test_kernels_gpu.py -m gpu -q -x 2>&1 | tail -2 | tee $O/pytest_kernels.log
+  ;;
+*) echo "usage: $0 <a..z, A..O>"; exit 2;;
 esac
