@@ -43,8 +43,12 @@ def _is_package_entry_point(argv):
             orig = sys.orig_argv
         except AttributeError:      # Python < 3.10
             return True
-        if "-m" in orig and orig.index("-m") + 1 < len(orig):
-            return orig[orig.index("-m") + 1].split(".")[0].replace("-", "_") == __name__.split(".")[0]
+        import re
+        for i, tok in enumerate(orig[1:-1], 1):     # "-m", or combined short flags ending in m: -um, -Im, -Bum ...
+            if re.fullmatch(r"-[A-Za-z]*m", tok):
+                return orig[i + 1].split(".")[0].replace("-", "_") == __name__.split(".")[0]
+            if not tok.startswith("-"):
+                break
         return False
     base = os.path.basename(argv[0])
     return base in ("train.py", "generate.py") and os.path.dirname(os.path.abspath(argv[0])) == os.path.dirname(os.path.abspath(__file__))

@@ -5,7 +5,7 @@ without going through its export script.
 What accelerate 0.27 writes for this training script, and what each piece becomes here:
 
     model.safetensors / pytorch_model.bin            1st prepared model   (``_1`` suffix: 2nd)
-        text-encoder LoRA ``CustomModel`` (:856-872): keys ``params.<i>``, i in ``text_encoder.named_parameters()`` order  -> te.lora_bank
+        text-encoder LoRA ``CustomModel`` (:856-872): keys ``params.<i>``, i in the order of the list ``_modify_text_encoder`` returns (attention q, k, v, out of all layers, then fc1, fc2 of all layers)  -> te.lora_bank
         U-Net ``AttnProcsLayers`` (:818): keys by attention-processor name (diffusers' state-dict hook)                   -> unet.lora_bank
       prepare order (:1653-1657): the text-encoder model first (when trained), then the U-Net layers
     optimizer.bin        torch AdamW ``state_dict``; parameter indices follow ``params_to_optimize`` (:889-895): U-Net parameters in
@@ -24,16 +24,22 @@ import random
 import numpy as np
 import torch
 
-TE_ORDER = ("self_attn.k_proj", "self_attn.v_proj", "self_attn.q_proj", "self_attn.out_proj", "mlp.fc1", "mlp.fc2")   # transformers CLIPEncoderLayer
+TE_ATTN, TE_MLP = ("q_proj", "k_proj", "v_proj", "out_proj"), ("fc1", "fc2")
 
 
 def te_reference_param_order(num_layers):
-    """Names of the text-encoder LoRA tensors in ``text_encoder.named_parameters()`` order (:836-842): CLIPAttention registers k_proj, v_proj,
-    q_proj, out_proj; the MLP fc1, fc2; a LoRALinearLayer its ``down`` then ``up``."""
+    """Names of the text-encoder LoRA tensors in the order of the parameter LIST that ``LoraLoaderMixin._modify_text_encoder`` returns
+    (diffusers 0.19.3; :831): the reference builds its CustomModel (``params.<i>``), the AdamW parameter indices and the EMA shadows by
+    iterating over THAT list (:836-842 -- ``named_parameters()`` is only searched for each entry's name).  The list holds q, k, v, out_proj
+    of every layer's attention first, then -- ``patch_mlp=True`` -- fc1, fc2 of every layer's MLP; a LoRALinearLayer yields ``down`` then ``up``."""
     out = []
     for i in range(num_layers):
-        for tgt in TE_ORDER:
-            p = f"text_model.encoder.layers.{i}.{tgt}.lora_linear_layer."
+        for tgt in TE_ATTN:
+            p = f"text_model.encoder.layers.{i}.self_attn.{tgt}.lora_linear_layer."
+            out += [p + "down.weight", p + "up.weight"]
+    for i in range(num_layers):
+        for tgt in TE_MLP:
+            p = f"text_model.encoder.layers.{i}.mlp.{tgt}.lora_linear_layer."
             out += [p + "down.weight", p + "up.weight"]
     return out
 
@@ -93,10 +99,13 @@ def load_accelerate_state(trainer, path, restore_rng=True):
         if set(un_names) != set(trainer.unet.lora_bank.names):
             raise ValueError("U-Net LoRA names of this build do not match the reference order table")
 
+    pending = []         # (bank, buffer, name, tensor): every shape is validated BEFORE the first copy, so a mismatch leaves the trainer untouched
+
     def put(bank, buf, name, t):
         if tuple(t.shape) != tuple(bank.shape(name)):
-            raise ValueError(f"{path}: {name} has shape {tuple(t.shape)}, expected {tuple(bank.shape(name))} (different LoRA rank?)")
-        bank.view(name, buf).copy_(t.to(bank.flat.device, torch.float32))
+            raise ValueError(f"{path}: {name} has shape {tuple(t.shape)}, expected {tuple(bank.shape(name))} (different LoRA rank, or a "
+                             f"parameter order this reader does not know)")
+        pending.append((bank, buf, name, t))
 
     # ---- models, in prepare order: text encoder first (:1653), then the U-Net (:1656)
     mi = 0
@@ -125,22 +134,37 @@ def load_accelerate_state(trainer, path, restore_rng=True):
         st = opt["state"].get(i)
         bank = banks[which][0]
         if st is None:          # parameter never stepped
-            bank.view(n, bank.exp_avg).zero_(); bank.view(n, bank.exp_avg_sq).zero_()
+            put(bank, bank.exp_avg, n, torch.zeros(bank.shape(n))); put(bank, bank.exp_avg_sq, n, torch.zeros(bank.shape(n)))
             continue
         put(bank, bank.exp_avg, n, st["exp_avg"])
         put(bank, bank.exp_avg_sq, n, st["exp_avg_sq"])
         steps.add(int(st["step"]))
     if len(steps) > 1:
         raise ValueError(f"{path}: parameters carry different AdamW step counts {sorted(steps)}")
-    trainer.opt_step = steps.pop() if steps else 0
+    opt_step = steps.pop() if steps else 0
+    base = os.path.basename(os.path.normpath(path))
+    global_step = int(base.split("-")[1]) if "-" in base and base.split("-")[1].isdigit() else 0
 
-    # ---- lr scheduler
+    # ---- lr scheduler.  The reference prepares it through accelerate (:1648) with split_batches=False: AcceleratedScheduler.step() advances the
+    # inner LambdaLR ``num_processes`` times per optimiser step (which is why :1642-1643 scale warm-up and max steps by num_processes), so a
+    # W-process run stores last_epoch = W * global_step.  This build's lr_lambda counts ONE unit per step with unscaled warm-up / max steps.
+    lr_step = None
     sch = os.path.join(path, "scheduler.bin")
     if os.path.exists(sch):
-        trainer.lr_step = int(torch.load(sch, map_location="cpu", weights_only=False).get("last_epoch", 0))
+        last_epoch = int(torch.load(sch, map_location="cpu", weights_only=False).get("last_epoch", 0))
+        n_rng = len([f for f in os.listdir(path) if f.startswith("random_states_") and f.endswith(".pkl")])
+        if global_step > 0 and last_epoch % global_step == 0:
+            w_ref = last_epoch // global_step
+        else:
+            w_ref = max(n_rng, 1)
+        if w_ref < 1 or last_epoch % w_ref != 0 or (n_rng and w_ref != n_rng and global_step > 0):
+            raise ValueError(f"{path}: scheduler last_epoch {last_epoch} is not a multiple of the run's process count "
+                             f"(global step {global_step}, {n_rng} random_states files)")
+        lr_step = last_epoch // w_ref
 
     # ---- EMA models, registered text encoder first (:1654), then U-Net (:1657); trainer.banks is [unet, text_encoder] (step.py)
     ci = 0
+    ema_steps = []
     for which in ("text_encoder", "unet"):
         if which not in banks:
             continue
@@ -157,9 +181,18 @@ def load_accelerate_state(trainer, path, restore_rng=True):
             raise ValueError(f"{p}: {len(shadow)} shadow parameters, expected {len(names)}")
         for n, t in zip(names, shadow):
             put(bank, bank.ema, n, t)
+        ema_steps.append((bank, int(ema.get("optimization_step", 0))))
+
+    # ---- everything validated: commit
+    for bank, buf, name, t in pending:
+        bank.view(name, buf).copy_(t.to(bank.flat.device, torch.float32))
+    trainer.opt_step = opt_step
+    if lr_step is not None:
+        trainer.lr_step = lr_step
+    for bank, st in ema_steps:
         for b, e in zip(trainer.banks, trainer.ema):
             if b is bank:
-                e.optimization_step = int(ema.get("optimization_step", 0))
+                e.optimization_step = st
 
     # ---- RNG streams of this rank
     if restore_rng:
@@ -176,5 +209,4 @@ def load_accelerate_state(trainer, path, restore_rng=True):
         trainer.unet.refresh_lora()
     if train_te:
         trainer.te.refresh_lora()
-    base = os.path.basename(os.path.normpath(path))
-    return int(base.split("-")[1]) if "-" in base and base.split("-")[1].isdigit() else 0
+    return global_step

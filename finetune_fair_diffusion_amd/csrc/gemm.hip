@@ -824,9 +824,8 @@ extern "C" int fd_gemm(const fd_gemm_desc* dp, void* stream) {
         FD_REQUIRE(t == 256320 || t == 128320 || t == 128160 || t == 256256 || t == 512128 || t == 256128,
                    "fd_gemm(conv up2 phases): shape not taken by the big-tile kernels (Cin %% 64, enough tiles); use FD_CONV_UP2");
     }
-    if (sel >= 1000000) {
-        return (sel % 1000000 == 128320) ? launch_big<128, 320, 4, 4>(d, s, sel / 1000000) : launch_big<128, 160, 4, 2>(d, s, sel / 1000000);
-    }
+    // the same order of tests as fd_gemm_kernel_name: persistent streaming kernel, ping-pong kernel (split-K slices too under policy bit 64),
+    // then the lockstep big tiles
     if (pps_takes(d, sel)) {
         static const int pps_wg = bench_env("FD_GEMM_PPS_WG") ? atoi(bench_env("FD_GEMM_PPS_WG")) : 256;
         return fd_gemm_launch_pps(d, s, pps_wg);
@@ -836,6 +835,9 @@ extern "C" int fd_gemm(const fd_gemm_desc* dp, void* stream) {
         const int rc = fd_gemm_launch_pp(d, s, (pp_mode() & 4) != 0, bm, nsplit);
         if (rc != 0 || nsplit == 1) return rc;
         return launch_splitk_reduce(d, s, nsplit);
+    }
+    if (sel >= 1000000) {
+        return (sel % 1000000 == 128320) ? launch_big<128, 320, 4, 4>(d, s, sel / 1000000) : launch_big<128, 160, 4, 2>(d, s, sel / 1000000);
     }
     switch (sel) {
         case 16016: return launch_skinny<1>(d, s);

@@ -518,7 +518,7 @@ extern "C" int fd_groupnorm_bwd(const void* x1, int C1, const void* x2, int C2, 
 // (64 B per lane, four times the row data) for every row.  Here a wave issues the loads of R rows before it touches any of them (R x the bytes in
 // flight) and keeps gamma / beta in registers across them.  The arithmetic of a row is unchanged -- lane-local sums over its own vectors, then
 // the wave shuffle tree -- so the statistics are bit-identical to the one-row form (outputs too at C = 320; at wider C a few fp16 outputs move by
-// one ulp with the compiler's FMA contraction).  32768 x 320: forward 41.8 -> 17.4 us (backward, if it were multi-row too: 26.4 -> 18.3 us);
+// one ulp with the compiler's FMA contraction).  32768 x 320: forward 41.8 -> 17.4 us, backward 26.4 -> 18.3 us;
 // 16384 x 640: 41.9 -> 17.5 (profiles/r03_layernorm_rows_per_wave_ab.txt).  MAXV: vectors per lane (C <= 512 * MAXV).
 template <bool BWD, int MAXV, int R>
 __global__ __launch_bounds__(256) void layernorm_kernel(const f16* x, const f16* dy, const float* gamma, const float* beta,
@@ -548,23 +548,6 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const f16* x, const f16*
                 if (BWD) dv[r][i] = *(const f16x8*)(dy + (int64_t)(row0 + r) * C + v * 8);
             }
         }
-#ifdef FD_LN_BWD_PRELOAD      // diagnosis: every input of every row is read before the first row is stored
-    f16x8 avp[BWD ? R : 1][MAXV];
-    float mp[BWD ? R : 1], rp[BWD ? R : 1];
-    if (BWD) {
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            mp[r] = rp[r] = 0.f;
-            if (row0 + r < M) { mp[r] = mean_rstd[(row0 + r) * 2]; rp[r] = mean_rstd[(row0 + r) * 2 + 1]; }
-#pragma unroll
-            for (int i = 0; i < MAXV; ++i) {
-                const int v = lane + i * 64;
-                avp[r][i] = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
-                if (add && row0 + r < M && v < V) avp[r][i] = *(const f16x8*)(add + (int64_t)(row0 + r) * C + v * 8);
-            }
-        }
-    }
-#endif
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int row = row0 + r;
@@ -607,11 +590,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const f16* x, const f16*
                 }
             }
         } else {
-#ifdef FD_LN_BWD_PRELOAD
-            const float mean = mp[r], rstd = rp[r];
-#else
             const float mean = mean_rstd[row * 2], rstd = mean_rstd[row * 2 + 1];
-#endif
 #pragma unroll
             for (int i = 0; i < MAXV; ++i) {
                 const int v = lane + i * 64;
@@ -629,12 +608,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const f16* x, const f16*
             for (int i = 0; i < MAXV; ++i) {
                 const int v = lane + i * 64;
                 if (v < V) {
-#ifdef FD_LN_BWD_PRELOAD
-                    const f16x8 av = avp[r][i];
-#else
                     f16x8 av = {0, 0, 0, 0, 0, 0, 0, 0};
                     if (add) av = *(const f16x8*)(add + (int64_t)row * C + v * 8);
-#endif
                     f16x8 o;
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
@@ -654,18 +629,12 @@ static void launch_layernorm(hipStream_t s, const f16* x, const f16* dy, const f
                              float* mean_rstd, int M, int C, float eps) {
 #if defined(FD_LN_ONE_ROW)      // measurement: the one-row-per-wave form
     constexpr int R1 = 1, R2 = 1, R4 = 1;
-#elif defined(FD_LN_FWD_ONE_ROW)
-    constexpr int R1 = BWD ? 4 : 1, R2 = BWD ? 4 : 1, R4 = BWD ? 2 : 1;
-#elif defined(FD_LN_BWD_ONE_ROW)
-    constexpr int R1 = BWD ? 1 : 4, R2 = BWD ? 1 : 4, R4 = BWD ? 1 : 2;
-#elif defined(FD_LN_BWD_MULTI_ROW)   // measurement only, see below
-    constexpr int R1 = 4, R2 = 4, R4 = 2;
 #else
-    // Shipped: the FORWARD owns 4 / 4 / 2 rows per wave; the backward stays at one.  With a multi-row backward the B = 8 / S = 20 schedule test
-    // (three backward streams vs one) differs by 3e-4 run to run although the kernel is bit-identical to the one-row form in isolation, on one
-    // stream, and under row shifts / doubling (scratch/diag_ln_rowpos.py); forward multi-row + backward one-row passes bit-exactly.  Not
-    // understood yet (profiles/r03_layernorm_rows_per_wave_ab.txt); the backward's gain (26 -> 18 us at 32768 x 320) is left on the table.
-    constexpr int R1 = BWD ? 1 : 4, R2 = BWD ? 1 : 4, R4 = BWD ? 1 : 2;
+    // Both directions own 4 / 4 / 2 rows per wave.  (Round 3 shipped the backward at one row: its multi-row form made the three-stream
+    // backward's gradients differ run to run.  Root cause, round 4: not a cross-stream race but packed-fp32 VALU code -- hipcc's SLP pass had
+    // turned this kernel's per-element arithmetic into v_pk_{add,mul,fma}_f32, and those sequences returned wrong lanes whenever another
+    // stream's kernel shared the SIMD; the library is built without packed-fp32 instructions since, csrc/Makefile.)
+    constexpr int R1 = 4, R2 = 4, R4 = 2;
 #endif
     if (C <= 512) hipLaunchKernelGGL((layernorm_kernel<BWD, 1, R1>), dim3((M + 4 * R1 - 1) / (4 * R1)), dim3(256), 0, s, x, dy, gamma, beta, add, out, mean_rstd, M, C, eps);
     else if (C <= 1024) hipLaunchKernelGGL((layernorm_kernel<BWD, 2, R2>), dim3((M + 4 * R2 - 1) / (4 * R2)), dim3(256), 0, s, x, dy, gamma, beta, add, out, mean_rstd, M, C, eps);

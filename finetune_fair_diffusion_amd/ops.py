@@ -26,7 +26,14 @@ def _p(t):
     return ctypes.c_void_p(t.data_ptr())
 
 
+# Race detector (tests/test_fullsize_gpu.py, scratch/diag_hazard.py): DELAY = (probability, max_cycles, random.Random) makes a call spin the
+# CURRENT stream for a random number of cycles first (torch.cuda._sleep), which shifts the relative timing of the step's streams; results must not change.
+DELAY = None
+
+
 def _call(name, *args):
+    if DELAY is not None and DELAY[2].random() < DELAY[0]:
+        torch.cuda._sleep(int(DELAY[2].random() * DELAY[1]))
     L = _lib.get()
     rc = getattr(L, name)(*args)
     if rc != 0:

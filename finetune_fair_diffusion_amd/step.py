@@ -75,6 +75,20 @@ def _record_stream(obj, stream):
             _record_stream(v, stream)
 
 
+def _all_tensors(obj, out=None):
+    """Every tensor reachable from a recorded-forward context (the race detector's ``bwd_keep_alive`` holds them past the backward)."""
+    out = [] if out is None else out
+    if torch.is_tensor(obj):
+        out.append(obj)
+    elif isinstance(obj, dict):
+        for v in obj.values():
+            _all_tensors(v, out)
+    elif isinstance(obj, (list, tuple)):
+        for v in obj:
+            _all_tensors(v, out)
+    return out
+
+
 def _pow2_scale(amax, target):
     if not math.isfinite(amax) or amax <= 0:
         return 1.0
@@ -185,6 +199,13 @@ class FairnessTrainer:
         self.concurrent_bwd = os.environ.get("FD_NO_CONCURRENT_BWD") is None
         self.bwd_streams = int(os.environ.get("FD_BWD_STREAMS", "3"))     # measured: 2 -> 1647, 3 -> 1589, 4 -> 1633 ms per step (run-to-run noise ~2 %)
         self._side = None
+        # race-detector knobs (tests / scratch/diag_hazard.py; never set by the product): ``bwd_virtual`` deals the timesteps to the same per-stream
+        # gradient buffers but enqueues all of them on the launch stream -- same fp32 summation order as the concurrent schedule, so every
+        # buffer must come out BIT-identical; ``bwd_keep_alive`` holds every consumed activation context until the backward has been joined;
+        # ``debug_partials`` (a list) receives clones of the per-stream buffers before they are summed.
+        self.bwd_virtual = False
+        self.bwd_keep_alive = False
+        self.debug_partials = None
         # R2 of the NEXT step does not depend on this step's update (frozen original models, its own noise and prompt): when the caller hands
         # over the next step's inputs (``train_step(..., next_step=...)``) its first denoising steps are enqueued on the R2 stream as soon as
         # this step's R2 has finished, i.e. underneath the VAE decode / classifier / loss / VAE backward tail, whose launches leave most of the
@@ -774,6 +795,8 @@ class FairnessTrainer:
                 self.unet.prepare_backward()         # lazily built weight copies exist before any side stream can read them
                 nst = max(1, min(self.bwd_streams, S)) if self.concurrent_bwd else 1
                 sides = [self._side_stream(k) for k in range(1, nst)]
+                virtual = self.bwd_virtual
+                graveyard = [] if self.bwd_keep_alive else None
                 # upstream gradient of the CFG pair eps = eps_u + gs (eps_c - eps_u): [(1 - gs) g ; gs g], built once; a timestep scales it.
                 # Built on the launch stream BEFORE the side streams take their dependency on it: enqueued after ``wait_stream`` (as it was for
                 # most of round 3) the side streams' first timesteps could read it while its ``cat`` was still running -- a race that showed
@@ -787,10 +810,12 @@ class FairnessTrainer:
                     k = i % nst
                     on_side = k > 0
                     side = sides[k - 1] if on_side else None
-                    with (torch.cuda.stream(side) if on_side else contextlib.nullcontext()):
+                    with (torch.cuda.stream(side) if (on_side and not virtual) else contextlib.nullcontext()):
                         if i in ctxs:
                             self.unet._ctx = ctxs.pop(i)        # activations kept from the forward rollout
-                            if on_side:
+                            if graveyard is not None:
+                                graveyard.append(_all_tensors(self.unet._ctx))
+                            if on_side and not virtual:
                                 _record_stream(self.unet._ctx, side)
                         else:                                   # gradient-checkpointed recompute of this timestep
                             x = ops.to_f16(inputs[i])
@@ -800,10 +825,14 @@ class FairnessTrainer:
                         self.unet.backward_step(gpair * float(coefs[i] * gscale), gscale)
                 for bank in self.banks:
                     bank.accum = bank.grad
+                if self.debug_partials is not None:
+                    torch.cuda.synchronize()
+                    self.debug_partials.append([self.banks[0].grad.clone()] + [self.banks[0].grad_alt(k).clone() for k in range(1, nst)])
                 for k, side in enumerate(sides, 1):
                     cur.wait_stream(side)
                     for bank in self.banks:
                         bank.grad.add_(bank.grad_alt(k))
+                graveyard = None
                 denc = self.unet.finish_prompt_backward(gscale, need_denc=rec_te)
                 if rec_te:
                     L = enc_g.shape[1]

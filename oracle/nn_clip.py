@@ -141,8 +141,9 @@ class CLIPTextModel(nn.Module):
 
 
 def modify_text_encoder(te: CLIPTextModel, rank: int, patch_mlp: bool = True, seed: int = 0):
-    """``LoraLoaderMixin._modify_text_encoder`` restated: wraps q/k/v/out_proj (+fc1/fc2)
-    of every layer; returns the list of LoRA parameters in registration order."""
+    """``LoraLoaderMixin._modify_text_encoder`` (diffusers 0.19.3 loaders.py; called at 1-main-debias.py:831) restated: first the q/k/v/out_proj
+    of EVERY layer's attention module, then -- with ``patch_mlp`` -- the fc1/fc2 of every layer's MLP (two separate loops, so the returned
+    parameter LIST is attention-first; the reference's CustomModel / AdamW / EMAModel follow this list order, :836-842)."""
     g = torch.random.get_rng_state()
     torch.manual_seed(seed)
     params = []
@@ -152,7 +153,8 @@ def modify_text_encoder(te: CLIPTextModel, rank: int, patch_mlp: bool = True, se
             p = PatchedLoraProjection(getattr(a, n), rank)
             setattr(a, n, p)
             params.extend(p.lora_linear_layer.parameters())
-        if patch_mlp:
+    if patch_mlp:
+        for layer in te.text_model.encoder.layers:
             for n in ("fc1", "fc2"):
                 p = PatchedLoraProjection(getattr(layer.mlp, n), rank)
                 setattr(layer.mlp, n, p)

@@ -476,6 +476,99 @@ def test_sd15_b8_s20_shipped_schedule_equals_reference_schedule(full, dev):
     _check_grad_equal_to_rounding("B=8 S=20, shipped schedule run twice", tr.banks[0], grads[0], ga)
 
 
+def test_sd15_three_stream_backward_bit_exact_under_delay_injection(full, dev):
+    """Race detector for the three-stream backward.  ``bwd_virtual`` deals the 20 timesteps to the same three gradient
+    buffers but enqueues them on ONE stream: same fp32 summation order, so every per-stream buffer of the concurrent schedule must be
+    BIT-identical to it -- also when random spins are injected into the streams (``ops.DELAY``: every C-ABI call spins its stream for up to
+    ~100 us with probability 2 %), which shifts the streams against each other differently in every run.  With the round-3 library the
+    four-rows-per-wave LayerNorm backward failed this in every run (packed-fp32 VALU hazard); that kernel is the shipped one now."""
+    import random
+    from finetune_fair_diffusion_amd import ops
+    om, pm = full
+    tr, _ = _bench_size_trainer(pm, dev)
+    noises = torch.randn(8, 4, 64, 64, generator=torch.Generator().manual_seed(79))
+    tokens = sd15_tokens()
+
+    def run(virtual, delay=None):
+        tr.bwd_virtual, tr.debug_partials, ops.DELAY = virtual, [], delay
+        try:
+            out = tr.train_step(tokens, noises, 20)
+            torch.cuda.synchronize()
+        finally:
+            ops.DELAY, tr.bwd_virtual = None, False
+        parts, tr.debug_partials = tr.debug_partials[0], None
+        return out, parts
+
+    run(False)                               # allocator growth, lazily built operands
+    out_v, ref = run(True)
+    assert len(ref) == 3 and all(float(p.abs().max()) > 0 for p in ref)
+    for rep in range(5):
+        out_c, got = run(False, delay=None if rep == 0 else (0.02, 200000, random.Random(rep)))
+        assert torch.equal(out_c["images"], out_v["images"])
+        for k, (a, b) in enumerate(zip(got, ref)):
+            assert torch.equal(a, b), f"run {rep}: gradient buffer of backward stream {k} differs from the one-stream order by " \
+                                      f"{float((a - b).abs().max() / b.abs().max()):.3e} of max |g|"
+
+
+def test_sd15_backward_ops_reproduce_themselves_under_the_concurrent_schedule(full, dev):
+    """Kernel-level race detector: inside the shipped three-stream backward every side-effect-free op of the U-Net backward (GEMMs, convolutions,
+    LayerNorm / GroupNorm / GEGLU backward, adds) is executed TWICE on the same inputs and the two outputs are compared on the device.  A kernel
+    whose result depends on what shares the chip with it (the round-3 hazard was exactly that: correct alone, wrong lanes beside other streams'
+    kernels) shows up as a non-zero count here although every isolated kernel test passes."""
+    from finetune_fair_diffusion_amd import ops
+    om, pm = full
+    tr, _ = _bench_size_trainer(pm, dev)
+    noises = torch.randn(8, 4, 64, 64, generator=torch.Generator().manual_seed(80))
+    tokens = sd15_tokens()
+    tr.train_step(tokens, noises, 20)
+    torch.cuda.synchronize()
+    names = ("gemm", "conv3x3", "conv_up2_bwd", "groupnorm_bwd", "geglu_bwd_interleaved", "layernorm_bwd", "add", "downsum2x2")
+    bad = {n: torch.zeros((), dtype=torch.int64, device=dev) for n in names}
+    calls = {n: 0 for n in names}
+    orig = {n: getattr(ops, n) for n in names}
+    on = [False]
+
+    def wrap(name):
+        fn = orig[name]
+
+        def w(*a, **k):
+            out = fn(*a, **k)
+            if not on[0] or k.get("out") is not None:
+                return out
+            out2 = fn(*a, **k)
+            calls[name] += 1
+            for x, y in zip(out if isinstance(out, tuple) else (out,), out2 if isinstance(out2, tuple) else (out2,)):
+                if torch.is_tensor(x):
+                    bad[name] += (x != y).any()
+            return out
+        return w
+
+    orig_bs = tr.unet.backward_step
+
+    def backward_step(*a, **k):
+        on[0] = True
+        try:
+            return orig_bs(*a, **k)
+        finally:
+            on[0] = False
+
+    try:
+        for n in names:
+            setattr(ops, n, wrap(n))
+        tr.unet.backward_step = backward_step
+        for _ in range(2):
+            tr.train_step(tokens, noises, 20)
+        torch.cuda.synchronize()
+    finally:
+        for n in names:
+            setattr(ops, n, orig[n])
+        tr.unet.backward_step = orig_bs
+    counts = {n: int(bad[n]) for n in names}
+    print("ops executed twice:", calls, "pairs that differed:", counts)
+    assert calls["layernorm_bwd"] >= 1800 and calls["gemm"] > 5000
+    assert all(v == 0 for v in counts.values()), counts
+
+
 def test_sd15_b8_s50_mixed_keep_recompute_equals_all_recompute(full, dev):
     """(1b) BASELINE configs[3]'s rollout length (S=50) at B=8, SD-v1.5 size: 50 recorded timesteps (7.8 GB each) do not fit in 288 GB, so the
     step keeps as many as fit and recomputes the rest right before their backward (step.py rollout_steps / train_step; the reference's
