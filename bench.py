@@ -84,6 +84,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}"
+    # one process per GPU: this rank's share of the host (CPU affinity inside one NUMA node, intra-op threads) before the first HIP call
+    from finetune_fair_diffusion_amd import affinity
+    pinned = affinity.pin_rank(local, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
     if a.share_gpu0:
         local = 0
     torch.cuda.set_device(local)
@@ -172,6 +175,7 @@ def main():
                    "grad_is_finite": bool(out["grad_is_finite"]),
                    "peak_hbm_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
                    "hip_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "4 (runtime default)"),
+                   "rank0_cpu_affinity": None if pinned is None else {"cpus": len(pinned[0]), "first": pinned[0][0], "last": pinned[0][-1], "torch_threads": pinned[1]},
                    "r3_activation_gb_per_timestep": round(tr.last_ctx_bytes / 2 ** 30, 2),
                    "r3_timesteps_kept_in_hbm": min(a.S, 1 + max(tr.last_ctx_budget, 0)) if tr.keep_activations else 0},
     }

@@ -501,28 +501,51 @@ __global__ void warp_affine_fwd_kernel(const f16* img, const int32_t* src_index,
         chips[i] = (f16)v;
     }
 }
-__global__ void warp_affine_bwd_kernel(const float* dchips, const int32_t* src_index, const float* A, float* dimg, int H, int W, int S,
-                                       int64_t n) {
+// Backward as a fixed-order GATHER (round 4; it was a scatter with fp32 atomics, the last order-free sum on the way to dL/d(image)): one thread
+// per IMAGE pixel.  For every chip k that samples this image (ascending k), the output pixels whose bilinear footprint can contain the pixel lie
+// in the inverse-mapped bounding box of [xx-1, xx+1] x [yy-1, yy+1]; each candidate recomputes its sampling position with the forward's own
+// expression and adds its tap weight, oy-major / ox-minor.  dimg[b,c,yy,xx] += sum -- no two threads touch one element.
+__global__ void warp_affine_bwd_kernel(const float* dchips, const int32_t* src_index, const float* A, float* dimg, int n_chips, int H, int W,
+                                       int S, int64_t n) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const int ox = (int)(i % S);
-        int64_t p = i / S;
-        const int oy = (int)(p % S); p /= S;
+        const int xx = (int)(i % W);
+        int64_t p = i / W;
+        const int yy = (int)(p % H); p /= H;
         const int c = (int)(p % 3);
-        const int k = (int)(p / 3);
-        const float* a = A + k * 6;
-        const float xs = a[0] * ox + a[1] * oy + a[2], ys = a[3] * ox + a[4] * oy + a[5];
-        const float xf = floorf(xs), yf = floorf(ys);
-        const int x0 = (int)xf, y0 = (int)yf;
-        const float lx = xs - xf, ly = ys - yf;
-        float* ip = dimg + ((int64_t)src_index[k] * 3 + c) * H * W;
-        const float g = dchips[i];
-        auto put = [&](int yy, int xx, float wgt) {
-            if (yy >= 0 && yy < H && xx >= 0 && xx < W) atomicAdd(ip + (int64_t)yy * W + xx, g * wgt);
-        };
-        put(y0, x0, (1.f - ly) * (1.f - lx));
-        put(y0, x0 + 1, (1.f - ly) * lx);
-        put(y0 + 1, x0, ly * (1.f - lx));
-        put(y0 + 1, x0 + 1, ly * lx);
+        const int b = (int)(p / 3);
+        float acc = 0.f;
+        bool any = false;
+        for (int k = 0; k < n_chips; ++k) {
+            if (src_index[k] != b) continue;
+            const float* a = A + k * 6;
+            const float det = a[0] * a[4] - a[1] * a[3];
+            int oxlo = 0, oxhi = S - 1, oylo = 0, oyhi = S - 1;
+            if (fabsf(det) > 1e-12f) {
+                const float i00 = a[4] / det, i01 = -a[1] / det, i10 = -a[3] / det, i11 = a[0] / det;
+                float xlo = 1e30f, xhi = -1e30f, ylo = 1e30f, yhi = -1e30f;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float X = (float)(xx + ((q & 1) ? 1 : -1)) - a[2], Y = (float)(yy + ((q & 2) ? 1 : -1)) - a[5];
+                    const float ox = i00 * X + i01 * Y, oy = i10 * X + i11 * Y;
+                    xlo = fminf(xlo, ox); xhi = fmaxf(xhi, ox); ylo = fminf(ylo, oy); yhi = fmaxf(yhi, oy);
+                }
+                if (xhi < -1.f || yhi < -1.f || xlo > (float)S || ylo > (float)S) continue;
+                oxlo = max(0, (int)floorf(xlo) - 1); oxhi = min(S - 1, (int)ceilf(xhi) + 1);
+                oylo = max(0, (int)floorf(ylo) - 1); oyhi = min(S - 1, (int)ceilf(yhi) + 1);
+            }
+            const float* gp = dchips + ((int64_t)k * 3 + c) * S * S;
+            for (int oy = oylo; oy <= oyhi; ++oy)
+                for (int ox = oxlo; ox <= oxhi; ++ox) {
+                    const float xs = a[0] * ox + a[1] * oy + a[2], ys = a[3] * ox + a[4] * oy + a[5];
+                    const float xf = floorf(xs), yf = floorf(ys);
+                    const int dx = xx - (int)xf, dy = yy - (int)yf;
+                    if (dx < 0 || dx > 1 || dy < 0 || dy > 1) continue;
+                    const float lx = xs - xf, ly = ys - yf;
+                    acc += gp[(int64_t)oy * S + ox] * ((dy ? ly : 1.f - ly) * (dx ? lx : 1.f - lx));
+                    any = true;
+                }
+        }
+        if (any) dimg[i] += acc;
     }
 }
 extern "C" int fd_warp_affine_fwd(const void* img, const int32_t* src_index, const float* A, float fill, void* chips, int n_chips, int H, int W,
@@ -532,10 +555,10 @@ extern "C" int fd_warp_affine_fwd(const void* img, const int32_t* src_index, con
     hipLaunchKernelGGL(warp_affine_fwd_kernel, grid1d(n), dim3(256), 0, (hipStream_t)stream, (const f16*)img, src_index, A, fill, (f16*)chips, H, W, S, n);
     return fd_check_launch("fd_warp_affine_fwd");
 }
-extern "C" int fd_warp_affine_bwd(const float* dchips, const int32_t* src_index, const float* A, float* dimg, int n_chips, int H, int W, int S,
-                                  void* stream) {
-    const int64_t n = (int64_t)n_chips * 3 * S * S;
-    if (n == 0) return FD_OK;
-    hipLaunchKernelGGL(warp_affine_bwd_kernel, grid1d(n), dim3(256), 0, (hipStream_t)stream, dchips, src_index, A, dimg, H, W, S, n);
+extern "C" int fd_warp_affine_bwd(const float* dchips, const int32_t* src_index, const float* A, float* dimg, int n_chips, int B, int H, int W,
+                                  int S, void* stream) {
+    if (n_chips == 0) return FD_OK;
+    const int64_t n = (int64_t)B * 3 * H * W;       // one thread per IMAGE pixel (gather)
+    hipLaunchKernelGGL(warp_affine_bwd_kernel, grid1d(n), dim3(256), 0, (hipStream_t)stream, dchips, src_index, A, dimg, n_chips, H, W, S, n);
     return fd_check_launch("fd_warp_affine_bwd");
 }

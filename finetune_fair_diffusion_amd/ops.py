@@ -683,9 +683,9 @@ def warp_affine(img, src_index, A, S, fill=-1.0):
 
 
 def warp_affine_bwd(dchips, src_index, A, dimg, S):
-    """dimg [B,3,H,W] fp32 += scatter of dchips [n,3,S,S] fp32."""
-    _, _, H, W = dimg.shape
-    _call("fd_warp_affine_bwd", _p(_chk(dchips, F32)), _p(src_index), _p(_chk(A, F32)), _p(_chk(dimg, F32)), A.shape[0], H, W, S, _stream())
+    """dimg [B,3,H,W] fp32 += the adjoint of ``warp_affine`` applied to dchips [n,3,S,S] fp32 (fixed-order gather: bit-reproducible)."""
+    B, _, H, W = dimg.shape
+    _call("fd_warp_affine_bwd", _p(_chk(dchips, F32)), _p(src_index), _p(_chk(A, F32)), _p(_chk(dimg, F32)), A.shape[0], B, H, W, S, _stream())
     return dimg
 
 

@@ -35,6 +35,7 @@ from . import ops
 from .fairness import (EXPERIMENT_ATTRS, EXPERIMENT_REG_FLAGS, SyntheticFaceProvider, face_grad_factors, face_grad_factors_multi,
                        fair_loss_and_grad, gen_dynamic_weights, gen_dynamic_weights_multi,
                        generate_dynamic_targets, mc_transport_plan, microbatch_weights, targets_from_plan)
+from . import fairness_dev as FD
 from .layers import F16, F32
 from .lr_schedule import lr_lambda
 from .vit import feature_loss_and_grad
@@ -95,6 +96,19 @@ def _pow2_scale(amax, target):
     return float(2.0 ** round(math.log2(target / amax)))
 
 
+def _pow2_scale_dev(amax, target):
+    """``_pow2_scale`` evaluated ON THE DEVICE (``amax``: device tensor of any shape -> same-shape fp32 power of two, 1 where amax is 0 or not
+    finite): the loss scales of the VAE / ViT / SFNet / U-Net backwards no longer bounce through the host, so the tail of the step has no
+    read-back between the two logits copies and the end of the step (FD_HOST_SCALES=1 restores the four host syncs for A/B)."""
+    a = amax.float()
+    ok = torch.isfinite(a) & (a > 0)
+    s = torch.exp2(torch.round(torch.log2(target / torch.where(ok, a, torch.ones_like(a)))))
+    return torch.where(ok, s, torch.ones_like(s))
+
+
+_HOST_SCALES = os.environ.get("FD_HOST_SCALES") is not None
+# FD_HOST_TAIL=1 (A/B): exp-1's targets / loss assembly on the HOST as in rounds 1-3 (two logits read-backs in the tail); default: on the device
+_HOST_TAIL = os.environ.get("FD_HOST_TAIL") is not None
 _NO_PINNED_H2D = os.environ.get("FD_NO_PINNED_H2D") is not None
 _FINE_MARKS = os.environ.get("FD_FINE_MARKS") is not None
 _MAIN_PRIORITY = int(os.environ.get("FD_MAIN_PRIORITY", "0"))
@@ -157,6 +171,12 @@ class FairnessTrainer:
         # which classifier columns carry which attribute (exp-1: CelebA attr 20 of 40x2 logits `:1370`; exp-3/5: 2+4; exp-4: 2+4+2)
         self.experiment = experiment
         _, self.attrs, self.class_cdfs, self.age_asym = EXPERIMENT_ATTRS[experiment]
+        # exp-1 (one binary attribute): probabilities, dynamic targets, loss, dynamic weights and hook factors stay ON THE DEVICE (fairness_dev.py);
+        # what the caller is told about the step (probabilities, targets, per-image losses) comes back in ONE read-back together with the
+        # finite flag.  The multi-attribute experiments keep the host path (their OT solve has its own worker thread / device solver).
+        self.device_tail = len(self.attrs) == 1 and self.attrs[0][2] == 2 and not _HOST_TAIL
+        self._binom = {}
+        self._pending_readback = None
         self.target_rng = torch.Generator().manual_seed(1234 + rank)
         self.rank, self.world = rank, world_size
         # collectives run whenever there is more than one rank -- or, with FD_FORCE_COLLECTIVES=1 and an initialised process group, on a
@@ -317,8 +337,13 @@ class FairnessTrainer:
         cur = torch.cuda.current_stream().cuda_stream
         n = getattr(self, "_snap_calls", 0)
         self._snap_calls = n + 1
-        if n < 2 or n % 256 == 0:     # the pools settle within two steps; the snapshot walks every block of the allocator (tens of ms of host
-                                      # time at 175 GB) right at the start of a step, where the device queue is empty: refreshed rarely
+        reserved = torch.cuda.memory_reserved()
+        grown = abs(reserved - getattr(self, "_snap_reserved", -1)) > (1 << 30)      # the pools moved by > 1 GiB since the last walk (a new S / batch,
+                                                                                      # fragmentation in a long run): the side-stream share is stale
+        if n < 2 or n % 256 == 0 or grown:
+            # the pools settle within two steps; the snapshot walks every block of the allocator (tens of ms of host time at 175 GB) right at
+            # the start of a step, where the device queue is empty: refreshed rarely -- and whenever ``memory_reserved`` has moved
+            self._snap_reserved = reserved
             other = 0
             try:
                 for seg in torch.cuda.memory_snapshot():
@@ -376,6 +401,23 @@ class FairnessTrainer:
             per.append(dict(name=name, preds=preds, probs=probs, logits=la_full))
         return ind, boxes, per
 
+    def classify_dev(self, h):
+        """``classify_end`` without the read-back (exp-1, ``device_tail``): the per-attribute tensors stay on the device."""
+        N, ind, boxes, sel, logits_dev = h["N"], h["ind"], h["boxes"], h["sel"], h["logits_dev"]
+        name, c0, k = self.attrs[0]
+        if logits_dev is None:
+            probs = torch.full((N, k), -1.0, dtype=F32, device=self.device)
+            preds = torch.full((N,), -1, dtype=torch.long, device=self.device)
+            lg = probs.clone()
+        else:
+            probs, preds, lg = FD.probs_preds(logits_dev, _h2d(sel, self.device), N, c0, k)
+        return ind, boxes, [dict(name=name, preds=preds, probs=probs, logits=lg, ind_dev=_h2d(ind, self.device))]
+
+    def _binom_tables(self, n):
+        if n not in self._binom:
+            self._binom[n] = tuple(t.to(self.device) for t in FD.binomial_tables(n))
+        return self._binom[n]
+
     def classify(self, images, record=False):
         """get_face + get_face_gender[_race[_age]] (:1794-1795; exp-3 :1387-1457; exp-4 :1378-1475).
         Returns indicators, boxes and per attribute (preds [N], probs [N,k] (-1 filled), logits [N,k])."""
@@ -424,6 +466,15 @@ class FairnessTrainer:
           * exp-3/4/5: the 100 Monte-Carlo transport solves of this rank start on a WORKER THREAD -- they only need the gathered
             probabilities, and nothing needs the targets before R3's loss, so they run underneath the R2 rollout that the main thread
             keeps enqueueing (the reference solves them serially between R1 and R2 on every rank, exp-3 `:1488-1536`)."""
+        if getattr(self, "device_tail", False) and per[0]["probs"].is_cuda:
+            pd = per[0]["probs"]
+            if self.collectives:
+                gl = [torch.empty_like(pd) for _ in range(self.world)]
+                dist.all_gather(gl, pd.contiguous())
+                pd = torch.cat(gl)
+            t_all, u_all = FD.dynamic_targets(pd, self._binom_tables(pd.shape[0]), threshold=self.args.uncertainty_threshold)
+            self._tgt = dict(B=B, dev=[(t_all[B * self.rank:B * (self.rank + 1)], u_all[B * self.rank:B * (self.rank + 1)])])
+            return
         if not self.collectives:
             gathered = [a["probs"] for a in per]
         else:
@@ -465,6 +516,9 @@ class FairnessTrainer:
         """Second half: join the solver, ONE all-reduce of the summed plans (exchange point c11), marginals, threshold, this rank's slice.
         ``last_ot_ms`` = (host solve time, time the main thread actually waited here)."""
         st, args, B = self._tgt, self.args, self._tgt["B"]
+        if "dev" in st:
+            self._tgt = None
+            return st["dev"]
         t0 = time.perf_counter()
         if not st["single"]:
             if "thread" in st:
@@ -639,10 +693,13 @@ class FairnessTrainer:
         if share and self.use_img_loss and not _NO_TAIL_REORDER:
             small_g, fullbox_g = self.resize_small(images)
             pre_g = (fullbox_g,) + tuple(self.image_features(small_g, record=True))
-        ind, boxes, per = self.classify_end(h_g)
+        dv = self.device_tail
+        rb = {}                # device_tail: what the step reports about itself, read back ONCE at the end (name -> device tensor)
+        ind, boxes, per = self.classify_dev(h_g) if dv else self.classify_end(h_g)
         # ---- dynamic targets from the global batch (:1805-1837): gathered now, solved underneath R2, consumed by R3's loss
         self.start_dynamic_targets(per, B)
-        out.update(images=images, probs=per[0]["probs"], preds=per[0]["preds"])
+        out.update(images=images)
+        (rb if dv else out).update(probs=per[0]["probs"], preds=per[0]["preds"])
         # ---- R2: images from the frozen original models (:1844-1858)
         if conc:
             self._mark("R2_tail_and_regularisers")
@@ -657,7 +714,7 @@ class FairnessTrainer:
             self._mark("R2_classify_regularisers")
         h_o = self.classify_begin(images_ori)
         if _NO_TAIL_REORDER:
-            ind_o, boxes_o, per_o = self.classify_end(h_o)
+            ind_o, boxes_o, per_o = self.classify_dev(h_o) if dv else self.classify_end(h_o)
         ind_o = h_o["ind"]
         if self.use_img_loss:                                                    # :1860-1862
             e_co, e_do = self.image_features(self.resize_small(images_ori)[0])
@@ -669,11 +726,15 @@ class FairnessTrainer:
             if len(idx_o):
                 face_ori[idx_o.long()] = F.normalize(face_features(self.face_net, ch_o)[0], dim=-1)
         if not _NO_TAIL_REORDER:                 # the read-back of R2's logits comes after its feature encoders have been enqueued
-            ind_o, boxes_o, per_o = self.classify_end(h_o)
-        out.update(images_ori=images_ori, preds_ori=per_o[0]["preds"], probs_ori=per_o[0]["probs"])
+            ind_o, boxes_o, per_o = self.classify_dev(h_o) if dv else self.classify_end(h_o)
+        out.update(images_ori=images_ori)
+        (rb if dv else out).update(preds_ori=per_o[0]["preds"], probs_ori=per_o[0]["probs"])
         tgt = self.finish_dynamic_targets()
         targets = tgt[0][0]
-        out.update(targets=targets, uncertainty=tgt[0][1], targets_by_attr={a["name"]: t for a, (t, _) in zip(per, tgt)})
+        if dv:
+            rb.update(targets=targets, uncertainty=tgt[0][1])
+        else:
+            out.update(targets=targets, uncertainty=tgt[0][1], targets_by_attr={a["name"]: t for a, (t, _) in zip(per, tgt)})
         # ---- R3: rollout with gradient (:1889-1933), all micro-batches at once with weights 1/n_j
         w, N_backward = microbatch_weights(B, args.train_GPU_batch_size)
         if share:
@@ -685,16 +746,25 @@ class FairnessTrainer:
                                                  keep_activations=self.keep_activations)
             self._mark("R3_fwd_vae")
             images_g = self.decode(x_final, record=True)
-            ind_g, boxes_g, per_g = self.classify(images_g, record=True)
+            ind_g, boxes_g, per_g = self.classify_dev(self.classify_begin(images_g, record=True)) if dv else self.classify(images_g, record=True)
         self._mark("R3_loss_and_image_grad")
-        dlog_full = torch.zeros((B, self.clf.num_classes), dtype=F32)
         loss_by_attr = {}
-        for (name, c0, k), a, (t_a, _) in zip(self.attrs, per_g, tgt):      # loss_ij = sum over attributes (:1932; exp-3 :2146)
-            lf, dl = fair_loss_and_grad(a["logits"], t_a, ind_g, w)
-            loss_by_attr[name] = lf
+        if dv:
+            name, c0, k = self.attrs[0]
+            ind_dev, w_dev = per_g[0]["ind_dev"], _h2d(w, dev)
+            lf, dl = FD.fair_loss_and_grad(per_g[0]["logits"], targets, ind_dev, w_dev)
+            dlog_full = torch.zeros((B, self.clf.num_classes), dtype=F32, device=dev)
             dlog_full[:, c0:c0 + k] = dl
-        loss_fair = loss_by_attr[self.attrs[0][0]]
-        out.update(loss_fair=loss_fair, loss_fair_by_attr=loss_by_attr, images_grad=images_g, N_backward=N_backward)
+            rb["loss_fair"] = lf
+            out.update(images_grad=images_g, N_backward=N_backward)
+        else:
+            dlog_full = torch.zeros((B, self.clf.num_classes), dtype=F32)
+            for (name, c0, k), a, (t_a, _) in zip(self.attrs, per_g, tgt):      # loss_ij = sum over attributes (:1932; exp-3 :2146)
+                lf, dl = fair_loss_and_grad(a["logits"], t_a, ind_g, w)
+                loss_by_attr[name] = lf
+                dlog_full[:, c0:c0 + k] = dl
+            loss_fair = loss_by_attr[self.attrs[0][0]]
+            out.update(loss_fair=loss_fair, loss_fair_by_attr=loss_by_attr, images_grad=images_g, N_backward=N_backward)
         sel = ind_g.nonzero().view(-1)
         Himg, Wimg = images_g.shape[2], images_g.shape[3]
         d_img = None
@@ -708,39 +778,66 @@ class FairnessTrainer:
                 e_c, e_d = self.image_features(small, record=True)
             self._fine("L_a_clip_dino_fwd_enqueued")
             tl, pl = [t for t, _ in tgt], [a["preds"] for a in per_o]
-            if len(tl) == 1:
-                dyn = gen_dynamic_weights(ind_g, targets, per_o[0]["preds"], factor=self.factors1[0])
+            if dv:
+                dyn = FD.dynamic_weights(ind_dev, targets, per_o[0]["preds"], self.factors1[0])
+                wi = w_dev * args.weight_loss_img * dyn
             else:
-                dyn = gen_dynamic_weights_multi(ind_g, tl, pl, self.factors1)
-            wi = _h2d(w * args.weight_loss_img * dyn, dev)
+                if len(tl) == 1:
+                    dyn = gen_dynamic_weights(ind_g, targets, per_o[0]["preds"], factor=self.factors1[0])
+                else:
+                    dyn = gen_dynamic_weights_multi(ind_g, tl, pl, self.factors1)
+                wi = _h2d(w * args.weight_loss_img * dyn, dev)
             loss_clip, de_c = feature_loss_and_grad(e_c, clip_ori, wi)
             loss_dino, de_d = feature_loss_and_grad(e_d, dino_ori, wi)
-            am = torch.stack([de_c.abs().max(), de_d.abs().max()]).float().cpu()        # ONE read-back for both scales
-            self._fine("L_b_after_amax_readback")
-            dsmall = self.clip.backward(de_c, _pow2_scale(float(am[0]), 1.0))
-            self.dino.backward(de_d, _pow2_scale(float(am[1]), 1.0), out=dsmall)
+            am = torch.stack([de_c.abs().max(), de_d.abs().max()]).float()
+            if _HOST_SCALES:
+                am = am.cpu()        # ONE read-back for both scales
+                self._fine("L_b_after_amax_readback")
+                dsmall = self.clip.backward(de_c, _pow2_scale(float(am[0]), 1.0))
+                self.dino.backward(de_d, _pow2_scale(float(am[1]), 1.0), out=dsmall)
+            else:
+                # power-of-two scales chosen on the device: the scaled gradient enters with gscale = 1 and the result is un-scaled by the
+                # exact inverse (a power-of-two multiply commutes with every rounding: same bits as the host-scale path)
+                sc = _pow2_scale_dev(am, 1.0)
+                dsmall = self.clip.backward(de_c * sc[0], 1.0).mul_(1.0 / sc[0])
+                dsmall.addcmul_(self.dino.backward(de_d * sc[1], 1.0), 1.0 / sc[1])
             d_img = ops.crop_resize_bwd(dsmall, fullbox, B, Himg, Wimg, args.img_size_small)
             # apply_grad_hook_face (:1904, :1584-1617) acts on this path only: the classifier saw the un-hooked images
-            if len(tl) == 1:
-                rects, facs = face_grad_factors(boxes_g, boxes_o, targets, per_o[0]["preds"], self.factors2[0], Himg, Wimg)
+            if dv:       # the rectangle is a function of the two boxes (host); the factor of targets / original predictions (device)
+                zt = torch.zeros(B, dtype=torch.long)
+                rects, _ = face_grad_factors(boxes_g, boxes_o, zt, zt, 1.0, Himg, Wimg)
+                has_box = _h2d(~(boxes_g == -1).all(dim=1), dev)
+                ops.rect_scale(d_img, _h2d(rects, dev), FD.hook_factors(has_box, targets, per_o[0]["preds"], self.factors2[0]))
+                rb.update(loss_CLIP=loss_clip.float(), loss_DINO=loss_dino.float(), dynamic_weights=dyn)
             else:
-                rects, facs = face_grad_factors_multi(boxes_g, boxes_o, tl, pl, self.factors2, Himg, Wimg)
-            ops.rect_scale(d_img, _h2d(rects, dev), _h2d(facs, dev))
+                if len(tl) == 1:
+                    rects, facs = face_grad_factors(boxes_g, boxes_o, targets, per_o[0]["preds"], self.factors2[0], Himg, Wimg)
+                else:
+                    rects, facs = face_grad_factors_multi(boxes_g, boxes_o, tl, pl, self.factors2, Himg, Wimg)
+                ops.rect_scale(d_img, _h2d(rects, dev), _h2d(facs, dev))
+                # (the per-image regulariser values are only reported: they are read back at the end of the step, not here)
+                deferred.append(lambda lc=loss_clip, ld=loss_dino: out.update(
+                    loss_CLIP=lc.float().cpu(), loss_DINO=ld.float().cpu(), dynamic_weights=dyn,
+                    loss=sum(loss_by_attr.values()) + args.weight_loss_img * dyn * (lc.float().cpu() + ld.float().cpu())))
             self._fine("L_c_clip_dino_bwd_enqueued")
-            # (the per-image regulariser values are only reported: they are read back at the end of the step, not here)
-            deferred.append(lambda lc=loss_clip, ld=loss_dino: out.update(
-                loss_CLIP=lc.float().cpu(), loss_DINO=ld.float().cpu(), dynamic_weights=dyn,
-                loss=sum(loss_by_attr.values()) + args.weight_loss_img * dyn * (lc.float().cpu() + ld.float().cpu())))
         if self.use_face_loss:
             # face-realism term (:1917-1932): target = the original image's own face features when the target class equals the
             # original prediction with confidence >= face_gender_confidence_level, else the nearest database face
             from .sfnet import face_features, face_features_backward
             # exp-1 searches only for images with a target (:1926); the multi-attribute scripts search for every face (exp-3 :2135)
-            from_ori = ind_g.clone()
-            for (t_a, _), a in zip(tgt, per_o):
-                from_ori &= (t_a != -1) & (t_a == a["preds"]) & (a["probs"].max(dim=-1).values >= self.face_conf)
-            has = (ind_g & (targets != -1)) if len(tgt) == 1 else ind_g.clone()
-            loss_face = torch.full((B,), -1.0)
+            if dv:
+                # which faces carry a target is only known on the device: every face goes through the face network and the ones without a
+                # target get weight 0 (same loss and gradient: their term is multiplied out; the reference skips them, :1926)
+                from_ori = ind_dev & (targets != -1) & (targets == per_o[0]["preds"]) & (per_o[0]["probs"].max(dim=-1).values >= self.face_conf)
+                has_d = ind_dev & (targets != -1)
+                has = ind_g
+                loss_face = torch.full((B,), -1.0, dtype=F32, device=dev)
+            else:
+                from_ori = ind_g.clone()
+                for (t_a, _), a in zip(tgt, per_o):
+                    from_ori &= (t_a != -1) & (t_a == a["preds"]) & (a["probs"].max(dim=-1).values >= self.face_conf)
+                has = (ind_g & (targets != -1)) if len(tgt) == 1 else ind_g.clone()
+                loss_face = torch.full((B,), -1.0)
             rows = has.nonzero().view(-1)
             if len(rows):
                 chips_f, idx_f, A_f = self.aligned_faces(images_g, has)
@@ -749,25 +846,38 @@ class FairnessTrainer:
                 self._fine("L_c2_sfnet_fwd_enqueued")
                 fn = F.normalize(feats, dim=-1)
                 tgt = self.nearest_face_feats(fn)
-                use_ori = _h2d(from_ori[rows], dev)
-                tgt = torch.where(use_ori[:, None], face_ori[_h2d(rows, dev)], tgt)
-                wf = _h2d(w[rows] * args.weight_loss_face, dev)
+                rows_d = _h2d(rows, dev)
+                use_ori = from_ori[rows_d] if dv else _h2d(from_ori[rows], dev)
+                tgt = torch.where(use_ori[:, None], face_ori[rows_d], tgt)
+                wf = (w_dev[rows_d] * args.weight_loss_face * has_d[rows_d]) if dv else _h2d(w[rows] * args.weight_loss_face, dev)
                 lf_rows, df = feature_loss_and_grad(feats, tgt, wf)
                 self._fine("L_c3_nearest_and_loss_enqueued")
-                deferred.append(lambda lf_rows=lf_rows, rows=rows: loss_face.__setitem__(rows, lf_rows.float().cpu()))
-                dfmax = float(df.abs().max())
-                self._fine("L_c4_df_amax_readback")
-                dch = face_features_backward(self.face_net, fctx, df, _pow2_scale(dfmax, 1.0))
+                if dv:
+                    loss_face[rows_d] = torch.where(has_d[rows_d], lf_rows.float(), torch.full_like(lf_rows, -1.0, dtype=F32))
+                else:
+                    deferred.append(lambda lf_rows=lf_rows, rows=rows: loss_face.__setitem__(rows, lf_rows.float().cpu()))
+                if _HOST_SCALES:
+                    dfmax = float(df.abs().max())
+                    self._fine("L_c4_df_amax_readback")
+                    dch = face_features_backward(self.face_net, fctx, df, _pow2_scale(dfmax, 1.0))
+                else:
+                    sf = _pow2_scale_dev(df.abs().max(), 1.0)
+                    dch = face_features_backward(self.face_net, fctx, df * sf, 1.0).mul_(1.0 / sf)
                 self._fine("L_c5_sfnet_bwd_enqueued")
                 if d_img is None:
                     d_img = torch.zeros((B, 3, Himg, Wimg), dtype=F32, device=dev)
                 ops.warp_affine_bwd(dch.contiguous(), idx_f, A_f, d_img, args.size_aligned_face)   # un-hooked images (:1901)
-            deferred.append(lambda: out.update(loss_face=loss_face, loss=out.get("loss", sum(loss_by_attr.values())) + args.weight_loss_face * loss_face))
+            if dv:
+                rb["loss_face"] = loss_face
+            else:
+                deferred.append(lambda: out.update(loss_face=loss_face, loss=out.get("loss", sum(loss_by_attr.values())) + args.weight_loss_face * loss_face))
             self._fine("L_d_face_branch_done")
-        if (len(sel) and float(dlog_full.abs().sum()) > 0) or d_img is not None:
-            if len(sel) and float(dlog_full.abs().sum()) > 0:
-                dlog = dlog_full[sel]
-                dchips = self.clf.backward(_h2d(dlog, dev), self.clf_gscale)
+        # (device_tail: whether any logit gradient is non-zero is not known to the host -- the classifier backward runs whenever there is a face)
+        any_dlog = bool(len(sel)) and (dv or float(dlog_full.abs().sum()) > 0)
+        if any_dlog or d_img is not None:
+            if any_dlog:
+                dlog = dlog_full[_h2d(sel, dev)] if dv else _h2d(dlog_full[sel], dev)
+                dchips = self.clf.backward(dlog.contiguous(), self.clf_gscale)
                 full = dchips
                 if len(sel) != B:
                     full = torch.zeros((B,) + tuple(dchips.shape[1:]), dtype=F32, device=dev)
@@ -779,12 +889,23 @@ class FairnessTrainer:
             else:
                 self.clf._ctx = None
             self._mark("R3_bwd_vae")
-            vscale = _pow2_scale(float(d_img.abs().max()), 64.0)
-            dz = self.vae.backward_images(d_img, vscale)
-            g = dz * (1.0 / self.vae.config.scaling_factor)          # dL/dx_final  [B,4,h,w] fp32
             coefs = self.sch.grad_coefs() * self.sch.chain_coefs()   # hook (:1128) x scheduler recurrence (:1131)
             gs = args.guidance_scale
-            gscale = _pow2_scale(float(g.abs().max()) * float(abs(coefs).max()) * max(abs(gs), abs(1 - gs)), 64.0)
+            if _HOST_SCALES:
+                vscale = _pow2_scale(float(d_img.abs().max()), 64.0)
+                dz = self.vae.backward_images(d_img, vscale)
+                g = dz * (1.0 / self.vae.config.scaling_factor)          # dL/dx_final  [B,4,h,w] fp32
+                gscale = _pow2_scale(float(g.abs().max()) * float(abs(coefs).max()) * max(abs(gs), abs(1 - gs)), 64.0)
+                step_scale, inv_gscale = [float(c * gscale) for c in coefs], None
+            else:
+                vs = _pow2_scale_dev(d_img.abs().max(), 64.0)
+                dz = self.vae.backward_images(d_img * vs, 1.0)
+                g = dz * ((1.0 / self.vae.config.scaling_factor) / vs)   # dL/dx_final  [B,4,h,w] fp32
+                # the U-Net backward's scale stays on the device too: the timesteps' upstream gradients are multiplied by (c_i * gscale) as device
+                # scalars, the kernels run with gscale = 1 and the LoRA gradients are un-scaled ONCE, after the per-stream buffers have been summed
+                gscale_dev = _pow2_scale_dev(g.abs().max() * (float(abs(coefs).max()) * max(abs(gs), abs(1 - gs))), 64.0)
+                step_scale = _h2d(torch.as_tensor(coefs, dtype=F32), dev) * gscale_dev
+                inv_gscale, gscale = 1.0 / gscale_dev, 1.0
             out.update(g=g, coefs=coefs, gscale=gscale)
             self._mark("R3_bwd_unet")
             if train_unet or train_te or train_prefix:
@@ -822,7 +943,7 @@ class FairnessTrainer:
                             self.unet.forward_step(x if _CFG_PAIR else x.repeat(2, 1, 1, 1), i, record=True, pair=_CFG_PAIR)
                         for bank in self.banks:
                             bank.accum = bank.grad_alt(k) if on_side else bank.grad
-                        self.unet.backward_step(gpair * float(coefs[i] * gscale), gscale)
+                        self.unet.backward_step(gpair * step_scale[i], gscale)
                 for bank in self.banks:
                     bank.accum = bank.grad
                 if self.debug_partials is not None:
@@ -840,6 +961,9 @@ class FairnessTrainer:
                     if train_prefix:     # the prefix vectors sit at positions 1..n of the PROMPT row (row 1; row 0 is the uncond sequence)
                         n = self.prefix.n
                         self.prefix.bank.grad_view("token_embedding.weight")[1:].add_(dx0[1, 1:1 + n].float(), alpha=1.0 / gscale)
+                if inv_gscale is not None:      # device-side loss scale: every bank's gradient of this step carries it exactly once
+                    for bank in self.banks:
+                        bank.grad.mul_(inv_gscale)
         else:
             self.vae._ctx = self.clf._ctx = None
         ctxs.clear()
@@ -847,7 +971,25 @@ class FairnessTrainer:
             fn()
         # ---- gradient sync, guard, update (:1998-2029)
         self._mark("sync_update")
+        if dv:       # ONE read-back for everything the step reports, taken together with the finite flag inside sync_and_update
+            keys = sorted(rb)
+            self._pending_readback = torch.cat([rb[k].reshape(-1).to(F32) for k in keys]) if keys else None
         out["grad_is_finite"] = self.sync_and_update(N_backward)
+        if dv:
+            host = self._readback_host if self._pending_readback is None else self._pending_readback.cpu()    # (a replaced sync_and_update: read here)
+            self._pending_readback = None
+            off = 0
+            for k in keys:
+                n = rb[k].numel()
+                v = host[off:off + n].reshape(rb[k].shape)
+                off += n
+                out[k] = v.long() if rb[k].dtype == torch.long else v
+            name = self.attrs[0][0]
+            out.update(targets_by_attr={name: out["targets"]}, loss_fair_by_attr={name: out["loss_fair"]}, loss=out["loss_fair"].clone())
+            if "loss_CLIP" in out:
+                out["loss"] = out["loss"] + args.weight_loss_img * out["dynamic_weights"] * (out["loss_CLIP"] + out["loss_DINO"])
+            if "loss_face" in out:
+                out["loss"] = out["loss"] + args.weight_loss_face * out["loss_face"]
         self._mark("end")
         return out
 
@@ -857,7 +999,12 @@ class FairnessTrainer:
         self.allreduce_grads()
         for bank in self.banks:
             ops.grad_finite_scale(bank.grad, 1.0 / (self.world * N_backward), self.flag)
-        finite = int(self.flag.item()) == 0  # checked after the all-reduce so every rank takes the same branch
+        pend, self._pending_readback = getattr(self, "_pending_readback", None), None
+        if pend is not None:      # the step's reported values ride the flag's read-back: one device -> host copy per step
+            host = torch.cat([self.flag.to(F32), pend]).cpu()
+            finite, self._readback_host = int(host[0]) == 0, host[1:]
+        else:
+            finite = int(self.flag.item()) == 0  # checked after the all-reduce so every rank takes the same branch
         self.last_lr = args.learning_rate * lr_lambda(getattr(args, "lr_scheduler", "constant"), self.lr_step,
                                                       getattr(args, "lr_warmup_steps", 0), getattr(args, "max_train_steps", 1),
                                                       getattr(args, "lr_num_cycles", 1), getattr(args, "lr_power", 1.0), args.learning_rate)

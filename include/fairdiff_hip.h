@@ -236,11 +236,12 @@ int fd_patchify_bwd(const void* dpatches, float* dchips, const float* std3, int 
                     void* stream);
 /* face alignment of the face-realism term (image_pipeline :292-312: skimage SimilarityTransform + kornia.warp_affine, bilinear,
  * zeros padding in 0..255 space == -1 in [-1,1] space).  A [n,6] fp32: row-major 2x3 map from output pixel (x,y,1) to the input
- * sampling position in pixels; src_index [n]: image of chip k.  chips [n,3,S,S] fp16; bwd accumulates into dimg [B,3,H,W] fp32. */
+ * sampling position in pixels; src_index [n]: image of chip k.  chips [n,3,S,S] fp16; bwd accumulates into dimg [B,3,H,W] fp32
+ * as a fixed-order gather (one thread per image pixel, chips in ascending k: bit-reproducible, no atomics). */
 int fd_warp_affine_fwd(const void* img, const int32_t* src_index, const float* A, float fill, void* chips, int n_chips, int H, int W,
                        int S, void* stream);
-int fd_warp_affine_bwd(const float* dchips, const int32_t* src_index, const float* A, float* dimg, int n_chips, int H, int W, int S,
-                       void* stream);
+int fd_warp_affine_bwd(const float* dchips, const int32_t* src_index, const float* A, float* dimg, int n_chips, int B, int H, int W,
+                       int S, void* stream);
 /* apply_grad_hook_face (:1584-1617) in the backward: dimg [B,3,H,W] fp32 *= factors[b] inside rects[b] = [x0,y0,x1,y1) */
 int fd_rect_scale(float* dimg, const int32_t* rects, const float* factors, int B, int H, int W, void* stream);
 

@@ -20,5 +20,14 @@ for f in sorted(glob.glob('gpurun_out/r04a_bench_*.json')):
     except Exception as e: print(f, 'ERR', e)
 PY
     ;;
+b)  # full GPU suite + smoke on the library without packed-fp32 VALU (multi-row LayerNorm backward, gather warp backward)
+    timeout 1500 python -m pytest tests -m gpu -x -q --durations=15 > gpurun_out/r04b_gpu_suite.log 2>&1; tail -25 gpurun_out/r04b_gpu_suite.log
+    timeout 300 python __graft_entry__.py smoke > gpurun_out/r04b_smoke.log 2>&1; tail -2 gpurun_out/r04b_smoke.log
+    ;;
+c)  # which change moved the exp-3 tiny-model gradient cosine (0.981 in round 2 -> 0.966)?  same test under the A/B switches
+    T="python -m pytest tests/test_engine_gpu.py -x -q -s -k test_full_step_multi_attribute_exp3"
+    (echo "## default"; $T; echo "## FD_HOST_SCALES=1"; FD_HOST_SCALES=1 $T; echo "## round-3 library"; FAIRDIFF_LIB=$P/libfairdiff_hip_slp_r03.so $T; echo "## round-3 library + host scales"; FD_HOST_SCALES=1 FAIRDIFF_LIB=$P/libfairdiff_hip_slp_r03.so $T) 2>&1 | grep -i "##\|cosine\|passed\|failed" > gpurun_out/r04c_exp3_cosine_ab.txt
+    cat gpurun_out/r04c_exp3_cosine_ab.txt
+    ;;
 *) echo "unknown pass $1";;
 esac

@@ -14,7 +14,7 @@ sys.path.insert(0, HERE)
 sys.path.insert(0, os.path.dirname(HERE))
 import util_models as U  # noqa: E402
 
-B_PER_RANK, S, NOISE_SEED = 3, 3, 4242
+B_PER_RANK, S, NOISE_SEED = int(os.environ.get("FD_TEST_B_PER_RANK", "3")), 3, 4242
 
 
 def build(experiment, dev, rank, world):

@@ -301,6 +301,41 @@ def test_no_packed_fp32_valu_in_shipped_code_objects():
         assert nk > 150, (lib, nk)
 
 
+def test_device_side_exp1_loss_assembly_equals_the_host_statement():
+    """fairness_dev.py (what the step runs ON THE DEVICE for exp-1 since round 4: ranks -> binomial targets / uncertainties -> threshold, cross-entropy
+    with -1 sentinels and its logit gradient, dynamic weights, hook factors) against fairness.py, the host restatement that the
+    reference-executed goldens pin -- on CPU tensors, 300 random batches of 1..24 images with missing faces."""
+    from finetune_fair_diffusion_amd import fairness as FH, fairness_dev as FD
+    g = torch.Generator().manual_seed(0)
+    tabs = FD.binomial_tables(24)
+    for trial in range(300):
+        n = int(torch.randint(1, 25, (1,), generator=g))
+        p1 = torch.rand(n, generator=g)
+        probs = torch.stack([1 - p1, p1], -1)
+        nf = torch.rand(n, generator=g) < 0.2
+        probs[nf] = -1
+        t_ref, u_ref = FH.generate_dynamic_targets(probs, w_uncertainty=True)
+        t, u = FD.dynamic_targets(probs, tabs)
+        assert torch.equal(t, t_ref) and torch.equal(u, u_ref), (trial, t, t_ref)
+        thr = float(torch.rand(1, generator=g)) * 0.5
+        t2 = t_ref.clone()
+        t2[u_ref > thr] = -1
+        assert torch.equal(FD.dynamic_targets(probs, tabs, threshold=thr)[0], t2)
+        face, logits, w = ~nf, torch.randn(n, 2, generator=g) * 3, torch.rand(n, generator=g)
+        l_ref, d_ref = FH.fair_loss_and_grad(logits, t2, face, w)
+        l, d = FD.fair_loss_and_grad(logits, t2, face, w)
+        assert torch.allclose(l, l_ref, atol=1e-6) and torch.allclose(d, d_ref, atol=1e-6) and torch.equal(l == -1, l_ref == -1)
+        po = torch.randint(-1, 2, (n,), generator=g)
+        assert torch.equal(FD.dynamic_weights(face, t2, po, 0.2), FH.gen_dynamic_weights(face, t2, po, 0.2))
+        boxes = torch.randint(0, 60, (n, 4), generator=g).int()
+        boxes[nf] = -1
+        _, f_ref = FH.face_grad_factors(boxes, boxes, t2, po, 0.3, 64, 64)
+        assert torch.equal(FD.hook_factors(~(boxes == -1).all(dim=1), t2, po, 0.3), f_ref)
+        sel = face.nonzero().view(-1)
+        pr, pd, lg = FD.probs_preds(logits[sel], sel, n, 0, 2)
+        assert torch.equal(pr == -1, probs == -1) and torch.equal(pd[sel], torch.softmax(logits[sel], -1).max(-1).indices) and bool((pd[nf] == -1).all())
+
+
 def test_product_fails_loudly_without_library(monkeypatch):
     from finetune_fair_diffusion_amd import lib
     monkeypatch.setattr(lib, "LIB_PATH", "/nonexistent/libfairdiff_hip.so")

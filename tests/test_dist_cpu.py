@@ -156,3 +156,66 @@ def test_resume_keeps_per_rank_rng_streams_gloo_world2(tmp_path):
     assert out[0]["got"]["noise"] != out[1]["got"]["noise"] and out[0]["got"]["ot"] != out[1]["got"]["ot"]
     assert out[0]["other_world"] != out[1]["other_world"]
     assert sorted(os.listdir(tmp_path / "checkpoint_tmp-3")) == ["rng_rank0.pth", "rng_rank1.pth", "trainer_state.pth"]
+
+
+# ------------------------------------------------------------------ eight ranks: rank-count assumptions of the exchange points
+def _exchange8_worker(rank, world, port, out):
+    """Eight ranks x 3 images through the product's own ``start / finish_dynamic_targets`` (all-gather of the device-side probabilities, global
+    exp-1 targets, this rank's slice, :1805-1837) and the flat gradient all-reduce (:1998-2011)."""
+    _init(rank, world, port)
+    import types
+    from finetune_fair_diffusion_amd.fairness import EXPERIMENT_ATTRS
+    from finetune_fair_diffusion_amd.layers import ParamBank
+    from finetune_fair_diffusion_amd.step import FairnessTrainer
+    B = 3
+    tr = FairnessTrainer.__new__(FairnessTrainer)
+    tr.world, tr.rank, tr.device, tr.collectives = world, rank, torch.device("cpu"), True
+    tr.args = types.SimpleNamespace(uncertainty_threshold=0.3)
+    _, tr.attrs, tr.class_cdfs, tr.age_asym = EXPERIMENT_ATTRS["exp-1"]
+    tr.overlap_targets, tr._tgt = False, None
+    g = torch.Generator().manual_seed(300 + rank)
+    p1 = torch.rand(B, generator=g)
+    probs = torch.stack([1 - p1, p1], -1)
+    if rank == 5:
+        probs[1] = -1                        # an image without a face on one rank
+    tr._probs_dev = probs.clone()
+    tr.start_dynamic_targets([dict(probs=probs)], B)
+    (t, u), = tr.finish_dynamic_targets()
+    bank = ParamBank({"a.down.weight": (4, 8), "a.up.weight": (8, 4)}, torch.device("cpu"))
+    bank.grad.copy_(torch.arange(bank.numel, dtype=torch.float32) * (rank + 1))
+    tr.banks = [bank]
+    tr.allreduce_grads()
+    out[rank] = dict(probs=probs.numpy(), t=t.numpy(), u=u.numpy(), grad=bank.grad.numpy().copy())
+    dist.destroy_process_group()
+
+
+def test_exchange_points_gloo_world8():
+    from finetune_fair_diffusion_amd.fairness import generate_dynamic_targets
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_exchange8_worker, args=(8, 29631, out), nprocs=8, join=True)
+    allp = torch.tensor(np.concatenate([out[r]["probs"] for r in range(8)]))
+    t_ref, u_ref = generate_dynamic_targets(allp, w_uncertainty=True)
+    t_ref = t_ref.clone()
+    t_ref[u_ref > 0.3] = -1
+    got_t = np.concatenate([out[r]["t"] for r in range(8)])
+    got_u = np.concatenate([out[r]["u"] for r in range(8)])
+    assert got_t.shape == (24,) and np.array_equal(got_t, t_ref.numpy()) and np.allclose(got_u, u_ref.numpy())
+    assert got_t[5 * 3 + 1] == -1 and (got_t != -1).sum() >= 4          # rank 5's faceless image has no target; the confident ranks keep theirs
+    expect = np.arange(len(out[0]["grad"]), dtype=np.float32) * 36     # sum over ranks of (rank + 1)
+    for r in range(8):
+        assert np.array_equal(out[r]["grad"], expect)
+
+
+def test_rank_cpu_shares_partition_the_numa_nodes():
+    """affinity.rank_cpus: eight ranks on a two-socket host -> four per node, disjoint contiguous shares that cover each node; one rank per
+    node when there are as many nodes as ranks; fewer CPUs than ranks still yields a non-empty share."""
+    from finetune_fair_diffusion_amd import affinity as A
+    nodes = [list(range(0, 64)) + list(range(128, 192)), list(range(64, 128)) + list(range(192, 256))]
+    shares = [A.rank_cpus(r, 8, nodes) for r in range(8)]
+    assert all(len(s) == 32 for s in shares)
+    assert sorted(c for s in shares[:4] for c in s) == sorted(nodes[0]) and sorted(c for s in shares[4:] for c in s) == sorted(nodes[1])
+    assert [A.rank_cpus(r, 2, nodes) for r in range(2)] == nodes
+    assert all(A.rank_cpus(r, 8, [[0, 1, 2]]) for r in range(8))
+    assert A._parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]
+    assert A.pin_rank(0, 1) is None                    # a single-rank run is never pinned

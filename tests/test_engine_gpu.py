@@ -578,6 +578,20 @@ def test_face_alignment_warp_vs_oracle(dev):
     dimg = torch.zeros(B, 3, H, W, dtype=torch.float32, device=dev)
     ops.warp_affine_bwd(gw.to(dev).contiguous(), idx, A, dimg, crop)
     check("d images (warp)", dimg, x.grad, 1e-4)
+    # the backward is a fixed-order gather (round 4): accumulates into what dimg holds, bit-reproducible, two chips of ONE image summed in chip order
+    d2 = torch.full((B, 3, H, W), 0.25, dtype=torch.float32, device=dev)
+    ops.warp_affine_bwd(gw.to(dev).contiguous(), idx, A, d2, crop)
+    assert torch.equal(d2 == 0.25, dimg == 0) and float((d2 - 0.25 - dimg).abs().max()) < 1e-5 * float(dimg.abs().max())
+    same = torch.tensor([1, 1, 0], dtype=torch.int32, device=dev)          # chips 0 and 1 sample image 1, chip 2 image 0
+    runs = []
+    for _ in range(2):
+        d3 = torch.zeros(B, 3, H, W, dtype=torch.float32, device=dev)
+        ops.warp_affine_bwd(gw.to(dev).contiguous(), same, A, d3, crop)
+        runs.append(d3)
+    assert torch.equal(runs[0], runs[1]) and float(runs[0][2].abs().max()) == 0
+    xs = imgs.clone().requires_grad_(True)
+    (torch.stack([OS.image_pipeline(xs[int(same[i])], lms[i], crop) for i in range(B)]) * gw).sum().backward()
+    check("d images (two chips on one image)", runs[0], xs.grad, 1e-4)
 
 
 def test_sfnet20_features_and_input_gradient_vs_oracle(dev):

@@ -23,18 +23,20 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _launch(experiment, out_dir):
+def _launch(experiment, out_dir, world=2, b_per_rank=None):
     env = dict(os.environ)
     for k in ("FD_DTYPE", "FAIRDIFF_LIB", "RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+    if b_per_rank is not None:
+        env["FD_TEST_B_PER_RANK"] = str(b_per_rank)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(HERE, "run_two_rank_step.py"), experiment, str(out_dir)]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     print(r.stdout[-3000:])
     print(r.stderr[-3000:])
-    assert r.returncode == 0, "two-rank run failed"
-    return [torch.load(os.path.join(out_dir, f"rank{k}.pt")) for k in range(2)]
+    assert r.returncode == 0, f"{world}-rank run failed"
+    return [torch.load(os.path.join(out_dir, f"rank{k}.pt")) for k in range(world)]
 
 
 def test_two_ranks_equal_one_rank_with_twice_the_batch_exp1(dev, tmp_path):
@@ -75,3 +77,31 @@ def test_two_ranks_multi_attribute_exchange_points_exp3(dev, tmp_path):
     n_t = sum(int((t != -1).sum()) for r in (r0, r1) for t in r["targets"].values())
     print("exp-3 two ranks: targets", {k: v.tolist() for k, v in r0["targets"].items()}, {k: v.tolist() for k, v in r1["targets"].items()})
     assert n_t >= 2
+
+
+def test_eight_ranks_one_global_batch_exp1(dev, tmp_path, monkeypatch):
+    """World size 8 through the product's ``train_step`` (rank-count assumptions -- this rank's slice of the global targets
+    :1836, the gather order, the 1 / (world * N_backward) gradient scale :2005): eight processes (gloo, all on cuda:0; per-rank CPU shares from
+    affinity.pin_rank are exercised by the launcher's LOCAL_WORLD_SIZE) with 2 images each against ONE process with all 16 images."""
+    monkeypatch.setenv("FD_TEST_B_PER_RANK", "2")
+    import importlib
+    importlib.reload(R)
+    try:
+        ranks = _launch("exp-1", tmp_path, world=8, b_per_rank=2)
+        assert all(r["finite"] for r in ranks)
+        for r in ranks[1:]:
+            for a, b in zip(ranks[0]["grads"] + ranks[0]["params"], r["grads"] + r["params"]):
+                assert torch.equal(a, b)
+        tr = R.build("exp-1", dev, 0, 1)
+        out = tr.train_step(U.tiny_tokens(), R.global_noises(8), R.S)
+        one = R.snapshot(tr, out)
+        tg = torch.cat([r["targets"]["gender"] for r in ranks])
+        assert tg.shape == (16,) and tg.tolist() == one["targets"]["gender"].tolist() and int((tg != -1).sum()) >= 6, (tg, one["targets"])
+        for k, (g8, g1) in enumerate(zip(ranks[0]["grads"], one["grads"])):
+            cos = float(F.cosine_similarity(g8.double(), g1.double(), dim=0))
+            ratio = float(g8.norm() / g1.norm())
+            print(f"bank {k}: eight ranks vs one rank with 8x batch: cosine {cos:.6f}  norm ratio {ratio:.4f}")
+            assert cos > 0.995 and 0.97 < ratio < 1.03
+    finally:
+        monkeypatch.delenv("FD_TEST_B_PER_RANK")
+        importlib.reload(R)
