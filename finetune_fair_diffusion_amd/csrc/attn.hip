@@ -513,7 +513,10 @@ __global__ __launch_bounds__(256, dkdv_waves(D, QTR)) void attn_bwd_dkdv_kernel(
                                                             const f16* __restrict__ V, const f16* __restrict__ dO,
                                                             const f16* __restrict__ dOt, const float* __restrict__ LSE,
                                                             const float* __restrict__ Dd, void* __restrict__ dKo, void* __restrict__ dVo,
-                                                            int H, int Tq, int Tk, int Tkr, int kv_div, float scale, int ldq, int ldkv, int lddkv) {
+                                                            int H, int Tq, int Tk, int Tkr, int kv_div, float scale, int ldq, int ldkv, int lddkv,
+                                                            int64_t slab) {
+    // ATOMIC + slab > 0: no atomics -- sample j of a K/V group stores its fp32 partial into slab j (slab = elements per [Bk*Tkr, lddkv] buffer);
+    // the caller sums the kv_div slabs in a fixed order (fd_sum_slabs): bit-reproducible shared dK / dV
     constexpr int DK = (D + 15) / 16 * 16, DV = (D + 31) / 32 * 32, DKP = DK + FD_ATTN_BWD_PAD;
     constexpr int NKS = DK / 16, NDV = DV / 32;
     extern __shared__ __attribute__((aligned(16))) f16 smem[];
@@ -686,7 +689,11 @@ __global__ __launch_bounds__(256, dkdv_waves(D, QTR)) void attn_bwd_dkdv_kernel(
             for (int rq = 0; rq < 4; ++rq) {
                 const int d0 = i * 32 + 8 * rq + 4 * g;
                 if (d0 < D) {
-                    if (ATOMIC) {
+                    if (ATOMIC && slab > 0) {
+                        const int64_t so = (int64_t)(b - bk * kv_div) * slab + off + d0;
+                        *(f32x4*)((float*)dKo + so) = (f32x4){dk[i][rq * 4] * scale, dk[i][rq * 4 + 1] * scale, dk[i][rq * 4 + 2] * scale, dk[i][rq * 4 + 3] * scale};
+                        *(f32x4*)((float*)dVo + so) = (f32x4){dv[i][rq * 4], dv[i][rq * 4 + 1], dv[i][rq * 4 + 2], dv[i][rq * 4 + 3]};
+                    } else if (ATOMIC) {
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             atomicAdd((float*)dKo + off + d0 + j, dk[i][rq * 4 + j] * scale);
@@ -811,12 +818,15 @@ extern "C" int fd_attn_bwd_dkdv(const void* q, const void* qt, const void* k, co
     FD_REQUIRE(qtr || (qt && d_ot), "fd_attn_bwd_dkdv: qt and d_ot must both be given or both be NULL");
     FD_REQUIRE(B > 0 && H > 0 && Tq > 0 && Tk > 0 && (qtr || (Tq & 7) == 0) && Tkr >= Tk && kv_div >= 1, "fd_attn_bwd_dkdv: bad shape (Tq %% 8)");
     dim3 grid(((Tk + 127) / 128) * H * B);
+    // accumulate == 2: fp32 per-sample slabs instead of atomics (dk, dv: [kv_div][Bk*Tkr][lddkv] fp32, every element written)
+    const int64_t slab = accumulate == 2 ? (int64_t)(B / kv_div) * Tkr * lddkv : 0;
+    FD_REQUIRE(accumulate != 2 || (B % kv_div) == 0, "fd_attn_bwd_dkdv: B must be a multiple of kv_div");
 #define LAUNCH(DD, AT, TRQ)                                                                                                            \
     {                                                                                                                                  \
         ALLOW_LDS((attn_bwd_dkdv_kernel<DD, AT, TRQ>), (dkdv_lds<DD, TRQ>()));                                                         \
         hipLaunchKernelGGL((attn_bwd_dkdv_kernel<DD, AT, TRQ>), grid, dim3(256), (dkdv_lds<DD, TRQ>()), (hipStream_t)stream,           \
                            (const f16*)q, (const f16*)qt, (const f16*)k, (const f16*)v, (const f16*)d_o, (const f16*)d_ot, lse, D, dk, \
-                           dv, H, Tq, Tk, Tkr, kv_div, scale, ldq, ldkv, lddkv);                                                       \
+                           dv, H, Tq, Tk, Tkr, kv_div, scale, ldq, ldkv, lddkv, slab);                                                 \
     }
 #define CALL(DD)                                                     \
     if (kv_div > 1 || accumulate) {                                  \

@@ -489,3 +489,24 @@ extern "C" int fd_rect_scale(float* dimg, const int32_t* rects, const float* fac
     hipLaunchKernelGGL(rect_scale_kernel, grid_for(n), dim3(256), 0, (hipStream_t)stream, dimg, rects, factors, H, W, n);
     return fd_check_launch("fd_rect_scale");
 }
+
+
+// ---------------------------------------------------------------- fixed-order sum of fp32 slabs (deterministic shared dK / dV, attn.hip)
+__global__ void sum_slabs_kernel(const float* __restrict__ in, float* __restrict__ out, int nslab, int64_t n4) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        f32x4 a = ((const f32x4*)in)[i];
+        for (int s = 1; s < nslab; ++s) {
+            const f32x4 b = ((const f32x4*)in)[(int64_t)s * n4 + i];
+            a[0] += b[0]; a[1] += b[1]; a[2] += b[2]; a[3] += b[3];
+        }
+        ((f32x4*)out)[i] = a;
+    }
+}
+extern "C" int fd_sum_slabs(const float* in, float* out, int nslab, int64_t n, void* stream) {
+    FD_REQUIRE(in && out && nslab >= 1 && n > 0 && (n & 3) == 0, "fd_sum_slabs: n must be a positive multiple of 4");
+    const int64_t n4 = n >> 2;
+    int blocks = (int)((n4 + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(sum_slabs_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, in, out, nslab, n4);
+    return fd_check_launch("fd_sum_slabs");
+}

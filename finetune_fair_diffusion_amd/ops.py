@@ -472,9 +472,13 @@ def attn_fwd(q, k, vt, B, H, Tq, Tk, d, kv_div=1, scale=None, need_lse=False, kv
     return (o, lse) if need_lse else o
 
 
-def attn_bwd(q, k, v, o, do, lse, B, H, Tq, Tk, d, kv_div=1, scale=None, kt=None, dk_acc=None, dv_acc=None, kv_rows=None, dqkv=None, tr=None):
+def attn_bwd(q, k, v, o, do, lse, B, H, Tq, Tk, d, kv_div=1, scale=None, kt=None, dk_acc=None, dv_acc=None, kv_rows=None, dqkv=None, tr=None,
+             dk_out=None, dv_out=None):
     """Returns (dq, dk, dv).  With ``dk_acc`` / ``dv_acc`` (fp32 [Bk*Tk, C]; mandatory when kv_div > 1, i.e. shared K/V) dk/dv are ADDED
     into those buffers with fp32 atomics -- safe for launches that run concurrently on different streams.
+    With ``dk_out`` / ``dv_out`` instead (fp32 [Bk*Tk, C], WRITTEN): no atomics -- every sample of a K/V group writes its own fp32 slab and the
+    kv_div slabs are summed in a fixed order (``fd_sum_slabs``); the training step gives every timestep its own pair, so the shared
+    cross-attention dK / dV -- and with them every LoRA gradient -- are bit-reproducible run to run and across schedules.
     q, k, v are 2-D and may be column slices of a wider buffer; with ``dqkv`` [M, 3*H*d] (self-attention, kv_div == 1) the three
     gradients are written as its column slices (returned as views), so that the projections' input gradient is ONE GEMM over K = 3*H*d."""
     scale = scale if scale is not None else d ** -0.5
@@ -497,7 +501,12 @@ def attn_bwd(q, k, v, o, do, lse, B, H, Tq, Tk, d, kv_div=1, scale=None, kt=None
     else:
         dq = torch.empty((q.shape[0], C), dtype=F16, device=q.device)
         lddkv = C
-        if dk_acc is not None:      # shared K/V (kv_div > 1) or a cross-step accumulator: fp32 buffers updated with atomics
+        if dk_out is not None:      # deterministic form: per-sample slabs, reduced below
+            assert dk_out.dtype == F32 and dv_out.dtype == F32 and dk_out.shape == (k.shape[0], C) and dv_out.shape == dk_out.shape and Tkr == Tk
+            assert dk_out.is_contiguous() and dv_out.is_contiguous() and B % kv_div == 0
+            slabs = torch.empty((2, kv_div) + tuple(dk_out.shape), dtype=F32, device=q.device)
+            dk, dv = slabs[0], slabs[1]
+        elif dk_acc is not None:    # shared K/V (kv_div > 1) or a cross-step accumulator: fp32 buffers updated with atomics
             dk, dv = dk_acc, dv_acc
             assert dk.dtype == F32 and dv.dtype == F32 and dk.shape == (k.shape[0], C) and Tkr == Tk
         else:
@@ -509,7 +518,12 @@ def attn_bwd(q, k, v, o, do, lse, B, H, Tq, Tk, d, kv_div=1, scale=None, kt=None
     qt = None if tr else transpose_btc(q, B, Tq, C, Tq)
     dot = None if tr else transpose_btc(do, B, Tq, C, Tq)
     _call("fd_attn_bwd_dkdv", _p(q), _p(qt), _p(k), _p(v), _p(do), _p(dot), _p(lse), _p(Dd), _p(dk), _p(dv), B, H, Tq, Tk, Tkr, d, kv_div, scale,
-          _rows(q), _rows(k), lddkv, int(dk_acc is not None), _stream())
+          _rows(q), _rows(k), lddkv, 2 if dk_out is not None else int(dk_acc is not None), _stream())
+    if dk_out is not None:
+        n = dk_out.numel()
+        _call("fd_sum_slabs", _p(dk), _p(dk_out), kv_div, n, _stream())
+        _call("fd_sum_slabs", _p(dv), _p(dv_out), kv_div, n, _stream())
+        dk, dv = dk_out, dv_out
     return dq, dk, dv
 
 

@@ -36,6 +36,7 @@ from .fairness import (EXPERIMENT_ATTRS, EXPERIMENT_REG_FLAGS, SyntheticFaceProv
                        fair_loss_and_grad, gen_dynamic_weights, gen_dynamic_weights_multi,
                        generate_dynamic_targets, mc_transport_plan, microbatch_weights, targets_from_plan)
 from . import fairness_dev as FD
+from . import unet as unet_mod
 from .layers import F16, F32
 from .lr_schedule import lr_lambda
 from .vit import feature_loss_and_grad
@@ -109,6 +110,9 @@ def _pow2_scale_dev(amax, target):
 _HOST_SCALES = os.environ.get("FD_HOST_SCALES") is not None
 # FD_HOST_TAIL=1 (A/B): exp-1's targets / loss assembly on the HOST as in rounds 1-3 (two logits read-backs in the tail); default: on the device
 _HOST_TAIL = os.environ.get("FD_HOST_TAIL") is not None
+_R2_SIDE_OLD = os.environ.get("FD_R2_SIDE_HOST_ORDER") is not None
+# FD_ATOMIC_DKDV=1 (A/B): shared cross-attention dK / dV accumulated with fp32 atomics across samples, timesteps and streams, as in rounds 1-3
+_ATOMIC_DKDV = os.environ.get("FD_ATOMIC_DKDV") is not None
 _NO_PINNED_H2D = os.environ.get("FD_NO_PINNED_H2D") is not None
 _FINE_MARKS = os.environ.get("FD_FINE_MARKS") is not None
 _MAIN_PRIORITY = int(os.environ.get("FD_MAIN_PRIORITY", "0"))
@@ -344,6 +348,7 @@ class FairnessTrainer:
             # the pools settle within two steps; the snapshot walks every block of the allocator (tens of ms of host time at 175 GB) right at
             # the start of a step, where the device queue is empty: refreshed rarely -- and whenever ``memory_reserved`` has moved
             self._snap_reserved = reserved
+            self._snap_walks = getattr(self, "_snap_walks", 0) + 1
             other = 0
             try:
                 for seg in torch.cuda.memory_snapshot():
@@ -400,6 +405,25 @@ class FairnessTrainer:
                 preds[sel] = p.max(dim=-1).indices
             per.append(dict(name=name, preds=preds, probs=probs, logits=la_full))
         return ind, boxes, per
+
+    def _r2_side_forwards(self, images_ori, B, consumer):
+        """Classifier forward and regulariser features of the frozen side's images, enqueued on the CURRENT (R2) stream; the tensors are handed to
+        ``consumer`` (the launch stream waits on the event recorded behind them)."""
+        r = dict(h_o=self.classify_begin(images_ori))
+        if self.use_img_loss:                                                    # :1860-1862
+            e_co, e_do = self.image_features(self.resize_small(images_ori)[0])
+            r.update(clip_ori=F.normalize(e_co, dim=-1), dino_ori=F.normalize(e_do, dim=-1))
+        if self.use_face_loss:                                                   # :1870
+            from .sfnet import face_features
+            ch_o, idx_o, _ = self.aligned_faces(images_ori, r["h_o"]["ind"])
+            face_ori = torch.zeros((B, 512), dtype=F32, device=self.device)
+            if len(idx_o):
+                face_ori[idx_o.long()] = F.normalize(face_features(self.face_net, ch_o)[0], dim=-1)
+            r["face_ori"] = face_ori
+        for t in (r["h_o"]["logits_dev"], r.get("clip_ori"), r.get("dino_ori"), r.get("face_ori")):
+            if t is not None:
+                t.record_stream(consumer)
+        return r
 
     def classify_dev(self, h):
         """``classify_end`` without the read-back (exp-1, ``device_tail``): the per-attribute tensors stay on the device."""
@@ -665,6 +689,11 @@ class FairnessTrainer:
                 for _ in g2:           # (nothing left when both rollouts have S steps)
                     pass
                 images_ori = self.decode(r2["lat"])
+                # the frozen side's classifier and regulariser forwards (:1860-1870) depend on images_ori only: enqueued HERE, on the R2 stream, they run
+                # beside R1's last denoising steps instead of on the launch stream between R1's classifier and the loss (FD_R2_SIDE_HOST_ORDER=1: as before)
+                r2side = None
+                if not _R2_SIDE_OLD:
+                    r2side = self._r2_side_forwards(images_ori, B, cur)
             ev_r2 = torch.cuda.Event()
             ev_r2.record(side)         # what the main stream waits for below: this step's R2, not a prefetch queued behind it
             can_prefetch = (next_step is not None and self.r2_prefetch_steps > 0 and not next_step["noises"].is_cuda and
@@ -712,21 +741,25 @@ class FairnessTrainer:
             self._mark("R2_vae")
             images_ori = torch.cat([self.decode(x) for x in lats])
             self._mark("R2_classify_regularisers")
-        h_o = self.classify_begin(images_ori)
-        if _NO_TAIL_REORDER:
+        if conc and r2side is not None:
+            h_o, clip_ori, dino_ori, face_ori = r2side["h_o"], r2side.get("clip_ori"), r2side.get("dino_ori"), r2side.get("face_ori")
             ind_o, boxes_o, per_o = self.classify_dev(h_o) if dv else self.classify_end(h_o)
-        ind_o = h_o["ind"]
-        if self.use_img_loss:                                                    # :1860-1862
-            e_co, e_do = self.image_features(self.resize_small(images_ori)[0])
-            clip_ori, dino_ori = F.normalize(e_co, dim=-1), F.normalize(e_do, dim=-1)
-        if self.use_face_loss:                                                   # :1870
-            from .sfnet import face_features
-            ch_o, idx_o, _ = self.aligned_faces(images_ori, ind_o)
-            face_ori = torch.zeros((B, 512), dtype=F32, device=dev)
-            if len(idx_o):
-                face_ori[idx_o.long()] = F.normalize(face_features(self.face_net, ch_o)[0], dim=-1)
-        if not _NO_TAIL_REORDER:                 # the read-back of R2's logits comes after its feature encoders have been enqueued
-            ind_o, boxes_o, per_o = self.classify_dev(h_o) if dv else self.classify_end(h_o)
+        else:
+            h_o = self.classify_begin(images_ori)
+            if _NO_TAIL_REORDER:
+                ind_o, boxes_o, per_o = self.classify_dev(h_o) if dv else self.classify_end(h_o)
+            ind_o = h_o["ind"]
+            if self.use_img_loss:                                                    # :1860-1862
+                e_co, e_do = self.image_features(self.resize_small(images_ori)[0])
+                clip_ori, dino_ori = F.normalize(e_co, dim=-1), F.normalize(e_do, dim=-1)
+            if self.use_face_loss:                                                   # :1870
+                from .sfnet import face_features
+                ch_o, idx_o, _ = self.aligned_faces(images_ori, ind_o)
+                face_ori = torch.zeros((B, 512), dtype=F32, device=dev)
+                if len(idx_o):
+                    face_ori[idx_o.long()] = F.normalize(face_features(self.face_net, ch_o)[0], dim=-1)
+            if not _NO_TAIL_REORDER:                 # the read-back of R2's logits comes after its feature encoders have been enqueued
+                ind_o, boxes_o, per_o = self.classify_dev(h_o) if dv else self.classify_end(h_o)
         out.update(images_ori=images_ori)
         (rb if dv else out).update(preds_ori=per_o[0]["preds"], probs_ori=per_o[0]["probs"])
         tgt = self.finish_dynamic_targets()
@@ -914,6 +947,8 @@ class FairnessTrainer:
                 # launches which cannot fill the chip alone overlap with a neighbouring timestep's.  Shared cross-attention dK/dV: fp32 atomics.
                 cur = torch.cuda.current_stream()
                 self.unet.prepare_backward()         # lazily built weight copies exist before any side stream can read them
+                if not _ATOMIC_DKDV:
+                    self.unet.prepare_backward_slots(S)   # per-timestep dK / dV pairs of the shared cross-attention K / V: no atomics, fixed-order sum
                 nst = max(1, min(self.bwd_streams, S)) if self.concurrent_bwd else 1
                 sides = [self._side_stream(k) for k in range(1, nst)]
                 virtual = self.bwd_virtual
@@ -943,7 +978,9 @@ class FairnessTrainer:
                             self.unet.forward_step(x if _CFG_PAIR else x.repeat(2, 1, 1, 1), i, record=True, pair=_CFG_PAIR)
                         for bank in self.banks:
                             bank.accum = bank.grad_alt(k) if on_side else bank.grad
+                        unet_mod.BWD_SLOT[0] = i
                         self.unet.backward_step(gpair * step_scale[i], gscale)
+                unet_mod.BWD_SLOT[0] = None
                 for bank in self.banks:
                     bank.accum = bank.grad
                 if self.debug_partials is not None:

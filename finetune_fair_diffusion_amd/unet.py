@@ -23,6 +23,11 @@ from .layers import (F16, F32, Conv3x3, Linear, LoRAPair, Norm, ParamBank, Resne
 from .weights import UNetConfig, unet_attn_names, unet_lora_param_shapes, unet_param_shapes
 
 
+# Index of the timestep whose backward is being enqueued (host-side, set by the training step right before ``backward_step``): selects the
+# per-timestep dK / dV slot of every cross-attention layer (``prepare_backward_slots``).  None outside a slotted backward.
+BWD_SLOT = [None]
+
+
 class _Out:
     def __init__(self, sample):
         self.sample = sample
@@ -120,6 +125,10 @@ class TransformerBlock:
     def finish_cross_backward(self, gscale, need_denc):
         """Backward of prepare_cross from the accumulated (over steps and samples) dK/dV."""
         c, lo = self.cross, self.lora2
+        if c.get("slots") is not None:      # per-timestep slots (deterministic form): summed here in timestep order, plus whatever the atomics form added
+            c["dK"] += c["slots"][:, 0].sum(dim=0)
+            c["dV"] += c["slots"][:, 1].sum(dim=0)
+            c["slots"] = None
         dK, dV = ops.to_f16(c["dK"]), ops.to_f16(c["dV"])
         rp = lo.k.rp if lo is not None else 0
         te = c["te"]
@@ -199,8 +208,13 @@ class TransformerBlock:
         kv_div = B // cr["Bk"]
         # dK/dV of every sample and every timestep add into ONE fp32 accumulator pair with atomics (also at kv_div == 1: the timesteps'
         # backwards run on several HIP streams, step.py, and a plain read-modify-write of the shared buffer would lose updates)
-        dq2, _, _ = ops.attn_bwd(c["q2"], cr["K"], cr["V"], c["o2"], do2, c["lse2"], B, h, HW, cr["L"], d, kv_div, kt=cr["Kt"],
-                                 dk_acc=cr["dK"], dv_acc=cr["dV"])
+        slot = BWD_SLOT[0] if cr.get("slots") is not None else None
+        if slot is not None:     # this timestep's own fp32 dK / dV pair, written without atomics (bit-reproducible; ops.attn_bwd)
+            dq2, _, _ = ops.attn_bwd(c["q2"], cr["K"], cr["V"], c["o2"], do2, c["lse2"], B, h, HW, cr["L"], d, kv_div, kt=cr["Kt"],
+                                     dk_out=cr["slots"][slot, 0], dv_out=cr["slots"][slot, 1])
+        else:
+            dq2, _, _ = ops.attn_bwd(c["q2"], cr["K"], cr["V"], c["o2"], do2, c["lse2"], B, h, HW, cr["L"], d, kv_div, kt=cr["Kt"],
+                                     dk_acc=cr["dK"], dv_acc=cr["dV"])
         if pair:
             # the shared prefix received the gradient of both halves
             B = B // 2
@@ -383,6 +397,15 @@ class UNet2DConditionModel:
             if blk["up"] is not None:
                 blk["up"].wd, blk["up"].wd_up2p
         self._bwd_ready = True
+
+    def prepare_backward_slots(self, S):
+        """One fp32 (dK, dV) pair per timestep and cross-attention layer, zero-initialised on the CURRENT stream before the backward streams
+        fork: each timestep's backward writes only its own pair (no atomics), ``finish_prompt_backward`` sums them in timestep order.
+        2 x S x 154 x C floats per layer -- 250 MB over the 16 layers at S = 20."""
+        for t in self.transformers:
+            cr = t.cross
+            if cr is not None and "dK" in cr:
+                cr["slots"] = torch.zeros((S, 2) + tuple(cr["dK"].shape), dtype=F32, device=cr["dK"].device)
 
     def load_state_dict(self, sd, strict=False):
         """LoRA tensors by diffusers key (gen-images.py:520-521 calls exactly this with strict=False)."""

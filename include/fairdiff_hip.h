@@ -144,11 +144,15 @@ int fd_attn_bwd_dq(const void* q, const void* k, const void* v, const void* kt, 
 /* dk,dv from (q, qt, k, v, dO, dOt, lse, D).  qt == dOt == NULL (the shipped form): Q^T and dO^T come from the row-major q / dO tiles
  * through LDS transpose reads (no Tq % 8 restriction); else qt, dOt:[B,H*d,Tq] are transposed copies.  When kv_div>1 the kv batch is shared by
  * kv_div consecutive samples; dk/dv are then fp32 [Bk,Tk,H*d] accumulated with atomics, else fp16 (overwritten).
- * ``accumulate`` != 0 selects the fp32-atomic form at kv_div == 1 too: several launches -- timesteps of the truncated chain whose
- * backwards run on different HIP streams -- may then add into one accumulator concurrently. */
+ * ``accumulate`` == 1 selects the fp32-atomic form at kv_div == 1 too: several launches -- timesteps of the truncated chain whose
+ * backwards run on different HIP streams -- may then add into one accumulator concurrently.
+ * ``accumulate`` == 2 (round 4, what the training step uses): NO atomics -- dk / dv are fp32 [kv_div][Bk*Tkr][lddkv] and sample j of every
+ * K/V group WRITES slab j; fd_sum_slabs then adds the slabs in a fixed order: shared dK / dV are bit-reproducible. */
 int fd_attn_bwd_dkdv(const void* q, const void* qt, const void* k, const void* v, const void* d_o, const void* d_ot,
                      const float* lse, const float* D, void* dk, void* dv, int B, int H, int Tq, int Tk, int Tkr, int d,
                      int kv_div, float scale, int ldq, int ldkv, int lddkv, int accumulate, void* stream);
+/* out[i] = sum_{s < nslab} in[s*n + i], s ascending (fp32): the fixed-order reduction behind accumulate == 2 */
+int fd_sum_slabs(const float* in, float* out, int nslab, int64_t n, void* stream);
 
 /* ---- FP8 (OCP e4m3fn) self-attention forward: BASELINE configs[4] "bf16 + MFMA fp8 attention" (per-tile scaled QK^T / PV,
  * self-attention only).  Same reference op as fd_attn_fwd for the attn1 layers; the reference itself only ran fp16 (:401-405).

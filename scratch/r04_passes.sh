@@ -29,5 +29,39 @@ c)  # which change moved the exp-3 tiny-model gradient cosine (0.981 in round 2 
     (echo "## default"; $T; echo "## FD_HOST_SCALES=1"; FD_HOST_SCALES=1 $T; echo "## round-3 library"; FAIRDIFF_LIB=$P/libfairdiff_hip_slp_r03.so $T; echo "## round-3 library + host scales"; FD_HOST_SCALES=1 FAIRDIFF_LIB=$P/libfairdiff_hip_slp_r03.so $T) 2>&1 | grep -i "##\|cosine\|passed\|failed" > gpurun_out/r04c_exp3_cosine_ab.txt
     cat gpurun_out/r04c_exp3_cosine_ab.txt
     ;;
+d)  # device-resident tail (exp-1): suite subsets, then whole-step A/B host tail vs device tail, and the batch-16 / S=10 probe (same image-timesteps
+    # per step as the headline: does a 2x larger backward batch pay?)
+    timeout 1200 python -m pytest tests/test_engine_gpu.py tests/test_fullsize_gpu.py tests/test_two_rank_gpu.py -q -s > gpurun_out/r04d_tests.log 2>&1; grep -i 'cosine\|passed\|failed\|FAILED' gpurun_out/r04d_tests.log | tail -60
+    for i in 1 2; do
+      $B --steps 6 --warmup 2 > gpurun_out/r04d_bench_devtail_$i.json 2> gpurun_out/r04d_bench_devtail_$i.err
+      FD_HOST_TAIL=1 FD_HOST_SCALES=1 $B --steps 6 --warmup 2 > gpurun_out/r04d_bench_hosttail_$i.json 2> gpurun_out/r04d_bench_hosttail_$i.err
+    done
+    $B --steps 4 --warmup 2 --batch 16 --S 10 > gpurun_out/r04d_bench_b16_s10.json 2> gpurun_out/r04d_bench_b16_s10.err
+    (FAIRDIFF_LIB=$P/libfairdiff_hip_lnmr.so timeout 200 python scratch/repro_packed_fp32_hazard.py 1500; timeout 200 python scratch/repro_packed_fp32_hazard.py 1500) 2>&1 | grep -v amdgpu.ids > gpurun_out/r04d_repro_packed_fp32.txt; cat gpurun_out/r04d_repro_packed_fp32.txt
+    python - <<'PY'
+import json,glob
+for f in sorted(glob.glob('gpurun_out/r04d_bench_*.json')):
+    try:
+        d=json.loads(open(f).read().strip().splitlines()[-1]); print(f, round(d['value'],3), round(d['ms_per_step'],1), d['config']['phase_ms'], d['config']['host_ms_between_phase_marks'])
+    except Exception as e: print(f, 'ERR', e)
+PY
+    ;;
+e)  # 50-step soak at S = 50 (configs[3] rollout length), exp-4, all loss terms: allocator numbers per step
+    timeout 900 python scratch/soak_s50.py 50 2>&1 | grep -v amdgpu.ids > gpurun_out/r04e_soak_s50_exp4.txt; tail -4 gpurun_out/r04e_soak_s50_exp4.txt
+    ;;
+f)  # schedule knobs re-measured with the device-resident tail: R2-side forwards on the R2 stream vs the launch stream, prefetch depth, backward streams
+    for v in "" "FD_R2_SIDE_HOST_ORDER=1" "FD_R2_PREFETCH_STEPS=6" "FD_R2_PREFETCH_STEPS=10" "FD_R2_PREFETCH_STEPS=12" "FD_BWD_STREAMS=2" "FD_BWD_STREAMS=4" "" "FD_R2_SIDE_HOST_ORDER=1"; do
+      n=$(echo "$v" | tr '=' '_'); [ -z "$n" ] && n=default
+      env $v $B --steps 6 --warmup 2 > gpurun_out/r04f_${n}_$RANDOM.json 2>/dev/null
+    done
+    timeout 600 python -m pytest tests/test_two_rank_gpu.py -q -s -k eight > gpurun_out/r04f_eight_ranks.log 2>&1; grep -v "amdgpu.ids\|socket.cpp\|Gloo" gpurun_out/r04f_eight_ranks.log | tail -40
+    python - <<'PY'
+import json,glob
+for f in sorted(glob.glob('gpurun_out/r04f_*.json')):
+    try:
+        d=json.loads(open(f).read().strip().splitlines()[-1]); print(f, round(d['value'],3), round(d['ms_per_step'],1), d['config']['phase_ms'])
+    except Exception as e: print(f, 'ERR', e)
+PY
+    ;;
 *) echo "unknown pass $1";;
 esac

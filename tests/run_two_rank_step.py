@@ -57,4 +57,10 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    except BaseException:
+        import traceback
+        with open(os.path.join(sys.argv[2], f"rank{os.environ.get('RANK', '0')}.err"), "w") as f:     # the launcher's own traceback hides the child's
+            traceback.print_exc(file=f)
+        raise

@@ -351,6 +351,17 @@ def test_attention_fwd_bwd(ops, dev, B, H, Tq, Tk, d, kv_div, tr):
         assert torch.equal(dq, dq2), "transpose-read dQ differs"
         if kv_div == 1:            # the shared-K/V form adds with fp32 atomics: order-dependent low bits
             assert torch.equal(dk, dk2) and torch.equal(dv, dv2), "transpose-read dK / dV differ"
+    if Tq % 8 == 0 or tr:
+        # the deterministic form of shared dK / dV (round 4): per-sample fp32 slabs + fixed-order sum instead of atomics -- same values as the
+        # atomics form up to the order of kv_div fp32 additions, BIT-identical between two launches, also at kv_div == 1
+        outs = []
+        for _ in range(2):
+            dko, dvo = torch.full((Bk * Tk, C), 7.0, dtype=torch.float32, device=dev), torch.full((Bk * Tk, C), -3.0, dtype=torch.float32, device=dev)
+            dq3, _, _ = ops.attn_bwd(q2, k2, v2, o, do.reshape(B * Tq, C), lse, B, H, Tq, Tk, d, kv_div, dk_out=dko, dv_out=dvo, tr=tr)
+            outs.append((dq3, dko, dvo))
+        assert all(torch.equal(a, b) for a, b in zip(outs[0], outs[1])) and torch.equal(outs[0][0], dq)
+        check("attn dk (slabs)", outs[0][1].reshape(Bk, Tk, C), kr.grad, 5e-3)
+        check("attn dv (slabs)", outs[0][2].reshape(Bk, Tk, C), vr.grad, 5e-3)
 
 
 @pytest.mark.parametrize("B,H,T,d", [(2, 8, 1024, 40), (2, 8, 256, 80), (1, 4, 64, 160)])

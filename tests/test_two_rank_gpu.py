@@ -35,6 +35,10 @@ def _launch(experiment, out_dir, world=2, b_per_rank=None):
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     print(r.stdout[-3000:])
     print(r.stderr[-3000:])
+    for k in range(world):
+        ep = os.path.join(out_dir, f"rank{k}.err")
+        if os.path.exists(ep):
+            print(f"---- rank {k} traceback\n" + open(ep).read()[-2500:])
     assert r.returncode == 0, f"{world}-rank run failed"
     return [torch.load(os.path.join(out_dir, f"rank{k}.pt")) for k in range(world)]
 
