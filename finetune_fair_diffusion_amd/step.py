@@ -235,6 +235,9 @@ class FairnessTrainer:
         # this step's R2 has finished, i.e. underneath the VAE decode / classifier / loss / VAE backward tail, whose launches leave most of the
         # chip idle (host syncs, small kernels).  Same kernels on the same inputs: results are bit-identical with and without it.
         self.r2_prefetch_steps = int(os.environ.get("FD_R2_PREFETCH_STEPS", "8"))     # same-box A/B: 0 -> 1442-1448 ms, 6 -> 1431-1436, 8 -> 1429, 10 -> 1440
+        # ... and ``r2_prefetch_late`` more of them are enqueued behind the U-Net backward's last timestep: they run while the backward streams
+        # drain unevenly, through the optimiser step and under the first (host-paced) forward of the next step
+        self.r2_prefetch_late = int(os.environ.get("FD_R2_PREFETCH_LATE", "0"))
         self._r2_pre = None
         self._sch_r2 = None
         self.last_r2_prefetched = 0
@@ -1004,6 +1007,12 @@ class FairnessTrainer:
         else:
             self.vae._ctx = self.clf._ctx = None
         ctxs.clear()
+        if self._r2_pre is not None and self.r2_prefetch_late > 0:
+            k2 = max(0, min(self.r2_prefetch_late, self._r2_pre["S"] - self._r2_pre["k"]))
+            with torch.cuda.stream(self._side_stream("r2")):
+                for _ in range(k2):
+                    next(self._r2_pre["gen"], None)
+            self._r2_pre["k"] += k2
         for fn in deferred:
             fn()
         # ---- gradient sync, guard, update (:1998-2029)

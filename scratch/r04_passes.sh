@@ -63,5 +63,34 @@ for f in sorted(glob.glob('gpurun_out/r04f_*.json')):
     except Exception as e: print(f, 'ERR', e)
 PY
     ;;
+g)  # deterministic shared dK / dV (slabs + per-timestep slots): tests, then whole-step A/B against the atomics form; late R2 prefetch
+    timeout 1500 python -m pytest tests/test_kernels_gpu.py tests/test_engine_gpu.py tests/test_fullsize_gpu.py -q -x > gpurun_out/r04g_tests.log 2>&1; tail -6 gpurun_out/r04g_tests.log
+    for v in "" "FD_ATOMIC_DKDV=1" "FD_R2_PREFETCH_LATE=2" "FD_R2_PREFETCH_LATE=4" "" "FD_ATOMIC_DKDV=1" "FD_R2_PREFETCH_LATE=3"; do
+      n=$(echo "$v" | tr '=' '_'); [ -z "$n" ] && n=default
+      env $v $B --steps 6 --warmup 2 > gpurun_out/r04g_${n}_$RANDOM.json 2>/dev/null
+    done
+    python - <<'PY'
+import json,glob
+for f in sorted(glob.glob('gpurun_out/r04g_*.json')):
+    try:
+        d=json.loads(open(f).read().strip().splitlines()[-1]); print(f, round(d['value'],3), round(d['ms_per_step'],1), d['config']['phase_ms'])
+    except Exception as e: print(f, 'ERR', e)
+PY
+    ;;
+h)  # rocprofv3 kernel trace of the current tree (3-step bench) -> profiles/r04_bench_step_kernel_stats_*.csv
+    O=gpurun_out/r04h; mkdir -p $O; R=$PWD
+    cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/prof_r04h -o r04h -- python3 $R/bench.py --steps 2 --warmup 1 --no_cpu_baseline --no_roofline > $R/$O/bench_prof.json 2> $R/$O/bench_prof.err
+    cd $R
+    DB=$(find /tmp/prof_r04h -name "*.db" | head -1)
+    python scratch/profsum.py $DB $O/kernel_stats.csv 45 > $O/kernel_stats_top.txt
+    cut -c1-170 $O/kernel_stats_top.txt
+    ;;
+i)  # final validation: full GPU suite with durations, smoke, default bench line, 20-step bench line (runs the cfg1 CPU protocol itself)
+    timeout 2400 python -m pytest tests -m gpu -q --durations=12 > gpurun_out/r04i_gpu_suite.log 2>&1; tail -22 gpurun_out/r04i_gpu_suite.log
+    timeout 300 python __graft_entry__.py smoke > gpurun_out/r04i_smoke.log 2>&1; tail -1 gpurun_out/r04i_smoke.log
+    timeout 900 python bench.py > gpurun_out/r04i_bench_default.json 2> gpurun_out/r04i_bench_default.err; cut -c1-400 gpurun_out/r04i_bench_default.json
+    ;;
+j)  timeout 2400 python bench.py --steps 20 --warmup 5 > gpurun_out/r04j_bench_20_steps.json 2> gpurun_out/r04j_bench_20_steps.err; cut -c1-600 gpurun_out/r04j_bench_20_steps.json
+    ;;
 *) echo "unknown pass $1";;
 esac
