@@ -14,6 +14,9 @@
 #include "common.h"
 
 #define LOG2E 1.4426950408889634f
+#ifndef FD_ATTN_LAZY
+#define FD_ATTN_LAZY 8.0f      // 0 = move the softmax reference point with every new maximum (rounds 1-3)
+#endif
 
 __device__ __forceinline__ f32x16 mfma32(f16x8 a, f16x8 b, f32x16 c) { return FD_MFMA_32x32x16(a, b, c); }
 __device__ __forceinline__ f32x16 zero16() {
@@ -186,38 +189,55 @@ constexpr int dkdv_waves(int D, bool QTR = false) { return D <= 64 ? 2 : 1; }
 
 // ================================================================================== forward
 // VTR: ``Vt`` points at V itself ([Bk, Tkr, .] rows of stride ldk, like K) and the PV operand comes from a row-major tile through read_tr
-template <int D, bool VTR>
-__global__ __launch_bounds__(256, fwd_waves(D)) void attn_fwd_kernel(const f16* __restrict__ Q, const f16* __restrict__ K, const f16* __restrict__ Vt,
+// QB: 32-query column blocks per wave.  QB = 1: 4 waves x 32 queries per workgroup (rounds 1-3).  QB = 2 (round 4): a wave owns 64 consecutive
+// queries, so every K / V fragment it reads from LDS feeds two MFMAs and the staged K / V tile serves 256 queries instead of 128 -- both the
+// fragment traffic and the staging per query halve (the forward was co-limited by exactly those: MFMAs + fragment reads alone 410 of 646 us,
+// staging + barriers ~190, profiles/r02_attn_fwd_d40_ablation.txt), at two waves per SIMD instead of three.
+template <int D, bool VTR, int QB>
+__global__ __launch_bounds__(256, QB == 1 ? fwd_waves(D) : (D <= 64 ? 2 : 1)) void attn_fwd_kernel(const f16* __restrict__ Q, const f16* __restrict__ K, const f16* __restrict__ Vt,
                                                        f16* __restrict__ O, float* __restrict__ LSE, int H, int Tq, int Tk, int Tkp,
                                                        int Tkr, int kv_div, float scale, int ldq, int ldk) {
     constexpr int DK = (D + 15) / 16 * 16, DV = (D + 31) / 32 * 32, DKP = DK + 8;
     constexpr int NKS = DK / 16, NDV = DV / 32;
+    constexpr int RB = 128 * QB;                // query rows per workgroup
     extern __shared__ __attribute__((aligned(16))) f16 smem[];
     constexpr int VP = tr_stride(DV);
     f16* Ks = smem;               // [64][DKP]
     f16* Vts = smem + 64 * DKP;   // [DV][TS]   (VTR: [64][VP], keys x d)
 
     int b, h, qblk;
-    attn_block_coords((Tq + 127) / 128, H, gridDim.x / (((Tq + 127) / 128) * H), b, h, qblk);
-    const int q0 = qblk * 128;
+    attn_block_coords((Tq + RB - 1) / RB, H, gridDim.x / (((Tq + RB - 1) / RB) * H), b, h, qblk);
+    const int q0 = qblk * RB;
     const int bk = b / kv_div;
     const int C = H * D;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int ql = lane & 31, g = lane >> 5;
-    const int t = q0 + wave * 32 + ql;
-    const bool tvalid = t < Tq;
-
-    f16x8 qf[NKS];
+    int t[QB];
+    bool tvalid[QB];
 #pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) {
-        const int col = ks * 16 + g * 8;
-        qf[ks] = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
-        if (tvalid && col < D) qf[ks] = *(const f16x8*)(Q + ((int64_t)b * Tq + t) * ldq + h * D + col);
+    for (int qb = 0; qb < QB; ++qb) {
+        t[qb] = q0 + (wave * QB + qb) * 32 + ql;
+        tvalid[qb] = t[qb] < Tq;
     }
-    f32x16 oacc[NDV];
+
+    f16x8 qf[QB][NKS];
 #pragma unroll
-    for (int i = 0; i < NDV; ++i) oacc[i] = zero16();
-    float m_run = -INFINITY, l_run = 0.f;
+    for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            const int col = ks * 16 + g * 8;
+            qf[qb][ks] = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
+            if (tvalid[qb] && col < D) qf[qb][ks] = *(const f16x8*)(Q + ((int64_t)b * Tq + t[qb]) * ldq + h * D + col);
+        }
+    f32x16 oacc[QB][NDV];
+    float m_run[QB], l_run[QB];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+#pragma unroll
+        for (int i = 0; i < NDV; ++i) oacc[qb][i] = zero16();
+        m_run[qb] = -INFINITY;
+        l_run[qb] = 0.f;
+    }
     const float sl2 = scale * LOG2E;
 
     const f16* Kb = K + (int64_t)bk * Tkr * ldk + h * D;
@@ -256,14 +276,16 @@ __global__ __launch_bounds__(256, fwd_waves(D)) void attn_fwd_kernel(const f16* 
         if (VTR) store_rows<D, VP>(vreg, Vts);
         else store_cols<D>(vreg, Vts);
         __syncthreads();
-        f32x16 s[2];
+        f32x16 s[QB][2];
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
-            s[kt] = zero16();
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) s[qb][kt] = zero16();
 #pragma unroll
             for (int ks = 0; ks < NKS; ++ks) {
                 const f16x8 kf = *(const f16x8*)(Ks + (kt * 32 + ql) * DKP + ks * 16 + g * 8);
-                s[kt] = mfma32(kf, qf[ks], s[kt]);
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb) s[qb][kt] = mfma32(kf, qf[qb][ks], s[qb][kt]);
             }
         }
         // next tile's loads are issued behind the QK^T MFMAs and fly under the softmax and the PV MFMAs (issued in front of them the
@@ -281,69 +303,82 @@ __global__ __launch_bounds__(256, fwd_waves(D)) void attn_fwd_kernel(const f16* 
         if (k0 + 64 > Tk) {
             asm volatile("" ::: "memory");   // keeps this a real (wave-uniform) branch: if-converted it costs ~90 VALU on every tile
 #pragma unroll
+            for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (k0 + kt * 32 + crow(r, g) >= Tk) s[qb][kt][r] = -INFINITY;
+        }
+        f16x8 pf[QB][4];
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+            float mx = -INFINITY;
+#pragma unroll
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    if (k0 + kt * 32 + crow(r, g) >= Tk) s[kt][r] = -INFINITY;
-        }
-        float mx = -INFINITY;
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[qb][kt][r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            // Lazy reference point (round 4): the running "max" only moves when a tile's maximum exceeds it by more than 2^LAZY in the
+            // probability domain, so p <= 2^LAZY (exact in fp16, fp32 row sums) and after the first tiles the 32 v_mul of the O rescale
+            // and its wave-wide vote almost never execute.  O / l and LSE = m + log l do not depend on the reference point.
+            constexpr float LAZY = FD_ATTN_LAZY;
+            const float m_new = (mx - m_run[qb]) * sl2 > LAZY ? mx : m_run[qb];          // reference point of the RAW scores (-inf at the start: first tile always moves it)
+            const float alpha = __builtin_amdgcn_exp2f((m_run[qb] - m_new) * sl2);
+            const float nm = -m_new * sl2;
+            float rs = 0.f;
 #pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
+            for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kt][r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run, mx);          // running max of the RAW scores
-        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * sl2);
-        const float nm = -m_new * sl2;
-        float rs = 0.f;
-        f16x8 pf[4];
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float p = __builtin_amdgcn_exp2f(fmaf(s[kt][r], sl2, nm));
-                if (!ONES) rs += p;
-                pf[kt * 2 + (r >> 3)][r & 7] = (f16)p;
+                for (int r = 0; r < 16; ++r) {
+                    const float p = __builtin_amdgcn_exp2f(fmaf(s[qb][kt][r], sl2, nm));
+                    if (!ONES) rs += p;
+                    pf[qb][kt * 2 + (r >> 3)][r & 7] = (f16)p;
+                }
+            if (!ONES) {
+                rs += __shfl_xor(rs, 32, 64);
+                l_run[qb] = l_run[qb] * alpha + rs;
             }
-        if (!ONES) {
-            rs += __shfl_xor(rs, 32, 64);
-            l_run = l_run * alpha + rs;
-        }
-        if (__any(m_new != m_run)) {                   // rescale O only when some row's max moved
+            if (__any(m_new != m_run[qb])) {                   // rescale O only when some row's max moved
 #pragma unroll
-            for (int i = 0; i < NDV; ++i)
+                for (int i = 0; i < NDV; ++i)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
+                    for (int r = 0; r < 16; ++r) oacc[qb][i][r] *= alpha;
+            }
+            m_run[qb] = m_new;
         }
-        m_run = m_new;
 #pragma unroll
         for (int st = 0; st < 4; ++st)
 #pragma unroll
             for (int i = 0; i < NDV; ++i) {
                 const f16x8 vf = VTR ? read_tr(Vts, VP, st * 16, i * 32, ql, g) : read_perm(Vts, i * 32 + ql, st * 16, g);
-                oacc[i] = mfma32(vf, pf[st], oacc[i]);
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb) oacc[qb][i] = mfma32(vf, pf[qb][st], oacc[qb][i]);
             }
     }
-    if (ONES) {                                        // row D of O^T: lane-half GL, register RL of tile D / 32 (crow), for this lane's query column
-        constexpr int LOC = D % 32, GL = (LOC >> 2) & 1, RL = (LOC & 3) + 4 * (LOC >> 3);
-        l_run = __shfl(oacc[D / 32][RL], ql + 32 * GL, 64);
-    }
-    if (tvalid) {
-        const float inv = 1.f / l_run;
-        f16* Op = O + ((int64_t)b * Tq + t) * C + h * D;
 #pragma unroll
-        for (int i = 0; i < NDV; ++i)
+    for (int qb = 0; qb < QB; ++qb) {
+        if (ONES) {                                    // row D of O^T: lane-half GL, register RL of tile D / 32 (crow), for this lane's query column
+            constexpr int LOC = D % 32, GL = (LOC >> 2) & 1, RL = (LOC & 3) + 4 * (LOC >> 3);
+            l_run[qb] = __shfl(oacc[qb][D / 32][RL], ql + 32 * GL, 64);
+        }
+        if (tvalid[qb]) {
+            const float inv = 1.f / l_run[qb];
+            f16* Op = O + ((int64_t)b * Tq + t[qb]) * C + h * D;
 #pragma unroll
-            for (int rq = 0; rq < 4; ++rq) {
-                const int dv = i * 32 + 8 * rq + 4 * g;
-                if (dv < D) {
-                    f16x4 o;
+            for (int i = 0; i < NDV; ++i)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) o[j] = (f16)(oacc[i][rq * 4 + j] * inv);
-                    *(f16x4*)(Op + dv) = o;
+                for (int rq = 0; rq < 4; ++rq) {
+                    const int dv = i * 32 + 8 * rq + 4 * g;
+                    if (dv < D) {
+                        f16x4 o;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) o[j] = (f16)(oacc[qb][i][rq * 4 + j] * inv);
+                        *(f16x4*)(Op + dv) = o;
+                    }
                 }
-            }
-        if (LSE && g == 0) LSE[((int64_t)b * H + h) * Tq + t] = m_run * scale + log2f(l_run) / LOG2E;
+            if (LSE && g == 0) LSE[((int64_t)b * H + h) * Tq + t[qb]] = m_run[qb] * scale + log2f(l_run[qb]) / LOG2E;
+        }
     }
 }
 
@@ -712,6 +747,24 @@ __global__ __launch_bounds__(256, dkdv_waves(D, QTR)) void attn_bwd_dkdv_kernel(
 }
 
 // ================================================================================== host side
+// Query blocks per wave of the forward (1 or 2).  FD_ATTN_FWD_QB (bench-hooks build only) forces a value for A/B.
+#ifdef FD_BENCH_HOOKS
+#include <stdlib.h>
+static inline const char* bench_env_attn(const char* n) { return getenv(n); }
+#else
+static inline const char* bench_env_attn(const char*) { return nullptr; }
+#endif
+#ifndef FD_ATTN_FWD_QB2
+#define FD_ATTN_FWD_QB2 1        // shipped policy: two query blocks per wave for long sequences of the small head dims (0: always one)
+#endif
+static int fwd_qb(int d, int Tq, int Tk, int BH) {
+    // measured, B16 H8 T4096 d40 (profiles/r04_attention_fwd_lazy_qb_ab.txt): 660 us (one block, eager reference point) -> 632 (lazy) -> 593 (lazy, two blocks);
+    // T = 1024 / d = 80 and the 77-key cross attention do not gain (kept at one block)
+    int qb = (FD_ATTN_FWD_QB2 && d <= 64 && Tq >= 2048 && Tk >= 2048 && (long)BH * ((Tq + 255) / 256) >= 128) ? 2 : 1;
+    static const char* e = bench_env_attn("FD_ATTN_FWD_QB");
+    if (e) qb = atoi(e) == 2 && d <= 64 ? 2 : 1;
+    return qb;
+}
 
 template <int D, bool TR> static constexpr size_t fwd_lds() {
     constexpr int DKP = (D + 15) / 16 * 16 + 8, DV = (D + 31) / 32 * 32;
@@ -755,19 +808,24 @@ extern "C" int fd_attn_fwd(const void* q, const void* k, const void* vt, void* o
     FD_REQUIRE((ldq & 7) == 0 && (ldk & 7) == 0, "fd_attn_fwd: row strides must be multiples of 8");
     const bool vtr = Tkp == 0;        // vt is V itself: rows of stride ldk, like k
     FD_REQUIRE(B > 0 && H > 0 && Tq > 0 && Tk > 0 && (vtr || (Tkp >= Tk && (Tkp & 7) == 0)) && Tkr >= Tk && kv_div >= 1, "fd_attn_fwd: bad shape");
-    dim3 grid(((Tq + 127) / 128) * H * B);
-#define CALL(DD)                                                                                                                      \
-    if (vtr) {                                                                                                                        \
-        ALLOW_LDS((attn_fwd_kernel<DD, true>), (fwd_lds<DD, true>()));                                                                \
-        hipLaunchKernelGGL((attn_fwd_kernel<DD, true>), grid, dim3(256), (fwd_lds<DD, true>()), (hipStream_t)stream, (const f16*)q,  \
-                           (const f16*)k, (const f16*)vt, (f16*)o, lse, H, Tq, Tk, Tkp, Tkr, kv_div, scale, ldq, ldk);                \
-    } else {                                                                                                                          \
-        ALLOW_LDS((attn_fwd_kernel<DD, false>), (fwd_lds<DD, false>()));                                                              \
-        hipLaunchKernelGGL((attn_fwd_kernel<DD, false>), grid, dim3(256), (fwd_lds<DD, false>()), (hipStream_t)stream, (const f16*)q, \
-                           (const f16*)k, (const f16*)vt, (f16*)o, lse, H, Tq, Tk, Tkp, Tkr, kv_div, scale, ldq, ldk);                \
+    // 64 queries per wave (QB = 2) for the long self-attention sequences of the small head dims: halves the LDS fragment traffic and the K / V
+    // staging per query (see attn_fwd_kernel).  Short sequences keep QB = 1 (more workgroups, three waves per SIMD).
+    const int qb = vtr ? fwd_qb(d, Tq, Tk, B * H) : 1;       // the transposed-copy form (measurement only) stays at one block
+    dim3 grid(((Tq + 128 * qb - 1) / (128 * qb)) * H * B);
+#define LAUNCH_F(DD, TRV, QBV)                                                                                                         \
+    {                                                                                                                                  \
+        ALLOW_LDS((attn_fwd_kernel<DD, TRV, QBV>), (fwd_lds<DD, TRV>()));                                                              \
+        hipLaunchKernelGGL((attn_fwd_kernel<DD, TRV, QBV>), grid, dim3(256), (fwd_lds<DD, TRV>()), (hipStream_t)stream, (const f16*)q, \
+                           (const f16*)k, (const f16*)vt, (f16*)o, lse, H, Tq, Tk, Tkp, Tkr, kv_div, scale, ldq, ldk);                 \
     }
+#define CALL(DD)                                                                 \
+    if (vtr) {                                                                   \
+        if (qb == 2 && DD <= 64) LAUNCH_F(DD, true, (DD <= 64 ? 2 : 1))          \
+        else LAUNCH_F(DD, true, 1)                                               \
+    } else LAUNCH_F(DD, false, 1)
     FD_DISPATCH_D(d, CALL)
 #undef CALL
+#undef LAUNCH_F
     return fd_check_launch("fd_attn_fwd");
 }
 

@@ -92,5 +92,38 @@ i)  # final validation: full GPU suite with durations, smoke, default bench line
     ;;
 j)  timeout 2400 python bench.py --steps 20 --warmup 5 > gpurun_out/r04j_bench_20_steps.json 2> gpurun_out/r04j_bench_20_steps.err; cut -c1-600 gpurun_out/r04j_bench_20_steps.json
     ;;
+k)  # forward attention with 64 queries per wave (QB = 2): correctness under the kernel tests, isolated A/B, whole-step A/B (bench-hooks library, FD_ATTN_FWD_QB)
+    L=$P/libfairdiff_hip_bench.so
+    FAIRDIFF_LIB=$L FD_ATTN_FWD_QB=2 timeout 600 python -m pytest tests/test_kernels_gpu.py -q -x -k "attention" > gpurun_out/r04k_attn_tests_qb2.log 2>&1; tail -3 gpurun_out/r04k_attn_tests_qb2.log
+    (echo "## QB=1"; FAIRDIFF_LIB=$L FD_ATTN_FWD_QB=1 python scratch/mb_attn_tr.py; echo "## QB=2"; FAIRDIFF_LIB=$L FD_ATTN_FWD_QB=2 python scratch/mb_attn_tr.py) 2>&1 | grep -v amdgpu.ids > gpurun_out/r04k_attn_fwd_qb_isolated.txt; cat gpurun_out/r04k_attn_fwd_qb_isolated.txt
+    for i in 1 2; do
+      FAIRDIFF_LIB=$L FD_ATTN_FWD_QB=1 $B --steps 6 --warmup 2 > gpurun_out/r04k_step_qb1_$i.json 2>/dev/null
+      FAIRDIFF_LIB=$L FD_ATTN_FWD_QB=2 $B --steps 6 --warmup 2 > gpurun_out/r04k_step_qb2_$i.json 2>/dev/null
+    done
+    python - <<'PY'
+import json,glob
+for f in sorted(glob.glob('gpurun_out/r04k_step_*.json')):
+    try:
+        d=json.loads(open(f).read().strip().splitlines()[-1]); print(f, round(d['value'],3), round(d['ms_per_step'],1), d['config']['phase_ms'])
+    except Exception as e: print(f, 'ERR', e)
+PY
+    ;;
+l)  # attention forward: lazy softmax reference point (default) vs moving it with every maximum (-DFD_ATTN_LAZY=0), each at QB = 1 / 2; parity first
+    L=$P/libfairdiff_hip_bench.so; N=$P/libfairdiff_hip_bench_nolazy.so
+    for q in 1 2; do FAIRDIFF_LIB=$L FD_ATTN_FWD_QB=$q timeout 600 python -m pytest tests/test_kernels_gpu.py -q -x -k "attention" 2>&1 | tail -1; done
+    (for lib in $N $L; do for q in 1 2; do echo "## $(basename $lib) QB=$q"; FAIRDIFF_LIB=$lib FD_ATTN_FWD_QB=$q python scratch/mb_attn_tr.py 2>&1 | grep -v amdgpu.ids | head -4; done; done) > gpurun_out/r04l_attn_fwd_lazy_qb_isolated.txt; cat gpurun_out/r04l_attn_fwd_lazy_qb_isolated.txt
+    for i in 1 2; do
+      FAIRDIFF_LIB=$N FD_ATTN_FWD_QB=1 $B --steps 6 --warmup 2 > gpurun_out/r04l_step_nolazy_qb1_$i.json 2>/dev/null
+      FAIRDIFF_LIB=$L FD_ATTN_FWD_QB=1 $B --steps 6 --warmup 2 > gpurun_out/r04l_step_lazy_qb1_$i.json 2>/dev/null
+      FAIRDIFF_LIB=$L FD_ATTN_FWD_QB=2 $B --steps 6 --warmup 2 > gpurun_out/r04l_step_lazy_qb2_$i.json 2>/dev/null
+    done
+    python - <<'PY'
+import json,glob
+for f in sorted(glob.glob('gpurun_out/r04l_step_*.json')):
+    try:
+        d=json.loads(open(f).read().strip().splitlines()[-1]); print(f, round(d['value'],3), round(d['ms_per_step'],1), d['config']['phase_ms'])
+    except Exception as e: print(f, 'ERR', e)
+PY
+    ;;
 *) echo "unknown pass $1";;
 esac
