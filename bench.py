@@ -273,7 +273,7 @@ def cpu_model():
 T_START = time.perf_counter()
 # wall-clock budget of the whole bench.py process (the driver's limit is 1800 s): the cfg1 CPU protocol drops from median-of-3 to fewer timed
 # steps (and says so) when its warm-up step shows that three would not fit
-BUDGET_S = float(os.environ.get("FD_BENCH_BUDGET_S", "1500"))
+BUDGET_S = float(os.environ.get("FD_BENCH_BUDGET_S", "1200"))
 
 
 def cpu_baseline(S, full=False, t_start=None):
