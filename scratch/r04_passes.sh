@@ -125,5 +125,13 @@ for f in sorted(glob.glob('gpurun_out/r04l_step_*.json')):
     except Exception as e: print(f, 'ERR', e)
 PY
     ;;
+m)  # the hazard, one level deeper: the SLP-vectorised norm.hip (packed fp32; everything else as shipped) under the pair detector -- as built,
+    # with every s_waitcnt forced to zero, and with an s_nop 2 in front of every instruction; then 20 delay-injected runs of the shipped library
+    for v in slp slp_wc0 slp_snop; do
+      echo "## libfairdiff_hip_norm_$v.so"; FAIRDIFF_LIB=$P/libfairdiff_hip_norm_$v.so timeout 300 python scratch/diag_hazard3.py 8 2>&1 | grep -v amdgpu.ids | grep "pairs\|differing elements\|rows mod"
+    done > gpurun_out/r04m_hazard_waitcnt_snop.txt; cat gpurun_out/r04m_hazard_waitcnt_snop.txt
+    timeout 400 python scratch/diag_hazard.py delayx20 > gpurun_out/r04m_delay_x20_full.txt 2>&1
+    (echo "delay-injected runs, per-stream buffers compared bitwise with the one-stream order: lines = 20 runs x 3 buffers"; echo "bit-identical buffers: $(grep '^\[delay' gpurun_out/r04m_delay_x20_full.txt | grep -c " 0 'rest' tensors differ (max rel 0.00e+00), 0 kv")"; echo "buffers with any difference: $(grep '^\[delay' gpurun_out/r04m_delay_x20_full.txt | grep -vc " 0 'rest' tensors differ (max rel 0.00e+00), 0 kv")") > gpurun_out/r04m_delay_x20_shipped.txt; cat gpurun_out/r04m_delay_x20_shipped.txt
+    ;;
 *) echo "unknown pass $1";;
 esac
