@@ -96,6 +96,10 @@ def load():
     built = lib.fd_working_dtype().decode()
     if built != WORKING_DTYPE:
         raise RuntimeError(f"{LIB_PATH} was built for {built} but this process runs with FD_DTYPE={WORKING_DTYPE}")
+    info = lib.fd_build_info().decode()
+    if "packed_fp32=off" not in info and os.environ.get("FD_ALLOW_PACKED_FP32") is None:
+        raise RuntimeError(f"{LIB_PATH} was built with packed-fp32 VALU code ({info}): on gfx950 such kernels returned wrong lanes whenever kernels of several "
+                           "streams shared a SIMD (DESIGN.md, round 4).  Rebuild with csrc/Makefile's flags (FD_ALLOW_PACKED_FP32=1 loads it anyway, for measurement).")
     return lib
 
 

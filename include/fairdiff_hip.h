@@ -45,6 +45,9 @@ int fd_version(void);
 /* "fp16" (libfairdiff_hip.so: the reference's mixed_precision fp16, configs 1-4) or "bf16" (libfairdiff_hip_bf16.so, built from the same
  * sources with -DFD_BF16: BASELINE configs[4]).  Every "fp16" in the prototypes below means this 16-bit working dtype. */
 const char* fd_working_dtype(void);
+/* "packed_fp32=off" when every translation unit was compiled without packed-fp32 VALU code (-fno-slp-vectorize, -packed-fp32-ops): the
+ * loader refuses a library built otherwise -- such sequences returned wrong lanes under multi-stream SIMD sharing on gfx950. */
+const char* fd_build_info(void);
 
 /* ---- MFMA GEMM  C[M,N] = act(alpha * (A[M,K] . B[N,K]^T + A2[M,K2] . B2[N,K2]^T) + bias + rowbias) + residual
  * Replaces torch.nn.Linear / 1x1 Conv2d inside diffusers Attention/FeedForward/Transformer2DModel/
