@@ -133,5 +133,18 @@ m)  # the hazard, one level deeper: the SLP-vectorised norm.hip (packed fp32; ev
     timeout 400 python scratch/diag_hazard.py delayx20 > gpurun_out/r04m_delay_x20_full.txt 2>&1
     (echo "delay-injected runs, per-stream buffers compared bitwise with the one-stream order: lines = 20 runs x 3 buffers"; echo "bit-identical buffers: $(grep '^\[delay' gpurun_out/r04m_delay_x20_full.txt | grep -c " 0 'rest' tensors differ (max rel 0.00e+00), 0 kv")"; echo "buffers with any difference: $(grep '^\[delay' gpurun_out/r04m_delay_x20_full.txt | grep -vc " 0 'rest' tensors differ (max rel 0.00e+00), 0 kv")") > gpurun_out/r04m_delay_x20_shipped.txt; cat gpurun_out/r04m_delay_x20_shipped.txt
     ;;
+n)  # ViT-sized GEMMs of the tail (M = 2112 rows, N = 1280: 68 tiles of 128x320 -- below the 80-tile threshold, so they run on 64x64 tiles): lower the threshold
+    L=$P/libfairdiff_hip_bench.so
+    for i in 1 2; do
+      for t in 80 64 48; do FAIRDIFF_LIB=$L FD_GEMM_T128=$t $B --steps 6 --warmup 2 > gpurun_out/r04n_t128_${t}_$i.json 2>/dev/null; done
+    done
+    python - <<'PY'
+import json,glob
+for f in sorted(glob.glob('gpurun_out/r04n_*.json')):
+    try:
+        d=json.loads(open(f).read().strip().splitlines()[-1]); print(f, round(d['value'],3), round(d['ms_per_step'],1), d['config']['phase_ms'])
+    except Exception as e: print(f, 'ERR', e)
+PY
+    ;;
 *) echo "unknown pass $1";;
 esac
