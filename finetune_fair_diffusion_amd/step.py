@@ -238,6 +238,8 @@ class FairnessTrainer:
         # ... and ``r2_prefetch_late`` more of them are enqueued behind the U-Net backward's last timestep: they run while the backward streams
         # drain unevenly, through the optimiser step and under the first (host-paced) forward of the next step
         self.r2_prefetch_late = int(os.environ.get("FD_R2_PREFETCH_LATE", "0"))
+        # the frozen model's forward (R2: a third of the step's U-Net passes) replayed as a hipGraph (FD_R2_GRAPH=1; measurement in DESIGN section 4 "round 4")
+        self.r2_graph = os.environ.get("FD_R2_GRAPH") is not None
         self._r2_pre = None
         self._sch_r2 = None
         self.last_r2_prefetched = 0
@@ -307,6 +309,10 @@ class FairnessTrainer:
         With ``keep_activations`` the per-step backward contexts are kept for as many timesteps as fit in HBM
         (288 GB holds the whole 20-step chain at batch 8); the remaining steps are recomputed in the backward."""
         sch = self.sch if sch is None else sch       # a prefetched R2 rollout of the NEXT step brings its own scheduler object (S may differ)
+        graphed = None
+        if (self.r2_graph and unet is self.eval_unet and unet is not self.unet and unet.lora_bank is None and _CFG_PAIR
+                and not keep_inputs and not keep_activations and not record_prompt and torch.cuda.current_stream() != torch.cuda.default_stream()):
+            graphed = getattr(unet, "graphed", None) or unet_mod.GraphedForward(unet)
         sch.set_timesteps(S)
         unet.prepare_timesteps(sch.timesteps)
         unet.prepare_prompt(enc, record=record_prompt)
@@ -319,6 +325,11 @@ class FairnessTrainer:
             if keep_inputs:
                 inputs.append(lat.clone())
             rec = keep_activations and (i == 0 or budget > 0)
+            if graphed is not None:        # the frozen model's non-recording forward as ONE hipGraph launch (unet.GraphedForward)
+                eps = graphed(lat, i, _CFG_PAIR)
+                sch.cfg_step(i, eps, gs, lat, state)
+                yield i
+                continue
             x = ops.to_f16(lat)
             eps = unet.forward_step(x if _CFG_PAIR else x.repeat(2, 1, 1, 1), i, record=rec, pair=_CFG_PAIR)   # cat([latents] * 2) (:1043)
             if rec:

@@ -146,5 +146,20 @@ for f in sorted(glob.glob('gpurun_out/r04n_*.json')):
     except Exception as e: print(f, 'ERR', e)
 PY
     ;;
+o)  # hipGraph replay of the frozen model's forward: bit-identity, then whole-step A/B
+    timeout 600 python scratch/check_r2_graph.py 2>&1 | grep -v amdgpu.ids > gpurun_out/r04o_r2_graph_check.txt; cat gpurun_out/r04o_r2_graph_check.txt | tail -12
+    for i in 1 2; do
+      $B --steps 6 --warmup 3 > gpurun_out/r04o_step_eager_$i.json 2>/dev/null
+      FD_R2_GRAPH=1 $B --steps 6 --warmup 3 > gpurun_out/r04o_step_graph_$i.json 2> gpurun_out/r04o_step_graph_$i.err
+    done
+    python - <<'PY'
+import json,glob
+for f in sorted(glob.glob('gpurun_out/r04o_step_*.json')):
+    try:
+        d=json.loads(open(f).read().strip().splitlines()[-1]); print(f, round(d['value'],3), round(d['ms_per_step'],1), d['config']['phase_ms'], d['config']['host_ms_between_phase_marks'])
+    except Exception as e: print(f, 'ERR', e)
+PY
+    tail -3 gpurun_out/r04o_step_graph_1.err
+    ;;
 *) echo "unknown pass $1";;
 esac

@@ -1131,8 +1131,8 @@ def test_r2_prefetch_under_the_tail_is_bit_identical(dev):
     first denoising steps are enqueued underneath step n's tail (step.py ``r2_prefetch_steps``).  Same kernels on the same inputs: three
     consecutive steps (different numbers of denoising steps, so the prefetch's own scheduler object is exercised) must give bit-identical
     R1 / R2 images, probabilities, targets and losses with and without it; a prefetch for inputs that then do not arrive is dropped harmlessly.
-    (The optimiser update is captured instead of applied: gradients are reproducible to rounding only -- the fp32 atomics behind attn2.to_k /
-    to_v -- and AdamW would turn that into parameter noise that has nothing to do with the prefetch.)"""
+    The same holds when the frozen model's forward is replayed as a hipGraph (``r2_graph``; one capture serves every step and both S).
+    (The optimiser update is captured instead of applied so that the three steps of every mode start from the same parameters.)"""
     from finetune_fair_diffusion_amd.step import FairnessTrainer
     sds = U.synthetic_sds(train_unet=True, train_te=True, lora_up_std=0.05)
     tokens = U.tiny_tokens()
@@ -1140,29 +1140,32 @@ def test_r2_prefetch_under_the_tail_is_bit_identical(dev):
     noises = [torch.randn(4, 4, 32, 32, generator=g) for _ in range(5)]
     Ss = [4, 3, 4, 4]
     runs = {}
-    for mode in ("plain", "prefetch"):
+    for mode in ("plain", "prefetch", "graph"):      # "graph": prefetch + the frozen model's forward replayed as a hipGraph (unet.GraphedForward)
         pm = U.product_models(sds, dev, train_unet=True, train_te=True)
         args = U.make_args(train_unet=True, train_text_encoder=True, uncertainty_threshold=0.7)
         tr = FairnessTrainer(args, pm["text_encoder"], pm["unet"], pm["vae"], pm["classifier"], pm["scheduler"], eval_text_encoder=pm["eval_text_encoder"],
                              eval_unet=pm["eval_unet"], device=dev)
         tr.r2_prefetch_steps = 2
+        tr.r2_graph = mode == "graph"
         grads = []
         tr.sync_and_update = lambda nb, apply=True: (grads.append([b.grad.clone() for b in tr.banks]), True)[1]
         outs, pre = [], []
         for i in range(3):
-            nxt = dict(tokens_ori=tokens, noises=noises[i + 1], S=Ss[i + 1]) if mode == "prefetch" else None
-            if mode == "prefetch" and i == 1:
+            nxt = dict(tokens_ori=tokens, noises=noises[i + 1], S=Ss[i + 1]) if mode != "plain" else None
+            if mode != "plain" and i == 1:
                 nxt = dict(tokens_ori=tokens, noises=noises[4], S=Ss[2])       # announces inputs that will NOT arrive: must be dropped at step 2
             o = tr.train_step(tokens, noises[i], Ss[i], next_step=nxt)
             pre.append(tr.last_r2_prefetched)
             outs.append((o["images"].clone(), o["images_ori"].clone(), o["loss_fair"].clone(), o["probs"].clone(), o["targets"].clone()))
         runs[mode] = (outs, pre, grads)
-    assert runs["plain"][1] == [0, 0, 0] and runs["prefetch"][1] == [0, 2, 0], runs["prefetch"][1]
-    for i, (a, b) in enumerate(zip(runs["plain"][0], runs["prefetch"][0])):
-        assert all(torch.equal(x, y) for x, y in zip(a, b)), f"step {i}"
-    for ga, gb in zip(runs["plain"][2], runs["prefetch"][2]):
-        for x, y in zip(ga, gb):
-            assert float((x - y).abs().max()) <= 4e-3 * float(x.abs().max())
+    assert runs["plain"][1] == [0, 0, 0] and runs["prefetch"][1] == [0, 2, 0] and runs["graph"][1] == [0, 2, 0], (runs["prefetch"][1], runs["graph"][1])
+    assert getattr(pm["eval_unet"], "graphed", None) is not None and len(pm["eval_unet"].graphed.graphs) == 1      # the last trainer replayed ONE captured forward
+    for other in ("prefetch", "graph"):
+        for i, (a, b) in enumerate(zip(runs["plain"][0], runs[other][0])):
+            assert all(torch.equal(x, y) for x, y in zip(a, b)), f"{other}: step {i}"
+        for ga, gb in zip(runs["plain"][2], runs[other][2]):
+            for x, y in zip(ga, gb):
+                assert torch.equal(x, y)         # since round 4 (no atomics on the path) the gradients are bit-identical too
 
 
 def test_single_image_step_concurrent_backward_streams_equal_one_stream(dev, monkeypatch):
