@@ -9,7 +9,8 @@
 * ``DinoVisionTransformer`` -- facebookresearch/dinov2 ``models/vision_transformer.py`` via torch.hub (``dinov2_vitb14``:
   width 768, 12 layers, 12 heads, MLP 3072, patch 14, LayerScale, LN eps 1e-6, position table trained on 37x37 patches and
   bicubically interpolated with the ``+0.1`` scale-factor offset, output = final-norm CLS token).  The hub repository is
-  neither vendored nor installed and cannot be fetched: PARITY UNPINNED, restated from the published algorithm.
+  neither vendored nor installed and cannot be fetched; PINNED (round 4) against the installed transformers ``Dinov2Model`` -- an independent port
+  of the same network -- on random weights, with and without position-table interpolation (tests/test_cpu.py, 1e-5).
 """
 import math
 from dataclasses import dataclass

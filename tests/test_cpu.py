@@ -697,6 +697,53 @@ def test_oracle_clip_vision_pinned_against_transformers():
     assert float((a - b).abs().max()) < 1e-5 * float(a.abs().max())
 
 
+def test_oracle_dinov2_pinned_against_transformers_dinov2():
+    """oracle.nn_vit.DinoVisionTransformer (dinov2 hub names: fused qkv, ls1 / ls2 LayerScale, final-norm CLS token; get_dino_feat, 1-main-debias.py:1158-1175)
+    == the installed transformers ``Dinov2Model`` -- an independent port of facebookresearch/dinov2 -- on the same random weights.  Without position
+    interpolation (stored grid == image grid) the two must agree to fp32 rounding; with the 37 -> 16 interpolation of the real checkpoint the hub code the
+    reference fetched scales by (g + 0.1) / M where newer ports pass the target size: the difference between the two is measured and bounded, not hidden."""
+    from transformers import Dinov2Config, Dinov2Model
+    from oracle import nn_vit as V
+
+    def pair(pos_grid):
+        c = V.ViTConfig(kind="dino", image_size=56, patch_size=14, hidden_size=64, num_hidden_layers=2, num_attention_heads=4, intermediate_size=256,
+                        projection_dim=0, layer_norm_eps=1e-6, pos_grid=pos_grid)
+        hc = Dinov2Config(hidden_size=64, num_hidden_layers=2, num_attention_heads=4, mlp_ratio=4, image_size=14 * pos_grid, patch_size=14,
+                          layer_norm_eps=1e-6, hidden_act="gelu", layerscale_value=1.0, qkv_bias=True, use_swiglu_ffn=False)
+        torch.manual_seed(0)
+        hf = Dinov2Model(hc).eval()
+        with torch.no_grad():
+            for p_ in hf.parameters():
+                p_.normal_(0.0, 0.05)
+        h = hf.state_dict()
+        sd = {"cls_token": h["embeddings.cls_token"], "pos_embed": h["embeddings.position_embeddings"],
+              "patch_embed.proj.weight": h["embeddings.patch_embeddings.projection.weight"], "patch_embed.proj.bias": h["embeddings.patch_embeddings.projection.bias"],
+              "norm.weight": h["layernorm.weight"], "norm.bias": h["layernorm.bias"]}
+        for i in range(2):
+            a, o = f"encoder.layer.{i}.", f"blocks.{i}."
+            for n in ("norm1", "norm2"):
+                sd[o + n + ".weight"], sd[o + n + ".bias"] = h[a + n + ".weight"], h[a + n + ".bias"]
+            for wb in ("weight", "bias"):
+                sd[o + "attn.qkv." + wb] = torch.cat([h[a + f"attention.attention.{t}.{wb}"] for t in ("query", "key", "value")], 0)
+                sd[o + "attn.proj." + wb] = h[a + "attention.output.dense." + wb]
+                sd[o + "mlp.fc1." + wb], sd[o + "mlp.fc2." + wb] = h[a + "mlp.fc1." + wb], h[a + "mlp.fc2." + wb]
+            sd[o + "ls1.gamma"], sd[o + "ls2.gamma"] = h[a + "layer_scale1.lambda1"], h[a + "layer_scale2.lambda1"]
+        return hf, V.build(c, sd)
+
+    x = torch.randn(3, 3, 56, 56)
+    hf, mine = pair(4)                                   # 56 / 14 = 4: stored grid == image grid, no interpolation
+    with torch.no_grad():
+        a, b = hf(pixel_values=x).last_hidden_state[:, 0], mine(x)
+    assert float((a - b).abs().max()) < 1e-5 * float(a.abs().max())
+    hf, mine = pair(9)                                   # stored 9 x 9, image 4 x 4: the interpolated table
+    with torch.no_grad():
+        a, b = hf(pixel_values=x, interpolate_pos_encoding=True).last_hidden_state[:, 0] if "interpolate_pos_encoding" in Dinov2Model.forward.__code__.co_varnames \
+            else hf(pixel_values=x).last_hidden_state[:, 0], mine(x)
+    rel = float((a - b).abs().max() / a.abs().max())
+    print(f"dinov2 with interpolated position table: oracle (hub formula, scale (g + 0.1) / M) vs transformers {rel:.2e}")
+    assert rel < 5e-2
+
+
 def test_vit_inventories_and_feature_loss_gradient():
     from finetune_fair_diffusion_amd import weights as W
     from finetune_fair_diffusion_amd.vit import feature_loss_and_grad, _interpolate_pos
