@@ -176,8 +176,11 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(fd_gemm_desc p, int ntm,
 // CONV: 0 = dense operands, 1 = the 3x3 gathers (stride 1 / stride 2 / nearest-up2 / transposed stride 2), 2 = the Upsample2D phase pair
 // (FD_CONV_UP2P, FD_CONV_UP2P_BWD) -- its own instantiation: compiled into variant 1 the extra gather arithmetic cost the 8-wave 256x320
 // and the 512x128 gathers 34 and 52 spilled registers
-template <int BM, int BN, int WGM, int WGN, int CONV>
+// CV = 3 / 4: variants 0 / 1 with the GroupNorm-statistics epilogue (fd_gemm_desc.gn_stats).
+template <int BM, int BN, int WGM, int WGN, int CV>
 __global__ __launch_bounds__(WGM * WGN * 64) void gemm_big_kernel(fd_gemm_desc p, int ntm, int ntn, int gn) {
+    constexpr int CONV = CV >= 3 ? CV - 3 : CV;
+    constexpr bool WSTATS = CV >= 3;
     constexpr int NW = WGM * WGN;                   // 8 or 16 waves
     static_assert(NW == 8 || NW == 16, "8 or 16 waves");
     constexpr int WTM = BM / WGM, WTN = BN / WGN;   // wave tile
@@ -468,7 +471,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_big_kernel(fd_gemm_desc p
         constexpr int TMC = (NW * WTM * (WTN + 4) <= LDS_HALFS) ? TM : TM / 2;
         static_assert(NW * TMC * 16 * (WTN + 4) <= LDS_HALFS, "epilogue staging does not fit");
         __syncthreads();
-        gemm_epilogue_lds<TM, TN, TMC>(p, acc, smem + wave * (TMC * 16) * (WTN + 4), m0 + wm * WTM, n0 + wn * WTN, lane, 0, 0);
+        gemm_epilogue_lds<TM, TN, TMC, WSTATS>(p, acc, smem + wave * (TMC * 16) * (WTN + 4), m0 + wm * WTM, n0 + wn * WTN, lane, 0, 0);
     } else {
         gemm_epilogue<TM, TN>(p, acc, m0 + wm * WTM, n0 + wn * WTN, l15, lg, 0, 0);
     }
@@ -524,6 +527,18 @@ static int launch_big(const fd_gemm_desc& d, hipStream_t s, int nsplit = 1) {
     const int nph = (d.conv && d.conv_mode == FD_CONV_UP2P) ? 4 : 1;
     long gnl = l2_budget / ((long)BN * ktot * 2);
     const int gn = (int)(gnl < 1 ? 1 : (gnl > ntn ? ntn : gnl));
+    if constexpr (BN / WGN == 80) {
+        if (d.gn_stats && nsplit == 1 && !(d.conv && d.conv_mode >= FD_CONV_UP2P)) {     // the statistics-epilogue instantiations (fd_gemm checked eligibility)
+            static std::once_flag once_st;
+            std::call_once(once_st, [] {
+                (void)hipFuncSetAttribute((const void*)gemm_big_kernel<BM, BN, WGM, WGN, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                (void)hipFuncSetAttribute((const void*)gemm_big_kernel<BM, BN, WGM, WGN, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            });
+            if (d.conv) hipLaunchKernelGGL((gemm_big_kernel<BM, BN, WGM, WGN, 4>), dim3(ntm * ntn, 1), dim3(WGM * WGN * 64), lds, s, d, ntm, ntn, gn);
+            else hipLaunchKernelGGL((gemm_big_kernel<BM, BN, WGM, WGN, 3>), dim3(ntm * ntn, 1), dim3(WGM * WGN * 64), lds, s, d, ntm, ntn, gn);
+            return fd_check_launch("fd_gemm(big, statistics epilogue)");
+        }
+    }
     if (d.conv && d.conv_mode >= FD_CONV_UP2P)
         hipLaunchKernelGGL((gemm_big_kernel<BM, BN, WGM, WGN, 2>), dim3(ntm * ntn * nph, nsplit), dim3(WGM * WGN * 64), lds, s, d, ntm, ntn, gn);
     else if (d.conv) hipLaunchKernelGGL((gemm_big_kernel<BM, BN, WGM, WGN, 1>), dim3(ntm * ntn, nsplit), dim3(WGM * WGN * 64), lds, s, d, ntm, ntn, gn);
@@ -781,11 +796,27 @@ extern "C" int fd_gemm_kernel_name(const fd_gemm_desc* dp, char* buf, int n) {
         default: fam = bm == 16 ? "gemm_skinny_kernel" : "gemm_glds_kernel"; break;
     }
     if (pps_takes(d, sel)) snprintf(buf, n, "gemm_pps_kernel<%d>", d.act == FD_ACT_GEGLU ? 1 : 0);
-    else if (pp_takes(d, sel)) snprintf(buf, n, "gemm_pp_kernel<%d, %d, %s>", pp_takes(d, sel), d.conv ? 1 : 0, (pp_mode() & 4) ? "true" : "false");
-    else if (wgm) snprintf(buf, n, "%s<%d, %d, %d, %d, %d>", fam, bm, bn, wgm, wgn, cv);
+    else if (pp_takes(d, sel)) snprintf(buf, n, "gemm_pp_kernel<%d, %d, %s>", pp_takes(d, sel), (d.conv ? 1 : 0) + ((d.gn_stats && sel < 1000000) ? 2 : 0),
+                                        (pp_mode() & 4) ? "true" : "false");
+    else if (wgm) snprintf(buf, n, "%s<%d, %d, %d, %d, %d>", fam, bm, bn, wgm, wgn, (d.gn_stats && cv < 2 && sel < 1000000) ? cv + 3 : cv);
     else if (bm == 16) snprintf(buf, n, "%s<%d, %d, 1>", fam, bn / 16, d.K >= 1280 ? 4 : d.K >= 640 ? 2 : 1);
     else snprintf(buf, n, "%s<%d, %d, %s>", fam, bm, bn, d.conv ? "true" : "false");
     return sel / 1000000;   // split-K factor (0 or 1 = none)
+}
+
+// Rows per chunk of fd_gemm_desc.gn_stats: 32 for every kernel that has the statistics epilogue (gemm_epilogue_lds<..., true> forms the sums in
+// canonical 32-row chunks whatever its tile), 0 when the kernel fd_gemm would launch has none.  Same order of tests as fd_gemm / fd_gemm_kernel_name.
+extern "C" int fd_gemm_stats_rows(const fd_gemm_desc* dp) {
+    fd_gemm_desc d = *dp;
+    if (d.K2 <= 0 || !d.A2) d.K2 = 0;
+    const bool lds_epi = d.out_dtype == FD_OUT_F16 && (d.N & 7) == 0 && (d.ldc & 7) == 0 && (!d.residual || (d.ldr & 7) == 0) &&
+                         (!d.rowbias || (d.ld_rowbias & 3) == 0);
+    if (!lds_epi || d.act == FD_ACT_GEGLU || d.batch > 1 || (d.N % 80) != 0) return 0;
+    if (d.conv && d.conv_mode >= FD_CONV_UP2P) return 0;        // phase-major output rows: a chunk is not a run of pixels of one image
+    const int sel = fd_gemm_tile(&d);
+    if (sel >= 1000000 || pps_takes(d, sel)) return 0;          // split-K: the epilogue runs in splitk_reduce_kernel
+    if (pp_takes(d, sel)) return 32;
+    return (sel == 256320 || sel == 128320 || sel == 128160) ? 32 : 0;
 }
 
 extern "C" int fd_gemm(const fd_gemm_desc* dp, void* stream) {
@@ -816,6 +847,8 @@ extern "C" int fd_gemm(const fd_gemm_desc* dp, void* stream) {
         FD_REQUIRE(!d.conv && d.batch <= 1 && d.out_dtype == FD_OUT_F16 && !d.rowbias && d.alpha == 1.f && (d.N & 15) == 0 &&
                        (d.ldc & 7) == 0 && d.K2 == 0 && (!d.residual || (d.ldr & 7) == 0),
                    "fd_gemm(GEGLU): needs a plain fp16 GEMM with N %% 16 == 0 and ldc, ldr %% 8 == 0");
+    if (d.gn_stats) FD_REQUIRE(fd_gemm_stats_rows(&d) > 0, "fd_gemm: gn_stats set but the kernel for M=%d N=%d K=%d has no statistics epilogue "
+                               "(ask fd_gemm_stats_rows first)", d.M, d.N, d.K);
     hipStream_t s = (hipStream_t)stream;
     static const bool w16 = bench_env("FD_GEMM_W8") == nullptr;   // 16-wave variants by default (A/B switch for measurement)
     const int sel = fd_gemm_tile(&d);

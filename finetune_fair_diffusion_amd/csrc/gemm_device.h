@@ -101,7 +101,7 @@ __device__ __forceinline__ void gemm_epilogue(const fd_gemm_desc& p, f32x4 (&acc
 // row segments per store instruction; short-K GEMMs are bound by exactly that store path.  Here each wave parks its
 // WTM x WTN tile in LDS (bias / row-bias / activation already applied) and re-reads it as 16 bytes per lane so that a
 // store instruction covers whole 128-byte row segments; the residual is added on the way out with 16-byte loads.
-template <int TM, int TN, int TMC = TM>
+template <int TM, int TN, int TMC = TM, bool WSTATS = false>
 __device__ __forceinline__ void gemm_epilogue_lds(const fd_gemm_desc& p, f32x4 (&acc)[TM][TN], f16* wave_lds, int mbase, int nbase,
                                                   int lane, int64_t zC, int64_t zR) {
     // TMC: 16-row groups staged per pass (the wave-private LDS region holds TMC*16 rows; big tiles need two passes)
@@ -116,6 +116,16 @@ __device__ __forceinline__ void gemm_epilogue_lds(const fd_gemm_desc& p, f32x4 (
     // the epilogue mode is uniform over the launch: branch once, outside the per-element loops (a per-element runtime switch on
     // p.act plus the always-on alpha / row-bias arithmetic made short-K GEMMs VALU-bound here: 149 -> 100 us of epilogue on FF1)
     const bool plain = (p.act == FD_ACT_NONE) && !RB && p.alpha == 1.f && !FD_DBG_IS(p, 5);
+    // GroupNorm statistics of the stored tile (fd_gemm_desc.gn_stats), in CANONICAL chunks of 32 rows: whatever kernel and tile produced C, the
+    // sums of rows [32 c, 32 c + 32) x 10-channel unit are formed by the same procedure -- lane (cr, column chunk) adds its 8 columns over the rows
+    // cr, cr + 6, ... of the chunk, then lane u < 8 adds the 10 columns of unit u, columns ascending, row lanes ascending -- so a sample's statistics
+    // do not depend on the batch it is computed in nor on the tile policy (the CFG-pair prefix evaluates N samples where the duplicated batch has 2N).
+    // (WSTATS kernels are separate instantiations -- template code 3 / 4 of gemm_big_kernel, 2 / 3 of gemm_pp_kernel: compiled into the plain ones the
+    // extra live registers pushed the 16-wave 256 x 320 kernel, capped at 128, into scratch)
+    static_assert(!WSTATS || (WTN == 80 && WTMC % 32 == 0 && 32 * LDW * 2 >= 64 * 16 * 4), "statistics epilogue: 80-column wave tiles, passes of whole 32-row chunks");
+    constexpr int SUB = WSTATS ? WTMC / 32 : 1;
+    float* const gst = WSTATS ? p.gn_stats : nullptr;
+    float s0[SUB][8], s1[SUB][8];
 #pragma unroll
     for (int c0 = 0; c0 < TM; c0 += TMC) {
         if (plain) {
@@ -158,26 +168,87 @@ __device__ __forceinline__ void gemm_epilogue_lds(const fd_gemm_desc& p, f32x4 (
         // wave-private region: no block barrier needed, only this wave's own LDS writes must have landed
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
+        if (!WSTATS) {
 #pragma unroll
-        for (int r0 = 0; r0 < WTMC; r0 += RPI) {
-            const int row = r0 + cr;
-            const int m = mbase + c0 * 16 + row, n = nbase + cc;
-            if (cr < RPI && row < WTMC && m < p.M && n < p.N) {
-                // LDS rows are 8-byte aligned (LDW*2 bytes is a multiple of 8): two 8-byte reads
-                const f16x4 lo = *(const f16x4*)(wave_lds + row * LDW + cc);
-                const f16x4 hi = *(const f16x4*)(wave_lds + row * LDW + cc + 4);
-                f16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                if (R) {
-                    const f16x8 rv = *(const f16x8*)(R + (int64_t)m * p.ldr + n);
+            for (int r0 = 0; r0 < WTMC; r0 += RPI) {
+                const int row = r0 + cr;
+                const int m = mbase + c0 * 16 + row, n = nbase + cc;
+                if (cr < RPI && row < WTMC && m < p.M && n < p.N) {
+                    // LDS rows are 8-byte aligned (LDW*2 bytes is a multiple of 8): two 8-byte reads
+                    const f16x4 lo = *(const f16x4*)(wave_lds + row * LDW + cc);
+                    const f16x4 hi = *(const f16x4*)(wave_lds + row * LDW + cc + 4);
+                    f16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    if (R) {
+                        const f16x8 rv = *(const f16x8*)(R + (int64_t)m * p.ldr + n);
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) v[k] = (f16)((float)v[k] + (float)rv[k]);
+                        for (int k = 0; k < 8; ++k) v[k] = (f16)((float)v[k] + (float)rv[k]);
+                    }
+                    *(f16x8*)((f16*)p.C + zC + (int64_t)m * p.ldc + n) = v;
                 }
-                *(f16x8*)((f16*)p.C + zC + (int64_t)m * p.ldc + n) = v;
+            }
+        } else {
+#pragma unroll
+            for (int sub = 0; sub < SUB; ++sub) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) s0[sub][k] = s1[sub][k] = 0.f;
+#pragma unroll
+                for (int r0 = 0; r0 < 32; r0 += RPI) {
+                    const int row = sub * 32 + r0 + cr;
+                    const int m = mbase + c0 * 16 + row, n = nbase + cc;
+                    if (cr < RPI && r0 + cr < 32 && m < p.M && n < p.N) {
+                        const f16x4 lo = *(const f16x4*)(wave_lds + row * LDW + cc);
+                        const f16x4 hi = *(const f16x4*)(wave_lds + row * LDW + cc + 4);
+                        f16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                        if (R) {
+                            const f16x8 rv = *(const f16x8*)(R + (int64_t)m * p.ldr + n);
+#pragma unroll
+                            for (int k = 0; k < 8; ++k) v[k] = (f16)((float)v[k] + (float)rv[k]);
+                        }
+                        *(f16x8*)((f16*)p.C + zC + (int64_t)m * p.ldc + n) = v;
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) {
+                            const float x = (float)v[k];
+                            s0[sub][k] += x;
+                            s1[sub][k] = __builtin_fmaf(x, x, s1[sub][k]);
+                        }
+                    }
+                }
             }
         }
-        if (c0 + TMC < TM) {   // the next pass overwrites the staging rows: this wave's reads must have returned
+        if (c0 + TMC < TM || gst) {   // the next pass (or the statistics) overwrites the staging rows: this wave's reads must have returned
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
+        }
+        if (WSTATS && gst) {
+            float* red = (float*)wave_lds;          // 64 lanes x 16 floats: inside the first 32 staging rows
+#pragma unroll
+            for (int sub = 0; sub < SUB; ++sub) {
+                if (cr < RPI) {
+                    *(f32x4*)(red + lane * 16) = (f32x4){s0[sub][0], s0[sub][1], s0[sub][2], s0[sub][3]};
+                    *(f32x4*)(red + lane * 16 + 4) = (f32x4){s0[sub][4], s0[sub][5], s0[sub][6], s0[sub][7]};
+                    *(f32x4*)(red + lane * 16 + 8) = (f32x4){s1[sub][0], s1[sub][1], s1[sub][2], s1[sub][3]};
+                    *(f32x4*)(red + lane * 16 + 12) = (f32x4){s1[sub][4], s1[sub][5], s1[sub][6], s1[sub][7]};
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+                const int mrow = mbase + c0 * 16 + sub * 32;
+                if (lane < WTN / 10 && mrow < p.M && nbase < p.N) {
+                    float t0 = 0.f, t1 = 0.f;
+                    for (int c = lane * 10; c < lane * 10 + 10; ++c) {
+                        const int ch = c >> 3, j = c & 7;
+#pragma unroll
+                        for (int r = 0; r < RPI; ++r) {
+                            t0 += red[(r * CPR + ch) * 16 + j];
+                            t1 += red[(r * CPR + ch) * 16 + 8 + j];
+                        }
+                    }
+                    const int64_t slot = (int64_t)(mrow >> 5) * (p.N / 10) + nbase / 10 + lane;
+                    *(float2*)(gst + slot * 2) = make_float2(t0, t1);
+                }
+                // the next chunk's sums / the next pass's staging overwrite ``red``: the unit lanes' reads must have returned
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+            }
         }
     }
 }

@@ -33,8 +33,11 @@
 // LDS-staged epilogues are those of the other GEMM kernels (gemm_device.h).
 #include "gemm_pp_device.h"
 
-template <int BM, int CONV, bool PRIO>
+// CV = 2 / 3: variants 0 / 1 (dense / stride-1 3x3 gather) with the GroupNorm-statistics epilogue (fd_gemm_desc.gn_stats)
+template <int BM, int CV, bool PRIO>
 __global__ __launch_bounds__(512) void gemm_pp_kernel(fd_gemm_desc p, int ntm, int ntn, int gn) {
+    constexpr int CONV = CV & 1;
+    constexpr bool WSTATS = CV >= 2;
     constexpr int WTM = BM / 2, WTN = 80, TM = WTM / 16, TN = 5;
     constexpr int NGA = BM / 16, NAW = NGA / PP_NW;      // A groups per k-step, per wave (2 or 1)
     constexpr int STAGE = pp_stage<BM>();
@@ -224,19 +227,19 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(fd_gemm_desc p, int ntm, i
     if (p.act == FD_ACT_GEGLU) {
         gemm_epilogue_geglu_lds<TM, TN, TMC>(p, acc, smem + wave * (TMC * 16) * (WTN + 4), m0 + wm * WTM, n0 + wn * WTN, lane);
     } else if (lds_epi) {
-        gemm_epilogue_lds<TM, TN, TMC>(p, acc, smem + wave * (TMC * 16) * (WTN + 4), m0 + wm * WTM, n0 + wn * WTN, lane, 0, 0);
+        gemm_epilogue_lds<TM, TN, TMC, WSTATS>(p, acc, smem + wave * (TMC * 16) * (WTN + 4), m0 + wm * WTM, n0 + wn * WTN, lane, 0, 0);
     } else {
         gemm_epilogue<TM, TN>(p, acc, m0 + wm * WTM, n0 + wn * WTN, l15, lg, 0, 0);
     }
 }
 
-template <int BM, int CONV, bool PRIO>
+template <int BM, int CV, bool PRIO>
 static void launch_pp(const fd_gemm_desc& d, hipStream_t s, int ntm, int ntn, int gn, int nsplit) {
     static std::once_flag once;
     std::call_once(once, [] {
-        (void)hipFuncSetAttribute((const void*)gemm_pp_kernel<BM, CONV, PRIO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pp_lds<BM>());
+        (void)hipFuncSetAttribute((const void*)gemm_pp_kernel<BM, CV, PRIO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pp_lds<BM>());
     });
-    hipLaunchKernelGGL((gemm_pp_kernel<BM, CONV, PRIO>), dim3(ntm * ntn, nsplit), dim3(512), pp_lds<BM>(), s, d, ntm, ntn, gn);
+    hipLaunchKernelGGL((gemm_pp_kernel<BM, CV, PRIO>), dim3(ntm * ntn, nsplit), dim3(512), pp_lds<BM>(), s, d, ntm, ntn, gn);
 }
 
 template <int BM>
@@ -246,6 +249,11 @@ static void launch_pp_bm(const fd_gemm_desc& d, hipStream_t s, bool prio, int ns
     const long ktot = ((long)d.K + d.K2) / nsplit;
     long gnl = l2_budget / ((long)PP_BN * ktot * 2);
     const int gn = (int)(gnl < 1 ? 1 : (gnl > ntn ? ntn : gnl));
+    if (d.gn_stats && nsplit == 1) {     // statistics-epilogue instantiations
+        if (d.conv) { if (prio) launch_pp<BM, 3, true>(d, s, ntm, ntn, gn, 1); else launch_pp<BM, 3, false>(d, s, ntm, ntn, gn, 1); }
+        else { if (prio) launch_pp<BM, 2, true>(d, s, ntm, ntn, gn, 1); else launch_pp<BM, 2, false>(d, s, ntm, ntn, gn, 1); }
+        return;
+    }
     if (d.conv) { if (prio) launch_pp<BM, 1, true>(d, s, ntm, ntn, gn, nsplit); else launch_pp<BM, 1, false>(d, s, ntm, ntn, gn, nsplit); }
     else { if (prio) launch_pp<BM, 0, true>(d, s, ntm, ntn, gn, nsplit); else launch_pp<BM, 0, false>(d, s, ntm, ntn, gn, nsplit); }
 }

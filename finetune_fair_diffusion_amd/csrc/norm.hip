@@ -138,12 +138,63 @@ __device__ __forceinline__ void gn_block_stats(const GNArgs& a, const float* par
     __syncthreads();
 }
 
-__global__ void gn_apply_kernel(GNArgs a, f16* y, const float* partial, float n, float* stats_out) {
+// Statistics that arrive from the PRODUCERS of x1 / x2 (fd_gemm_desc.gn_stats): per row chunk and 10-channel unit the (sum, sum of squares) of
+// the stored values.  A group is a run of units; the (unit, chunk) pairs of a group, unit-major, are cut into blockDim / G slices that are summed
+// by different threads and combined in slice order -- the geometry depends on (C, HW, G, chunk heights) only: bit-reproducible.
+struct GNUnits { const float* st1; const float* st2; int nch1, nch2; };
+
+__device__ __forceinline__ void gn_block_stats_units(const GNArgs& a, const GNUnits& u, int b, float n, float* st /* LDS [G*2] */,
+                                                     float* ps /* LDS [blockDim / G][G][2] */, float* out /* global [B,G,2] or nullptr */) {
+    const int C = a.C1 + a.C2, upg = C / a.G / 10, U1 = a.C1 / 10, U2 = a.C2 / 10;
+    const int nparts = blockDim.x / a.G;
+    const int g = threadIdx.x % a.G, part = threadIdx.x / a.G;
+    if (part < nparts) {
+        int L = 0;
+        for (int k = 0; k < upg; ++k) L += (g * upg + k < U1) ? u.nch1 : u.nch2;
+        const int lo = L * part / nparts, hi = L * (part + 1) / nparts;
+        float a0 = 0.f, a1 = 0.f;
+        int base = 0;
+        for (int k = 0; k < upg; ++k) {
+            const int uu = g * upg + k;
+            const bool first = uu < U1;
+            const float* sp = first ? u.st1 : u.st2;
+            const int nch = first ? u.nch1 : u.nch2, U = first ? U1 : U2, ul = first ? uu : uu - U1;
+            const int c0 = max(lo - base, 0), c1 = min(hi - base, nch);
+            for (int c = c0; c < c1; ++c) {
+                const float2 v = *(const float2*)(sp + ((int64_t)(b * nch + c) * U + ul) * 2);
+                a0 += v.x;
+                a1 += v.y;
+            }
+            base += nch;
+        }
+        ps[(part * a.G + g) * 2] = a0;
+        ps[(part * a.G + g) * 2 + 1] = a1;
+    }
+    __syncthreads();
+    if (threadIdx.x < a.G) {
+        float a0 = 0.f, a1 = 0.f;
+        for (int q = 0; q < nparts; ++q) {
+            a0 += ps[(q * a.G + g) * 2];
+            a1 += ps[(q * a.G + g) * 2 + 1];
+        }
+        const float v0 = a0 / n;
+        const float v1 = rsqrtf(fmaxf(a1 / n - v0 * v0, 0.f) + a.eps);
+        st[g * 2] = v0;
+        st[g * 2 + 1] = v1;
+        if (out) { out[(b * a.G + g) * 2] = v0; out[(b * a.G + g) * 2 + 1] = v1; }
+    }
+    __syncthreads();
+}
+
+template <bool UNITS>
+__global__ void gn_apply_kernel(GNArgs a, f16* y, const float* partial, float n, float* stats_out, GNUnits un) {
     __shared__ float st[128];
+    __shared__ float ps[UNITS ? 1024 : 1];
     const int C = a.C1 + a.C2, V = C >> 3, cg = C / a.G;
     const int b = blockIdx.y, chunk = blockIdx.x;
     const int v = threadIdx.x % V, rsub = threadIdx.x / V, rpb = blockDim.x / V;
-    gn_block_stats<0>(a, partial, b, n, st, chunk == 0 ? stats_out : nullptr);
+    if (UNITS) gn_block_stats_units(a, un, b, n, st, ps, chunk == 0 ? stats_out : nullptr);
+    else gn_block_stats<0>(a, partial, b, n, st, chunk == 0 ? stats_out : nullptr);
     if (rsub >= rpb) return;
     const int c0 = v * 8;
     float sc[8], sh[8];
@@ -484,8 +535,32 @@ extern "C" int fd_groupnorm_fwd(const void* x1, int C1, const void* x2, int C2, 
     }
     hipLaunchKernelGGL(gn_reduce_kernel<0>, dim3(a.nchunks, B), dim3(threads), threads * 16 * sizeof(float), s, a, scratch);
     const float n = (float)HW * (float)((C1 + C2) / groups);
-    hipLaunchKernelGGL(gn_apply_kernel, dim3(a.nchunks, B), dim3(threads), 0, s, a, (f16*)y, (const float*)scratch, n, mean_rstd);
+    hipLaunchKernelGGL(gn_apply_kernel<false>, dim3(a.nchunks, B), dim3(threads), 0, s, a, (f16*)y, (const float*)scratch, n, mean_rstd, GNUnits{});
     return fd_check_launch("fd_groupnorm_fwd");
+}
+
+// The apply pass alone, its statistics assembled from the producers' gn_stats buffers (the statistics pass of the two-launch
+// form re-read x; here x is read once, by the pass that normalises it).
+extern "C" int fd_groupnorm_fwd_stats(const void* x1, int C1, const void* x2, int C2, int B, int HW, int groups, float eps, const float* gamma,
+                                      const float* beta, int silu, void* y, float* mean_rstd, const float* st1, int rows1, const float* st2,
+                                      int rows2, void* stream) {
+    FD_REQUIRE(gn_check(C1, C2, groups) == 0, "fd_groupnorm_fwd_stats: bad channels C1=%d C2=%d groups=%d", C1, C2, groups);
+    const int C = C1 + C2;
+    FD_REQUIRE(C1 % 10 == 0 && C2 % 10 == 0 && (C / groups) % 10 == 0, "fd_groupnorm_fwd_stats: C1=%d, C2=%d and the group width %d must be multiples of 10",
+               C1, C2, C / groups);
+    FD_REQUIRE(st1 && rows1 > 0 && HW % rows1 == 0, "fd_groupnorm_fwd_stats: rows1=%d must divide HW=%d", rows1, HW);
+    FD_REQUIRE(C2 == 0 || (x2 && st2 && rows2 > 0 && HW % rows2 == 0), "fd_groupnorm_fwd_stats: rows2=%d must divide HW=%d", rows2, HW);
+    GNArgs a = {};
+    a.x1 = (const f16*)x1; a.x2 = (const f16*)x2; a.C1 = C1; a.C2 = C2; a.B = B; a.HW = HW; a.G = groups; a.eps = eps;
+    a.gamma = gamma; a.beta = beta; a.silu = silu;
+    int threads;
+    FD_REQUIRE(gn_geometry(C, HW, threads, a.rows_per_chunk, a.nchunks) == 0, "fd_groupnorm: C too large");
+    FD_REQUIRE(threads / groups >= 1 && (threads / groups) * groups * 2 <= 1024, "fd_groupnorm_fwd_stats: %d threads for %d groups", threads, groups);
+    GNUnits un = {st1, st2, HW / rows1, C2 ? HW / rows2 : 0};
+    const float n = (float)HW * (float)(C / groups);
+    hipLaunchKernelGGL(gn_apply_kernel<true>, dim3(a.nchunks, B), dim3(threads), 0, (hipStream_t)stream, a, (f16*)y, (const float*)nullptr, n,
+                       mean_rstd, un);
+    return fd_check_launch("fd_groupnorm_fwd_stats");
 }
 
 extern "C" int fd_groupnorm_bwd(const void* x1, int C1, const void* x2, int C2, const void* dy, int B, int HW, int groups,

@@ -228,7 +228,7 @@ class ResnetBlock:
         """x [M,C1] (+ skip [M,C2] concatenated on channels). temb_row: [1, Cout] fp16 or None."""
         HW, M = H * W, B * H * W
         g, st1 = ops.groupnorm(x, skip, B, HW, self.groups, self.eps, self.norm1.gamma, self.norm1.beta, True)
-        h, _, _ = ops.conv3x3(g, self.conv1.wk, B, H, W, bias=self.conv1.bias, rowbias=temb_row)
+        h, _, _ = ops.conv3x3(g, self.conv1.wk, B, H, W, bias=self.conv1.bias, rowbias=temb_row, gn_stats=True)      # feeds norm2
         g2, st2 = ops.groupnorm(h, None, B, HW, self.groups, self.eps, self.norm2.gamma, self.norm2.beta, True)
         if self.shortcut is not None:
             C1 = x.shape[1]
@@ -238,7 +238,7 @@ class ResnetBlock:
                 sc = ops.gemm(x, self.shortcut.w[:, :C1], a2=skip, b2=self.shortcut.w[:, C1:], bias=self.shortcut.bias)
         else:
             sc = x
-        out, _, _ = ops.conv3x3(g2, self.conv2.wk, B, H, W, bias=self.conv2.bias, residual=sc)
+        out, _, _ = ops.conv3x3(g2, self.conv2.wk, B, H, W, bias=self.conv2.bias, residual=sc, gn_stats=True)      # feeds the next block's norm
         if ctx is not None:
             ctx.append(dict(x=x, skip=skip, st1=st1, h=h, st2=st2))
         return out

@@ -36,6 +36,7 @@ class GemmDesc(ctypes.Structure):
         ("conv", ctypes.c_int32), ("conv_mode", ctypes.c_int32), ("Bn", ctypes.c_int32), ("H", ctypes.c_int32),
         ("W", ctypes.c_int32), ("Cin", ctypes.c_int32), ("Ho", ctypes.c_int32), ("Wo", ctypes.c_int32),
         ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_int64),
+        ("gn_stats", ctypes.c_void_p),
     ]
 
 

@@ -85,9 +85,20 @@ class OpTimer:
 TIMER = None
 
 
-def _gemm_call(d, conv):
+GN_STATS = os.environ.get("FD_NO_GN_STATS") is None      # A/B switch: GroupNorm statistics from the producer's epilogue (fd_gemm_desc.gn_stats)
+
+
+def _gemm_call(d, conv, out=None, gn_stats=False):
     ws = gemm_workspace()
     d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * 4
+    if gn_stats and GN_STATS:
+        # the kernel fd_gemm picks decides the chunk height (its wave-tile rows); 0 = no statistics epilogue for this problem.  The buffer rides on
+        # the output tensor OBJECT: ``groupnorm`` finds it there, and anything that makes a new tensor of the output (cat, slicing) drops it
+        rows = _lib.get().fd_gemm_stats_rows(ctypes.byref(d))
+        if rows > 0:
+            st = torch.empty(((d.M + rows - 1) // rows, d.N // 10, 2), dtype=F32, device=out.device)
+            d.gn_stats = st.data_ptr()
+            out.gn_stats = (st, rows)
     if TIMER is None:
         _call("fd_gemm", ctypes.byref(d), _stream())
         return
@@ -115,7 +126,7 @@ def _chk(t, dtype=F16):
 
 # ----------------------------------------------------------------------------- GEMM / conv
 def gemm(a, b, *, a2=None, b2=None, bias=None, rowbias=None, rows_per_batch=0, residual=None, act="none", alpha=1.0,
-         out=None, out_dtype=F16, n=None, aux=None):
+         out=None, out_dtype=F16, n=None, aux=None, gn_stats=False):
     """C[M,N] = act(alpha*(a.b^T + a2.b2^T) + bias + rowbias) + residual.  a:[M,K] (row stride free), b:[N,K].
     act="geglu": b / bias rows interleaved (value_c, gate_c) -> C[M, N/2] = value * gelu(gate) (see ``interleave_geglu``)."""
     M, K = a.shape
@@ -141,7 +152,7 @@ def gemm(a, b, *, a2=None, b2=None, bias=None, rowbias=None, rows_per_batch=0, r
         d.residual, d.ldr = aux.data_ptr(), N
     d.alpha, d.M, d.N, d.K = alpha, M, N, K
     d.act, d.out_dtype, d.batch = ACT[act], 1 if out.dtype == F32 else 0, 1
-    _gemm_call(d, False)
+    _gemm_call(d, False, out, gn_stats)
     return out
 
 
@@ -200,7 +211,7 @@ def gemm_batched_from(a_view, b, Z, rows):
     return out
 
 
-def conv3x3(x, w, B, H, W, *, mode=CONV_NORMAL, bias=None, rowbias=None, residual=None, act="none", out=None):
+def conv3x3(x, w, B, H, W, *, mode=CONV_NORMAL, bias=None, rowbias=None, residual=None, act="none", out=None, gn_stats=False):
     """Implicit-GEMM 3x3 conv (pad 1).  x: [B*H*W, Cin] channels-last fp16, w: [Cout, 9*Cin] (ky,kx,ci order).
     Returns ([B*Ho*Wo, Cout], Ho, Wo)."""
     Cin = x.shape[1]
@@ -228,7 +239,7 @@ def conv3x3(x, w, B, H, W, *, mode=CONV_NORMAL, bias=None, rowbias=None, residua
     d.alpha, d.M, d.N, d.K, d.act, d.batch = 1.0, M, Cout, 9 * Cin, ACT[act], 1
     d.out_dtype = 1 if out.dtype == F32 else 0
     d.conv, d.conv_mode, d.Bn, d.H, d.W, d.Cin, d.Ho, d.Wo = 1, mode, B, H, W, Cin, Ho, Wo
-    _gemm_call(d, True)
+    _gemm_call(d, True, out, gn_stats)
     return out, Ho, Wo
 
 
@@ -327,6 +338,13 @@ def groupnorm(x1, x2, B, HW, groups, eps, gamma, beta, silu):
     C1, C2 = x1.shape[1], (x2.shape[1] if x2 is not None else 0)
     st = torch.empty((B, groups, 2), dtype=F32, device=x1.device)
     y = torch.empty((B * HW, C1 + C2), dtype=F16, device=x1.device)
+    s1, s2 = getattr(x1, "gn_stats", None), (getattr(x2, "gn_stats", None) if x2 is not None else None)
+    if (s1 is not None and (x2 is None or s2 is not None) and HW % s1[1] == 0 and (s2 is None or HW % s2[1] == 0)
+            and ((C1 + C2) // groups) % 10 == 0 and s1[0].shape[0] * s1[1] == B * HW and (s2 is None or s2[0].shape[0] * s2[1] == B * HW)):
+        # every producer of the input left per-chunk sums behind: no statistics pass, x is read once
+        _call("fd_groupnorm_fwd_stats", _p(_chk(x1)), C1, _p(x2), C2, B, HW, groups, eps, _p(gamma), _p(beta), int(silu), _p(y), _p(st),
+              _p(s1[0]), s1[1], _p(s2[0]) if s2 is not None else None, s2[1] if s2 is not None else 0, _stream())
+        return y, st
     sc = scratch(B * 64 * groups * 2, x1.device)
     _call("fd_groupnorm_fwd", _p(_chk(x1)), C1, _p(x2), C2, B, HW, groups, eps, _p(gamma), _p(beta), int(silu), _p(y), _p(st), _p(sc), _stream())
     return y, st

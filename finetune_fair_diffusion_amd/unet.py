@@ -181,7 +181,7 @@ class TransformerBlock:
         proj = torch.empty((n3.shape[0], self.ff1_wi.shape[0]), dtype=F16, device=n3.device) if rec else None
         gg = ops.gemm(n3, self.ff1_wi, bias=self.ff1_bi, act="geglu", aux=proj)
         h3 = ops.gemm(gg, self.ff2.w, bias=self.ff2.bias, residual=h2)
-        out = ops.gemm(h3, self.proj_out.w, bias=self.proj_out.bias, residual=xf)
+        out = ops.gemm(h3, self.proj_out.w, bias=self.proj_out.bias, residual=xf, gn_stats=True)      # feeds the next ResnetBlock's norm1 / conv_norm_out
         if rec:
             ctx.append(dict(x=x, st=st, h0=h0, ln1=ln1, n1=n1, t1=t1, qkv=qkv, o=o, lse=lse, to1=to1, h1=h1, ln2=ln2, n2=n2,
                             tq2=tq2, q2=q2f, o2=o2, lse2=lse2, to2=to2, h2=h2, ln3=ln3, proj=proj, pair=pair))
@@ -477,7 +477,7 @@ class UNet2DConditionModel:
                         pair, B = False, 2 * B
                 skips.append((x, H, W))
             if blk["down"] is not None:
-                x, H, W = ops.conv3x3(x, blk["down"].wk, B, H, W, mode=ops.CONV_STRIDE2, bias=blk["down"].bias)
+                x, H, W = ops.conv3x3(x, blk["down"].wk, B, H, W, mode=ops.CONV_STRIDE2, bias=blk["down"].bias, gn_stats=True)
                 skips.append((x, H, W))
         x = self.mid["res"][0].forward(x, None, B, H, W, temb(self.mid["res"][0]), ctx)
         x = self.mid["attn"][0].forward(x, B, H, W, ctx)

@@ -73,8 +73,19 @@ typedef struct fd_gemm_desc {
     int32_t conv, conv_mode, Bn, H, W, Cin, Ho, Wo;
     /* optional fp32 workspace for split-K (small-M, long-K problems); NULL disables split-K */
     void* workspace; int64_t workspace_bytes;
+    /* optional second output (NULL = none): per-row-chunk sums of the STORED fp16 values for the GroupNorm that consumes C
+     * (norm1 / norm2 of ResnetBlock2D, Transformer2DModel.norm): gn_stats[(m / rows) * (N / 10) + n / 10][2] = (sum, sum of squares) over
+     * the rows [rows * (m / rows), ...) of C and the 10 channels [10 * (n / 10), ...) -- 10 divides every group width of the SD-v1.5 U-Net
+     * (10 / 20 / 30 / 40 / 60 / 80 channels), so one buffer serves a tensor both as a GroupNorm's only input and as one half of a
+     * channel concatenation.  ``rows`` = fd_gemm_stats_rows() (32 for every kernel that can write the statistics, formed by one canonical
+     * procedure per chunk: they do not depend on the tile policy or the batch size; 0 = this problem's kernel cannot): size the buffer
+     * ceil(M / rows) * (N / 10) * 2 floats; fd_gemm fails if gn_stats is set and the chosen kernel cannot write it. */
+    float* gn_stats;
 } fd_gemm_desc;
 int fd_gemm(const fd_gemm_desc* d, void* stream);
+/* rows per statistics chunk of ``gn_stats`` for this problem (32), or 0 when the kernel fd_gemm would launch has no statistics epilogue
+ * (split-K, the 64-column wave tiles, fp32 / GEGLU outputs, N not a multiple of 80) */
+int fd_gemm_stats_rows(const fd_gemm_desc* d);
 /* tile variant fd_gemm would pick for this problem, as BM*1000+BN (128128 / 128064 / 64064) */
 int fd_gemm_tile(const fd_gemm_desc* d);
 /* name of the kernel fd_gemm launches for this problem as rocprofv3 --kernel-trace spells it (host buffer ``buf`` of ``n`` bytes);
@@ -95,6 +106,12 @@ int fd_clamp_bwd(const void* pre, int64_t ldx, const float* dimg, float* dpre, i
 /* y = act(GN(x)); mean_rstd [B,groups,2] receives the statistics for the backward; scratch: B*64*groups*2 floats */
 int fd_groupnorm_fwd(const void* x1, int C1, const void* x2, int C2, int B, int HW, int groups, float eps, const float* gamma,
                      const float* beta, int silu, void* y, float* mean_rstd, float* scratch, void* stream);
+/* the same with the statistics pass replaced by the producers' ``gn_stats`` buffers (fd_gemm_desc): st1 / st2 belong to x1 / x2 (st2 NULL
+ * when C2 == 0), rows1 / rows2 are their chunk heights and must divide HW; C1, C2 and C / groups must be multiples of 10.  One launch,
+ * x is read once. */
+int fd_groupnorm_fwd_stats(const void* x1, int C1, const void* x2, int C2, int B, int HW, int groups, float eps, const float* gamma,
+                           const float* beta, int silu, void* y, float* mean_rstd, const float* st1, int rows1, const float* st2, int rows2,
+                           void* stream);
 /* backward: dx = d/dx [ act(GN(x)) ] . dy ; writes the two channel slices to dx1/dx2, optionally adding add1/add2 */
 int fd_groupnorm_bwd(const void* x1, int C1, const void* x2, int C2, const void* dy, int B, int HW, int groups,
                      const float* mean_rstd, const float* gamma, const float* beta, int silu,

@@ -161,5 +161,21 @@ for f in sorted(glob.glob('gpurun_out/r04o_step_*.json')):
 PY
     tail -3 gpurun_out/r04o_step_graph_1.err
     ;;
+p)  # GroupNorm statistics from the producers' epilogues (fd_gemm_desc.gn_stats): kernel tests, the U-Net / step tests, then whole-step A/B (FD_NO_GN_STATS=1)
+    timeout 900 python -m pytest tests/test_kernels_gpu.py -x -q -s -k "groupnorm or statistics or gemm_big or conv3x3" > gpurun_out/r04p_kernel_tests.log 2>&1; grep -i "gn_stats\|passed\|failed\|Error" gpurun_out/r04p_kernel_tests.log | tail -30
+    timeout 900 python -m pytest tests/test_engine_gpu.py -x -q -k "unet or full_step or pair" > gpurun_out/r04p_engine_tests.log 2>&1; tail -5 gpurun_out/r04p_engine_tests.log
+    for i in 1 2; do
+      $B --steps 6 --warmup 3 > gpurun_out/r04p_step_stats_$i.json 2> gpurun_out/r04p_step_stats_$i.err
+      FD_NO_GN_STATS=1 $B --steps 6 --warmup 3 > gpurun_out/r04p_step_nostats_$i.json 2>/dev/null
+    done
+    python - <<'PY'
+import json,glob
+for f in sorted(glob.glob('gpurun_out/r04p_step_*.json')):
+    try:
+        d=json.loads(open(f).read().strip().splitlines()[-1]); print(f, round(d['value'],3), round(d['ms_per_step'],1), d['config']['phase_ms'])
+    except Exception as e: print(f, 'ERR', e)
+PY
+    tail -3 gpurun_out/r04p_step_stats_1.err
+    ;;
 *) echo "unknown pass $1";;
 esac

@@ -240,6 +240,101 @@ def test_groupnorm_is_batch_invariant_and_reproducible(ops, dev, HW, C1, C2):
         assert torch.equal(d1, dx1[sl]) and (not C2 or torch.equal(d2, dx2[sl]))
 
 
+def _unit_sums(c, rows=32):
+    """fp64 statement of fd_gemm_desc.gn_stats: per 32-row chunk and 10-channel unit the (sum, sum of squares) of the stored values."""
+    M, N = c.shape
+    pad = (-M) % rows
+    x = torch.cat([c.double(), torch.zeros(pad, N, dtype=torch.float64, device=c.device)]).reshape((M + pad) // rows, rows, N // 10, 10)
+    return torch.stack([x.sum((1, 3)), (x * x).sum((1, 3))], -1)
+
+
+@pytest.mark.parametrize("kind,shape", [("dense", (32768, 320, 320)), ("dense", (51300, 320, 1280)), ("dense", (12800, 640, 640)), ("dense", (7000, 480, 1024)),
+                                        ("conv", (16, 64, 320, 320)), ("conv", (3, 64, 320, 640)), ("conv", (16, 16, 1280, 1280)), ("conv2", (16, 64, 320, 320))])
+def test_gemm_groupnorm_statistics_epilogue(ops, dev, kind, shape):
+    """fd_gemm_desc.gn_stats: the producer of a GroupNorm's input leaves per-chunk sums of the values it STORED; the output
+    itself is bit-identical to the launch without statistics.  Covers the lockstep 256x320 / 128x320 / 128x160 tiles, the ping-pong convolutions,
+    the stride-2 gather, residual / bias / row-bias epilogues and an M tail that ends inside a chunk."""
+    if kind == "dense":
+        M, N, K = shape
+        a, b = rnd(M, K, dev=dev, seed=1), rnd(N, K, dev=dev, scale=0.1, seed=2)
+        bias, res = rnd(N, dev=dev, dtype=torch.float32, seed=5), rnd(M, N, dev=dev, seed=6)
+        run = lambda st: ops.gemm(a, b, bias=bias, residual=res, gn_stats=st)
+    else:
+        B, H, Cin, Cout = shape
+        x, w = rnd(B * H * H, Cin, dev=dev, seed=1), rnd(Cout, 9 * Cin, dev=dev, scale=0.05, seed=2)
+        bias, rb = rnd(Cout, dev=dev, dtype=torch.float32, seed=3), rnd(1, Cout, dev=dev, seed=4)
+        mode = ops.CONV_STRIDE2 if kind == "conv2" else ops.CONV_NORMAL
+        run = lambda st: ops.conv3x3(x, w, B, H, H, mode=mode, bias=bias, rowbias=rb, gn_stats=st)[0]
+    plain, c = run(False), run(True)
+    assert torch.equal(plain, c)
+    assert getattr(plain, "gn_stats", None) is None and c.gn_stats[1] == 32
+    st = c.gn_stats[0]
+    ref = _unit_sums(c)
+    assert st.shape == ref.shape
+    err = float(((st.double() - ref).abs() / (ref.abs() + 1.0)).max())
+    print(f"[gn_stats {kind} {shape}] max err {err:.2e}")
+    assert err < 2e-5
+    c2 = run(True)
+    assert torch.equal(c2.gn_stats[0], st)          # fixed order
+
+
+def test_gemm_groupnorm_statistics_do_not_depend_on_the_tile_policy(ops, dev):
+    """The chunks are formed by one canonical procedure: the first rows of a big launch (256x320 tiles) and a small launch over those rows alone
+    (128x320 tiles) carry bit-identical statistics -- the CFG-pair prefix evaluates N samples where the duplicated batch has 2N."""
+    import ctypes
+    from finetune_fair_diffusion_amd import lib
+    M, Ms, N, K = 32768, 8192, 640, 640
+    a, b = rnd(M, K, dev=dev, seed=1), rnd(N, K, dev=dev, scale=0.1, seed=2)
+    res = rnd(M, N, dev=dev, seed=3)
+    tiles = []
+    for m in (M, Ms):
+        d = lib.GemmDesc(); d.M, d.N, d.K, d.batch, d.ldc = m, N, K, 1, N
+        ws = ops.gemm_workspace()
+        d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * 4
+        tiles.append(lib.get().fd_gemm_tile(ctypes.byref(d)))
+    assert tiles == [256320, 128320], tiles
+    big = ops.gemm(a, b, residual=res, gn_stats=True)
+    small = ops.gemm(a[:Ms], b, residual=res[:Ms], gn_stats=True)
+    assert torch.equal(big[:Ms], small)
+    assert torch.equal(big.gn_stats[0][:Ms // 32], small.gn_stats[0])
+
+
+@pytest.mark.parametrize("B,HW,C1,C2,silu", [(4, 4096, 320, 0, True), (16, 1024, 640, 320, True), (4, 4096, 640, 320, False), (16, 256, 1280, 1280, True),
+                                             (2, 16384, 320, 0, True), (2, 16384, 640, 320, True)])
+def test_groupnorm_from_producer_statistics(ops, dev, B, HW, C1, C2, silu):
+    """fd_groupnorm_fwd_stats: the apply pass alone, statistics assembled from the producers' chunk sums (two producers for a channel
+    concatenation whose 30- / 80-channel groups straddle the sources).  Against torch, against the two-launch form, per sample vs batched."""
+    G, eps, M = 32, 1e-5, B * HW
+    K = 320
+    a1, a2 = rnd(M, K, dev=dev, seed=1), rnd(M, K, dev=dev, seed=2)
+    b1, b2 = rnd(C1, K, dev=dev, scale=0.1, seed=3), (rnd(C2, K, dev=dev, scale=0.1, seed=4) if C2 else None)
+    res1 = rnd(M, C1, dev=dev, seed=5)
+    x1 = ops.gemm(a1, b1, residual=res1, gn_stats=True)
+    x2 = ops.gemm(a2, b2, gn_stats=True) if C2 else None
+    assert x1.gn_stats is not None and (x2 is None or x2.gn_stats is not None)
+    C = C1 + C2
+    gamma = rnd(C, dev=dev, dtype=torch.float32, seed=6) * 0.2 + 1
+    beta = rnd(C, dev=dev, dtype=torch.float32, seed=7) * 0.2
+    xc = (torch.cat([x1, x2], 1) if C2 else x1).float().reshape(B, HW, C).permute(0, 2, 1)
+    ref = F.group_norm(xc, G, gamma, beta, eps)
+    ref = F.silu(ref) if silu else ref
+    y, st = ops.groupnorm(x1, x2, B, HW, G, eps, gamma, beta, silu)
+    check("groupnorm from producer statistics", y.reshape(B, HW, C).permute(0, 2, 1), ref, 2e-3)
+    y0, st0 = ops.groupnorm(x1.clone(), x2.clone() if C2 else None, B, HW, G, eps, gamma, beta, silu)     # clones carry no statistics: reduce + apply
+    check("mean / rstd vs the two-launch form", st, st0, 2e-5)
+    assert float((y.float() - y0.float()).abs().max()) <= 2e-3 * float(y0.float().abs().max())
+    y2, st2 = ops.groupnorm(x1, x2, B, HW, G, eps, gamma, beta, silu)
+    assert torch.equal(y, y2) and torch.equal(st, st2)
+    for bi in range(B):                                   # a sample alone: other tiles, same statistics, same output
+        sl = slice(bi * HW, (bi + 1) * HW)
+        x1b = ops.gemm(a1[sl], b1, residual=res1[sl], gn_stats=True)
+        x2b = ops.gemm(a2[sl], b2, gn_stats=True) if C2 else None
+        if getattr(x1b, "gn_stats", None) is None or (C2 and getattr(x2b, "gn_stats", None) is None):
+            continue                                      # the small problem went to a kernel without the statistics epilogue
+        yb, stb = ops.groupnorm(x1b, x2b, 1, HW, G, eps, gamma, beta, silu)
+        assert torch.equal(yb, y[sl]) and torch.equal(stb[0], st[bi])
+
+
 @pytest.mark.parametrize("M,C", [(1000, 320), (333, 1280), (64, 768)])
 def test_layernorm(ops, dev, M, C):
     x = rnd(M, C, dev=dev, seed=1) * 3 + 1
