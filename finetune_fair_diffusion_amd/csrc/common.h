@@ -12,11 +12,13 @@ typedef __bf16 f16;
 #define FD_MFMA_16x16x32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
 #define FD_MFMA_32x32x16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
 #define FD_WD_NAME "bf16"
+#define FD_DOT2(a, b, c) __builtin_amdgcn_fdot2_f32_bf16(a, b, c, false)     // v_dot2c_f32_bf16: c + a.x * b.x + a.y * b.y, fp32 accumulate
 #else
 typedef _Float16 f16;
 #define FD_MFMA_16x16x32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0)
 #define FD_MFMA_32x32x16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
 #define FD_WD_NAME "fp16"
+#define FD_DOT2(a, b, c) __builtin_amdgcn_fdot2(a, b, c, false)              // v_dot2c_f32_f16
 #endif
 typedef f16 f16x2 __attribute__((ext_vector_type(2)));
 typedef f16 f16x4 __attribute__((ext_vector_type(4)));

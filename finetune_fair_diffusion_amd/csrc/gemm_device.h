@@ -117,15 +117,18 @@ __device__ __forceinline__ void gemm_epilogue_lds(const fd_gemm_desc& p, f32x4 (
     // p.act plus the always-on alpha / row-bias arithmetic made short-K GEMMs VALU-bound here: 149 -> 100 us of epilogue on FF1)
     const bool plain = (p.act == FD_ACT_NONE) && !RB && p.alpha == 1.f && !FD_DBG_IS(p, 5);
     // GroupNorm statistics of the stored tile (fd_gemm_desc.gn_stats), in CANONICAL chunks of 32 rows: whatever kernel and tile produced C, the
-    // sums of rows [32 c, 32 c + 32) x 10-channel unit are formed by the same procedure -- lane (cr, column chunk) adds its 8 columns over the rows
-    // cr, cr + 6, ... of the chunk, then lane u < 8 adds the 10 columns of unit u, columns ascending, row lanes ascending -- so a sample's statistics
-    // do not depend on the batch it is computed in nor on the tile policy (the CFG-pair prefix evaluates N samples where the duplicated batch has 2N).
+    // sums of rows [32 c, 32 c + 32) x 10-channel unit are formed by the same procedure -- lane (cr, column chunk) accumulates the four column PAIRS
+    // of its 8 columns over the rows cr, cr + 6, ... of the chunk (v_dot2c: two 16-bit values per fp32 accumulate, no conversions -- three VALU
+    // operations per element made the 16-wave short-K kernels 18 % slower, 29 -> 35 us at 65536x320x320), then pair totals over the six row lanes,
+    // then lane u < 8 adds the five pairs of unit u -- so a sample's statistics do not depend on the batch it is computed in nor on the tile
+    // policy (the CFG-pair prefix evaluates N samples where the duplicated batch has 2N).
     // (WSTATS kernels are separate instantiations -- template code 3 / 4 of gemm_big_kernel, 2 / 3 of gemm_pp_kernel: compiled into the plain ones the
     // extra live registers pushed the 16-wave 256 x 320 kernel, capped at 128, into scratch)
-    static_assert(!WSTATS || (WTN == 80 && WTMC % 32 == 0 && 32 * LDW * 2 >= 64 * 16 * 4), "statistics epilogue: 80-column wave tiles, passes of whole 32-row chunks");
+    static_assert(!WSTATS || (WTN == 80 && WTMC % 32 == 0 && 32 * LDW * 2 >= (64 * 8 + WTN) * 4), "statistics epilogue: 80-column wave tiles, passes of whole 32-row chunks");
     constexpr int SUB = WSTATS ? WTMC / 32 : 1;
     float* const gst = WSTATS ? p.gn_stats : nullptr;
-    float s0[SUB][8], s1[SUB][8];
+    float s0[SUB][4], s1[SUB][4];
+    const f16x2 ones = {(f16)1.f, (f16)1.f};
 #pragma unroll
     for (int c0 = 0; c0 < TM; c0 += TMC) {
         if (plain) {
@@ -190,7 +193,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const fd_gemm_desc& p, f32x4 (
 #pragma unroll
             for (int sub = 0; sub < SUB; ++sub) {
 #pragma unroll
-                for (int k = 0; k < 8; ++k) s0[sub][k] = s1[sub][k] = 0.f;
+                for (int k = 0; k < 4; ++k) s0[sub][k] = s1[sub][k] = 0.f;
 #pragma unroll
                 for (int r0 = 0; r0 < 32; r0 += RPI) {
                     const int row = sub * 32 + r0 + cr;
@@ -206,10 +209,10 @@ __device__ __forceinline__ void gemm_epilogue_lds(const fd_gemm_desc& p, f32x4 (
                         }
                         *(f16x8*)((f16*)p.C + zC + (int64_t)m * p.ldc + n) = v;
 #pragma unroll
-                        for (int k = 0; k < 8; ++k) {
-                            const float x = (float)v[k];
-                            s0[sub][k] += x;
-                            s1[sub][k] = __builtin_fmaf(x, x, s1[sub][k]);
+                        for (int k = 0; k < 4; ++k) {
+                            const f16x2 pr = {v[2 * k], v[2 * k + 1]};
+                            s0[sub][k] = FD_DOT2(pr, ones, s0[sub][k]);
+                            s1[sub][k] = FD_DOT2(pr, pr, s1[sub][k]);
                         }
                     }
                 }
@@ -220,27 +223,37 @@ __device__ __forceinline__ void gemm_epilogue_lds(const fd_gemm_desc& p, f32x4 (
             __builtin_amdgcn_wave_barrier();
         }
         if (WSTATS && gst) {
-            float* red = (float*)wave_lds;          // 64 lanes x 16 floats: inside the first 32 staging rows
+            float* red = (float*)wave_lds;          // 64 lanes x 8 floats (+ 40 pair totals x 2): inside the first 32 staging rows
 #pragma unroll
             for (int sub = 0; sub < SUB; ++sub) {
                 if (cr < RPI) {
-                    *(f32x4*)(red + lane * 16) = (f32x4){s0[sub][0], s0[sub][1], s0[sub][2], s0[sub][3]};
-                    *(f32x4*)(red + lane * 16 + 4) = (f32x4){s0[sub][4], s0[sub][5], s0[sub][6], s0[sub][7]};
-                    *(f32x4*)(red + lane * 16 + 8) = (f32x4){s1[sub][0], s1[sub][1], s1[sub][2], s1[sub][3]};
-                    *(f32x4*)(red + lane * 16 + 12) = (f32x4){s1[sub][4], s1[sub][5], s1[sub][6], s1[sub][7]};
+                    *(f32x4*)(red + lane * 8) = (f32x4){s0[sub][0], s0[sub][1], s0[sub][2], s0[sub][3]};
+                    *(f32x4*)(red + lane * 8 + 4) = (f32x4){s1[sub][0], s1[sub][1], s1[sub][2], s1[sub][3]};
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+                // stage 1, lanes 0..39: totals of column pair ``lane`` over the RPI row lanes, ascending; stage 2, lane u < 8: the five pairs of unit u
+                float* pairsum = red + 64 * 8;          // [40][2]
+                if (lane < WTN / 2) {
+                    const int ch = lane >> 2, j = lane & 3;
+                    float t0 = 0.f, t1 = 0.f;
+#pragma unroll
+                    for (int r = 0; r < RPI; ++r) {
+                        t0 += red[(r * CPR + ch) * 8 + j];
+                        t1 += red[(r * CPR + ch) * 8 + 4 + j];
+                    }
+                    *(float2*)(pairsum + lane * 2) = make_float2(t0, t1);
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_wave_barrier();
                 const int mrow = mbase + c0 * 16 + sub * 32;
                 if (lane < WTN / 10 && mrow < p.M && nbase < p.N) {
                     float t0 = 0.f, t1 = 0.f;
-                    for (int c = lane * 10; c < lane * 10 + 10; ++c) {
-                        const int ch = c >> 3, j = c & 7;
 #pragma unroll
-                        for (int r = 0; r < RPI; ++r) {
-                            t0 += red[(r * CPR + ch) * 16 + j];
-                            t1 += red[(r * CPR + ch) * 16 + 8 + j];
-                        }
+                    for (int c = 0; c < 5; ++c) {
+                        const float2 v = *(const float2*)(pairsum + (lane * 5 + c) * 2);
+                        t0 += v.x;
+                        t1 += v.y;
                     }
                     const int64_t slot = (int64_t)(mrow >> 5) * (p.N / 10) + nbase / 10 + lane;
                     *(float2*)(gst + slot * 2) = make_float2(t0, t1);
