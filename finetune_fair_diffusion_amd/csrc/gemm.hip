@@ -773,50 +773,63 @@ extern "C" int fd_gemm_tile(const fd_gemm_desc* dp) {
     return 64064;
 }
 
+// ONE dispatch decision shared by fd_gemm, fd_gemm_kernel_name and fd_gemm_stats_rows (the launcher and the name function had drifted
+// apart once): which kernel family takes the problem, with which tile / wave grid / split-K factor, and whether that kernel can write gn_stats.
+enum { GK_SKINNY, GK_GLDS, GK_BIG, GK_PP, GK_PPS };
+struct GemmPlan { int kind, bm, bn, wgm, wgn, nsplit, cv; bool stats_ok; };
+static GemmPlan gemm_plan(const fd_gemm_desc& d /* K2 already normalised */) {
+    GemmPlan g = {};
+    const int sel = fd_gemm_tile(&d), t = sel % 1000000;
+    static const bool w16 = bench_env("FD_GEMM_W8") == nullptr;   // 16-wave variants by default (A/B switch for measurement)
+    g.nsplit = sel >= 1000000 ? sel / 1000000 : 1;
+    g.bm = t / 1000; g.bn = t % 1000;
+    g.cv = d.conv ? (d.conv_mode >= FD_CONV_UP2P ? 2 : 1) : 0;
+    // order: persistent streaming kernel, ping-pong kernel (split-K slices too under policy bit 64), then the lockstep tiles
+    if (pps_takes(d, sel)) g.kind = GK_PPS;
+    else if (const int bm = pp_takes(d, sel)) { g.kind = GK_PP; g.bm = bm; g.bn = 320; g.wgm = 2; g.wgn = 4; }
+    else if (g.nsplit > 1) { g.kind = GK_BIG; g.wgm = 4; g.wgn = t == 128320 ? 4 : 2; }
+    else switch (t) {
+        case 256320: g.kind = GK_BIG; g.wgm = (w16 && !d.conv) ? 4 : 2; g.wgn = 4; break;
+        case 128320: g.kind = GK_BIG; g.wgm = w16 ? 4 : 2; g.wgn = 4; break;
+        case 128160: g.kind = GK_BIG; g.wgm = 4; g.wgn = 2; break;
+        case 256256: g.kind = GK_BIG; g.wgm = 2; g.wgn = 4; break;
+        case 512128: g.kind = GK_BIG; g.wgm = 8; g.wgn = 2; break;
+        case 256128: g.kind = GK_BIG; g.wgm = 4; g.wgn = 2; break;
+        default: g.kind = g.bm == 16 ? GK_SKINNY : GK_GLDS; break;
+    }
+    // the statistics epilogue lives in gemm_epilogue_lds<..., true>: 80-column wave tiles, fp16 LDS-staged epilogue, no split-K (its epilogue runs in
+    // splitk_reduce_kernel), not the phase-major output of the up-sampling pair (a chunk there is not a run of pixels of one image)
+    const bool lds_epi = d.out_dtype == FD_OUT_F16 && (d.N & 7) == 0 && (d.ldc & 7) == 0 && (!d.residual || (d.ldr & 7) == 0) &&
+                         (!d.rowbias || (d.ld_rowbias & 3) == 0);
+    g.stats_ok = (g.kind == GK_PP || (g.kind == GK_BIG && g.bn / g.wgn == 80)) && g.nsplit == 1 && g.cv < 2 && lds_epi && d.act != FD_ACT_GEGLU &&
+                 d.batch <= 1 && (d.N % 80) == 0;
+    return g;
+}
+
 // Name of the kernel fd_gemm launches for this problem, spelled as rocprofv3 --kernel-trace prints it (template arguments included), so
 // that bench.py's live HIP-event roofline and the committed profiles/ summaries key the same thing.  Split-K launches add a
 // ``splitk_reduce_kernel`` that the bench's events bracket together with the GEMM.
 extern "C" int fd_gemm_kernel_name(const fd_gemm_desc* dp, char* buf, int n) {
     fd_gemm_desc d = *dp;
     if (d.K2 <= 0 || !d.A2) d.K2 = 0;
-    const int sel = fd_gemm_tile(&d);
-    const int t = sel % 1000000;
-    const bool w16 = bench_env("FD_GEMM_W8") == nullptr;
-    const int cv = d.conv ? (d.conv_mode >= FD_CONV_UP2P ? 2 : 1) : 0;
-    int bm = t / 1000, bn = t % 1000, wgm = 0, wgn = 0;
-    const char* fam = "gemm_big_kernel";
-    if (sel >= 1000000) { wgm = 4; wgn = t == 128320 ? 4 : 2; }
-    else switch (t) {
-        case 256320: wgm = (w16 && !d.conv) ? 4 : 2; wgn = 4; break;
-        case 128320: wgm = w16 ? 4 : 2; wgn = 4; break;
-        case 128160: wgm = 4; wgn = 2; break;
-        case 256256: wgm = 2; wgn = 4; break;
-        case 512128: wgm = 8; wgn = 2; break;
-        case 256128: wgm = 4; wgn = 2; break;
-        default: fam = bm == 16 ? "gemm_skinny_kernel" : "gemm_glds_kernel"; break;
+    const GemmPlan g = gemm_plan(d);
+    const bool st = d.gn_stats && g.stats_ok;
+    switch (g.kind) {
+        case GK_PPS: snprintf(buf, n, "gemm_pps_kernel<%d>", d.act == FD_ACT_GEGLU ? 1 : 0); break;
+        case GK_PP: snprintf(buf, n, "gemm_pp_kernel<%d, %d, %s>", g.bm, (d.conv ? 1 : 0) + (st ? 2 : 0), (pp_mode() & 4) ? "true" : "false"); break;
+        case GK_BIG: snprintf(buf, n, "gemm_big_kernel<%d, %d, %d, %d, %d>", g.bm, g.bn, g.wgm, g.wgn, st ? g.cv + 3 : g.cv); break;
+        case GK_SKINNY: snprintf(buf, n, "gemm_skinny_kernel<%d, %d, 1>", g.bn / 16, d.K >= 1280 ? 4 : d.K >= 640 ? 2 : 1); break;
+        default: snprintf(buf, n, "gemm_glds_kernel<%d, %d, %s>", g.bm, g.bn, d.conv ? "true" : "false"); break;
     }
-    if (pps_takes(d, sel)) snprintf(buf, n, "gemm_pps_kernel<%d>", d.act == FD_ACT_GEGLU ? 1 : 0);
-    else if (pp_takes(d, sel)) snprintf(buf, n, "gemm_pp_kernel<%d, %d, %s>", pp_takes(d, sel), (d.conv ? 1 : 0) + ((d.gn_stats && sel < 1000000) ? 2 : 0),
-                                        (pp_mode() & 4) ? "true" : "false");
-    else if (wgm) snprintf(buf, n, "%s<%d, %d, %d, %d, %d>", fam, bm, bn, wgm, wgn, (d.gn_stats && cv < 2 && sel < 1000000) ? cv + 3 : cv);
-    else if (bm == 16) snprintf(buf, n, "%s<%d, %d, 1>", fam, bn / 16, d.K >= 1280 ? 4 : d.K >= 640 ? 2 : 1);
-    else snprintf(buf, n, "%s<%d, %d, %s>", fam, bm, bn, d.conv ? "true" : "false");
-    return sel / 1000000;   // split-K factor (0 or 1 = none)
+    return g.nsplit > 1 ? g.nsplit : 0;   // split-K factor (0 = none)
 }
 
 // Rows per chunk of fd_gemm_desc.gn_stats: 32 for every kernel that has the statistics epilogue (gemm_epilogue_lds<..., true> forms the sums in
-// canonical 32-row chunks whatever its tile), 0 when the kernel fd_gemm would launch has none.  Same order of tests as fd_gemm / fd_gemm_kernel_name.
+// canonical 32-row chunks whatever its tile), 0 when the kernel fd_gemm would launch has none.
 extern "C" int fd_gemm_stats_rows(const fd_gemm_desc* dp) {
     fd_gemm_desc d = *dp;
     if (d.K2 <= 0 || !d.A2) d.K2 = 0;
-    const bool lds_epi = d.out_dtype == FD_OUT_F16 && (d.N & 7) == 0 && (d.ldc & 7) == 0 && (!d.residual || (d.ldr & 7) == 0) &&
-                         (!d.rowbias || (d.ld_rowbias & 3) == 0);
-    if (!lds_epi || d.act == FD_ACT_GEGLU || d.batch > 1 || (d.N % 80) != 0) return 0;
-    if (d.conv && d.conv_mode >= FD_CONV_UP2P) return 0;        // phase-major output rows: a chunk is not a run of pixels of one image
-    const int sel = fd_gemm_tile(&d);
-    if (sel >= 1000000 || pps_takes(d, sel)) return 0;          // split-K: the epilogue runs in splitk_reduce_kernel
-    if (pp_takes(d, sel)) return 32;
-    return (sel == 256320 || sel == 128320 || sel == 128160) ? 32 : 0;
+    return gemm_plan(d).stats_ok ? 32 : 0;
 }
 
 extern "C" int fd_gemm(const fd_gemm_desc* dp, void* stream) {
@@ -847,44 +860,41 @@ extern "C" int fd_gemm(const fd_gemm_desc* dp, void* stream) {
         FD_REQUIRE(!d.conv && d.batch <= 1 && d.out_dtype == FD_OUT_F16 && !d.rowbias && d.alpha == 1.f && (d.N & 15) == 0 &&
                        (d.ldc & 7) == 0 && d.K2 == 0 && (!d.residual || (d.ldr & 7) == 0),
                    "fd_gemm(GEGLU): needs a plain fp16 GEMM with N %% 16 == 0 and ldc, ldr %% 8 == 0");
-    if (d.gn_stats) FD_REQUIRE(fd_gemm_stats_rows(&d) > 0, "fd_gemm: gn_stats set but the kernel for M=%d N=%d K=%d has no statistics epilogue "
-                               "(ask fd_gemm_stats_rows first)", d.M, d.N, d.K);
     hipStream_t s = (hipStream_t)stream;
-    static const bool w16 = bench_env("FD_GEMM_W8") == nullptr;   // 16-wave variants by default (A/B switch for measurement)
-    const int sel = fd_gemm_tile(&d);
-    if (d.conv && d.conv_mode >= FD_CONV_UP2P) {
-        const int t = sel % 1000000;
-        FD_REQUIRE(t == 256320 || t == 128320 || t == 128160 || t == 256256 || t == 512128 || t == 256128,
-                   "fd_gemm(conv up2 phases): shape not taken by the big-tile kernels (Cin %% 64, enough tiles); use FD_CONV_UP2");
-    }
-    // the same order of tests as fd_gemm_kernel_name: persistent streaming kernel, ping-pong kernel (split-K slices too under policy bit 64),
-    // then the lockstep big tiles
-    if (pps_takes(d, sel)) {
-        static const int pps_wg = bench_env("FD_GEMM_PPS_WG") ? atoi(bench_env("FD_GEMM_PPS_WG")) : 256;
-        return fd_gemm_launch_pps(d, s, pps_wg);
-    }
-    if (const int bm = pp_takes(d, sel)) {
-        const int nsplit = sel >= 1000000 ? sel / 1000000 : 1;
-        const int rc = fd_gemm_launch_pp(d, s, (pp_mode() & 4) != 0, bm, nsplit);
-        if (rc != 0 || nsplit == 1) return rc;
-        return launch_splitk_reduce(d, s, nsplit);
-    }
-    if (sel >= 1000000) {
-        return (sel % 1000000 == 128320) ? launch_big<128, 320, 4, 4>(d, s, sel / 1000000) : launch_big<128, 160, 4, 2>(d, s, sel / 1000000);
-    }
-    switch (sel) {
-        case 16016: return launch_skinny<1>(d, s);
-        case 16032: return launch_skinny<2>(d, s);
-        case 16048: return launch_skinny<3>(d, s);
-        case 16064: return launch_skinny<4>(d, s);
-        case 256320: return (w16 && !d.conv) ? launch_big<256, 320, 4, 4>(d, s) : launch_big<256, 320, 2, 4>(d, s);
-        case 128320: return w16 ? launch_big<128, 320, 4, 4>(d, s) : launch_big<128, 320, 2, 4>(d, s);
-        case 128160: return launch_big<128, 160, 4, 2>(d, s);
-        case 256256: return launch_big<256, 256, 2, 4>(d, s);
-        case 512128: return launch_big<512, 128, 8, 2>(d, s);
-        case 256128: return launch_big<256, 128, 4, 2>(d, s);
-        case 128128: return launch<128, 128>(d, s);
-        case 128064: return launch<128, 64>(d, s);
-        default: return launch<64, 64>(d, s);
+    const GemmPlan g = gemm_plan(d);
+    if (d.gn_stats) FD_REQUIRE(g.stats_ok, "fd_gemm: gn_stats set but the kernel for M=%d N=%d K=%d has no statistics epilogue (ask fd_gemm_stats_rows first)",
+                               d.M, d.N, d.K);
+    if (d.conv && d.conv_mode >= FD_CONV_UP2P)
+        FD_REQUIRE(g.kind == GK_BIG, "fd_gemm(conv up2 phases): shape not taken by the big-tile kernels (Cin %% 64, enough tiles); use FD_CONV_UP2");
+    switch (g.kind) {
+        case GK_PPS: {
+            static const int pps_wg = bench_env("FD_GEMM_PPS_WG") ? atoi(bench_env("FD_GEMM_PPS_WG")) : 256;
+            return fd_gemm_launch_pps(d, s, pps_wg);
+        }
+        case GK_PP: {
+            const int rc = fd_gemm_launch_pp(d, s, (pp_mode() & 4) != 0, g.bm, g.nsplit);
+            if (rc != 0 || g.nsplit == 1) return rc;
+            return launch_splitk_reduce(d, s, g.nsplit);
+        }
+        case GK_SKINNY:
+            switch (g.bn) {
+                case 16: return launch_skinny<1>(d, s);
+                case 32: return launch_skinny<2>(d, s);
+                case 48: return launch_skinny<3>(d, s);
+                default: return launch_skinny<4>(d, s);
+            }
+        case GK_BIG:
+            switch (g.bm * 1000 + g.bn) {
+                case 256320: return g.wgm == 4 ? launch_big<256, 320, 4, 4>(d, s, g.nsplit) : launch_big<256, 320, 2, 4>(d, s, g.nsplit);
+                case 128320: return g.wgm == 4 ? launch_big<128, 320, 4, 4>(d, s, g.nsplit) : launch_big<128, 320, 2, 4>(d, s, g.nsplit);
+                case 128160: return launch_big<128, 160, 4, 2>(d, s, g.nsplit);
+                case 256256: return launch_big<256, 256, 2, 4>(d, s, g.nsplit);
+                case 512128: return launch_big<512, 128, 8, 2>(d, s, g.nsplit);
+                default: return launch_big<256, 128, 4, 2>(d, s, g.nsplit);
+            }
+        default:
+            if (g.bm == 128 && g.bn == 128) return launch<128, 128>(d, s);
+            if (g.bm == 128 && g.bn == 64) return launch<128, 64>(d, s);
+            return launch<64, 64>(d, s);
     }
 }

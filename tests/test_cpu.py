@@ -221,6 +221,47 @@ def test_oracle_invariants_zero_lora_and_cfg():
 
 
 # ------------------------------------------------------------------ C-ABI library: loads and exports every declared symbol
+def test_gemm_dispatch_name_statistics_rows_and_launcher_agree():
+    """fd_gemm, fd_gemm_kernel_name and fd_gemm_stats_rows share one plan (launcher and name function had drifted apart).  Host-only
+    functions: the kernel each of the step's shape families gets, its split-K factor, and which of them can write GroupNorm statistics."""
+    from finetune_fair_diffusion_amd import lib
+    L = lib.load()
+
+    def plan(M, N, K, conv=None, stats=False, **kw):
+        d = lib.GemmDesc()
+        d.M, d.N, d.K, d.batch, d.ldc, d.lda, d.ldb, d.alpha = M, N, K, 1, N, K, K, 1.0
+        d.workspace, d.workspace_bytes = 1 << 20, 64 << 20          # a non-null workspace enables split-K in the policy (never dereferenced here)
+        if conv is not None:
+            B, H, Cin, mode = conv
+            d.conv, d.conv_mode, d.Bn, d.H, d.W, d.Cin = 1, mode, B, H, H, Cin
+            d.Ho = d.Wo = H // 2 if mode == 1 else (2 * H if mode in (2, 4) else H)
+        for k, v in kw.items():
+            setattr(d, k, v)
+        if stats:
+            d.gn_stats = 1 << 20
+        buf = ctypes.create_string_buffer(128)
+        split = L.fd_gemm_kernel_name(ctypes.byref(d), buf, 128)
+        return buf.value.decode(), split, L.fd_gemm_stats_rows(ctypes.byref(d))
+
+    assert plan(65536, 320, 320) == ("gemm_big_kernel<256, 320, 4, 4, 0>", 0, 32)
+    assert plan(65536, 320, 320, stats=True) == ("gemm_big_kernel<256, 320, 4, 4, 3>", 0, 32)
+    assert plan(4096, 1280, 1280, stats=True) == ("gemm_big_kernel<128, 320, 4, 4, 3>", 0, 32)
+    assert plan(65536, 2560, 320, act=7) == ("gemm_pp_kernel<256, 0, true>", 0, 0)                           # FF1 / GEGLU: ping-pong, no statistics
+    assert plan(65536, 320, 2880, conv=(16, 64, 320, 0), stats=True) == ("gemm_pp_kernel<256, 3, true>", 0, 32)
+    assert plan(4096, 1280, 11520, conv=(16, 16, 1280, 0)) == ("gemm_pp_kernel<128, 1, true>", 0, 32)
+    assert plan(16384, 320, 2880, conv=(16, 64, 320, 1), stats=True) == ("gemm_big_kernel<128, 320, 4, 4, 4>", 0, 32)     # stride 2: lockstep gather
+    name, split, rows = plan(1024, 1280, 11520, conv=(16, 8, 1280, 0))                                        # 8^2 level: split-K, epilogue in the reduce kernel
+    assert name == "gemm_big_kernel<128, 320, 4, 4, 1>" and split == 8 and rows == 0
+    assert plan(65536, 8, 320)[0].startswith("gemm_skinny_kernel<1, 1") and plan(65536, 8, 320)[2] == 0
+    assert plan(51300, 512, 1096) == ("gemm_big_kernel<256, 256, 2, 4, 0>", 0, 0)                             # 64-column wave tiles: no statistics epilogue
+    assert plan(300, 320, 320) == ("gemm_glds_kernel<64, 64, false>", 0, 0)
+    # fd_gemm refuses gn_stats where the plan has no statistics epilogue (validated on the host, before any launch)
+    d = lib.GemmDesc()
+    d.A = d.B = d.C = d.gn_stats = 1 << 20
+    d.M, d.N, d.K, d.batch, d.ldc, d.lda, d.ldb = 300, 320, 320, 1, 320, 320, 320
+    assert L.fd_gemm(ctypes.byref(d), None) == -1 and b"no statistics epilogue" in L.fd_last_error()
+
+
 def test_library_exports_every_header_symbol():
     from finetune_fair_diffusion_amd import lib
     protos = lib.parse_header()
