@@ -190,13 +190,14 @@ class ParamBank:
 
 
 # ------------------------------------------------------------------------------------------ LoRA linear
-def lora_linear_fwd(x, lin, lora, t=None, residual=None, act="none", rowbias=None, rows_per_batch=0):
-    """y = x W^T (+ (x down^T) up^T) + b (+ residual); returns (y, t) with t = x down^T [M, rp]."""
+def lora_linear_fwd(x, lin, lora, t=None, residual=None, act="none", rowbias=None, rows_per_batch=0, ln=None):
+    """y = x W^T (+ (x down^T) up^T) + b (+ residual); returns (y, t) with t = x down^T [M, rp].
+    ``ln`` = (gamma, beta, eps): y is the triple (y, LayerNorm(y), per-row statistics) of ``ops.gemm(..., ln=...)``."""
     if lora is None:
-        return ops.gemm(x, lin.w, bias=lin.bias, residual=residual, act=act), None
+        return ops.gemm(x, lin.w, bias=lin.bias, residual=residual, act=act, ln=ln), None
     if t is None:
         t = ops.gemm(x, lora.down16)
-    y = ops.gemm(x, lin.w, a2=t, b2=lora.up16, bias=lin.bias, residual=residual, act=act)
+    y = ops.gemm(x, lin.w, a2=t, b2=lora.up16, bias=lin.bias, residual=residual, act=act, ln=ln)
     return y, t
 
 

@@ -37,6 +37,8 @@ class GemmDesc(ctypes.Structure):
         ("W", ctypes.c_int32), ("Cin", ctypes.c_int32), ("Ho", ctypes.c_int32), ("Wo", ctypes.c_int32),
         ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_int64),
         ("gn_stats", ctypes.c_void_p),
+        ("ln_out", ctypes.c_void_p), ("ld_ln", ctypes.c_int64), ("ln_gamma", ctypes.c_void_p), ("ln_beta", ctypes.c_void_p),
+        ("ln_stats", ctypes.c_void_p), ("ln_eps", ctypes.c_float),
     ]
 
 

@@ -86,11 +86,20 @@ TIMER = None
 
 
 GN_STATS = os.environ.get("FD_NO_GN_STATS") is None      # A/B switch: GroupNorm statistics from the producer's epilogue (fd_gemm_desc.gn_stats)
+LN_EPILOGUE = os.environ.get("FD_NO_LN_EPILOGUE") is None   # A/B switch: LayerNorm as a second output of the producing GEMM (fd_gemm_desc.ln_out)
 
 
-def _gemm_call(d, conv, out=None, gn_stats=False):
+def _gemm_call(d, conv, out=None, gn_stats=False, ln=None):
+    """``ln`` = (gamma, beta, eps): returns (normalised copy, per-row (mean, rstd)) when the kernel fd_gemm picks can write the LayerNorm of the
+    output rows itself, else None (the caller runs fd_layernorm_fwd)."""
     ws = gemm_workspace()
     d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * 4
+    fused_ln = None
+    if ln is not None and LN_EPILOGUE and _lib.get().fd_gemm_ln_ok(ctypes.byref(d)):
+        y = torch.empty((d.M, d.N), dtype=F16, device=out.device)
+        st = torch.empty((d.M, 2), dtype=F32, device=out.device)
+        d.ln_out, d.ld_ln, d.ln_gamma, d.ln_beta, d.ln_stats, d.ln_eps = y.data_ptr(), d.N, _chk(ln[0], F32).data_ptr(), _chk(ln[1], F32).data_ptr(), st.data_ptr(), ln[2]
+        fused_ln = (y, st)
     if gn_stats and GN_STATS:
         # the kernel fd_gemm picks decides the chunk height (its wave-tile rows); 0 = no statistics epilogue for this problem.  The buffer rides on
         # the output tensor OBJECT: ``groupnorm`` finds it there, and anything that makes a new tensor of the output (cat, slicing) drops it
@@ -101,7 +110,7 @@ def _gemm_call(d, conv, out=None, gn_stats=False):
             out.gn_stats = (st, rows)
     if TIMER is None:
         _call("fd_gemm", ctypes.byref(d), _stream())
-        return
+        return fused_ln
     buf = ctypes.create_string_buffer(128)
     split = _lib.get().fd_gemm_kernel_name(ctypes.byref(d), buf, 128)
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -117,6 +126,7 @@ def _gemm_call(d, conv, out=None, gn_stats=False):
     # splitk_reduce_kernel of a split launch together with its GEMM)
     TIMER.records.append((buf.value.decode(), flops, nbytes, a, b, split > 1))
     TIMER.shapes.append((d.M, d.N, d.K, d.K2, d.conv_mode if conv else -1, int(d.act), int(bool(d.residual)), split))
+    return fused_ln
 
 
 def _chk(t, dtype=F16):
@@ -126,7 +136,7 @@ def _chk(t, dtype=F16):
 
 # ----------------------------------------------------------------------------- GEMM / conv
 def gemm(a, b, *, a2=None, b2=None, bias=None, rowbias=None, rows_per_batch=0, residual=None, act="none", alpha=1.0,
-         out=None, out_dtype=F16, n=None, aux=None, gn_stats=False):
+         out=None, out_dtype=F16, n=None, aux=None, gn_stats=False, ln=None):
     """C[M,N] = act(alpha*(a.b^T + a2.b2^T) + bias + rowbias) + residual.  a:[M,K] (row stride free), b:[N,K].
     act="geglu": b / bias rows interleaved (value_c, gate_c) -> C[M, N/2] = value * gelu(gate) (see ``interleave_geglu``)."""
     M, K = a.shape
@@ -152,8 +162,15 @@ def gemm(a, b, *, a2=None, b2=None, bias=None, rowbias=None, rows_per_batch=0, r
         d.residual, d.ldr = aux.data_ptr(), N
     d.alpha, d.M, d.N, d.K = alpha, M, N, K
     d.act, d.out_dtype, d.batch = ACT[act], 1 if out.dtype == F32 else 0, 1
-    _gemm_call(d, False, out, gn_stats)
-    return out
+    if ln is None:
+        _gemm_call(d, False, out, gn_stats)
+        return out
+    # ln = (gamma, beta, eps): also return LayerNorm(out) and its per-row statistics -- from the GEMM's own epilogue where one tile holds whole rows
+    # (N == 320), from fd_layernorm_fwd otherwise
+    fused = _gemm_call(d, False, out, False, ln)
+    if fused is None:
+        fused = layernorm(out, ln[0], ln[1], ln[2], save_stats=True)
+    return out, fused[0], fused[1]
 
 
 def interleave_geglu(w, bias):

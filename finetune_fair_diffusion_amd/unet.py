@@ -149,8 +149,9 @@ class TransformerBlock:
         HW, C, h, d = H * W, self.C, self.heads, self.d
         rec = ctx is not None
         g, st = ops.groupnorm(x, None, B, HW, self.groups, 1e-6, self.norm.gamma, self.norm.beta, False)
-        h0 = ops.gemm(g, self.proj_in.w, bias=self.proj_in.bias)
-        n1, ln1 = ops.layernorm(h0, self.ln1.gamma, self.ln1.beta, 1e-5, save_stats=True)  # stats are 8 B/row: always kept
+        # the three LayerNorms ride in the epilogue of the GEMM that produces their input where its tile holds whole rows (C = 320); the statistics
+        # are 8 B per row: always kept
+        h0, n1, ln1 = ops.gemm(g, self.proj_in.w, bias=self.proj_in.bias, ln=(self.ln1.gamma, self.ln1.beta, 1e-5))
         l1 = self.lora1
         if l1 is not None:
             t1 = ops.gemm(n1, l1.down_qkv16)
@@ -166,8 +167,7 @@ class TransformerBlock:
                 o, lse = ops.attn_fwd(q, k, None, B, h, HW, HW, d, 1, need_lse=True, v=v)
             else:
                 o, lse = ops.attn_fwd(q, k, ops.transpose_btc(v, B, HW, C), B, h, HW, HW, d, 1, need_lse=True)
-        h1, to1 = lora_linear_fwd(o, self.o1, l1.out if l1 else None, residual=h0)
-        n2, ln2 = ops.layernorm(h1, self.ln2.gamma, self.ln2.beta, 1e-5, save_stats=True)
+        (h1, n2, ln2), to1 = lora_linear_fwd(o, self.o1, l1.out if l1 else None, residual=h0, ln=(self.ln2.gamma, self.ln2.beta, 1e-5))
         l2 = self.lora2
         q2, tq2 = lora_linear_fwd(n2, self.q2, l2.q if l2 else None)
         B2 = 2 * B if pair else B
@@ -175,8 +175,7 @@ class TransformerBlock:
         cr = self.cross
         kv_div = B2 // cr["Bk"]
         o2, lse2 = ops.attn_fwd(q2f, cr["K"], cr["Vt"], B2, h, HW, cr["L"], d, kv_div, need_lse=True, v=cr["V"] if cr["Vt"] is None else None)
-        h2, to2 = lora_linear_fwd(o2, self.o2, l2.out if l2 else None, residual=h1f)
-        n3, ln3 = ops.layernorm(h2, self.ln3.gamma, self.ln3.beta, 1e-5, save_stats=True)
+        (h2, n3, ln3), to2 = lora_linear_fwd(o2, self.o2, l2.out if l2 else None, residual=h1f, ln=(self.ln3.gamma, self.ln3.beta, 1e-5))
         # bit-identical to projection + fd_geglu_fwd (both halves are rounded to fp16 before the gate)
         proj = torch.empty((n3.shape[0], self.ff1_wi.shape[0]), dtype=F16, device=n3.device) if rec else None
         gg = ops.gemm(n3, self.ff1_wi, bias=self.ff1_bi, act="geglu", aux=proj)

@@ -81,11 +81,21 @@ typedef struct fd_gemm_desc {
      * procedure per chunk: they do not depend on the tile policy or the batch size; 0 = this problem's kernel cannot): size the buffer
      * ceil(M / rows) * (N / 10) * 2 floats; fd_gemm fails if gn_stats is set and the chosen kernel cannot write it. */
     float* gn_stats;
+    /* optional LayerNorm of the output row, written as a second output (NULL = none): ln_out[m, n] = (C[m, n] - mean_m) * rstd_m * ln_gamma[n] + ln_beta[n]
+     * over the N columns of the STORED row (BasicTransformerBlock.norm1 / norm2 / norm3 behind proj_in / attn1.to_out / attn2.to_out), ln_stats[m] =
+     * (mean_m, rstd_m) for fd_layernorm_bwd (may be NULL).  Only where one workgroup tile holds whole rows: ask fd_gemm_ln_ok() first. */
+    void* ln_out; int64_t ld_ln;
+    const float* ln_gamma; const float* ln_beta;
+    float* ln_stats;
+    float ln_eps;
 } fd_gemm_desc;
 int fd_gemm(const fd_gemm_desc* d, void* stream);
 /* rows per statistics chunk of ``gn_stats`` for this problem (32), or 0 when the kernel fd_gemm would launch has no statistics epilogue
  * (split-K, the 64-column wave tiles, fp32 / GEGLU outputs, N not a multiple of 80) */
 int fd_gemm_stats_rows(const fd_gemm_desc* d);
+/* 1 when the kernel fd_gemm would launch for this problem can write ``ln_out`` (dense fp16 GEMM, N == 320 == the tile width of the 16-wave lockstep
+ * kernels, bias / residual / LoRA-slab epilogue only, no split-K), else 0; fd_gemm fails if ln_out is set where this returns 0 */
+int fd_gemm_ln_ok(const fd_gemm_desc* d);
 /* tile variant fd_gemm would pick for this problem, as BM*1000+BN (128128 / 128064 / 64064) */
 int fd_gemm_tile(const fd_gemm_desc* d);
 /* name of the kernel fd_gemm launches for this problem as rocprofv3 --kernel-trace spells it (host buffer ``buf`` of ``n`` bytes);

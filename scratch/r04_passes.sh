@@ -177,5 +177,36 @@ for f in sorted(glob.glob('gpurun_out/r04p_step_*.json')):
 PY
     tail -3 gpurun_out/r04p_step_stats_1.err
     ;;
+q)  # LayerNorm as a second output of the producing GEMM (fd_gemm_desc.ln_out): kernel tests, the U-Net / step tests, isolated cost, whole-step A/B (FD_NO_LN_EPILOGUE=1)
+    timeout 600 python -m pytest tests/test_kernels_gpu.py -x -q -s -k "layernorm or gemm_big or statistics" > gpurun_out/r04q_kernel_tests.log 2>&1; grep -i "LayerNorm\|saved\|passed\|failed\|Error" gpurun_out/r04q_kernel_tests.log | tail -30
+    timeout 900 python -m pytest tests/test_engine_gpu.py -x -q -k "unet or full_step or pair" > gpurun_out/r04q_engine_tests.log 2>&1; tail -5 gpurun_out/r04q_engine_tests.log
+    timeout 200 python scratch/mb_ln_epilogue.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r04q_mb_ln_epilogue.txt
+    for i in 1 2; do
+      $B --steps 6 --warmup 3 > gpurun_out/r04q_step_ln_$i.json 2> gpurun_out/r04q_step_ln_$i.err
+      FD_NO_LN_EPILOGUE=1 $B --steps 6 --warmup 3 > gpurun_out/r04q_step_noln_$i.json 2>/dev/null
+    done
+    python - <<'PY'
+import json,glob
+for f in sorted(glob.glob('gpurun_out/r04q_step_*.json')):
+    try:
+        d=json.loads(open(f).read().strip().splitlines()[-1]); print(f, round(d['value'],3), round(d['ms_per_step'],1), d['config']['phase_ms'])
+    except Exception as e: print(f, 'ERR', e)
+PY
+    tail -3 gpurun_out/r04q_step_ln_1.err
+    ;;
+r)  # LayerNorm epilogue, second form (values back into the staging slot, segmented shuffle): whole-step A/B only
+    B2="python bench.py --no_cpu_baseline --no_roofline"
+    for i in 1 2 3; do
+      $B2 --steps 6 --warmup 3 > gpurun_out/r04r_step_ln_$i.json 2> gpurun_out/r04r_step_ln_$i.err
+      FD_NO_LN_EPILOGUE=1 $B2 --steps 6 --warmup 3 > gpurun_out/r04r_step_noln_$i.json 2>/dev/null
+    done
+    python - <<'PY'
+import json,glob
+for f in sorted(glob.glob('gpurun_out/r04r_step_*.json')):
+    try:
+        d=json.loads(open(f).read().strip().splitlines()[-1]); print(f, round(d['value'],3), round(d['ms_per_step'],1), d['config']['phase_ms'])
+    except Exception as e: print(f, 'ERR', e)
+PY
+    ;;
 *) echo "unknown pass $1";;
 esac
