@@ -255,6 +255,20 @@ def test_gemm_dispatch_name_statistics_rows_and_launcher_agree():
     assert plan(65536, 8, 320)[0].startswith("gemm_skinny_kernel<1, 1") and plan(65536, 8, 320)[2] == 0
     assert plan(51300, 512, 1096) == ("gemm_big_kernel<256, 256, 2, 4, 0>", 0, 0)                             # 64-column wave tiles: no statistics epilogue
     assert plan(300, 320, 320) == ("gemm_glds_kernel<64, 64, false>", 0, 0)
+    # LayerNorm second output: only where a 16-wave 320-wide tile holds whole rows
+    def ln_plan(M, N, K, **kw):
+        d = lib.GemmDesc()
+        d.M, d.N, d.K, d.batch, d.ldc, d.lda, d.ldb, d.alpha = M, N, K, 1, N, K, K, 1.0
+        d.workspace, d.workspace_bytes, d.ln_out = 1 << 20, 64 << 20, 1 << 20
+        for k, v in kw.items():
+            setattr(d, k, v)
+        buf = ctypes.create_string_buffer(128)
+        L.fd_gemm_kernel_name(ctypes.byref(d), buf, 128)
+        return buf.value.decode(), L.fd_gemm_ln_ok(ctypes.byref(d))
+    assert ln_plan(65536, 320, 320) == ("gemm_big_kernel<256, 320, 4, 4, 5>", 1)
+    assert ln_plan(12800, 320, 1280) == ("gemm_big_kernel<128, 320, 4, 4, 5>", 1)
+    assert ln_plan(65536, 640, 320) == ("gemm_big_kernel<256, 320, 4, 4, 0>", 0)          # a row spans two tiles
+    assert ln_plan(65536, 320, 320, act=1)[1] == 0 and ln_plan(4096, 320, 320)[1] == 0    # activation in the epilogue / too few tiles for the 320-wide kernels
     # fd_gemm refuses gn_stats where the plan has no statistics epilogue (validated on the host, before any launch)
     d = lib.GemmDesc()
     d.A = d.B = d.C = d.gn_stats = 1 << 20
