@@ -382,6 +382,25 @@ __global__ __launch_bounds__(256, QB == 1 ? fwd_waves(D) : (D <= 64 ? 2 : 1)) vo
     }
 }
 
+// ---- "-D through the matrix pipe" (round 4).  dS = P o (dP - D), D = rowsum(dO o O): where the contraction over d is padded (d = 40 -> 48: eight spare
+// k-slots behind column 39) the subtraction rides in the dP = dO . V^T MFMAs: three slots of the dO operand carry -D / 256 split into three 16-bit
+// pieces (hi + mid + lo: 33 / 24 significant bits in fp16 / bf16; the 1 / 256 keeps |D| up to 1.6e7 inside the fp16 range under loss scaling), the
+// same three slots of the V operand carry 256.0 -- products and accumulation are exact in the fp32 accumulator, so dP' = dP - D comes out of the
+// accumulation itself and the VALU-bound score loop loses one of its ~7.5 issue slots per element (and the dK/dV kernel its per-element LDS read of D).
+template <int D> constexpr bool dfold() {
+#ifdef FD_ATTN_NO_DFOLD
+    return false;
+#else
+    return D % 16 == 8;      // lane-half 1 of the last k-step holds columns D .. D + 7: all padding
+#endif
+}
+__device__ __forceinline__ void split3(float x, f16& h0, f16& h1, f16& h2) {
+    h0 = (f16)x;
+    const float r1 = x - (float)h0;
+    h1 = (f16)r1;
+    h2 = (f16)(r1 - (float)h1);
+}
+
 // ================================================================================== D = rowsum(dO * O)
 __global__ void attn_bwd_prep_kernel(const f16* O, const f16* dO, float* Dd, int H, int T, int d, int64_t n) {
     // one thread per (b, t, h)
@@ -457,6 +476,12 @@ __global__ __launch_bounds__(256, dq_waves(D)) void attn_bwd_dq_kernel(const f16
         dd = tvalid ? Dd[((int64_t)b * H + h) * Tq + t] : 0.f;
     }
     const float sl2 = scale * LOG2E;
+    constexpr bool DFOLD = dfold<D>();
+    if (DFOLD && g == 1) {                           // this lane's columns D .. D + 2 of its query's dO row
+        f16 h0, h1, h2;
+        split3(-dd * (1.f / 256.f), h0, h1, h2);
+        gf[NKS - 1][0] = h0; gf[NKS - 1][1] = h1; gf[NKS - 1][2] = h2;
+    }
     f32x16 acc[NDV];
 #pragma unroll
     for (int i = 0; i < NDV; ++i) acc[i] = zero16();
@@ -470,6 +495,10 @@ __global__ __launch_bounds__(256, dq_waves(D)) void attn_bwd_dq_kernel(const f16
     zero_row_pad<D, DKP>(Ks);
     zero_row_pad<D, DKP>(Vs);
     if (!KTR) zero_col_pad<D, DV>(Kts);
+    if (DFOLD) {
+        __syncthreads();                               // behind zero_row_pad's writes of the same columns
+        for (int c = threadIdx.x; c < 64 * 3; c += 256) Vs[(c / 3) * DKP + D + c % 3] = (f16)256.f;   // never overwritten: store_rows writes columns < D
+    }
     if (PF) {
         load_rows<D>(kreg, Kb, ldkv, 0, Tk);
         load_rows<D>(vreg, Vb, ldkv, 0, Tk);
@@ -512,7 +541,7 @@ __global__ __launch_bounds__(256, dq_waves(D)) void attn_bwd_dq_kernel(const f16
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float p = __builtin_amdgcn_exp2f(fmaf(s[r], sl2, -lse2));
-                dsf[kt * 2 + (r >> 3)][r & 7] = (f16)(p * (dp[r] - dd));   // the softmax scale is applied once to the accumulator
+                dsf[kt * 2 + (r >> 3)][r & 7] = (f16)(p * (DFOLD ? dp[r] : dp[r] - dd));   // the softmax scale is applied once to the accumulator
             }
         }
 #pragma unroll
@@ -583,6 +612,8 @@ __global__ __launch_bounds__(256, dkdv_waves(D, QTR)) void attn_bwd_dkdv_kernel(
             vf[ks] = *(const f16x8*)(V + ((int64_t)bk * Tkr + key) * ldkv + h * D + col);
         }
     }
+    constexpr bool DFOLD = dfold<D>();
+    if (DFOLD && g == 1) vf[NKS - 1][0] = vf[NKS - 1][1] = vf[NKS - 1][2] = (f16)256.f;       // columns D .. D + 2 of this lane's V row (see split3)
     f32x16 dk[NDV], dv[NDV];
 #pragma unroll
     for (int i = 0; i < NDV; ++i) { dk[i] = zero16(); dv[i] = zero16(); }
@@ -630,7 +661,13 @@ __global__ __launch_bounds__(256, dkdv_waves(D, QTR)) void attn_bwd_dkdv_kernel(
         if (threadIdx.x < 64) {
             const int tq = q0 + threadIdx.x;
             lse_s[threadIdx.x] = tq < Tq ? Lb[tq] * LOG2E : INFINITY;
-            dd_s[threadIdx.x] = tq < Tq ? Db[tq] : 0.f;
+            const float ddv = tq < Tq ? Db[tq] : 0.f;
+            if (DFOLD) {                                // -D of query row tq into columns D .. D + 2 of its dO row (store_rows writes columns < D only)
+                f16 h0, h1, h2;
+                split3(-ddv * (1.f / 256.f), h0, h1, h2);
+                f16* gp = Gs + threadIdx.x * DKP + D;
+                gp[0] = h0; gp[1] = h1; gp[2] = h2;
+            } else dd_s[threadIdx.x] = ddv;
         }
         __syncthreads();
         f16x8 pf[4], dsf[4];
@@ -640,7 +677,7 @@ __global__ __launch_bounds__(256, dkdv_waves(D, QTR)) void attn_bwd_dkdv_kernel(
             const int qi = qt * 32 + crow(r, g);
             const float p = __builtin_amdgcn_exp2f(fmaf(s[r], sl2, -lse_s[qi]));
             pf[qt * 2 + (r >> 3)][r & 7] = (f16)p;
-            dsf[qt * 2 + (r >> 3)][r & 7] = (f16)(p * (dp[r] - dd_s[qi]));   // scale applied to dK at the end
+            dsf[qt * 2 + (r >> 3)][r & 7] = (f16)(p * (DFOLD ? dp[r] : dp[r] - dd_s[qi]));   // scale applied to dK at the end
         };
         auto dvdk = [&](int st, int i) {
             const f16x8 ga = QTR ? read_tr(Gs, DKP, st * 16, i * 32, kl, g) : read_perm(Gts, i * 32 + kl, st * 16, g);
