@@ -187,13 +187,40 @@ constexpr int dkdv_waves(int D, bool QTR = false) { return (QTR && D == 40) ? 3 
 constexpr int dkdv_waves(int D, bool QTR = false) { return D <= 64 ? 2 : 1; }
 #endif
 
+// ---- "-D through the matrix pipe" (round 4).  dS = P o (dP - D), D = rowsum(dO o O): where the contraction over d is padded (d = 40 -> 48: eight spare
+// k-slots behind column 39) the subtraction rides in the dP = dO . V^T MFMAs: three slots of the dO operand carry -D / 256 split into three 16-bit
+// pieces (hi + mid + lo: 33 / 24 significant bits in fp16 / bf16; the 1 / 256 keeps |D| up to 1.6e7 inside the fp16 range under loss scaling), the
+// same three slots of the V operand carry 256.0 -- products and accumulation are exact in the fp32 accumulator, so dP' = dP - D comes out of the
+// accumulation itself and the VALU-bound score loop loses one of its ~7.5 issue slots per element (and the dK/dV kernel its per-element LDS read of D).
+// ---- "pre-scaled q" (round 4; negative ``scale`` argument of the three entry points).  The projection that writes q multiplies it by softmax_scale *
+// log2(e) in its fp32 epilogue (fd_gemm_desc.colscale: one rounding, as before), so the QK^T accumulator IS the exponent's argument up to the
+// reference point -- and the reference point (the running maximum in the forward, the saved log-sum-exp in the backward) rides in the same three
+// spare contraction slots as -D does: q's slots carry -m or -lse split into three 16-bit pieces, K's slots carry 1.0.  p = exp2(accumulator): the
+// fused multiply-add per score element is gone from all three kernels.  Head dims with the slots only (d = 40), transpose-read forms only.
+template <int D> constexpr bool pre_ok() { return D % 16 == 8; }
+#define FD_PRE_MASKED 30000.f        // "lse" of an invalid query row in the pre-scaled backward: exp2(s - 30000) == 0, and it splits into finite pieces
+
+template <int D> constexpr bool dfold() {
+#ifdef FD_ATTN_NO_DFOLD
+    return false;
+#else
+    return D % 16 == 8;      // lane-half 1 of the last k-step holds columns D .. D + 7: all padding
+#endif
+}
+__device__ __forceinline__ void split3(float x, f16& h0, f16& h1, f16& h2) {
+    h0 = (f16)x;
+    const float r1 = x - (float)h0;
+    h1 = (f16)r1;
+    h2 = (f16)(r1 - (float)h1);
+}
+
 // ================================================================================== forward
 // VTR: ``Vt`` points at V itself ([Bk, Tkr, .] rows of stride ldk, like K) and the PV operand comes from a row-major tile through read_tr
 // QB: 32-query column blocks per wave.  QB = 1: 4 waves x 32 queries per workgroup (rounds 1-3).  QB = 2 (round 4): a wave owns 64 consecutive
 // queries, so every K / V fragment it reads from LDS feeds two MFMAs and the staged K / V tile serves 256 queries instead of 128 -- both the
 // fragment traffic and the staging per query halve (the forward was co-limited by exactly those: MFMAs + fragment reads alone 410 of 646 us,
 // staging + barriers ~190, profiles/r02_attn_fwd_d40_ablation.txt), at two waves per SIMD instead of three.
-template <int D, bool VTR, int QB>
+template <int D, bool VTR, int QB, bool PRE = false>
 __global__ __launch_bounds__(256, QB == 1 ? fwd_waves(D) : (D <= 64 ? 2 : 1)) void attn_fwd_kernel(const f16* __restrict__ Q, const f16* __restrict__ K, const f16* __restrict__ Vt,
                                                        f16* __restrict__ O, float* __restrict__ LSE, int H, int Tq, int Tk, int Tkp,
                                                        int Tkr, int kv_div, float scale, int ldq, int ldk) {
@@ -235,9 +262,10 @@ __global__ __launch_bounds__(256, QB == 1 ? fwd_waves(D) : (D <= 64 ? 2 : 1)) vo
     for (int qb = 0; qb < QB; ++qb) {
 #pragma unroll
         for (int i = 0; i < NDV; ++i) oacc[qb][i] = zero16();
-        m_run[qb] = -INFINITY;
+        m_run[qb] = PRE ? 0.f : -INFINITY;      // PRE: a finite reference point in the log2 domain (q's slots hold -m_run: zero to start with)
         l_run[qb] = 0.f;
     }
+    static_assert(!PRE || (pre_ok<D>() && VTR), "pre-scaled q: head dims with three spare contraction slots, transpose-read form");
     const float sl2 = scale * LOG2E;
 
     const f16* Kb = K + (int64_t)bk * Tkr * ldk + h * D;
@@ -258,6 +286,10 @@ __global__ __launch_bounds__(256, QB == 1 ? fwd_waves(D) : (D <= 64 ? 2 : 1)) vo
 #else
     constexpr bool ONES = D < DV;
 #endif
+    if (PRE) {
+        __syncthreads();                               // behind zero_row_pad's writes of the same columns
+        for (int c = threadIdx.x; c < 64 * 3; c += 256) Ks[(c / 3) * DKP + D + c % 3] = (f16)1.f;   // never overwritten: store_rows writes columns < D
+    }
     if (ONES) {
         if (VTR) {
             for (int r = threadIdx.x; r < 64; r += 256) Vts[r * VP + D] = (f16)1.f;
@@ -277,17 +309,29 @@ __global__ __launch_bounds__(256, QB == 1 ? fwd_waves(D) : (D <= 64 ? 2 : 1)) vo
         else store_cols<D>(vreg, Vts);
         __syncthreads();
         f32x16 s[QB][2];
+        auto scores = [&]() {
 #pragma unroll
-        for (int kt = 0; kt < 2; ++kt) {
+            for (int kt = 0; kt < 2; ++kt) {
 #pragma unroll
-            for (int qb = 0; qb < QB; ++qb) s[qb][kt] = zero16();
+                for (int qb = 0; qb < QB; ++qb) s[qb][kt] = zero16();
 #pragma unroll
-            for (int ks = 0; ks < NKS; ++ks) {
-                const f16x8 kf = *(const f16x8*)(Ks + (kt * 32 + ql) * DKP + ks * 16 + g * 8);
+                for (int ks = 0; ks < NKS; ++ks) {
+                    const f16x8 kf = *(const f16x8*)(Ks + (kt * 32 + ql) * DKP + ks * 16 + g * 8);
 #pragma unroll
-                for (int qb = 0; qb < QB; ++qb) s[qb][kt] = mfma32(kf, qf[qb][ks], s[qb][kt]);
+                    for (int qb = 0; qb < QB; ++qb) s[qb][kt] = mfma32(kf, qf[qb][ks], s[qb][kt]);
+                }
             }
-        }
+        };
+        auto mask_tail = [&]() {
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (k0 + kt * 32 + crow(r, g) >= Tk) s[qb][kt][r] = -INFINITY;
+        };
+        scores();
         // next tile's loads are issued behind the QK^T MFMAs and fly under the softmax and the PV MFMAs (issued in front of them the
         // compiler parks an s_waitcnt vmcnt(0) before the first MFMA and the whole load latency is exposed every tile)
         if (k0 + 128 <= Tk) {                 // next tile is an interior one: planned, unchecked loads
@@ -302,15 +346,64 @@ __global__ __launch_bounds__(256, QB == 1 ? fwd_waves(D) : (D <= 64 ? 2 : 1)) vo
         // key mask only exists in the last (partial) tile, a wave-uniform branch
         if (k0 + 64 > Tk) {
             asm volatile("" ::: "memory");   // keeps this a real (wave-uniform) branch: if-converted it costs ~90 VALU on every tile
+            mask_tail();
+        }
+        f16x8 pf[QB][4];
+        if constexpr (PRE) {
+            // the accumulator already holds log2-domain scores relative to m_run: p = exp2(s), no arithmetic in front of the exponential.  The reference
+            // point moves on the first tile and afterwards only when a tile's maximum exceeds it by more than 2^LAZY -- a wave-uniform, rarely taken
+            // branch that rescales O, rewrites q's three slots with the new -m_run and simply RE-RUNS the tile's QK^T MFMAs against them
+            bool mv[QB];
+            float mxv[QB];
+            bool any_mv = false;
 #pragma unroll
-            for (int qb = 0; qb < QB; ++qb)
+            for (int qb = 0; qb < QB; ++qb) {
+                float mx = -INFINITY;
 #pragma unroll
                 for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        if (k0 + kt * 32 + crow(r, g) >= Tk) s[qb][kt][r] = -INFINITY;
-        }
-        f16x8 pf[QB][4];
+                    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[qb][kt][r]);
+                mxv[qb] = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                mv[qb] = k0 == 0 || mxv[qb] > FD_ATTN_LAZY;
+                any_mv = any_mv || mv[qb];
+            }
+            if (__any(any_mv)) {
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb) {
+                    const float delta = mv[qb] ? mxv[qb] : 0.f;
+                    const float alpha = __builtin_amdgcn_exp2f(-delta);
+#pragma unroll
+                    for (int i = 0; i < NDV; ++i)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) oacc[qb][i][r] *= alpha;
+                    if (!ONES) l_run[qb] *= alpha;
+                    m_run[qb] += delta;
+                    if (g == 1) {
+                        f16 h0, h1, h2;
+                        split3(-m_run[qb], h0, h1, h2);
+                        qf[qb][NKS - 1][0] = h0; qf[qb][NKS - 1][1] = h1; qf[qb][NKS - 1][2] = h2;
+                    }
+                }
+                scores();
+                if (k0 + 64 > Tk) mask_tail();
+            }
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) {
+                float rs = 0.f;
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float p = __builtin_amdgcn_exp2f(s[qb][kt][r]);
+                        if (!ONES) rs += p;
+                        pf[qb][kt * 2 + (r >> 3)][r & 7] = (f16)p;
+                    }
+                if (!ONES) {
+                    rs += __shfl_xor(rs, 32, 64);
+                    l_run[qb] += rs;
+                }
+            }
+        } else
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb) {
             float mx = -INFINITY;
@@ -377,28 +470,9 @@ __global__ __launch_bounds__(256, QB == 1 ? fwd_waves(D) : (D <= 64 ? 2 : 1)) vo
                         *(f16x4*)(Op + dv) = o;
                     }
                 }
-            if (LSE && g == 0) LSE[((int64_t)b * H + h) * Tq + t[qb]] = m_run[qb] * scale + log2f(l_run[qb]) / LOG2E;
+            if (LSE && g == 0) LSE[((int64_t)b * H + h) * Tq + t[qb]] = PRE ? (m_run[qb] + log2f(l_run[qb])) / LOG2E : m_run[qb] * scale + log2f(l_run[qb]) / LOG2E;
         }
     }
-}
-
-// ---- "-D through the matrix pipe" (round 4).  dS = P o (dP - D), D = rowsum(dO o O): where the contraction over d is padded (d = 40 -> 48: eight spare
-// k-slots behind column 39) the subtraction rides in the dP = dO . V^T MFMAs: three slots of the dO operand carry -D / 256 split into three 16-bit
-// pieces (hi + mid + lo: 33 / 24 significant bits in fp16 / bf16; the 1 / 256 keeps |D| up to 1.6e7 inside the fp16 range under loss scaling), the
-// same three slots of the V operand carry 256.0 -- products and accumulation are exact in the fp32 accumulator, so dP' = dP - D comes out of the
-// accumulation itself and the VALU-bound score loop loses one of its ~7.5 issue slots per element (and the dK/dV kernel its per-element LDS read of D).
-template <int D> constexpr bool dfold() {
-#ifdef FD_ATTN_NO_DFOLD
-    return false;
-#else
-    return D % 16 == 8;      // lane-half 1 of the last k-step holds columns D .. D + 7: all padding
-#endif
-}
-__device__ __forceinline__ void split3(float x, f16& h0, f16& h1, f16& h2) {
-    h0 = (f16)x;
-    const float r1 = x - (float)h0;
-    h1 = (f16)r1;
-    h2 = (f16)(r1 - (float)h1);
 }
 
 // ================================================================================== D = rowsum(dO * O)
@@ -423,7 +497,7 @@ __global__ void attn_bwd_prep_kernel(const f16* O, const f16* dO, float* Dd, int
 
 // ================================================================================== dQ
 // KTR: no transposed K in HBM (Kt == nullptr); the dQ operand K^T comes from the row-major K tile through read_tr
-template <int D, bool KTR>
+template <int D, bool KTR, bool PRE = false>
 __global__ __launch_bounds__(256, dq_waves(D)) void attn_bwd_dq_kernel(const f16* __restrict__ Q, const f16* __restrict__ K, const f16* __restrict__ V,
                                                           const f16* __restrict__ Kt, const f16* __restrict__ dO,
                                                           const float* __restrict__ LSE, float* __restrict__ Dd, f16* __restrict__ dQ,
@@ -457,7 +531,13 @@ __global__ __launch_bounds__(256, dq_waves(D)) void attn_bwd_dq_kernel(const f16
             gf[ks] = *(const f16x8*)(dO + ((int64_t)b * Tq + t) * C + h * D + col);
         }
     }
-    const float lse2 = tvalid ? LSE[((int64_t)b * H + h) * Tq + t] * LOG2E : INFINITY;
+    static_assert(!PRE || (pre_ok<D>() && KTR), "pre-scaled q: head dims with three spare contraction slots, transpose-read form");
+    const float lse2 = tvalid ? LSE[((int64_t)b * H + h) * Tq + t] * LOG2E : (PRE ? FD_PRE_MASKED : INFINITY);
+    if (PRE && g == 1) {                             // -lse of this lane's query into columns D .. D + 2 of its (pre-scaled) q row
+        f16 h0, h1, h2;
+        split3(-lse2, h0, h1, h2);
+        qf[NKS - 1][0] = h0; qf[NKS - 1][1] = h1; qf[NKS - 1][2] = h2;
+    }
     float dd;
     if (O) {   // D = rowsum(dO * O) computed here (each lane holds half of its query's columns) and published for the dK/dV kernel
         float part = 0.f;
@@ -495,9 +575,12 @@ __global__ __launch_bounds__(256, dq_waves(D)) void attn_bwd_dq_kernel(const f16
     zero_row_pad<D, DKP>(Ks);
     zero_row_pad<D, DKP>(Vs);
     if (!KTR) zero_col_pad<D, DV>(Kts);
-    if (DFOLD) {
+    if (DFOLD || PRE) {
         __syncthreads();                               // behind zero_row_pad's writes of the same columns
-        for (int c = threadIdx.x; c < 64 * 3; c += 256) Vs[(c / 3) * DKP + D + c % 3] = (f16)256.f;   // never overwritten: store_rows writes columns < D
+        for (int c = threadIdx.x; c < 64 * 3; c += 256) {    // never overwritten: store_rows writes columns < D
+            if (DFOLD) Vs[(c / 3) * DKP + D + c % 3] = (f16)256.f;
+            if (PRE) Ks[(c / 3) * DKP + D + c % 3] = (f16)1.f;
+        }
     }
     if (PF) {
         load_rows<D>(kreg, Kb, ldkv, 0, Tk);
@@ -540,7 +623,7 @@ __global__ __launch_bounds__(256, dq_waves(D)) void attn_bwd_dq_kernel(const f16
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float p = __builtin_amdgcn_exp2f(fmaf(s[r], sl2, -lse2));
+                const float p = __builtin_amdgcn_exp2f(PRE ? s[r] : fmaf(s[r], sl2, -lse2));
                 dsf[kt * 2 + (r >> 3)][r & 7] = (f16)(p * (DFOLD ? dp[r] : dp[r] - dd));   // the softmax scale is applied once to the accumulator
             }
         }
@@ -562,7 +645,7 @@ __global__ __launch_bounds__(256, dq_waves(D)) void attn_bwd_dq_kernel(const f16
                 if (dv < D) {
                     f16x4 o;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) o[j] = (f16)(acc[i][rq * 4 + j] * scale);
+                    for (int j = 0; j < 4; ++j) o[j] = (f16)(acc[i][rq * 4 + j] * scale);     // PRE: the launcher passes the true softmax scale here too (d/dq, not d/dq')
                     *(f16x4*)(P + dv) = o;
                 }
             }
@@ -572,7 +655,7 @@ __global__ __launch_bounds__(256, dq_waves(D)) void attn_bwd_dq_kernel(const f16
 // ================================================================================== dK, dV
 // block = 128 keys (4 waves x 32), loops over 32-query tiles.  S[q][key] = Q.K^T with K,V rows in VGPRs.
 // QTR: no transposed Q / dO in HBM (Qt == dOt == nullptr); the dK / dV operands Q^T, dO^T come from the row-major tiles through read_tr
-template <int D, bool ATOMIC, bool QTR>
+template <int D, bool ATOMIC, bool QTR, bool PRE = false>
 __global__ __launch_bounds__(256, dkdv_waves(D, QTR)) void attn_bwd_dkdv_kernel(const f16* __restrict__ Q, const f16* __restrict__ Qt, const f16* __restrict__ K,
                                                             const f16* __restrict__ V, const f16* __restrict__ dO,
                                                             const f16* __restrict__ dOt, const float* __restrict__ LSE,
@@ -613,7 +696,9 @@ __global__ __launch_bounds__(256, dkdv_waves(D, QTR)) void attn_bwd_dkdv_kernel(
         }
     }
     constexpr bool DFOLD = dfold<D>();
+    static_assert(!PRE || (pre_ok<D>() && QTR), "pre-scaled q: head dims with three spare contraction slots, transpose-read form");
     if (DFOLD && g == 1) vf[NKS - 1][0] = vf[NKS - 1][1] = vf[NKS - 1][2] = (f16)256.f;       // columns D .. D + 2 of this lane's V row (see split3)
+    if (PRE && g == 1) kf[NKS - 1][0] = kf[NKS - 1][1] = kf[NKS - 1][2] = (f16)1.f;           // ... and of its K row: they meet -lse in q's
     f32x16 dk[NDV], dv[NDV];
 #pragma unroll
     for (int i = 0; i < NDV; ++i) { dk[i] = zero16(); dv[i] = zero16(); }
@@ -660,7 +745,13 @@ __global__ __launch_bounds__(256, dkdv_waves(D, QTR)) void attn_bwd_dkdv_kernel(
         }
         if (threadIdx.x < 64) {
             const int tq = q0 + threadIdx.x;
-            lse_s[threadIdx.x] = tq < Tq ? Lb[tq] * LOG2E : INFINITY;
+            const float lsev = tq < Tq ? Lb[tq] * LOG2E : (PRE ? FD_PRE_MASKED : INFINITY);
+            if (PRE) {                                  // -lse of query row tq into columns D .. D + 2 of its (pre-scaled) q row
+                f16 h0, h1, h2;
+                split3(-lsev, h0, h1, h2);
+                f16* qp = Qs + threadIdx.x * DKP + D;
+                qp[0] = h0; qp[1] = h1; qp[2] = h2;
+            } else lse_s[threadIdx.x] = lsev;
             const float ddv = tq < Tq ? Db[tq] : 0.f;
             if (DFOLD) {                                // -D of query row tq into columns D .. D + 2 of its dO row (store_rows writes columns < D only)
                 f16 h0, h1, h2;
@@ -675,7 +766,7 @@ __global__ __launch_bounds__(256, dkdv_waves(D, QTR)) void attn_bwd_dkdv_kernel(
         // fragments zero everything it computes stays finite
         auto soft = [&](const f32x16& s, const f32x16& dp, int qt, int r) {
             const int qi = qt * 32 + crow(r, g);
-            const float p = __builtin_amdgcn_exp2f(fmaf(s[r], sl2, -lse_s[qi]));
+            const float p = __builtin_amdgcn_exp2f(PRE ? s[r] : fmaf(s[r], sl2, -lse_s[qi]));
             pf[qt * 2 + (r >> 3)][r & 7] = (f16)p;
             dsf[qt * 2 + (r >> 3)][r & 7] = (f16)(p * (DFOLD ? dp[r] : dp[r] - dd_s[qi]));   // scale applied to dK at the end
         };
@@ -849,17 +940,28 @@ extern "C" int fd_attn_fwd(const void* q, const void* k, const void* vt, void* o
     // staging per query (see attn_fwd_kernel).  Short sequences keep QB = 1 (more workgroups, three waves per SIMD).
     const int qb = vtr ? fwd_qb(d, Tq, Tk, B * H) : 1;       // the transposed-copy form (measurement only) stays at one block
     dim3 grid(((Tq + 128 * qb - 1) / (128 * qb)) * H * B);
-#define LAUNCH_F(DD, TRV, QBV)                                                                                                         \
+    // scale < 0: q arrives multiplied by |scale| * log2(e) (fd_gemm_desc.colscale in the projection) -- see "pre-scaled q" above
+    const bool pre = scale < 0.f;
+    scale = fabsf(scale);
+    FD_REQUIRE(!pre || (d % 16 == 8 && vtr), "fd_attn_fwd: pre-scaled q (negative scale) needs d %% 16 == 8 and the transpose-read form (Tkp == 0)");
+#define LAUNCH_F(DD, TRV, QBV, PREV)                                                                                                   \
     {                                                                                                                                  \
-        ALLOW_LDS((attn_fwd_kernel<DD, TRV, QBV>), (fwd_lds<DD, TRV>()));                                                              \
-        hipLaunchKernelGGL((attn_fwd_kernel<DD, TRV, QBV>), grid, dim3(256), (fwd_lds<DD, TRV>()), (hipStream_t)stream, (const f16*)q, \
-                           (const f16*)k, (const f16*)vt, (f16*)o, lse, H, Tq, Tk, Tkp, Tkr, kv_div, scale, ldq, ldk);                 \
+        ALLOW_LDS((attn_fwd_kernel<DD, TRV, QBV, PREV>), (fwd_lds<DD, TRV>()));                                                        \
+        hipLaunchKernelGGL((attn_fwd_kernel<DD, TRV, QBV, PREV>), grid, dim3(256), (fwd_lds<DD, TRV>()), (hipStream_t)stream,          \
+                           (const f16*)q, (const f16*)k, (const f16*)vt, (f16*)o, lse, H, Tq, Tk, Tkp, Tkr, kv_div, scale, ldq, ldk);  \
     }
 #define CALL(DD)                                                                 \
     if (vtr) {                                                                   \
-        if (qb == 2 && DD <= 64) LAUNCH_F(DD, true, (DD <= 64 ? 2 : 1))          \
-        else LAUNCH_F(DD, true, 1)                                               \
-    } else LAUNCH_F(DD, false, 1)
+        if constexpr (pre_ok<DD>()) {                                            \
+            if (pre) {                                                           \
+                if (qb == 2) LAUNCH_F(DD, true, (DD <= 64 ? 2 : 1), true)        \
+                else LAUNCH_F(DD, true, 1, true)                                 \
+                break;                                                           \
+            }                                                                    \
+        }                                                                        \
+        if (qb == 2 && DD <= 64) LAUNCH_F(DD, true, (DD <= 64 ? 2 : 1), false)   \
+        else LAUNCH_F(DD, true, 1, false)                                        \
+    } else LAUNCH_F(DD, false, 1, false)
     FD_DISPATCH_D(d, CALL)
 #undef CALL
 #undef LAUNCH_F
@@ -885,7 +987,19 @@ extern "C" int fd_attn_bwd_dq(const void* q, const void* k, const void* v, const
     const bool ktr = kt == nullptr;
     FD_REQUIRE(B > 0 && H > 0 && Tq > 0 && Tk > 0 && (ktr || (Tkp >= Tk && (Tkp & 7) == 0)) && Tkr >= Tk && kv_div >= 1, "fd_attn_bwd_dq: bad shape");
     dim3 grid(((Tq + 127) / 128) * H * B);
+    const bool pre = scale < 0.f;                    // q arrives multiplied by |scale| * log2(e): see "pre-scaled q"
+    scale = fabsf(scale);
+    FD_REQUIRE(!pre || (d % 16 == 8 && ktr), "fd_attn_bwd_dq: pre-scaled q (negative scale) needs d %% 16 == 8 and the transpose-read form (kt == NULL)");
 #define CALL(DD)                                                                                                                      \
+    if constexpr (pre_ok<DD>()) {                                                                                                     \
+        if (pre) {                                                                                                                    \
+            ALLOW_LDS((attn_bwd_dq_kernel<DD, true, true>), (dq_lds<DD, true>()));                                                    \
+            hipLaunchKernelGGL((attn_bwd_dq_kernel<DD, true, true>), grid, dim3(256), (dq_lds<DD, true>()), (hipStream_t)stream,      \
+                               (const f16*)q, (const f16*)k, (const f16*)v, (const f16*)kt, (const f16*)d_o, lse, D, (f16*)dq,        \
+                               (const f16*)o, H, Tq, Tk, Tkp, Tkr, kv_div, scale, ldq, ldkv, lddq);                                   \
+            break;                                                                                                                    \
+        }                                                                                                                             \
+    }                                                                                                                                 \
     if (ktr) {                                                                                                                        \
         ALLOW_LDS((attn_bwd_dq_kernel<DD, true>), (dq_lds<DD, true>()));                                                              \
         hipLaunchKernelGGL((attn_bwd_dq_kernel<DD, true>), grid, dim3(256), (dq_lds<DD, true>()), (hipStream_t)stream, (const f16*)q, \
@@ -916,18 +1030,28 @@ extern "C" int fd_attn_bwd_dkdv(const void* q, const void* qt, const void* k, co
     // accumulate == 2: fp32 per-sample slabs instead of atomics (dk, dv: [kv_div][Bk*Tkr][lddkv] fp32, every element written)
     const int64_t slab = accumulate == 2 ? (int64_t)(B / kv_div) * Tkr * lddkv : 0;
     FD_REQUIRE(accumulate != 2 || (B % kv_div) == 0, "fd_attn_bwd_dkdv: B must be a multiple of kv_div");
-#define LAUNCH(DD, AT, TRQ)                                                                                                            \
+    // scale < 0: q arrives multiplied by |scale| * log2(e) ("pre-scaled q"): dK = scale * dS^T . q = dS^T . q' / log2(e)
+    const bool pre = scale < 0.f;
+    scale = pre ? 1.f / LOG2E : scale;
+    FD_REQUIRE(!pre || (d % 16 == 8 && qtr), "fd_attn_bwd_dkdv: pre-scaled q (negative scale) needs d %% 16 == 8 and the transpose-read form (qt == NULL)");
+#define LAUNCH(DD, AT, TRQ, PREV)                                                                                                      \
     {                                                                                                                                  \
-        ALLOW_LDS((attn_bwd_dkdv_kernel<DD, AT, TRQ>), (dkdv_lds<DD, TRQ>()));                                                         \
-        hipLaunchKernelGGL((attn_bwd_dkdv_kernel<DD, AT, TRQ>), grid, dim3(256), (dkdv_lds<DD, TRQ>()), (hipStream_t)stream,           \
+        ALLOW_LDS((attn_bwd_dkdv_kernel<DD, AT, TRQ, PREV>), (dkdv_lds<DD, TRQ>()));                                                   \
+        hipLaunchKernelGGL((attn_bwd_dkdv_kernel<DD, AT, TRQ, PREV>), grid, dim3(256), (dkdv_lds<DD, TRQ>()), (hipStream_t)stream,     \
                            (const f16*)q, (const f16*)qt, (const f16*)k, (const f16*)v, (const f16*)d_o, (const f16*)d_ot, lse, D, dk, \
                            dv, H, Tq, Tk, Tkr, kv_div, scale, ldq, ldkv, lddkv, slab);                                                 \
     }
 #define CALL(DD)                                                     \
+    if constexpr (pre_ok<DD>()) {                                    \
+        if (pre) {                                                   \
+            if (kv_div > 1 || accumulate) LAUNCH(DD, true, true, true) else LAUNCH(DD, false, true, true) \
+            break;                                                   \
+        }                                                            \
+    }                                                                \
     if (kv_div > 1 || accumulate) {                                  \
-        if (qtr) LAUNCH(DD, true, true) else LAUNCH(DD, true, false) \
+        if (qtr) LAUNCH(DD, true, true, false) else LAUNCH(DD, true, false, false) \
     } else {                                                         \
-        if (qtr) LAUNCH(DD, false, true) else LAUNCH(DD, false, false) \
+        if (qtr) LAUNCH(DD, false, true, false) else LAUNCH(DD, false, false, false) \
     }
     FD_DISPATCH_D(d, CALL)
 #undef CALL

@@ -497,9 +497,10 @@ __global__ void splitk_reduce_kernel(fd_gemm_desc p, int nsplit) {
         for (int s = 1; s < nsplit; ++s) a += *(const f32x4*)(ws + (int64_t)s * p.M * p.N + e);
         const int rbrow = RB ? m / p.rows_per_batch : 0;
         float v[4];
+        const float al = n < p.colscale_cols ? p.alpha * p.colscale : p.alpha;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            float x = a[r] * p.alpha;
+            float x = a[r] * al;
             if (p.bias) x += p.bias[n + r];
             if (RB) x += (float)RB[(int64_t)rbrow * p.ld_rowbias + n + r];
             x = apply_act(x, p.act);
@@ -651,7 +652,7 @@ static bool skinny_ok(const fd_gemm_desc& d) {
     // M=16384 K=640: 6.8 vs 8.6, M=65536 K=320: 10.4 vs 10.3 at N=8 (both at the A stream's bandwidth) but 12.8 vs 10.7 at N=24, where
     // the B fragments re-read through L1 by every wave outweigh the A stream: wide-M problems with more than one column tile stay on the LDS tiles
     if (d.N > 16 && d.M >= 32768) return false;
-    return !off && !d.conv && d.batch <= 1 && d.K2 == 0 && d.N <= 64 && (d.N & 3) == 0 && (d.K & 31) == 0 && d.M >= 1024 && !d.bias && !d.rowbias &&
+    return !off && !d.conv && d.batch <= 1 && d.K2 == 0 && d.colscale_cols == 0 && d.N <= 64 && (d.N & 3) == 0 && (d.K & 31) == 0 && d.M >= 1024 && !d.bias && !d.rowbias &&
            !d.residual && d.act == FD_ACT_NONE && d.alpha == 1.f && d.out_dtype == FD_OUT_F16 && (d.ldc & 3) == 0;
 }
 
@@ -822,7 +823,7 @@ static GemmPlan gemm_plan(const fd_gemm_desc& d /* K2 already normalised */) {
                  d.batch <= 1 && (d.N % 80) == 0;
     // the LayerNorm second output lives in gemm_epilogue_ln: 16-wave lockstep 320-wide tiles whose one n-tile holds whole rows, bias / residual only
     g.ln_ok = g.kind == GK_BIG && g.bn == 320 && g.wgm == 4 && g.wgn == 4 && d.N == 320 && g.nsplit == 1 && g.cv == 0 && lds_epi &&
-              d.act == FD_ACT_NONE && !d.rowbias && d.alpha == 1.f && d.batch <= 1 && !d.gn_stats;
+              d.act == FD_ACT_NONE && !d.rowbias && d.alpha == 1.f && d.batch <= 1 && !d.gn_stats && d.colscale_cols == 0;
     return g;
 }
 
@@ -881,6 +882,8 @@ extern "C" int fd_gemm(const fd_gemm_desc* dp, void* stream) {
         FD_REQUIRE((int64_t)d.Bn * d.H * d.W * d.lda < (1LL << 31), "fd_gemm(conv): input larger than 2^31 elements");
     }
     if (d.rowbias) FD_REQUIRE(d.rows_per_batch > 0, "fd_gemm: rows_per_batch");
+    FD_REQUIRE(d.colscale_cols >= 0 && (d.colscale_cols & 3) == 0 && (d.colscale_cols == 0 || (d.act != FD_ACT_GEGLU && d.batch <= 1)),
+               "fd_gemm: colscale_cols=%d must be a multiple of 4 (not with GEGLU / batched launches)", d.colscale_cols);
     if (d.act == FD_ACT_GEGLU)
         // in this mode ``residual`` is an optional second OUTPUT [M, N] (ldr): the pre-gate projection, interleaved like B
         FD_REQUIRE(!d.conv && d.batch <= 1 && d.out_dtype == FD_OUT_F16 && !d.rowbias && d.alpha == 1.f && (d.N & 15) == 0 &&

@@ -60,6 +60,7 @@ __device__ __forceinline__ void gemm_epilogue(const fd_gemm_desc& p, f32x4 (&acc
             else
                 for (int r = 0; r < 4 && n + r < p.N; ++r) bv[r] = p.bias[n + r];
         }
+        const float al = n < p.colscale_cols ? p.alpha * p.colscale : p.alpha;     // fd_gemm_desc.colscale (colscale_cols % 4 == 0: uniform over a lane's 4 columns)
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int m = mbase + i * 16 + l15;
@@ -77,7 +78,7 @@ __device__ __forceinline__ void gemm_epilogue(const fd_gemm_desc& p, f32x4 (&acc
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                float x = acc[i][j][r] * p.alpha + bv[r] + (float)rbv[r];
+                float x = acc[i][j][r] * al + bv[r] + (float)rbv[r];
                 x = apply_act(x, p.act);
                 v[r] = x + (float)resv[r];
             }
@@ -116,6 +117,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const fd_gemm_desc& p, f32x4 (
     // the epilogue mode is uniform over the launch: branch once, outside the per-element loops (a per-element runtime switch on
     // p.act plus the always-on alpha / row-bias arithmetic made short-K GEMMs VALU-bound here: 149 -> 100 us of epilogue on FF1)
     const bool plain = (p.act == FD_ACT_NONE) && !RB && p.alpha == 1.f && !FD_DBG_IS(p, 5);
+    const bool cscale = p.colscale_cols > 0;          // fd_gemm_desc.colscale: its own copy of the plain loop (uniform branch), nothing for the others
     // GroupNorm statistics of the stored tile (fd_gemm_desc.gn_stats), in CANONICAL chunks of 32 rows: whatever kernel and tile produced C, the
     // sums of rows [32 c, 32 c + 32) x 10-channel unit are formed by the same procedure -- lane (cr, column chunk) accumulates the four column PAIRS
     // of its 8 columns over the rows cr, cr + 6, ... of the chunk (v_dot2c: two 16-bit values per fp32 accumulate, no conversions -- three VALU
@@ -131,7 +133,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const fd_gemm_desc& p, f32x4 (
     const f16x2 ones = {(f16)1.f, (f16)1.f};
 #pragma unroll
     for (int c0 = 0; c0 < TM; c0 += TMC) {
-        if (plain) {
+        if (plain && !cscale) {
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int n = nbase + j * 16 + lg * 4;
@@ -143,12 +145,26 @@ __device__ __forceinline__ void gemm_epilogue_lds(const fd_gemm_desc& p, f32x4 (
                     *(f16x4*)(wave_lds + (ii * 16 + l15) * LDW + j * 16 + lg * 4) = (f16x4){(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
                 }
             }
+        } else if (plain) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = nbase + j * 16 + lg * 4;
+                f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+                if (p.bias && n < p.N) bv = *(const f32x4*)(p.bias + n);
+                const float cs = n < p.colscale_cols ? p.colscale : 1.f;
+#pragma unroll
+                for (int ii = 0; ii < TMC; ++ii) {
+                    const f32x4 v = acc[c0 + ii][j] * cs + bv;
+                    *(f16x4*)(wave_lds + (ii * 16 + l15) * LDW + j * 16 + lg * 4) = (f16x4){(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+                }
+            }
         } else {
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int n = nbase + j * 16 + lg * 4;
                 f32x4 bv = {0.f, 0.f, 0.f, 0.f};
                 if (p.bias && n < p.N) bv = *(const f32x4*)(p.bias + n);
+                const float al = n < p.colscale_cols ? p.alpha * p.colscale : p.alpha;
 #pragma unroll
                 for (int ii = 0; ii < TMC; ++ii) {
                     const int i = c0 + ii;
@@ -158,10 +174,10 @@ __device__ __forceinline__ void gemm_epilogue_lds(const fd_gemm_desc& p, f32x4 (
                     f16x4 o;
                     if (p.act == FD_ACT_NONE) {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) o[r] = (f16)(acc[i][j][r] * p.alpha + bv[r] + (float)rbv[r]);
+                        for (int r = 0; r < 4; ++r) o[r] = (f16)(acc[i][j][r] * al + bv[r] + (float)rbv[r]);
                     } else {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) o[r] = (f16)apply_act(acc[i][j][r] * p.alpha + bv[r] + (float)rbv[r], p.act);
+                        for (int r = 0; r < 4; ++r) o[r] = (f16)apply_act(acc[i][j][r] * al + bv[r] + (float)rbv[r], p.act);
                     }
                     if (FD_DBG_IS(p, 5)) o = (f16x4){(f16)acc[i][j][0], (f16)acc[i][j][1], (f16)acc[i][j][2], (f16)acc[i][j][3]};   // FD_GEMM_DBG=5
                     *(f16x4*)(wave_lds + (ii * 16 + l15) * LDW + j * 16 + lg * 4) = o;

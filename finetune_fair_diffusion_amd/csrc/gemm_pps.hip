@@ -277,7 +277,7 @@ __global__ __launch_bounds__(512) void gemm_pps_kernel(fd_gemm_desc p, int ntm, 
 // rows can be stored as 16-byte pieces.  Everything else (convolutions, row bias, activations, alpha, fp32 output, recorded pre-gate
 // output, batched, ragged N) stays on the one-tile-per-workgroup kernels.
 bool fd_gemm_pps_eligible(const fd_gemm_desc& d) {
-    if (d.conv || d.batch > 1 || (d.N % 320) != 0 || (d.K & 7) != 0) return false;
+    if (d.conv || d.batch > 1 || (d.N % 320) != 0 || (d.K & 7) != 0 || d.colscale_cols) return false;
     if (d.out_dtype != FD_OUT_F16 || d.rowbias || d.alpha != 1.f || (d.ldc & 7) != 0) return false;
     if (d.act == FD_ACT_GEGLU) return d.residual == nullptr;
     if (d.act != FD_ACT_NONE) return false;

@@ -190,14 +190,15 @@ class ParamBank:
 
 
 # ------------------------------------------------------------------------------------------ LoRA linear
-def lora_linear_fwd(x, lin, lora, t=None, residual=None, act="none", rowbias=None, rows_per_batch=0, ln=None):
+def lora_linear_fwd(x, lin, lora, t=None, residual=None, act="none", rowbias=None, rows_per_batch=0, ln=None, colscale=None):
     """y = x W^T (+ (x down^T) up^T) + b (+ residual); returns (y, t) with t = x down^T [M, rp].
-    ``ln`` = (gamma, beta, eps): y is the triple (y, LayerNorm(y), per-row statistics) of ``ops.gemm(..., ln=...)``."""
+    ``ln`` = (gamma, beta, eps): y is the triple (y, LayerNorm(y), per-row statistics) of ``ops.gemm(..., ln=...)``.
+    ``colscale`` = (factor, columns): see ``ops.gemm`` (pre-scaled attention queries)."""
     if lora is None:
-        return ops.gemm(x, lin.w, bias=lin.bias, residual=residual, act=act, ln=ln), None
+        return ops.gemm(x, lin.w, bias=lin.bias, residual=residual, act=act, ln=ln, colscale=colscale), None
     if t is None:
         t = ops.gemm(x, lora.down16)
-    y = ops.gemm(x, lin.w, a2=t, b2=lora.up16, bias=lin.bias, residual=residual, act=act, ln=ln)
+    y = ops.gemm(x, lin.w, a2=t, b2=lora.up16, bias=lin.bias, residual=residual, act=act, ln=ln, colscale=colscale)
     return y, t
 
 

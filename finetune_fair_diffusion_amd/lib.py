@@ -39,6 +39,7 @@ class GemmDesc(ctypes.Structure):
         ("gn_stats", ctypes.c_void_p),
         ("ln_out", ctypes.c_void_p), ("ld_ln", ctypes.c_int64), ("ln_gamma", ctypes.c_void_p), ("ln_beta", ctypes.c_void_p),
         ("ln_stats", ctypes.c_void_p), ("ln_eps", ctypes.c_float),
+        ("colscale", ctypes.c_float), ("colscale_cols", ctypes.c_int32),
     ]
 
 

@@ -136,7 +136,7 @@ def _chk(t, dtype=F16):
 
 # ----------------------------------------------------------------------------- GEMM / conv
 def gemm(a, b, *, a2=None, b2=None, bias=None, rowbias=None, rows_per_batch=0, residual=None, act="none", alpha=1.0,
-         out=None, out_dtype=F16, n=None, aux=None, gn_stats=False, ln=None):
+         out=None, out_dtype=F16, n=None, aux=None, gn_stats=False, ln=None, colscale=None):
     """C[M,N] = act(alpha*(a.b^T + a2.b2^T) + bias + rowbias) + residual.  a:[M,K] (row stride free), b:[N,K].
     act="geglu": b / bias rows interleaved (value_c, gate_c) -> C[M, N/2] = value * gelu(gate) (see ``interleave_geglu``)."""
     M, K = a.shape
@@ -162,6 +162,8 @@ def gemm(a, b, *, a2=None, b2=None, bias=None, rowbias=None, rows_per_batch=0, r
         d.residual, d.ldr = aux.data_ptr(), N
     d.alpha, d.M, d.N, d.K = alpha, M, N, K
     d.act, d.out_dtype, d.batch = ACT[act], 1 if out.dtype == F32 else 0, 1
+    if colscale is not None:        # (factor, columns): the first ``columns`` output columns times ``factor`` in fp32 before rounding (pre-scaled q)
+        d.colscale, d.colscale_cols = colscale
     if ln is None:
         _gemm_call(d, False, out, gn_stats)
         return out
@@ -488,12 +490,24 @@ def to_f32(x, scale=1.0):
 # transpose reads (ds_read_b64_tr_b16).  FD_ATTN_NO_TR=1 restores the round-1/2 form with transposed copies made by fd_transpose_btc
 # (measurement switch; both forms are in the library).
 ATTN_TR = os.environ.get("FD_ATTN_NO_TR") is None
+LOG2E = 1.4426950408889634
+# "Pre-scaled q" (round 4): for head dims with spare contraction slots (d = 40) the projection writes q * (d^-0.5 * log2 e) -- in its fp32 epilogue, one
+# rounding as before (fd_gemm_desc.colscale) -- and the three attention kernels take the QK^T accumulator as the exponent's argument, the softmax
+# reference point / saved log-sum-exp riding in the spare slots (csrc/attn.hip).  FD_NO_PRESCALED_Q=1 restores the multiply-add per score element.
+PRESCALED_Q = os.environ.get("FD_NO_PRESCALED_Q") is None
 
 
-def attn_fwd(q, k, vt, B, H, Tq, Tk, d, kv_div=1, scale=None, need_lse=False, kv_rows=None, v=None):
+def q_prescale(d):
+    """Factor the q projection folds into its epilogue for head dim ``d``, or None where the attention kernels have no spare contraction slots
+    (or the transposed-copy forms are in use)."""
+    return (d ** -0.5) * LOG2E if (PRESCALED_Q and ATTN_TR and d % 16 == 8) else None
+
+
+def attn_fwd(q, k, vt, B, H, Tq, Tk, d, kv_div=1, scale=None, need_lse=False, kv_rows=None, v=None, prescaled=False):
     """q [B*Tq, H*d], k [Bk*Tkr, H*d] (2-D; rows may be strided: column slices of a wider buffer), and EITHER v (same shape and row
     stride as k; read through LDS transpose reads) OR vt [Bk, H*d, Tkp] (the transposed copy).
-    ``kv_rows``: rows per batch item of the k buffer when it is row-padded beyond the Tk keys (ViT token buffers)."""
+    ``kv_rows``: rows per batch item of the k buffer when it is row-padded beyond the Tk keys (ViT token buffers).
+    ``prescaled``: q holds q * scale * log2(e) (``q_prescale``); the C-ABI takes that as a negative ``scale``."""
     Tkr = kv_rows or Tk
     if v is not None:
         assert vt is None and _rows(v) == _rows(k) and v.shape == k.shape
@@ -502,13 +516,14 @@ def attn_fwd(q, k, vt, B, H, Tq, Tk, d, kv_div=1, scale=None, need_lse=False, kv
         vp, Tkp = _chk(vt), vt.shape[-1]
     o = torch.empty((q.shape[0], H * d), dtype=F16, device=q.device)
     lse = torch.empty((B, H, Tq), dtype=F32, device=q.device) if need_lse else None
+    scale = scale if scale is not None else d ** -0.5
     _call("fd_attn_fwd", _p(q), _p(k), _p(vp), _p(o), _p(lse), B, H, Tq, Tk, Tkp, Tkr, d, kv_div,
-          scale if scale is not None else d ** -0.5, _rows(q), _rows(k), _stream())
+          -scale if prescaled else scale, _rows(q), _rows(k), _stream())
     return (o, lse) if need_lse else o
 
 
 def attn_bwd(q, k, v, o, do, lse, B, H, Tq, Tk, d, kv_div=1, scale=None, kt=None, dk_acc=None, dv_acc=None, kv_rows=None, dqkv=None, tr=None,
-             dk_out=None, dv_out=None):
+             dk_out=None, dv_out=None, prescaled=False):
     """Returns (dq, dk, dv).  With ``dk_acc`` / ``dv_acc`` (fp32 [Bk*Tk, C]; mandatory when kv_div > 1, i.e. shared K/V) dk/dv are ADDED
     into those buffers with fp32 atomics -- safe for launches that run concurrently on different streams.
     With ``dk_out`` / ``dv_out`` instead (fp32 [Bk*Tk, C], WRITTEN): no atomics -- every sample of a K/V group writes its own fp32 slab and the
@@ -517,6 +532,8 @@ def attn_bwd(q, k, v, o, do, lse, B, H, Tq, Tk, d, kv_div=1, scale=None, kt=None
     q, k, v are 2-D and may be column slices of a wider buffer; with ``dqkv`` [M, 3*H*d] (self-attention, kv_div == 1) the three
     gradients are written as its column slices (returned as views), so that the projections' input gradient is ONE GEMM over K = 3*H*d."""
     scale = scale if scale is not None else d ** -0.5
+    if prescaled:           # q = q_true * scale * log2(e); dq is still the gradient w.r.t. q_true (what the projection's backward wants)
+        scale = -scale
     Tkr = kv_rows or Tk
     C = H * d
     assert _rows(k) == _rows(v)

@@ -153,28 +153,33 @@ class TransformerBlock:
         # are 8 B per row: always kept
         h0, n1, ln1 = ops.gemm(g, self.proj_in.w, bias=self.proj_in.bias, ln=(self.ln1.gamma, self.ln1.beta, 1e-5))
         l1 = self.lora1
+        # q leaves its projection multiplied by d^-0.5 * log2(e) where the attention kernels can take it that way (ops.q_prescale; not on the e4m3 path)
+        qs = None if ops.fp8_attn_ok(HW, d) else ops.q_prescale(d)
+        csq = (qs, C) if qs is not None else None
         if l1 is not None:
             t1 = ops.gemm(n1, l1.down_qkv16)
-            qkv = ops.gemm(n1, self.wqkv, a2=t1, b2=l1.up_qkv16)
+            qkv = ops.gemm(n1, self.wqkv, a2=t1, b2=l1.up_qkv16, colscale=csq)
         else:
             t1 = None
-            qkv = ops.gemm(n1, self.wqkv)
+            qkv = ops.gemm(n1, self.wqkv, colscale=csq)
         q, k, v = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]           # column slices (row stride 3C): the attention kernels take strides
         if ops.fp8_attn_ok(HW, d):       # BASELINE configs[4]: e4m3 QK^T / PV in self-attention (the backward stays in the working dtype)
             o, lse = ops.attn_fwd_fp8(q, k, v, B, h, HW, d, need_lse=True)
         else:
             if ops.ATTN_TR:
-                o, lse = ops.attn_fwd(q, k, None, B, h, HW, HW, d, 1, need_lse=True, v=v)
+                o, lse = ops.attn_fwd(q, k, None, B, h, HW, HW, d, 1, need_lse=True, v=v, prescaled=qs is not None)
             else:
                 o, lse = ops.attn_fwd(q, k, ops.transpose_btc(v, B, HW, C), B, h, HW, HW, d, 1, need_lse=True)
         (h1, n2, ln2), to1 = lora_linear_fwd(o, self.o1, l1.out if l1 else None, residual=h0, ln=(self.ln2.gamma, self.ln2.beta, 1e-5))
         l2 = self.lora2
-        q2, tq2 = lora_linear_fwd(n2, self.q2, l2.q if l2 else None)
+        cr = self.cross
+        qs2 = ops.q_prescale(d) if cr["Vt"] is None else None          # the prepared K / V are in the transpose-read form
+        q2, tq2 = lora_linear_fwd(n2, self.q2, l2.q if l2 else None, colscale=(qs2, C) if qs2 is not None else None)
         B2 = 2 * B if pair else B
         q2f, h1f, xf = (torch.cat([q2, q2]), torch.cat([h1, h1]), torch.cat([x, x])) if pair else (q2, h1, x)
-        cr = self.cross
         kv_div = B2 // cr["Bk"]
-        o2, lse2 = ops.attn_fwd(q2f, cr["K"], cr["Vt"], B2, h, HW, cr["L"], d, kv_div, need_lse=True, v=cr["V"] if cr["Vt"] is None else None)
+        o2, lse2 = ops.attn_fwd(q2f, cr["K"], cr["Vt"], B2, h, HW, cr["L"], d, kv_div, need_lse=True, v=cr["V"] if cr["Vt"] is None else None,
+                                prescaled=qs2 is not None)
         (h2, n3, ln3), to2 = lora_linear_fwd(o2, self.o2, l2.out if l2 else None, residual=h1f, ln=(self.ln3.gamma, self.ln3.beta, 1e-5))
         # bit-identical to projection + fd_geglu_fwd (both halves are rounded to fp16 before the gate)
         proj = torch.empty((n3.shape[0], self.ff1_wi.shape[0]), dtype=F16, device=n3.device) if rec else None
@@ -183,7 +188,7 @@ class TransformerBlock:
         out = ops.gemm(h3, self.proj_out.w, bias=self.proj_out.bias, residual=xf, gn_stats=True)      # feeds the next ResnetBlock's norm1 / conv_norm_out
         if rec:
             ctx.append(dict(x=x, st=st, h0=h0, ln1=ln1, n1=n1, t1=t1, qkv=qkv, o=o, lse=lse, to1=to1, h1=h1, ln2=ln2, n2=n2,
-                            tq2=tq2, q2=q2f, o2=o2, lse2=lse2, to2=to2, h2=h2, ln3=ln3, proj=proj, pair=pair))
+                            tq2=tq2, q2=q2f, o2=o2, lse2=lse2, to2=to2, h2=h2, ln3=ln3, proj=proj, pair=pair, qs=qs is not None, qs2=qs2 is not None))
         return out
 
     # -- backward ------------------------------------------------------------------------------
@@ -214,10 +219,10 @@ class TransformerBlock:
         slot = BWD_SLOT[0] if cr.get("slots") is not None else None
         if slot is not None:     # this timestep's own fp32 dK / dV pair, written without atomics (bit-reproducible; ops.attn_bwd)
             dq2, _, _ = ops.attn_bwd(c["q2"], cr["K"], cr["V"], c["o2"], do2, c["lse2"], B, h, HW, cr["L"], d, kv_div, kt=cr["Kt"],
-                                     dk_out=cr["slots"][slot, 0], dv_out=cr["slots"][slot, 1])
+                                     dk_out=cr["slots"][slot, 0], dv_out=cr["slots"][slot, 1], prescaled=c.get("qs2", False))
         else:
             dq2, _, _ = ops.attn_bwd(c["q2"], cr["K"], cr["V"], c["o2"], do2, c["lse2"], B, h, HW, cr["L"], d, kv_div, kt=cr["Kt"],
-                                     dk_acc=cr["dK"], dv_acc=cr["dV"])
+                                     dk_acc=cr["dK"], dv_acc=cr["dV"], prescaled=c.get("qs2", False))
         if pair:
             # the shared prefix received the gradient of both halves
             B = B // 2
@@ -232,7 +237,7 @@ class TransformerBlock:
         do1 = lora_linear_bwd(dh1, c["o"], c["to1"], self.o1, l1.out if l1 else None, gscale)
         qkv = c["qkv"]
         dqkv = torch.empty_like(qkv)                                    # dq | dk | dv as column slices: one dgrad GEMM over K = 3C
-        ops.attn_bwd(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], c["o"], do1, c["lse"], B, h, HW, HW, d, 1, dqkv=dqkv)
+        ops.attn_bwd(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], c["o"], do1, c["lse"], B, h, HW, HW, d, 1, dqkv=dqkv, prescaled=c.get("qs", False))
         if self._wqkvT is None:
             self._wqkvT = self.wqkv.t().contiguous()                    # [C, 3C]
         if l1 is not None:

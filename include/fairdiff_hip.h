@@ -88,6 +88,10 @@ typedef struct fd_gemm_desc {
     const float* ln_gamma; const float* ln_beta;
     float* ln_stats;
     float ln_eps;
+    /* optional per-column factor (colscale_cols == 0: none): columns n < colscale_cols of alpha * (A.B^T + A2.B2^T) are multiplied by ``colscale``
+     * in fp32 before bias / activation / rounding (colscale_cols must be a multiple of 4).  Attention.to_q inside the stacked q/k/v projection:
+     * q is written pre-multiplied by softmax_scale * log2(e), which the attention kernels then take as is (negative ``scale`` argument). */
+    float colscale; int32_t colscale_cols;
 } fd_gemm_desc;
 int fd_gemm(const fd_gemm_desc* d, void* stream);
 /* rows per statistics chunk of ``gn_stats`` for this problem (32), or 0 when the kernel fd_gemm would launch has no statistics epilogue
@@ -158,6 +162,10 @@ int fd_cast_f16_to_f32(const void* x, float* y, int64_t n, float scale, void* st
  *     (ds_read_b64_tr_b16; the shipped form); with Tkp > 0 a transposed copy [Bk,H*d,Tkp] (keys contiguous, Tkp>=Tk, Tkp%8==0).
  * sample b uses kv batch b / kv_div (cross-attention K/V are shared by each CFG half).
  * o:[B,Tq,H*d] fp16, lse:[B,H,Tq] fp32 (natural-log sum-exp of the scaled scores).
+ * scale: the softmax scale (d^-0.5).  NEGATIVE scale, all three entry points (d % 16 == 8 -- the U-Net's d = 40 --, transpose-read forms only):
+ *   "pre-scaled q" -- q holds q_true * |scale| * log2(e), written that way by its projection (fd_gemm_desc.colscale); the kernels then take the QK^T
+ *   accumulator as the exponent's argument, the softmax reference point (forward) or the saved log-sum-exp (backward) riding in spare contraction
+ *   slots of the padded head dim.  o, lse, dk, dv are unchanged in meaning and dq is still the gradient w.r.t. q_true.
  * ldq / ldk (and ldkv, lddq, lddkv below): row strides in elements of q, k/v and of the dq, dk/dv outputs; 0 = H*d (contiguous).
  * Non-trivial strides let q, k, v (and dq, dk, dv) be column slices of ONE [M, 3*H*d] buffer: the self-attention projections run as a
  * single GEMM with stacked weights and their input gradients as a single GEMM over K = 3*H*d.                                       */

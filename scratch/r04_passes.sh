@@ -208,5 +208,22 @@ for f in sorted(glob.glob('gpurun_out/r04r_step_*.json')):
     except Exception as e: print(f, 'ERR', e)
 PY
     ;;
+s)  # pre-scaled q: kernel tests (attention, colscale), engine tests, isolated attention timing, whole-step A/B (FD_NO_PRESCALED_Q=1)
+    timeout 600 python -m pytest tests/test_kernels_gpu.py -x -q -k "attention or column_scale or gemm_big or gemm_plain" > gpurun_out/r04s_kernel_tests.log 2>&1; tail -4 gpurun_out/r04s_kernel_tests.log
+    timeout 900 python -m pytest tests/test_engine_gpu.py -x -q -k "unet or full_step or pair or generate" > gpurun_out/r04s_engine_tests.log 2>&1; tail -5 gpurun_out/r04s_engine_tests.log
+    timeout 200 python scratch/mb_attn_pre.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r04s_mb_attn_pre.txt
+    for i in 1 2; do
+      $B --steps 6 --warmup 3 > gpurun_out/r04s_step_pre_$i.json 2> gpurun_out/r04s_step_pre_$i.err
+      FD_NO_PRESCALED_Q=1 $B --steps 6 --warmup 3 > gpurun_out/r04s_step_nopre_$i.json 2>/dev/null
+    done
+    python - <<'PY'
+import json,glob
+for f in sorted(glob.glob('gpurun_out/r04s_step_*.json')):
+    try:
+        d=json.loads(open(f).read().strip().splitlines()[-1]); print(f, round(d['value'],3), round(d['ms_per_step'],1), d['config']['phase_ms'])
+    except Exception as e: print(f, 'ERR', e)
+PY
+    tail -3 gpurun_out/r04s_step_pre_1.err
+    ;;
 *) echo "unknown pass $1";;
 esac

@@ -284,7 +284,7 @@ def test_library_exports_every_header_symbol():
     for name in protos:
         assert hasattr(L, name), name
     assert L.fd_version() >= 1
-    assert ctypes.sizeof(lib.GemmDesc) == 296  # keep the Python mirror in step with fd_gemm_desc
+    assert ctypes.sizeof(lib.GemmDesc) == 304  # keep the Python mirror in step with fd_gemm_desc
     # argument validation happens on the host before any launch: safe to exercise without a GPU
     d = lib.GemmDesc()
     assert L.fd_gemm(ctypes.byref(d), None) == -1 and b"null operand" in L.fd_last_error()

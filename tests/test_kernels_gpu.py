@@ -496,6 +496,61 @@ def test_attention_fwd_bwd(ops, dev, B, H, Tq, Tk, d, kv_div, tr):
         check("attn dv (slabs)", outs[0][2].reshape(Bk, Tk, C), vr.grad, 5e-3)
 
 
+@pytest.mark.parametrize("B,H,Tq,Tk,kv_div", [(2, 8, 1024, 1024, 1), (1, 8, 4096, 4096, 1), (4, 8, 1024, 13, 2), (2, 4, 300, 77, 1), (16, 8, 4096, 77, 8)])
+def test_attention_with_prescaled_q(ops, dev, B, H, Tq, Tk, kv_div):
+    """"Pre-scaled q" (negative ``scale`` of the C-ABI; d = 40): q arrives multiplied by d^-0.5 * log2(e), the kernels take the QK^T accumulator as the
+    exponent's argument and carry the softmax reference point / the saved log-sum-exp in the spare contraction slots.  Checked against torch on the
+    queries the stored values stand for (q' / factor): forward, LSE, and dq / dk / dv -- dq being the gradient w.r.t. the UNSCALED query, which is what the
+    projection's backward consumes; QB = 1 and QB = 2 forwards, shared K / V with the slab form, a partial last key tile, invalid query rows."""
+    d = 40
+    C, Bk = H * d, B // kv_div
+    fac = ops.q_prescale(d)
+    assert fac is not None and abs(fac - d ** -0.5 * 1.4426950408889634) < 1e-12
+    q, k, v = rnd(B, Tq, C, dev=dev, seed=1), rnd(Bk, Tk, C, dev=dev, seed=2), rnd(Bk, Tk, C, dev=dev, seed=3)
+    qp = (q.float() * fac).half()                        # what the projection's epilogue writes (one rounding)
+    qr, kr, vr = (qp.float() / fac).requires_grad_(True), k.float().requires_grad_(True), v.float().requires_grad_(True)
+    oref, lref = _attn_ref(qr, kr, vr, H, kv_div)
+    q2, k2, v2 = qp.reshape(B * Tq, C), k.reshape(Bk * Tk, C), v.reshape(Bk * Tk, C)
+    o, lse = ops.attn_fwd(q2, k2, None, B, H, Tq, Tk, d, kv_div, need_lse=True, v=v2, prescaled=True)
+    check("attn fwd (pre-scaled q)", o.reshape(B, Tq, C), oref, 3e-3)
+    check("attn lse (pre-scaled q)", lse, lref, 1e-3)
+    o_b, lse_b = ops.attn_fwd(q2, k2, None, B, H, Tq, Tk, d, kv_div, need_lse=True, v=v2, prescaled=True)
+    assert torch.equal(o, o_b) and torch.equal(lse, lse_b)
+    do = rnd(B, Tq, C, dev=dev, seed=4)
+    oref.backward(do.float())
+    dko, dvo = torch.empty(Bk * Tk, C, dtype=torch.float32, device=dev), torch.empty(Bk * Tk, C, dtype=torch.float32, device=dev)
+    dq, _, _ = ops.attn_bwd(q2, k2, v2, o, do.reshape(B * Tq, C), lse, B, H, Tq, Tk, d, kv_div, dk_out=dko, dv_out=dvo, prescaled=True)
+    check("attn dq (pre-scaled q)", dq.reshape(B, Tq, C), qr.grad, 5e-3)
+    check("attn dk (pre-scaled q)", dko.reshape(Bk, Tk, C), kr.grad, 5e-3)
+    check("attn dv (pre-scaled q)", dvo.reshape(Bk, Tk, C), vr.grad, 5e-3)
+    if kv_div == 1:
+        dq2, dk2, dv2 = ops.attn_bwd(q2, k2, v2, o, do.reshape(B * Tq, C), lse, B, H, Tq, Tk, d, 1, prescaled=True)     # fp16 outputs, no slabs
+        assert torch.equal(dq, dq2)
+        check("attn dk fp16 (pre-scaled q)", dk2.reshape(Bk, Tk, C), kr.grad, 5e-3)
+        check("attn dv fp16 (pre-scaled q)", dv2.reshape(Bk, Tk, C), vr.grad, 5e-3)
+
+
+@pytest.mark.parametrize("M,N,K,cols", [(4096, 960, 320, 320), (65536, 960, 320, 320), (300, 320, 320, 320), (1024, 3840, 1280, 1280), (2048, 2560, 320, 640)])
+def test_gemm_column_scale(ops, dev, M, N, K, cols):
+    """fd_gemm_desc.colscale: the first ``cols`` output columns times a factor in the fp32 epilogue, before bias and rounding (the q third of the stacked
+    q / k / v projection), on every tile family incl. split-K; the other columns bit-identical to the launch without it."""
+    a, b = rnd(M, K, dev=dev, seed=1), rnd(N, K, dev=dev, scale=0.1, seed=2)
+    a2, b2 = rnd(M, 8, dev=dev, seed=3), rnd(N, 8, dev=dev, seed=4)
+    fac = 0.2280966
+    plain = ops.gemm(a, b, a2=a2, b2=b2)
+    c = ops.gemm(a, b, a2=a2, b2=b2, colscale=(fac, cols))
+    assert torch.equal(c[:, cols:], plain[:, cols:])
+    ref = (a.float() @ b.float().t() + a2.float() @ b2.float().t())
+    ref[:, :cols] *= fac
+    check(f"gemm colscale {M}x{N}x{K}", c, ref, 2e-3)
+    bias = rnd(N, dev=dev, dtype=torch.float32, seed=5)
+    res = rnd(M, N, dev=dev, seed=6)
+    c2 = ops.gemm(a, b, bias=bias, residual=res, colscale=(fac, cols))
+    ref2 = a.float() @ b.float().t()
+    ref2[:, :cols] *= fac
+    check("gemm colscale + bias + residual", c2, ref2 + bias + res.float(), 2e-3)
+
+
 @pytest.mark.parametrize("B,H,T,d", [(2, 8, 1024, 40), (2, 8, 256, 80), (1, 4, 64, 160)])
 def test_attention_strided_qkv_slices(ops, dev, B, H, T, d):
     """q, k, v as column slices of ONE [M, 3C] projection buffer and dq, dk, dv written as slices of one [M, 3C] gradient buffer (the
