@@ -86,7 +86,11 @@ TIMER = None
 
 
 GN_STATS = os.environ.get("FD_NO_GN_STATS") is None      # A/B switch: GroupNorm statistics from the producer's epilogue (fd_gemm_desc.gn_stats)
-LN_EPILOGUE = os.environ.get("FD_NO_LN_EPILOGUE") is None   # A/B switch: LayerNorm as a second output of the producing GEMM (fd_gemm_desc.ln_out)
+# LayerNorm as a second output of the producing GEMM (fd_gemm_desc.ln_out): built, parity-tested, and OFF by default -- isolated it saves 8 us per pair at
+# M = 65536 (GEMM 30 + LayerNorm 28 -> 50 us), inside the multi-stream step the long exposed epilogue of a one-tile-per-CU kernel costs more than the
+# memory-bound pass it replaces, which overlaps with the other streams' kernels (same-box A/B 1361-1381 vs 1361-1372 ms; in-situ kernel time 73 us
+# against ~33 + 29; profiles/r04_layernorm_epilogue.txt).  FD_LN_EPILOGUE=1 turns it on.
+LN_EPILOGUE = os.environ.get("FD_LN_EPILOGUE") is not None
 
 
 def _gemm_call(d, conv, out=None, gn_stats=False, ln=None):

@@ -182,8 +182,8 @@ q)  # LayerNorm as a second output of the producing GEMM (fd_gemm_desc.ln_out): 
     timeout 900 python -m pytest tests/test_engine_gpu.py -x -q -k "unet or full_step or pair" > gpurun_out/r04q_engine_tests.log 2>&1; tail -5 gpurun_out/r04q_engine_tests.log
     timeout 200 python scratch/mb_ln_epilogue.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r04q_mb_ln_epilogue.txt
     for i in 1 2; do
-      $B --steps 6 --warmup 3 > gpurun_out/r04q_step_ln_$i.json 2> gpurun_out/r04q_step_ln_$i.err
-      FD_NO_LN_EPILOGUE=1 $B --steps 6 --warmup 3 > gpurun_out/r04q_step_noln_$i.json 2>/dev/null
+      FD_LN_EPILOGUE=1 $B --steps 6 --warmup 3 > gpurun_out/r04q_step_ln_$i.json 2> gpurun_out/r04q_step_ln_$i.err
+      $B --steps 6 --warmup 3 > gpurun_out/r04q_step_noln_$i.json 2>/dev/null
     done
     python - <<'PY'
 import json,glob
@@ -197,8 +197,8 @@ PY
 r)  # LayerNorm epilogue, second form (values back into the staging slot, segmented shuffle): whole-step A/B only
     B2="python bench.py --no_cpu_baseline --no_roofline"
     for i in 1 2 3; do
-      $B2 --steps 6 --warmup 3 > gpurun_out/r04r_step_ln_$i.json 2> gpurun_out/r04r_step_ln_$i.err
-      FD_NO_LN_EPILOGUE=1 $B2 --steps 6 --warmup 3 > gpurun_out/r04r_step_noln_$i.json 2>/dev/null
+      FD_LN_EPILOGUE=1 $B2 --steps 6 --warmup 3 > gpurun_out/r04r_step_ln_$i.json 2> gpurun_out/r04r_step_ln_$i.err
+      $B2 --steps 6 --warmup 3 > gpurun_out/r04r_step_noln_$i.json 2>/dev/null
     done
     python - <<'PY'
 import json,glob

@@ -337,12 +337,13 @@ def test_groupnorm_from_producer_statistics(ops, dev, B, HW, C1, C2, silu):
 
 @pytest.mark.parametrize("M,N,K,fused", [(32768, 320, 320, True), (65536, 320, 320, True), (12800, 320, 1280, True), (10250, 320, 320, True),
                                            (4096, 320, 320, False), (16384, 640, 640, False)])
-def test_gemm_layernorm_epilogue(ops, dev, M, N, K, fused):
+def test_gemm_layernorm_epilogue(ops, dev, M, N, K, fused, monkeypatch):
     """fd_gemm_desc.ln_out: the GEMM whose tile holds whole rows writes LayerNorm(row) as a second output.  C itself is
     bit-identical to the launch without it; the normalised copy and the saved statistics against torch and against fd_layernorm_fwd on the same
     C; M tails; shapes whose kernel cannot (small M, N != 320) fall back to the standalone pass inside ops.gemm."""
     import ctypes
     from finetune_fair_diffusion_amd import lib
+    monkeypatch.setattr(ops, "LN_EPILOGUE", True)          # off by default in the product (profiles/r04_layernorm_epilogue.txt); FD_LN_EPILOGUE=1 turns it on
     a, b = rnd(M, K, dev=dev, seed=1), rnd(N, K, dev=dev, scale=0.1, seed=2)
     a2, b2 = rnd(M, 8, dev=dev, seed=3), rnd(N, 8, dev=dev, seed=4)
     bias, res = rnd(N, dev=dev, dtype=torch.float32, seed=5), rnd(M, N, dev=dev, seed=6) * 3 + 0.5
