@@ -225,5 +225,18 @@ for f in sorted(glob.glob('gpurun_out/r04s_step_*.json')):
 PY
     tail -3 gpurun_out/r04s_step_pre_1.err
     ;;
+t)  # GroupNorm statistics epilogue, cleaner whole-step A/B (three alternations) on the final tree
+    for i in 1 2 3; do
+      $B --steps 6 --warmup 3 > gpurun_out/r04t_step_stats_$i.json 2>/dev/null
+      FD_NO_GN_STATS=1 $B --steps 6 --warmup 3 > gpurun_out/r04t_step_nostats_$i.json 2>/dev/null
+    done
+    python - <<'PY'
+import json,glob
+for f in sorted(glob.glob('gpurun_out/r04t_step_*.json')):
+    try:
+        d=json.loads(open(f).read().strip().splitlines()[-1]); print(f, round(d['value'],3), round(d['ms_per_step'],1), d['config']['phase_ms'])
+    except Exception as e: print(f, 'ERR', e)
+PY
+    ;;
 *) echo "unknown pass $1";;
 esac
