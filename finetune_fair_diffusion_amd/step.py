@@ -238,8 +238,10 @@ class FairnessTrainer:
         # ... and ``r2_prefetch_late`` more of them are enqueued behind the U-Net backward's last timestep: they run while the backward streams
         # drain unevenly, through the optimiser step and under the first (host-paced) forward of the next step
         self.r2_prefetch_late = int(os.environ.get("FD_R2_PREFETCH_LATE", "0"))
-        # the frozen model's forward (R2: a third of the step's U-Net passes) replayed as a hipGraph (FD_R2_GRAPH=1; measurement in DESIGN section 4 "round 4")
-        self.r2_graph = os.environ.get("FD_R2_GRAPH") is not None
+        # the frozen model's forward (R2: a third of the step's U-Net passes) replayed as a hipGraph: bit-identical to the eager forward, ~2900 C-ABI
+        # calls per forward become one launch -- the enqueue thread keeps a larger lead over the device in the rollout phase, where its lead is smallest
+        # (fewer of the +50..95 ms steps, median -5..-15 ms in 20-step runs: profiles/r04_step_jitter_r2_graph.txt).  FD_R2_GRAPH=0 turns it off.
+        self.r2_graph = os.environ.get("FD_R2_GRAPH", "1") != "0"
         self._r2_pre = None
         self._sch_r2 = None
         self.last_r2_prefetched = 0

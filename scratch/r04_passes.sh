@@ -238,5 +238,19 @@ for f in sorted(glob.glob('gpurun_out/r04t_step_*.json')):
     except Exception as e: print(f, 'ERR', e)
 PY
     ;;
+u)  # step-time jitter: 20-step runs with and without the hipGraph replay of the frozen model's forward (does the freed host time remove the +50..95 ms outliers?)
+    for i in 1 2; do
+      $B --steps 20 --warmup 5 > gpurun_out/r04u_eager_$i.json 2>/dev/null
+      FD_R2_GRAPH=1 $B --steps 20 --warmup 5 > gpurun_out/r04u_graph_$i.json 2> gpurun_out/r04u_graph_$i.err
+    done
+    python - <<'PY'
+import json,glob,statistics
+for f in sorted(glob.glob('gpurun_out/r04u_*.json')):
+    try:
+        d=json.loads(open(f).read().strip().splitlines()[-1]); h=d['config']['host_ms_per_step']
+        print(f, round(d['value'],3), round(d['ms_per_step'],1), 'median', round(statistics.median(h),1), 'outliers(>median+20):', sum(x>statistics.median(h)+20 for x in h), [round(x) for x in h])
+    except Exception as e: print(f, 'ERR', e)
+PY
+    ;;
 *) echo "unknown pass $1";;
 esac
