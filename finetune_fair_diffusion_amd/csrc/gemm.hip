@@ -176,12 +176,12 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(fd_gemm_desc p, int ntm,
 // CONV: 0 = dense operands, 1 = the 3x3 gathers (stride 1 / stride 2 / nearest-up2 / transposed stride 2), 2 = the Upsample2D phase pair
 // (FD_CONV_UP2P, FD_CONV_UP2P_BWD) -- its own instantiation: compiled into variant 1 the extra gather arithmetic cost the 8-wave 256x320
 // and the 512x128 gathers 34 and 52 spilled registers
-// CV = 3 / 4: variants 0 / 1 with the GroupNorm-statistics epilogue (fd_gemm_desc.gn_stats); CV = 5: variant 0 with the LayerNorm second output
+// CV = 3 / 4 / 6: variants 0 / 1 / 2 with the GroupNorm-statistics epilogue (fd_gemm_desc.gn_stats); CV = 5: variant 0 with the LayerNorm second output
 // (fd_gemm_desc.ln_out; BN == N == 320 only).
 template <int BM, int BN, int WGM, int WGN, int CV>
 __global__ __launch_bounds__(WGM * WGN * 64) void gemm_big_kernel(fd_gemm_desc p, int ntm, int ntn, int gn) {
-    constexpr int CONV = CV == 5 ? 0 : CV >= 3 ? CV - 3 : CV;
-    constexpr bool WSTATS = CV == 3 || CV == 4, WLN = CV == 5;
+    constexpr int CONV = CV == 5 ? 0 : CV == 6 ? 2 : CV >= 3 ? CV - 3 : CV;      // CV = 6: the phase pair (variant 2) with the statistics epilogue (FD_CONV_UP2PI)
+    constexpr bool WSTATS = CV == 3 || CV == 4 || CV == 6, WLN = CV == 5;
     constexpr int NW = WGM * WGN;                   // 8 or 16 waves
     static_assert(NW == 8 || NW == 16, "8 or 16 waves");
     constexpr int WTM = BM / WGM, WTN = BN / WGN;   // wave tile
@@ -204,12 +204,15 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_big_kernel(fd_gemm_desc p
     int tile = xcd_remap(blockIdx.x, gridDim.x);
     // FD_CONV_UP2P: the four output phases (py, px) of conv3x3(nearest-up2(x)) are four 2x2-tap problems over the low-res input with
     // their own pre-summed weights; they share one launch, phase-major in the tile index, weights and output
-    int phase = 0;
-    if (CONV == 2 && p.conv_mode == FD_CONV_UP2P) {
+    int phase = 0, up_phase = -1;      // up_phase >= 0: FD_CONV_UP2PI, the epilogue maps low-res rows of this phase to rows of the [Bn, 2H, 2W, N] result
+    if (CONV == 2 && (p.conv_mode == FD_CONV_UP2P || p.conv_mode == FD_CONV_UP2PI)) {
         phase = tile / (ntm * ntn);
         tile -= phase * (ntm * ntn);
         p.B = (const f16*)p.B + (int64_t)phase * p.N * p.ldb;
-        p.C = (f16*)p.C + (int64_t)phase * p.M * p.ldc;
+        if (p.conv_mode == FD_CONV_UP2PI) {
+            up_phase = phase;
+            p.conv_mode = FD_CONV_UP2P;            // same gather from here on
+        } else p.C = (f16*)p.C + (int64_t)phase * p.M * p.ldc;
     }
     const int ph_y = phase >> 1, ph_x = phase & 1;
     int mt, nt;
@@ -478,9 +481,9 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_big_kernel(fd_gemm_desc p
             gemm_epilogue_ln<TM, TN, TMC, WGM, WGN>(p, acc, smem + wave * (TMC * 16) * (WTN + 4), (float*)(smem + STAGE_HALFS), wm, wn, m0 + wm * WTM,
                                                     n0 + wn * WTN, lane);
         } else
-        gemm_epilogue_lds<TM, TN, TMC, WSTATS>(p, acc, smem + wave * (TMC * 16) * (WTN + 4), m0 + wm * WTM, n0 + wn * WTN, lane, 0, 0);
+        gemm_epilogue_lds<TM, TN, TMC, WSTATS>(p, acc, smem + wave * (TMC * 16) * (WTN + 4), m0 + wm * WTM, n0 + wn * WTN, lane, 0, 0, up_phase);
     } else {
-        gemm_epilogue<TM, TN>(p, acc, m0 + wm * WTM, n0 + wn * WTN, l15, lg, 0, 0);
+        gemm_epilogue<TM, TN>(p, acc, m0 + wm * WTM, n0 + wn * WTN, l15, lg, 0, 0, up_phase);
     }
 }
 
@@ -532,7 +535,7 @@ static int launch_big(const fd_gemm_desc& d, hipStream_t s, int nsplit = 1) {
     // n-tiles per band: the band's B slab (gn * BN rows of K halfs, per split) should fit an XCD's L2 next to the streaming A tiles
     static const long l2_budget = bench_env("FD_GEMM_L2_KB") ? atol(bench_env("FD_GEMM_L2_KB")) * 1024 : 3 * 1024 * 1024;
     const long ktot = ((long)d.K + d.K2) / nsplit;
-    const int nph = (d.conv && d.conv_mode == FD_CONV_UP2P) ? 4 : 1;
+    const int nph = (d.conv && (d.conv_mode == FD_CONV_UP2P || d.conv_mode == FD_CONV_UP2PI)) ? 4 : 1;
     long gnl = l2_budget / ((long)BN * ktot * 2);
     const int gn = (int)(gnl < 1 ? 1 : (gnl > ntn ? ntn : gnl));
     if constexpr (BN == 320 && WGM == 4 && WGN == 4) {
@@ -546,6 +549,14 @@ static int launch_big(const fd_gemm_desc& d, hipStream_t s, int nsplit = 1) {
         }
     }
     if constexpr (BN / WGN == 80) {
+        if (d.gn_stats && nsplit == 1 && d.conv && d.conv_mode == FD_CONV_UP2PI) {       // the phase pair writing the interleaved result, with statistics
+            static std::once_flag once_st6;
+            std::call_once(once_st6, [] {
+                (void)hipFuncSetAttribute((const void*)gemm_big_kernel<BM, BN, WGM, WGN, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            });
+            hipLaunchKernelGGL((gemm_big_kernel<BM, BN, WGM, WGN, 6>), dim3(ntm * ntn * nph, 1), dim3(WGM * WGN * 64), lds, s, d, ntm, ntn, gn);
+            return fd_check_launch("fd_gemm(big, phase pair with statistics epilogue)");
+        }
         if (d.gn_stats && nsplit == 1 && !(d.conv && d.conv_mode >= FD_CONV_UP2P)) {     // the statistics-epilogue instantiations (fd_gemm checked eligibility)
             static std::once_flag once_st;
             std::call_once(once_st, [] {
@@ -742,7 +753,7 @@ extern "C" int fd_gemm_tile(const fd_gemm_desc* dp) {
     // big-tile (BK=64, 8-wave) variants: unbatched, K-tiles of 64 must not straddle a conv tap
     static const int bigk = bench_env("FD_GEMM_BIGK") ? atoi(bench_env("FD_GEMM_BIGK")) : 320;
     if (!nobig && nb == 1 && (d.conv ? (d.Cin & 63) == 0 : (d.K + d.K2) >= bigk)) {
-        const long phs = (d.conv && d.conv_mode == FD_CONV_UP2P) ? 4 : 1;    // four phases share the launch
+        const long phs = (d.conv && (d.conv_mode == FD_CONV_UP2P || d.conv_mode == FD_CONV_UP2PI)) ? 4 : 1;    // four phases share the launch
         const long m256 = phs * ((d.M + 255) / 256), m128 = phs * ((d.M + 127) / 128);
         // Minimum tile counts for the 320-wide tiles.  Round 1 tuned them per kernel in isolation (200 / 160: "fill 256 CUs"); under the
         // multi-stream schedule of round 2 a launch that fills half the chip with efficient tiles beats one that fills it with smaller
@@ -819,8 +830,8 @@ static GemmPlan gemm_plan(const fd_gemm_desc& d /* K2 already normalised */) {
     // splitk_reduce_kernel), not the phase-major output of the up-sampling pair (a chunk there is not a run of pixels of one image)
     const bool lds_epi = d.out_dtype == FD_OUT_F16 && (d.N & 7) == 0 && (d.ldc & 7) == 0 && (!d.residual || (d.ldr & 7) == 0) &&
                          (!d.rowbias || (d.ld_rowbias & 3) == 0);
-    g.stats_ok = (g.kind == GK_PP || (g.kind == GK_BIG && g.bn / g.wgn == 80)) && g.nsplit == 1 && g.cv < 2 && lds_epi && d.act != FD_ACT_GEGLU &&
-                 d.batch <= 1 && (d.N % 80) == 0;
+    g.stats_ok = (g.kind == GK_PP || (g.kind == GK_BIG && g.bn / g.wgn == 80)) && g.nsplit == 1 && lds_epi && d.act != FD_ACT_GEGLU &&
+                 d.batch <= 1 && (d.N % 80) == 0 && (g.cv < 2 || (d.conv_mode == FD_CONV_UP2PI && (d.M & 31) == 0));
     // the LayerNorm second output lives in gemm_epilogue_ln: 16-wave lockstep 320-wide tiles whose one n-tile holds whole rows, bias / residual only
     g.ln_ok = g.kind == GK_BIG && g.bn == 320 && g.wgm == 4 && g.wgn == 4 && d.N == 320 && g.nsplit == 1 && g.cv == 0 && lds_epi &&
               d.act == FD_ACT_NONE && !d.rowbias && d.alpha == 1.f && d.batch <= 1 && !d.gn_stats && d.colscale_cols == 0;
@@ -838,7 +849,7 @@ extern "C" int fd_gemm_kernel_name(const fd_gemm_desc* dp, char* buf, int n) {
     switch (g.kind) {
         case GK_PPS: snprintf(buf, n, "gemm_pps_kernel<%d>", d.act == FD_ACT_GEGLU ? 1 : 0); break;
         case GK_PP: snprintf(buf, n, "gemm_pp_kernel<%d, %d, %s>", g.bm, (d.conv ? 1 : 0) + (st ? 2 : 0), (pp_mode() & 4) ? "true" : "false"); break;
-        case GK_BIG: snprintf(buf, n, "gemm_big_kernel<%d, %d, %d, %d, %d>", g.bm, g.bn, g.wgm, g.wgn, (d.ln_out && g.ln_ok) ? 5 : st ? g.cv + 3 : g.cv); break;
+        case GK_BIG: snprintf(buf, n, "gemm_big_kernel<%d, %d, %d, %d, %d>", g.bm, g.bn, g.wgm, g.wgn, (d.ln_out && g.ln_ok) ? 5 : st ? (g.cv == 2 ? 6 : g.cv + 3) : g.cv); break;
         case GK_SKINNY: snprintf(buf, n, "gemm_skinny_kernel<%d, %d, 1>", g.bn / 16, d.K >= 1280 ? 4 : d.K >= 640 ? 2 : 1); break;
         default: snprintf(buf, n, "gemm_glds_kernel<%d, %d, %s>", g.bm, g.bn, d.conv ? "true" : "false"); break;
     }
@@ -874,9 +885,11 @@ extern "C" int fd_gemm(const fd_gemm_desc* dp, void* stream) {
         FD_REQUIRE(d.batch <= 1, "fd_gemm: second slab is not batched");
     } else d.K2 = 0;
     if (d.conv) {
-        const int ntap = d.conv_mode == FD_CONV_UP2P ? 4 : d.conv_mode == FD_CONV_UP2P_BWD ? 16 : 9;
+        const bool up_fwd = d.conv_mode == FD_CONV_UP2P || d.conv_mode == FD_CONV_UP2PI;
+        const int ntap = up_fwd ? 4 : d.conv_mode == FD_CONV_UP2P_BWD ? 16 : 9;
         FD_REQUIRE((d.Cin & 31) == 0 && d.K == ntap * d.Cin, "fd_gemm(conv): Cin must be a multiple of 32 and K == taps*Cin");
-        if (d.conv_mode == FD_CONV_UP2P) FD_REQUIRE(!d.residual && !d.rowbias, "fd_gemm(conv up2 phases): bias-only epilogue");
+        if (up_fwd) FD_REQUIRE(!d.residual && !d.rowbias, "fd_gemm(conv up2 phases): bias-only epilogue");
+        if (d.conv_mode == FD_CONV_UP2PI) FD_REQUIRE(d.out_dtype == FD_OUT_F16, "fd_gemm(conv up2 phases, interleaved result): fp16 output");
         FD_REQUIRE(d.M == d.Bn * d.Ho * d.Wo, "fd_gemm(conv): M != B*Ho*Wo");
         FD_REQUIRE(d.batch <= 1, "fd_gemm(conv): not batched");
         FD_REQUIRE((int64_t)d.Bn * d.H * d.W * d.lda < (1LL << 31), "fd_gemm(conv): input larger than 2^31 elements");

@@ -42,11 +42,20 @@ __device__ __forceinline__ void glds16(const f16* src, f16* lds_dst) {
 }
 
 
+// FD_CONV_UP2PI: row of the [Bn, 2H, 2W, N] result that low-res row m = (b, y, x) of phase ``up_phase`` = py * 2 + px lands on (up_phase < 0: m itself)
+__device__ __forceinline__ int64_t up2p_row(const fd_gemm_desc& p, int m, int up_phase) {
+    if (up_phase < 0) return m;
+    const int hw = p.H * p.W;
+    const int b = m / hw, r = m - b * hw;
+    const int y = r / p.W, x = r - y * p.W;
+    return ((int64_t)(b * 2 * p.H + 2 * y + (up_phase >> 1))) * (2 * p.W) + 2 * x + (up_phase & 1);
+}
+
 // ---- shared epilogue: lane holds C[m][n..n+3] per 16x16 tile (swapped-operand MFMA layout).  Bias / row-bias / residual
 // are fetched as one vector per tile (the epilogue of a short-K GEMM is otherwise more VMEM instructions than its main loop).
 template <int TM, int TN>
 __device__ __forceinline__ void gemm_epilogue(const fd_gemm_desc& p, f32x4 (&acc)[TM][TN], int mbase, int nbase, int l15, int lg,
-                                              int64_t zC, int64_t zR) {
+                                              int64_t zC, int64_t zR, int up_phase = -1) {
     const f16* R = p.residual ? (const f16*)p.residual + zR : nullptr;
     const f16* RB = (const f16*)p.rowbias;
     const bool vec_ok = ((p.N & 3) == 0) && ((p.ldc & 3) == 0) && (!R || (p.ldr & 3) == 0) && (!RB || (p.ld_rowbias & 3) == 0);
@@ -82,13 +91,14 @@ __device__ __forceinline__ void gemm_epilogue(const fd_gemm_desc& p, f32x4 (&acc
                 x = apply_act(x, p.act);
                 v[r] = x + (float)resv[r];
             }
+            const int64_t crow = up2p_row(p, m, up_phase);
             if (p.out_dtype == FD_OUT_F32) {
-                float* C = (float*)p.C + zC + (int64_t)m * p.ldc + n;
+                float* C = (float*)p.C + zC + crow * p.ldc + n;
                 if (vec_ok) *(f32x4*)C = (f32x4){v[0], v[1], v[2], v[3]};
                 else
                     for (int r = 0; r < 4 && n + r < p.N; ++r) C[r] = v[r];
             } else {
-                f16* C = (f16*)p.C + zC + (int64_t)m * p.ldc + n;
+                f16* C = (f16*)p.C + zC + crow * p.ldc + n;
                 if (vec_ok) *(f16x4*)C = (f16x4){(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
                 else
                     for (int r = 0; r < 4 && n + r < p.N; ++r) C[r] = (f16)v[r];
@@ -104,7 +114,7 @@ __device__ __forceinline__ void gemm_epilogue(const fd_gemm_desc& p, f32x4 (&acc
 // store instruction covers whole 128-byte row segments; the residual is added on the way out with 16-byte loads.
 template <int TM, int TN, int TMC = TM, bool WSTATS = false>
 __device__ __forceinline__ void gemm_epilogue_lds(const fd_gemm_desc& p, f32x4 (&acc)[TM][TN], f16* wave_lds, int mbase, int nbase,
-                                                  int lane, int64_t zC, int64_t zR) {
+                                                  int lane, int64_t zC, int64_t zR, int up_phase = -1) {
     // TMC: 16-row groups staged per pass (the wave-private LDS region holds TMC*16 rows; big tiles need two passes)
     constexpr int WTN = TN * 16, WTMC = TMC * 16, LDW = WTN + 4;   // +4 halfs: 8-byte aligned rows, spreads the ds_write_b64 banks
     static_assert(TM % TMC == 0, "chunking");
@@ -202,7 +212,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const fd_gemm_desc& p, f32x4 (
 #pragma unroll
                         for (int k = 0; k < 8; ++k) v[k] = (f16)((float)v[k] + (float)rv[k]);
                     }
-                    *(f16x8*)((f16*)p.C + zC + (int64_t)m * p.ldc + n) = v;
+                    *(f16x8*)((f16*)p.C + zC + up2p_row(p, m, up_phase) * p.ldc + n) = v;
                 }
             }
         } else {
@@ -223,7 +233,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const fd_gemm_desc& p, f32x4 (
 #pragma unroll
                             for (int k = 0; k < 8; ++k) v[k] = (f16)((float)v[k] + (float)rv[k]);
                         }
-                        *(f16x8*)((f16*)p.C + zC + (int64_t)m * p.ldc + n) = v;
+                        *(f16x8*)((f16*)p.C + zC + up2p_row(p, m, up_phase) * p.ldc + n) = v;
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
                             const f16x2 pr = {v[2 * k], v[2 * k + 1]};
@@ -271,7 +281,8 @@ __device__ __forceinline__ void gemm_epilogue_lds(const fd_gemm_desc& p, f32x4 (
                         t0 += v.x;
                         t1 += v.y;
                     }
-                    const int64_t slot = (int64_t)(mrow >> 5) * (p.N / 10) + nbase / 10 + lane;
+                    // FD_CONV_UP2PI: the chunks of phase ``up_phase`` follow those of the phases before it (M % 32 == 0)
+                    const int64_t slot = (int64_t)((mrow >> 5) + (up_phase > 0 ? up_phase * (p.M >> 5) : 0)) * (p.N / 10) + nbase / 10 + lane;
                     *(float2*)(gst + slot * 2) = make_float2(t0, t1);
                 }
                 // the next chunk's sums / the next pass's staging overwrite ``red``: the unit lanes' reads must have returned

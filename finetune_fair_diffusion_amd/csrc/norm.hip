@@ -141,7 +141,8 @@ __device__ __forceinline__ void gn_block_stats(const GNArgs& a, const float* par
 // Statistics that arrive from the PRODUCERS of x1 / x2 (fd_gemm_desc.gn_stats): per row chunk and 10-channel unit the (sum, sum of squares) of
 // the stored values.  A group is a run of units; the (unit, chunk) pairs of a group, unit-major, are cut into blockDim / G slices that are summed
 // by different threads and combined in slice order -- the geometry depends on (C, HW, G, chunk heights) only: bit-reproducible.
-struct GNUnits { const float* st1; const float* st2; int nch1, nch2; };
+// per1 / per2 > 0: the source's chunks are phase-major (FD_CONV_UP2PI): chunk c of image b is row (c / per) * (B * per) + b * per + c % per of the table
+struct GNUnits { const float* st1; const float* st2; int nch1, nch2, per1, per2; };
 
 __device__ __forceinline__ void gn_block_stats_units(const GNArgs& a, const GNUnits& u, int b, float n, float* st /* LDS [G*2] */,
                                                      float* ps /* LDS [blockDim / G][G][2] */, float* out /* global [B,G,2] or nullptr */) {
@@ -158,10 +159,11 @@ __device__ __forceinline__ void gn_block_stats_units(const GNArgs& a, const GNUn
             const int uu = g * upg + k;
             const bool first = uu < U1;
             const float* sp = first ? u.st1 : u.st2;
-            const int nch = first ? u.nch1 : u.nch2, U = first ? U1 : U2, ul = first ? uu : uu - U1;
+            const int nch = first ? u.nch1 : u.nch2, U = first ? U1 : U2, ul = first ? uu : uu - U1, per = first ? u.per1 : u.per2;
             const int c0 = max(lo - base, 0), c1 = min(hi - base, nch);
             for (int c = c0; c < c1; ++c) {
-                const float2 v = *(const float2*)(sp + ((int64_t)(b * nch + c) * U + ul) * 2);
+                const int64_t row = per > 0 ? (int64_t)(c / per) * (a.B * per) + b * per + c % per : (int64_t)b * nch + c;
+                const float2 v = *(const float2*)(sp + (row * U + ul) * 2);
                 a0 += v.x;
                 a1 += v.y;
             }
@@ -541,9 +543,18 @@ extern "C" int fd_groupnorm_fwd(const void* x1, int C1, const void* x2, int C2, 
 
 // The apply pass alone, its statistics assembled from the producers' gn_stats buffers (the statistics pass of the two-launch
 // form re-read x; here x is read once, by the pass that normalises it).
+extern "C" int fd_groupnorm_fwd_stats_p(const void* x1, int C1, const void* x2, int C2, int B, int HW, int groups, float eps, const float* gamma,
+                                        const float* beta, int silu, void* y, float* mean_rstd, const float* st1, int rows1, int per1,
+                                        const float* st2, int rows2, int per2, void* stream);
 extern "C" int fd_groupnorm_fwd_stats(const void* x1, int C1, const void* x2, int C2, int B, int HW, int groups, float eps, const float* gamma,
                                       const float* beta, int silu, void* y, float* mean_rstd, const float* st1, int rows1, const float* st2,
                                       int rows2, void* stream) {
+    return fd_groupnorm_fwd_stats_p(x1, C1, x2, C2, B, HW, groups, eps, gamma, beta, silu, y, mean_rstd, st1, rows1, 0, st2, rows2, 0, stream);
+}
+
+extern "C" int fd_groupnorm_fwd_stats_p(const void* x1, int C1, const void* x2, int C2, int B, int HW, int groups, float eps, const float* gamma,
+                                        const float* beta, int silu, void* y, float* mean_rstd, const float* st1, int rows1, int per1,
+                                        const float* st2, int rows2, int per2, void* stream) {
     FD_REQUIRE(gn_check(C1, C2, groups) == 0, "fd_groupnorm_fwd_stats: bad channels C1=%d C2=%d groups=%d", C1, C2, groups);
     const int C = C1 + C2;
     FD_REQUIRE(C1 % 10 == 0 && C2 % 10 == 0 && (C / groups) % 10 == 0, "fd_groupnorm_fwd_stats: C1=%d, C2=%d and the group width %d must be multiples of 10",
@@ -556,7 +567,9 @@ extern "C" int fd_groupnorm_fwd_stats(const void* x1, int C1, const void* x2, in
     int threads;
     FD_REQUIRE(gn_geometry(C, HW, threads, a.rows_per_chunk, a.nchunks) == 0, "fd_groupnorm: C too large");
     FD_REQUIRE(threads / groups >= 1 && (threads / groups) * groups * 2 <= 1024, "fd_groupnorm_fwd_stats: %d threads for %d groups", threads, groups);
-    GNUnits un = {st1, st2, HW / rows1, C2 ? HW / rows2 : 0};
+    FD_REQUIRE(per1 >= 0 && per2 >= 0 && (per1 == 0 || (HW / rows1) % per1 == 0) && (per2 == 0 || !C2 || (HW / rows2) % per2 == 0),
+               "fd_groupnorm_fwd_stats: per1=%d / per2=%d must divide the chunks per image", per1, per2);
+    GNUnits un = {st1, st2, HW / rows1, C2 ? HW / rows2 : 0, per1, C2 ? per2 : 0};
     const float n = (float)HW * (float)(C / groups);
     hipLaunchKernelGGL(gn_apply_kernel<true>, dim3(a.nchunks, B), dim3(threads), 0, (hipStream_t)stream, a, (f16*)y, (const float*)nullptr, n,
                        mean_rstd, un);

@@ -109,7 +109,8 @@ def _gemm_call(d, conv, out=None, gn_stats=False, ln=None):
         # the output tensor OBJECT: ``groupnorm`` finds it there, and anything that makes a new tensor of the output (cat, slicing) drops it
         rows = _lib.get().fd_gemm_stats_rows(ctypes.byref(d))
         if rows > 0:
-            st = torch.empty(((d.M + rows - 1) // rows, d.N // 10, 2), dtype=F32, device=out.device)
+            nph = 4 if (conv and d.conv_mode == CONV_UP2PI) else 1          # four phase problems per launch: phase-major chunk order
+            st = torch.empty((nph * ((d.M + rows - 1) // rows), d.N // 10, 2), dtype=F32, device=out.device)
             d.gn_stats = st.data_ptr()
             out.gn_stats = (st, rows)
     if TIMER is None:
@@ -121,7 +122,7 @@ def _gemm_call(d, conv, out=None, gn_stats=False, ln=None):
     a.record()
     _call("fd_gemm", ctypes.byref(d), _stream())
     b.record()
-    nph = 4 if (conv and d.conv_mode == 4) else 1          # FD_CONV_UP2P: four phase problems per launch
+    nph = 4 if (conv and d.conv_mode in (4, 6)) else 1     # FD_CONV_UP2P / FD_CONV_UP2PI: four phase problems per launch
     flops = 2.0 * nph * d.M * d.N * (d.K + d.K2) * max(d.batch, 1)
     # algorithmic bytes: every operand element read once, the output written once (3x3 gather: the Cin-wide input rows, not 9x)
     a_elems = (d.Bn * d.H * d.W * d.Cin) if conv else d.M * d.K
@@ -266,17 +267,18 @@ def conv3x3(x, w, B, H, W, *, mode=CONV_NORMAL, bias=None, rowbias=None, residua
     return out, Ho, Wo
 
 
-CONV_UP2P, CONV_UP2P_BWD = 4, 5
+CONV_UP2P, CONV_UP2P_BWD, CONV_UP2PI = 4, 5, 6
 _BIG_TILES = (256320, 128320, 128160, 256128, 256256, 512128)
 _NO_UP2P = os.environ.get("FD_NO_UP2P") is not None      # A/B switch: nearest-up2 convs as 3x3 gathers at the high resolution
+_UP2P_SHUFFLE = os.environ.get("FD_UP2P_SHUFFLE") is not None   # A/B switch: phase-major output + fd_phase_shuffle instead of the row-mapping epilogue
 
 
-def _up2p_desc(x, w, out, B, H, W, Cin, Cout, bwd, bias=None):
+def _up2p_desc(x, w, out, B, H, W, Cin, Cout, bwd, bias=None, interleaved=False):
     d = _lib.GemmDesc()
     if bwd:   # x = dOut [B*2H*2W, Cin] (high-res), out [B*H*W, Cout]
         d.K, d.conv_mode, d.H, d.W = 16 * Cin, CONV_UP2P_BWD, 2 * H, 2 * W
-    else:     # x [B*H*W, Cin], out [4, B*H*W, Cout]
-        d.K, d.conv_mode, d.H, d.W = 4 * Cin, CONV_UP2P, H, W
+    else:     # x [B*H*W, Cin], out [4, B*H*W, Cout] phase-major, or (interleaved) the channels-last result [B*2H*2W, Cout] itself
+        d.K, d.conv_mode, d.H, d.W = 4 * Cin, (CONV_UP2PI if interleaved else CONV_UP2P), H, W
     d.A, d.lda, d.B, d.ldb, d.C, d.ldc = x.data_ptr(), Cin, w.data_ptr(), d.K, out.data_ptr(), Cout
     if bias is not None:
         d.bias = _chk(bias, F32).data_ptr()
@@ -292,12 +294,21 @@ def conv_up2(x, conv, B, H, W):
     over the low-res input (4/9 of the multiply-adds) when the big-tile kernels take the shape, else as a 3x3 gather at the high resolution."""
     Cin, Cout = conv.cin, conv.cout
     if not _NO_UP2P and Cin % 64 == 0 and Cout % 8 == 0:
-        ph = torch.empty((4 * B * H * W, Cout), dtype=F16, device=x.device)
-        d = _up2p_desc(_chk(x), conv.wk_up2p, ph, B, H, W, Cin, Cout, False, conv.bias)
+        out = torch.empty((4 * B * H * W, Cout), dtype=F16, device=x.device)
+        # the four phases go straight into the channels-last result (FD_CONV_UP2PI: the epilogue maps rows; no fd_phase_shuffle pass), and the
+        # epilogue leaves the GroupNorm statistics of the result behind in phase-major chunk order (``per`` = chunks per image and phase)
+        d = _up2p_desc(_chk(x), conv.wk_up2p, out, B, H, W, Cin, Cout, False, conv.bias, interleaved=not _UP2P_SHUFFLE)
         if _lib.get().fd_gemm_tile(ctypes.byref(d)) in _BIG_TILES:
-            _gemm_call(d, True)
-            out = torch.empty((4 * B * H * W, Cout), dtype=F16, device=x.device)
-            _call("fd_phase_shuffle", _p(ph), _p(out), B, H, W, Cout, _stream())
+            if _UP2P_SHUFFLE:       # A/B: phase-major output + a shuffle pass (rounds 2-3)
+                ph = out
+                d.C = ph.data_ptr()
+                _gemm_call(d, True)
+                out = torch.empty((4 * B * H * W, Cout), dtype=F16, device=x.device)
+                _call("fd_phase_shuffle", _p(ph), _p(out), B, H, W, Cout, _stream())
+                return out, 2 * H, 2 * W
+            _gemm_call(d, True, out, gn_stats=(H * W) % 32 == 0)
+            if getattr(out, "gn_stats", None) is not None:
+                out.gn_stats = out.gn_stats + ((H * W) // 32,)
             return out, 2 * H, 2 * W
     return conv3x3(x, conv.wk, B, H, W, mode=CONV_UP2, bias=conv.bias)
 
@@ -364,9 +375,12 @@ def groupnorm(x1, x2, B, HW, groups, eps, gamma, beta, silu):
     s1, s2 = getattr(x1, "gn_stats", None), (getattr(x2, "gn_stats", None) if x2 is not None else None)
     if (s1 is not None and (x2 is None or s2 is not None) and HW % s1[1] == 0 and (s2 is None or HW % s2[1] == 0)
             and ((C1 + C2) // groups) % 10 == 0 and s1[0].shape[0] * s1[1] == B * HW and (s2 is None or s2[0].shape[0] * s2[1] == B * HW)):
-        # every producer of the input left per-chunk sums behind: no statistics pass, x is read once
-        _call("fd_groupnorm_fwd_stats", _p(_chk(x1)), C1, _p(x2), C2, B, HW, groups, eps, _p(gamma), _p(beta), int(silu), _p(y), _p(st),
-              _p(s1[0]), s1[1], _p(s2[0]) if s2 is not None else None, s2[1] if s2 is not None else 0, _stream())
+        # every producer of the input left per-chunk sums behind: no statistics pass, x is read once.  A third entry of the
+        # tuple = chunks per image and phase of a phase-major table (the up-sampling convolution, FD_CONV_UP2PI)
+        per1 = s1[2] if len(s1) > 2 else 0
+        per2 = s2[2] if (s2 is not None and len(s2) > 2) else 0
+        _call("fd_groupnorm_fwd_stats_p", _p(_chk(x1)), C1, _p(x2), C2, B, HW, groups, eps, _p(gamma), _p(beta), int(silu), _p(y), _p(st),
+              _p(s1[0]), s1[1], per1, _p(s2[0]) if s2 is not None else None, s2[1] if s2 is not None else 0, per2, _stream())
         return y, st
     sc = scratch(B * 64 * groups * 2, x1.device)
     _call("fd_groupnorm_fwd", _p(_chk(x1)), C1, _p(x2), C2, B, HW, groups, eps, _p(gamma), _p(beta), int(silu), _p(y), _p(st), _p(sc), _stream())

@@ -38,7 +38,11 @@ enum { FD_CONV_NORMAL = 0, FD_CONV_STRIDE2 = 1, FD_CONV_UP2 = 2, FD_CONV_TRANS2 
        FD_CONV_UP2P = 4,
        /* its input gradient: A = dOut [Bn,H,W,Cin] at the HIGH resolution (H = 2*Ho), M = Bn*Ho*Wo, K = 16*Cin
         * (k = (((py*2+px)*2+dy)*2+dx)*Cin + c), B = [N][K].                                                                              */
-       FD_CONV_UP2P_BWD = 5 };
+       FD_CONV_UP2P_BWD = 5,
+       /* FD_CONV_UP2P writing its four phases straight into the channels-last result: C = [Bn, 2H, 2W, N], the row of phase (py, px) and low-res pixel
+        * (b, y, x) being ((b*2H + 2y+py)*2W + 2x+px) -- no fd_phase_shuffle pass.  gn_stats is allowed here: chunk (phase, m / 32) of the low-res rows,
+        * i.e. slot phase * (M / 32) + m / 32 (M % 32 == 0); fd_groupnorm_fwd_stats takes that layout through ``per`` (chunks per image and phase). */
+       FD_CONV_UP2PI = 6 };
 
 const char* fd_last_error(void);
 int fd_version(void);
@@ -126,6 +130,11 @@ int fd_groupnorm_fwd(const void* x1, int C1, const void* x2, int C2, int B, int 
 int fd_groupnorm_fwd_stats(const void* x1, int C1, const void* x2, int C2, int B, int HW, int groups, float eps, const float* gamma,
                            const float* beta, int silu, void* y, float* mean_rstd, const float* st1, int rows1, const float* st2, int rows2,
                            void* stream);
+/* the same for inputs whose statistics arrive in the phase-major chunk order of FD_CONV_UP2PI: per1 / per2 = chunks per image AND phase of st1 / st2
+ * (HW / rows / 4), or 0 for the plain image-major order */
+int fd_groupnorm_fwd_stats_p(const void* x1, int C1, const void* x2, int C2, int B, int HW, int groups, float eps, const float* gamma,
+                             const float* beta, int silu, void* y, float* mean_rstd, const float* st1, int rows1, int per1, const float* st2,
+                             int rows2, int per2, void* stream);
 /* backward: dx = d/dx [ act(GN(x)) ] . dy ; writes the two channel slices to dx1/dx2, optionally adding add1/add2 */
 int fd_groupnorm_bwd(const void* x1, int C1, const void* x2, int C2, const void* dy, int B, int HW, int groups,
                      const float* mean_rstd, const float* gamma, const float* beta, int silu,

@@ -82,6 +82,26 @@ def test_conv_up2_phase_decomposition(ops, dev, B, H, Cin, Cout):
     check(f"conv_up2 phases {Cin}->{Cout}@{H}", got, ref, 4e-3)
     old, _, _ = ops.conv3x3(xl, conv.wk, B, H, H, mode=ops.CONV_UP2, bias=conv.bias)
     check("conv_up2 phases vs 3x3 gather", y, old.float(), 4e-3)
+    # round 4: the phases are written straight into the channels-last result (FD_CONV_UP2PI, the epilogue maps rows): bit-identical to the phase-major
+    # launch + fd_phase_shuffle of rounds 2-3; where the kernel has the statistics epilogue (80-column wave tiles) the result carries GroupNorm chunk
+    # sums in phase-major order, which the norm consumes (``per``) -- against the two-launch norm on the same tensor
+    import pytest as _pt
+    mp = _pt.MonkeyPatch()
+    try:
+        mp.setattr(ops, "_UP2P_SHUFFLE", True)
+        y_sh, _, _ = ops.conv_up2(xl, conv, B, H, H)
+    finally:
+        mp.undo()
+    assert torch.equal(y, y_sh)
+    st = getattr(y, "gn_stats", None)
+    if Cout % 320 == 0:
+        assert st is not None and len(st) == 3 and st[1] == 32 and st[2] == H * H // 32 and st[0].shape == (4 * B * H * H // 32, Cout // 10, 2)
+        gamma = rnd(Cout, dev=dev, dtype=torch.float32, seed=5) * 0.2 + 1
+        beta = rnd(Cout, dev=dev, dtype=torch.float32, seed=6) * 0.2
+        yn, stn = ops.groupnorm(y, None, B, Ho * Wo, 32, 1e-5, gamma, beta, True)
+        yn0, stn0 = ops.groupnorm(y.clone(), None, B, Ho * Wo, 32, 1e-5, gamma, beta, True)
+        check("GroupNorm statistics from the phase-major chunk sums", stn, stn0, 2e-5)
+        assert float((yn.float() - yn0.float()).abs().max()) <= 2e-3 * float(yn0.float().abs().max())
     g = rnd(B, Cout, Ho, Wo, dev=dev, seed=4)
     ref.backward(g.float())
     gl = g.permute(0, 2, 3, 1).reshape(B * Ho * Wo, Cout).contiguous()
