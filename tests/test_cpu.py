@@ -289,6 +289,15 @@ def test_library_exports_every_header_symbol():
     d = lib.GemmDesc()
     assert L.fd_gemm(ctypes.byref(d), None) == -1 and b"null operand" in L.fd_last_error()
     assert L.fd_layernorm_fwd(None, None, None, None, None, 4, 12, 1e-5, None) == -1
+    # "pre-scaled q" (negative softmax scale) is refused on the host where the head dim has no spare contraction slots or a transposed-copy form is asked for
+    one = ctypes.c_void_p(1 << 20)
+    assert L.fd_attn_fwd(one, one, one, one, None, 2, 8, 256, 256, 0, 256, 80, 1, -0.1118, 0, 0, None) == -1 and b"pre-scaled q" in L.fd_last_error()
+    assert L.fd_attn_fwd(one, one, one, one, None, 2, 8, 256, 256, 256, 256, 40, 1, -0.158, 0, 0, None) == -1 and b"pre-scaled q" in L.fd_last_error()
+    assert L.fd_attn_bwd_dkdv(one, one, one, one, one, one, one, one, one, one, 2, 8, 256, 256, 256, 40, 1, -0.158, 0, 0, 0, 0, None) == -1
+    d = lib.GemmDesc()
+    d.A = d.B = d.C = 1 << 20
+    d.M, d.N, d.K, d.batch, d.ldc, d.lda, d.ldb, d.colscale_cols = 300, 320, 320, 1, 320, 320, 320, 6
+    assert L.fd_gemm(ctypes.byref(d), None) == -1 and b"colscale_cols" in L.fd_last_error()
     assert L.fd_working_dtype() == b"fp16" and "fd_attn_fwd_fp8" in protos and "fd_attn_fp8_quant_kv" in protos
     # the bf16 build (BASELINE configs[4]) of the same sources exports the same C-ABI
     path = os.path.join(os.path.dirname(lib.LIB_PATH), "libfairdiff_hip_bf16.so")
