@@ -189,6 +189,11 @@ def main():
     # the device, scratch/prof_queue_depth.py; pure enqueue cost is ~105 ms per 20-step rollout, scratch/prof_host_rollout.py with FD_TINY=1)
     line["config"]["host_ms_between_phase_marks"] = {k: round(v, 1) for k, v in host_phases.items()}
     line["config"]["host_ms_per_step"] = [round(1e3 * (b - a_), 1) for a_, b in zip(step_t[:-1], step_t[1:])]
+    hs = sorted(line["config"]["host_ms_per_step"])
+    if hs:      # ``value`` is the mean over the timed region (the contract); the median and the count of slow steps say how much of it is jitter
+        med = hs[len(hs) // 2] if len(hs) % 2 else 0.5 * (hs[len(hs) // 2 - 1] + hs[len(hs) // 2])
+        line["config"]["host_ms_per_step_median"] = round(med, 1)
+        line["config"]["steps_slower_than_median_plus_20ms"] = sum(x > med + 20.0 for x in hs)
     line["config"].update(r2_steps_prefetched_under_previous_tail=int(tr.last_r2_prefetched), r3_consumes_r1_forward=shared, r1_r2_rollouts_on_two_streams=bool(tr.concurrent_r2), backward_timesteps_on_two_streams=bool(tr.concurrent_bwd), executed_flop_per_image=f_exec,
                           step_mfma_frac_executed=value / world * f_exec / MFMA_PEAK_F16)
 
