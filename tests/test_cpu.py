@@ -234,7 +234,7 @@ def test_gemm_dispatch_name_statistics_rows_and_launcher_agree():
         if conv is not None:
             B, H, Cin, mode = conv
             d.conv, d.conv_mode, d.Bn, d.H, d.W, d.Cin = 1, mode, B, H, H, Cin
-            d.Ho = d.Wo = H // 2 if mode == 1 else (2 * H if mode in (2, 4) else H)
+            d.Ho = d.Wo = H // 2 if mode == 1 else (2 * H if mode == 2 else H)        # the phase pairs (4, 6) count low-res rows per phase
         for k, v in kw.items():
             setattr(d, k, v)
         if stats:
@@ -255,6 +255,9 @@ def test_gemm_dispatch_name_statistics_rows_and_launcher_agree():
     assert plan(65536, 8, 320)[0].startswith("gemm_skinny_kernel<1, 1") and plan(65536, 8, 320)[2] == 0
     assert plan(51300, 512, 1096) == ("gemm_big_kernel<256, 256, 2, 4, 0>", 0, 0)                             # 64-column wave tiles: no statistics epilogue
     assert plan(300, 320, 320) == ("gemm_glds_kernel<64, 64, false>", 0, 0)
+    # the up-sampling phase pair writing the channels-last result (FD_CONV_UP2PI = 6): statistics epilogue as instantiation <..., 6>; the phase-major form has none
+    assert plan(16384, 640, 4 * 640, conv=(16, 32, 640, 6), stats=True) == ("gemm_big_kernel<256, 320, 2, 4, 6>", 0, 32)
+    assert plan(16384, 640, 4 * 640, conv=(16, 32, 640, 4)) == ("gemm_big_kernel<256, 320, 2, 4, 2>", 0, 0)
     # LayerNorm second output: only where a 16-wave 320-wide tile holds whole rows
     def ln_plan(M, N, K, **kw):
         d = lib.GemmDesc()
