@@ -40,6 +40,14 @@ int fd_check_launch(const char* what);
         }                                      \
     } while (0)
 
+// every descriptor struct of the C-ABI starts with the caller's sizeof (include/fairdiff_hip.h): a binding compiled against another revision of the
+// header is refused before any field is read
+#define FD_REQUIRE_DESC(ptr, type, who)                                                                                                    \
+    FD_REQUIRE((ptr) && (ptr)->struct_size == (int32_t)sizeof(type),                                                                        \
+               who ": descriptor struct_size is %d but this library's " #type " has %d bytes (ABI revision %d): rebuild the binding against " \
+                   "include/fairdiff_hip.h and set struct_size = sizeof(" #type ")",                                                         \
+               (ptr) ? (int)(ptr)->struct_size : -1, (int)sizeof(type), FD_ABI_VERSION)
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -743,8 +743,12 @@ static int pp_takes(const fd_gemm_desc& d, int sel) {
 }
 
 // tile choice (BM*1000+BN): big tiles when the grid still fills 256 CUs a few times over
+static int gemm_tile(const fd_gemm_desc& d);
 extern "C" int fd_gemm_tile(const fd_gemm_desc* dp) {
-    const fd_gemm_desc& d = *dp;
+    FD_REQUIRE_DESC(dp, fd_gemm_desc, "fd_gemm_tile");
+    return gemm_tile(*dp);
+}
+static int gemm_tile(const fd_gemm_desc& d) {
     const long nb = d.batch > 1 ? d.batch : 1;
     static const bool nobig = bench_env("FD_GEMM_NOBIG") != nullptr;
     static const int force = bench_env("FD_GEMM_FORCE") ? atoi(bench_env("FD_GEMM_FORCE")) : 0;   // measurement only: force a big-tile code for dense
@@ -808,7 +812,7 @@ enum { GK_SKINNY, GK_GLDS, GK_BIG, GK_PP, GK_PPS };
 struct GemmPlan { int kind, bm, bn, wgm, wgn, nsplit, cv; bool stats_ok, ln_ok; };
 static GemmPlan gemm_plan(const fd_gemm_desc& d /* K2 already normalised */) {
     GemmPlan g = {};
-    const int sel = fd_gemm_tile(&d), t = sel % 1000000;
+    const int sel = gemm_tile(d), t = sel % 1000000;
     static const bool w16 = bench_env("FD_GEMM_W8") == nullptr;   // 16-wave variants by default (A/B switch for measurement)
     g.nsplit = sel >= 1000000 ? sel / 1000000 : 1;
     g.bm = t / 1000; g.bn = t % 1000;
@@ -842,6 +846,7 @@ static GemmPlan gemm_plan(const fd_gemm_desc& d /* K2 already normalised */) {
 // that bench.py's live HIP-event roofline and the committed profiles/ summaries key the same thing.  Split-K launches add a
 // ``splitk_reduce_kernel`` that the bench's events bracket together with the GEMM.
 extern "C" int fd_gemm_kernel_name(const fd_gemm_desc* dp, char* buf, int n) {
+    FD_REQUIRE_DESC(dp, fd_gemm_desc, "fd_gemm_kernel_name");
     fd_gemm_desc d = *dp;
     if (d.K2 <= 0 || !d.A2) d.K2 = 0;
     const GemmPlan g = gemm_plan(d);
@@ -859,18 +864,21 @@ extern "C" int fd_gemm_kernel_name(const fd_gemm_desc* dp, char* buf, int n) {
 // Rows per chunk of fd_gemm_desc.gn_stats: 32 for every kernel that has the statistics epilogue (gemm_epilogue_lds<..., true> forms the sums in
 // canonical 32-row chunks whatever its tile), 0 when the kernel fd_gemm would launch has none.
 extern "C" int fd_gemm_stats_rows(const fd_gemm_desc* dp) {
+    FD_REQUIRE_DESC(dp, fd_gemm_desc, "fd_gemm_stats_rows");
     fd_gemm_desc d = *dp;
     if (d.K2 <= 0 || !d.A2) d.K2 = 0;
     return gemm_plan(d).stats_ok ? 32 : 0;
 }
 
 extern "C" int fd_gemm_ln_ok(const fd_gemm_desc* dp) {
+    FD_REQUIRE_DESC(dp, fd_gemm_desc, "fd_gemm_ln_ok");
     fd_gemm_desc d = *dp;
     if (d.K2 <= 0 || !d.A2) d.K2 = 0;
     return gemm_plan(d).ln_ok ? 1 : 0;
 }
 
 extern "C" int fd_gemm(const fd_gemm_desc* dp, void* stream) {
+    FD_REQUIRE_DESC(dp, fd_gemm_desc, "fd_gemm");
     fd_gemm_desc d = *dp;
 #ifdef FD_BENCH_HOOKS
     static const char* dbg = bench_env("FD_GEMM_DBG");   // measurement only: 1 = no loads after the first tile, 2 = no MFMAs

@@ -213,6 +213,8 @@ extern "C" int fd_lora_wgrad(const void* X, int64_t ldx, const void* T, int64_t 
 // vectorised kernel's alignment (N %% CV == 0, ldx %% CV == 0 with CV = 8 / 4); anything else is rejected (callers fall back to fd_lora_wgrad).
 extern "C" int fd_lora_wgrad_multi(const fd_wgrad_desc* descs, int n, float* scratch, int64_t scratch_elems, void* stream) {
     FD_REQUIRE(n >= 1 && n <= FD_WGRAD_MAX, "fd_lora_wgrad_multi: 1..%d problems (got %d)", FD_WGRAD_MAX, n);
+    FD_REQUIRE_DESC(descs, fd_wgrad_desc, "fd_lora_wgrad_multi");       // element 0 first: its size is the array stride of the others
+    for (int i = 1; i < n; ++i) FD_REQUIRE_DESC(descs + i, fd_wgrad_desc, "fd_lora_wgrad_multi");
     WgradBatch b;
     b.n = n;
     int RP = 0;
@@ -284,6 +286,7 @@ __global__ void lora_refresh_kernel(RefreshBatch b) {
 
 extern "C" int fd_lora_refresh_multi(const fd_lora_refresh_desc* descs, int n, void* stream) {
     FD_REQUIRE(descs && n > 0, "fd_lora_refresh_multi: no pairs");
+    for (int i = 0; i < n; ++i) FD_REQUIRE_DESC(descs + i, fd_lora_refresh_desc, "fd_lora_refresh_multi");
     for (int i0 = 0; i0 < n; i0 += FD_REFRESH_MAX) {
         RefreshBatch b;
         b.n = n - i0 < FD_REFRESH_MAX ? n - i0 : FD_REFRESH_MAX;

@@ -122,7 +122,7 @@ def refresh_pairs(pairs, scale=1.0):
     pairs = list(pairs)
     if not pairs:
         return
-    arr = (_lib.LoraRefreshDesc * len(pairs))()
+    arr = _lib.LoraRefreshDesc.array(len(pairs))
     for d, p in zip(arr, pairs):
         if p.down16 is None:
             p.place()

@@ -18,9 +18,30 @@ LIB_PATH = os.environ.get("FAIRDIFF_LIB") or os.path.join(_HERE, _DEFAULT_LIB)  
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "fairdiff_hip.h")
 
 
-class GemmDesc(ctypes.Structure):
+ABI_VERSION = 3      # FD_ABI_VERSION of include/fairdiff_hip.h; load() refuses a library whose fd_version() differs
+
+
+class _Desc(ctypes.Structure):
+    """Descriptor structs of the C-ABI start with ``struct_size`` = sizeof as the caller sees it (the library refuses a mismatch): filled in at
+    construction, also for every element of a ctypes array of descriptors (``(T * n)()`` constructs its elements without calling __init__, so
+    arrays go through ``T.array(n)``)."""
+
+    def __init__(self, *a, **kw):
+        super().__init__(*a, **kw)
+        self.struct_size = ctypes.sizeof(type(self))
+
+    @classmethod
+    def array(cls, n):
+        arr = (cls * n)()
+        for i in range(n):
+            arr[i].struct_size = ctypes.sizeof(cls)
+        return arr
+
+
+class GemmDesc(_Desc):
     """Mirror of ``fd_gemm_desc`` (include/fairdiff_hip.h)."""
     _fields_ = [
+        ("struct_size", ctypes.c_int32),
         ("A", ctypes.c_void_p), ("lda", ctypes.c_int64),
         ("B", ctypes.c_void_p), ("ldb", ctypes.c_int64),
         ("A2", ctypes.c_void_p), ("lda2", ctypes.c_int64),
@@ -43,16 +64,16 @@ class GemmDesc(ctypes.Structure):
     ]
 
 
-class WgradDesc(ctypes.Structure):
+class WgradDesc(_Desc):
     """Mirror of ``fd_wgrad_desc`` (include/fairdiff_hip.h)."""
-    _fields_ = [("X", ctypes.c_void_p), ("ldx", ctypes.c_int64), ("T", ctypes.c_void_p), ("ldt", ctypes.c_int64),
+    _fields_ = [("struct_size", ctypes.c_int32), ("X", ctypes.c_void_p), ("ldx", ctypes.c_int64), ("T", ctypes.c_void_p), ("ldt", ctypes.c_int64),
                 ("G", ctypes.c_void_p), ("g_stride_n", ctypes.c_int64), ("g_stride_r", ctypes.c_int64),
                 ("M", ctypes.c_int32), ("N", ctypes.c_int32), ("R", ctypes.c_int32), ("scale", ctypes.c_float)]
 
 
-class LoraRefreshDesc(ctypes.Structure):
+class LoraRefreshDesc(_Desc):
     """Mirror of ``fd_lora_refresh_desc`` (include/fairdiff_hip.h)."""
-    _fields_ = [("down", ctypes.c_void_p), ("up", ctypes.c_void_p), ("d16", ctypes.c_void_p), ("ld_d16", ctypes.c_int64),
+    _fields_ = [("struct_size", ctypes.c_int32), ("down", ctypes.c_void_p), ("up", ctypes.c_void_p), ("d16", ctypes.c_void_p), ("ld_d16", ctypes.c_int64),
                 ("dT16", ctypes.c_void_p), ("ld_dT16", ctypes.c_int64), ("u16", ctypes.c_void_p), ("ld_u16", ctypes.c_int64),
                 ("uT16", ctypes.c_void_p), ("ld_uT16", ctypes.c_int64), ("r", ctypes.c_int32), ("rp", ctypes.c_int32),
                 ("K", ctypes.c_int32), ("N", ctypes.c_int32), ("scale", ctypes.c_float)]
@@ -97,6 +118,9 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
         fn.restype = ret
         fn.argtypes = argtypes
+    if lib.fd_version() != ABI_VERSION:
+        raise RuntimeError(f"{LIB_PATH} reports ABI revision {lib.fd_version()} but this package binds revision {ABI_VERSION} of include/fairdiff_hip.h: rebuild it "
+                           "(`make -C finetune_fair_diffusion_amd/csrc`)")
     built = lib.fd_working_dtype().decode()
     if built != WORKING_DTYPE:
         raise RuntimeError(f"{LIB_PATH} was built for {built} but this process runs with FD_DTYPE={WORKING_DTYPE}")

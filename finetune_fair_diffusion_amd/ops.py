@@ -663,7 +663,7 @@ def flush_wgrads(pend):
     for rp, items in by_rp.items():
         for i in range(0, len(items), WGRAD_MAX):
             chunk = items[i:i + WGRAD_MAX]
-            arr = (_lib.WgradDesc * len(chunk))()
+            arr = _lib.WgradDesc.array(len(chunk))
             for d, (X, T, G, sn, sr, R, scale) in zip(arr, chunk):
                 assert X.dtype == F16 and T.dtype == F16 and G.dtype == F32 and X.stride(1) == 1 and T.stride(1) == 1
                 d.X, d.ldx, d.T, d.ldt, d.G = X.data_ptr(), X.stride(0), T.data_ptr(), T.stride(0), G.data_ptr()

@@ -23,6 +23,8 @@ extern "C" {
 #define FD_OK 0
 #define FD_ERR_ARG (-1)
 #define FD_ERR_LAUNCH (-2)
+/* ABI revision of this header == fd_version() of a matching library.  3: every descriptor struct starts with ``struct_size`` (below). */
+#define FD_ABI_VERSION 3
 
 enum { FD_ACT_NONE = 0, FD_ACT_SILU = 1, FD_ACT_QUICK_GELU = 2, FD_ACT_GELU = 3, FD_ACT_RELU = 4,
        FD_ACT_HARDSWISH = 5, FD_ACT_HARDSIGMOID = 6,
@@ -45,7 +47,7 @@ enum { FD_CONV_NORMAL = 0, FD_CONV_STRIDE2 = 1, FD_CONV_UP2 = 2, FD_CONV_TRANS2 
        FD_CONV_UP2PI = 6 };
 
 const char* fd_last_error(void);
-int fd_version(void);
+int fd_version(void);               /* == FD_ABI_VERSION of the header the library was built from */
 /* "fp16" (libfairdiff_hip.so: the reference's mixed_precision fp16, configs 1-4) or "bf16" (libfairdiff_hip_bf16.so, built from the same
  * sources with -DFD_BF16: BASELINE configs[4]).  Every "fp16" in the prototypes below means this 16-bit working dtype. */
 const char* fd_working_dtype(void);
@@ -61,6 +63,10 @@ const char* fd_build_info(void);
  * The A operand may instead be gathered as an implicit-GEMM 3x3 convolution (conv != 0):
  * A is then a channels-last image [B,H,W,Cin] and K = 9*Cin with k = (ky*3+kx)*Cin + ci.        */
 typedef struct fd_gemm_desc {
+    /* FIRST field of every descriptor struct: sizeof(the struct) as the CALLER compiled it.  The entry points compare it with their own sizeof and
+     * fail with FD_ERR_ARG (fd_last_error() names both sizes) on a mismatch, so a binding written against an older header -- the struct has grown
+     * at its tail several times -- is refused instead of having fields read past its allocation. */
+    int32_t struct_size;
     const void* A;  int64_t lda;        /* fp16 [M,K] row-major (or image when conv) */
     const void* B;  int64_t ldb;        /* fp16 [N,K] row-major */
     const void* A2; int64_t lda2;       /* optional second K-slab (LoRA / channel-concat) */
@@ -229,6 +235,7 @@ int fd_lora_wgrad(const void* X, int64_t ldx, const void* T, int64_t ldt, float*
  * per problem as fd_lora_wgrad.  Requires N %% 8 == 0 and ldx %% 8 == 0 (R <= 8) or %% 4 (R <= 16). */
 #define FD_WGRAD_MAX 16
 typedef struct fd_wgrad_desc {
+    int32_t struct_size;                 /* sizeof(fd_wgrad_desc), checked for every element (see fd_gemm_desc) */
     const void* X; int64_t ldx;          /* fp16 [M, N], row stride ldx */
     const void* T; int64_t ldt;          /* fp16 [M, RP] (rank padded), row stride ldt */
     float* G; int64_t g_stride_n, g_stride_r;   /* G[n * g_stride_n + r * g_stride_r] += scale * sum_m X[m,n] T[m,r] */
@@ -242,6 +249,7 @@ int fd_lora_wgrad_multi(const fd_wgrad_desc* descs, int n, float* scratch, int64
  * j >= r zero),  uT16[j, n] = u16[n, j].  The four outputs are written through row strides, so that several pairs can live inside one stacked
  * buffer (the fused q/k/v projection of a self-attention layer).  Any number of pairs per call (chunked internally). */
 typedef struct fd_lora_refresh_desc {
+    int32_t struct_size;                           /* sizeof(fd_lora_refresh_desc), checked for every element (see fd_gemm_desc) */
     const float* down; const float* up;            /* fp32 [r, K], [N, r] */
     void* d16; int64_t ld_d16;                     /* 16-bit [rp, K] */
     void* dT16; int64_t ld_dT16;                   /* 16-bit [K, rp] */

@@ -5,6 +5,7 @@ import ctypes
 import json
 import math
 import os
+import re
 import sys
 
 import numpy as np
@@ -279,6 +280,79 @@ def test_gemm_dispatch_name_statistics_rows_and_launcher_agree():
     assert L.fd_gemm(ctypes.byref(d), None) == -1 and b"no statistics epilogue" in L.fd_last_error()
 
 
+def _header_struct_fields(name):
+    """[(field, ctypes type)] of ``typedef struct <name> { ... }`` in include/fairdiff_hip.h, in declaration order."""
+    from finetune_fair_diffusion_amd import lib
+    src = re.sub(r"/\*.*?\*/", " ", open(lib.HEADER_PATH).read(), flags=re.S)
+    body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (name, name), src, flags=re.S).group(1)
+    out = []
+    for decl in body.split(";"):
+        decl = " ".join(decl.split())
+        if not decl:
+            continue
+        if "*" in decl:                                   # ``const void* A`` / ``float* gn_stats`` / ``const float* down``
+            names, ct = [decl.split("*")[-1]], ctypes.c_void_p
+        else:                                             # ``int32_t M, N, K, K2`` / ``int64_t lda`` / ``float alpha``
+            t, rest = decl.split(" ", 1)
+            names, ct = rest.split(","), {"int32_t": ctypes.c_int32, "int64_t": ctypes.c_int64, "float": ctypes.c_float}[t]
+        out += [(n.strip(), ct) for n in names]
+    return out
+
+
+def test_integration_md_descriptor_mirror_matches_header_and_lib(tmp_path):
+    """VERDICT r4 row b: the reference-side stub documented in INTEGRATION.md had gone stale against the header (8 bytes short).  Three statements of
+    fd_gemm_desc must agree field for field -- the header (as gcc lays it out), lib.GemmDesc, and the ctypes class a maintainer copies out of
+    INTEGRATION.md -- likewise the two other descriptor structs, and every entry point refuses a descriptor whose struct_size is not its own sizeof."""
+    import subprocess
+    from finetune_fair_diffusion_amd import lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    md = open(os.path.join(root, "INTEGRATION.md")).read()
+    snippet = re.search(r"(class fd_gemm_desc\(ctypes\.Structure\):.*?\])\s*#[^\n]*\nassert L\.fd_version\(\) == (\d+)", md, flags=re.S)
+    assert snippet, "INTEGRATION.md: the fd_gemm_desc mirror (followed by the fd_version assert) is gone"
+    ns = {"ctypes": ctypes}
+    exec(snippet.group(1), ns)
+    doc_fields = ns["fd_gemm_desc"]._fields_
+    assert int(snippet.group(2)) == lib.ABI_VERSION
+    assert doc_fields == lib.GemmDesc._fields_ == _header_struct_fields("fd_gemm_desc")
+    assert doc_fields[0] == ("struct_size", ctypes.c_int32)
+    assert "struct_size=ctypes.sizeof(fd_gemm_desc)" in md, "INTEGRATION.md's example must fill struct_size"
+    assert lib.WgradDesc._fields_ == _header_struct_fields("fd_wgrad_desc") and lib.LoraRefreshDesc._fields_ == _header_struct_fields("fd_lora_refresh_desc")
+    # the compiler's own layout: sizeof and every offset
+    prog = ['#include <stdio.h>', '#include <stddef.h>', '#include "fairdiff_hip.h"', 'int main(void) {']
+    for cname, cls in (("fd_gemm_desc", lib.GemmDesc), ("fd_wgrad_desc", lib.WgradDesc), ("fd_lora_refresh_desc", lib.LoraRefreshDesc)):
+        prog.append('printf("%s %%zu\\n", sizeof(%s));' % (cname, cname))
+        for f, _ in cls._fields_:
+            prog.append('printf("%s.%s %%zu\\n", offsetof(%s, %s));' % (cname, f, cname, f))
+    prog += ['printf("version %d\\n", FD_ABI_VERSION);', 'return 0; }']
+    c = tmp_path / "layout.c"
+    c.write_text("\n".join(prog))
+    subprocess.run(["gcc", "-I", os.path.join(root, "include"), str(c), "-o", str(tmp_path / "layout")], check=True)
+    got = dict(line.rsplit(" ", 1) for line in subprocess.run([str(tmp_path / "layout")], check=True, capture_output=True, text=True).stdout.splitlines())
+    assert int(got["version"]) == lib.ABI_VERSION
+    for cname, cls in (("fd_gemm_desc", lib.GemmDesc), ("fd_wgrad_desc", lib.WgradDesc), ("fd_lora_refresh_desc", lib.LoraRefreshDesc)):
+        assert int(got[cname]) == ctypes.sizeof(cls), cname
+        for f, _ in cls._fields_:
+            assert int(got["%s.%s" % (cname, f)]) == getattr(cls, f).offset, (cname, f)
+    # the library checks it (host-side, before any launch)
+    L = lib.load()
+    assert L.fd_version() == lib.ABI_VERSION
+    d = lib.GemmDesc()
+    assert d.struct_size == ctypes.sizeof(lib.GemmDesc)
+    d.A = d.B = d.C = 1 << 20
+    d.M, d.N, d.K, d.batch, d.ldc, d.lda, d.ldb = 300, 320, 320, 1, 320, 320, 320
+    buf = ctypes.create_string_buffer(128)
+    for bad in (0, ctypes.sizeof(lib.GemmDesc) - 8, 304):          # 304: the round-4 layout a stale binding would claim
+        d.struct_size = bad
+        for fn, args in (("fd_gemm", (None,)), ("fd_gemm_tile", ()), ("fd_gemm_stats_rows", ()), ("fd_gemm_ln_ok", ()), ("fd_gemm_kernel_name", (buf, 128))):
+            assert getattr(L, fn)(ctypes.byref(d), *args) == -1 and b"struct_size" in L.fd_last_error(), (fn, bad)
+    w = lib.WgradDesc.array(2)
+    assert w[1].struct_size == ctypes.sizeof(lib.WgradDesc)
+    w[1].struct_size = 0
+    assert L.fd_lora_wgrad_multi(ctypes.byref(w), 2, None, 0, None) == -1 and b"struct_size" in L.fd_last_error()
+    r = (lib.LoraRefreshDesc * 1)()                                 # constructed without the helper: struct_size stays 0
+    assert L.fd_lora_refresh_multi(ctypes.byref(r), 1, None) == -1 and b"struct_size" in L.fd_last_error()
+
+
 def test_library_exports_every_header_symbol():
     from finetune_fair_diffusion_amd import lib
     protos = lib.parse_header()
@@ -286,8 +360,8 @@ def test_library_exports_every_header_symbol():
     L = lib.load()
     for name in protos:
         assert hasattr(L, name), name
-    assert L.fd_version() >= 1
-    assert ctypes.sizeof(lib.GemmDesc) == 304  # keep the Python mirror in step with fd_gemm_desc
+    assert L.fd_version() == lib.ABI_VERSION == 3
+    assert ctypes.sizeof(lib.GemmDesc) == 312  # keep the Python mirror in step with fd_gemm_desc (gcc's own sizeof / offsets: the test below)
     # argument validation happens on the host before any launch: safe to exercise without a GPU
     d = lib.GemmDesc()
     assert L.fd_gemm(ctypes.byref(d), None) == -1 and b"null operand" in L.fd_last_error()
