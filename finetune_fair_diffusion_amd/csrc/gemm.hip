@@ -697,9 +697,8 @@ static int launch(const fd_gemm_desc& d, hipStream_t s) {
 // gemm_pp.hip: the 8-wave 256x320 ping-pong kernel (BK = 32, four-stage ring, two wave groups half a k-step apart)
 bool fd_gemm_pp_eligible(const fd_gemm_desc& d);
 int fd_gemm_launch_pp(const fd_gemm_desc& d, hipStream_t s, bool prio, int bm, int nsplit);
-// gemm_pps.hip: the persistent form of the 128x320 ping-pong kernel for short-K dense projections (tiles streamed by <= 256 workgroups)
-bool fd_gemm_pps_eligible(const fd_gemm_desc& d);
-int fd_gemm_launch_pps(const fd_gemm_desc& d, hipStream_t s, int max_wg);
+// (round 5: the persistent streaming form of the 128x320 ping-pong kernel -- policy bit 128, measured and never selected -- and the register-B experiments
+// live in scratch/ with their measurements: gemm_pps_experiment.hip, gemm_rb_experiment.hip, gemm_rbk_experiment.hip)
 // Which problems the ping-pong kernels take (bits): 1 = stride-1 3x3 convolutions on the 256x320 tile, 2 = every dense GEMM on it,
 // 4 = s_setprio around the MFMA streams, 8 = stride-1 convolutions on the 128x320 tile, 16 = dense GEMMs on it, 32 = dense 256x320 GEMMs
 // with K <= 384 and N >= 2560 only (the FF1 projections of the 64^2 level), 64 = split-K launches of the 128x320 tile too.
@@ -720,14 +719,6 @@ static int pp_mode() {
 #else
     return FD_GEMM_PP_DEFAULT;
 #endif
-}
-// bit 128: dense GEMMs with at least PPS_MIN 128-row tiles go to the persistent streaming kernel
-static bool pps_takes(const fd_gemm_desc& d, int sel) {
-    const int t = sel % 1000000, split = sel / 1000000;
-    if (!(pp_mode() & 128) || split != 0 || (t != 256320 && t != 128320) || !fd_gemm_pps_eligible(d)) return false;
-    static const long pps_min = bench_env("FD_GEMM_PPS_MIN") ? atol(bench_env("FD_GEMM_PPS_MIN")) : 512;
-    static const long pps_maxk = bench_env("FD_GEMM_PPS_MAXK") ? atol(bench_env("FD_GEMM_PPS_MAXK")) : 1 << 30;
-    return (long)((d.M + 127) / 128) * (d.N / 320) >= pps_min && d.K + d.K2 <= pps_maxk;
 }
 // 0 = not taken, else the tile height (256 / 128)
 static int pp_takes(const fd_gemm_desc& d, int sel) {
@@ -808,7 +799,7 @@ static int gemm_tile(const fd_gemm_desc& d) {
 
 // ONE dispatch decision shared by fd_gemm, fd_gemm_kernel_name and fd_gemm_stats_rows (the launcher and the name function had drifted
 // apart once): which kernel family takes the problem, with which tile / wave grid / split-K factor, and whether that kernel can write gn_stats.
-enum { GK_SKINNY, GK_GLDS, GK_BIG, GK_PP, GK_PPS };
+enum { GK_SKINNY, GK_GLDS, GK_BIG, GK_PP };
 struct GemmPlan { int kind, bm, bn, wgm, wgn, nsplit, cv; bool stats_ok, ln_ok; };
 static GemmPlan gemm_plan(const fd_gemm_desc& d /* K2 already normalised */) {
     GemmPlan g = {};
@@ -817,9 +808,8 @@ static GemmPlan gemm_plan(const fd_gemm_desc& d /* K2 already normalised */) {
     g.nsplit = sel >= 1000000 ? sel / 1000000 : 1;
     g.bm = t / 1000; g.bn = t % 1000;
     g.cv = d.conv ? (d.conv_mode >= FD_CONV_UP2P ? 2 : 1) : 0;
-    // order: persistent streaming kernel, ping-pong kernel (split-K slices too under policy bit 64), then the lockstep tiles
-    if (pps_takes(d, sel)) g.kind = GK_PPS;
-    else if (const int bm = pp_takes(d, sel)) { g.kind = GK_PP; g.bm = bm; g.bn = 320; g.wgm = 2; g.wgn = 4; }
+    // order: ping-pong kernel (split-K slices too under policy bit 64), then the lockstep tiles
+    if (const int bm = pp_takes(d, sel)) { g.kind = GK_PP; g.bm = bm; g.bn = 320; g.wgm = 2; g.wgn = 4; }
     else if (g.nsplit > 1) { g.kind = GK_BIG; g.wgm = 4; g.wgn = t == 128320 ? 4 : 2; }
     else switch (t) {
         case 256320: g.kind = GK_BIG; g.wgm = (w16 && !d.conv) ? 4 : 2; g.wgn = 4; break;
@@ -852,7 +842,6 @@ extern "C" int fd_gemm_kernel_name(const fd_gemm_desc* dp, char* buf, int n) {
     const GemmPlan g = gemm_plan(d);
     const bool st = d.gn_stats && g.stats_ok;
     switch (g.kind) {
-        case GK_PPS: snprintf(buf, n, "gemm_pps_kernel<%d>", d.act == FD_ACT_GEGLU ? 1 : 0); break;
         case GK_PP: snprintf(buf, n, "gemm_pp_kernel<%d, %d, %s>", g.bm, (d.conv ? 1 : 0) + (st ? 2 : 0), (pp_mode() & 4) ? "true" : "false"); break;
         case GK_BIG: snprintf(buf, n, "gemm_big_kernel<%d, %d, %d, %d, %d>", g.bm, g.bn, g.wgm, g.wgn, (d.ln_out && g.ln_ok) ? 5 : st ? (g.cv == 2 ? 6 : g.cv + 3) : g.cv); break;
         case GK_SKINNY: snprintf(buf, n, "gemm_skinny_kernel<%d, %d, 1>", g.bn / 16, d.K >= 1280 ? 4 : d.K >= 640 ? 2 : 1); break;
@@ -920,10 +909,6 @@ extern "C" int fd_gemm(const fd_gemm_desc* dp, void* stream) {
     if (d.conv && d.conv_mode >= FD_CONV_UP2P)
         FD_REQUIRE(g.kind == GK_BIG, "fd_gemm(conv up2 phases): shape not taken by the big-tile kernels (Cin %% 64, enough tiles); use FD_CONV_UP2");
     switch (g.kind) {
-        case GK_PPS: {
-            static const int pps_wg = bench_env("FD_GEMM_PPS_WG") ? atoi(bench_env("FD_GEMM_PPS_WG")) : 256;
-            return fd_gemm_launch_pps(d, s, pps_wg);
-        }
         case GK_PP: {
             const int rc = fd_gemm_launch_pp(d, s, (pp_mode() & 4) != 0, g.bm, g.nsplit);
             if (rc != 0 || g.nsplit == 1) return rc;

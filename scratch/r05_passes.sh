@@ -37,5 +37,10 @@ a)  # evidence first: per-dispatch kernel trace of the shipp
     python scratch/r05_pmc_summary.py /tmp/pmc_r05a_fetch $O/pmc_fetch_in_situ.csv 30 > $O/pmc_fetch_top.txt 2>&1; head -12 $O/pmc_fetch_top.txt | cut -c1-200
     python scratch/r05_pmc_summary.py /tmp/pmc_r05a_write $O/pmc_write_in_situ.csv 30 > $O/pmc_write_top.txt 2>&1; head -12 $O/pmc_write_top.txt | cut -c1-200
     ;;
+b)  # register-B GEMMs (csrc/gemm_rb.hip): bit-exactness against the round-4 kernels on awkward shapes, then the A/B on the step's dense shapes with COLD A operands
+    L=$P/libfairdiff_hip_bench.so
+    MB_RB_NOASSERT=1 FAIRDIFF_LIB=$L timeout 900 python scratch/mb_rb.py $2 2>&1 | grep -v amdgpu.ids > gpurun_out/r05b_mb_rb.txt; cat gpurun_out/r05b_mb_rb.txt
+    ;;
+c)  FAIRDIFF_LIB=$P/libfairdiff_hip_bench.so timeout 600 python scratch/dbg_rb.py 2>&1 | grep -v amdgpu.ids | cut -c1-220 ;;
 *) echo "unknown pass $1";;
 esac
