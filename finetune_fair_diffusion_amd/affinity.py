@@ -2,10 +2,17 @@
 
 Eight ranks on one node each run a Python enqueue thread (~60 000 C-ABI calls per step), an OT worker thread (exp-3/4/5) and torch's
 intra-op pool; left alone, every rank's pool is sized for the whole machine (256 logical CPUs on the pool's hosts) and the kernel scheduler
-migrates the enqueue threads across sockets.  ``pin_rank`` gives rank r a contiguous share of ONE NUMA node's CPUs (nodes are dealt to ranks in
-order: ranks 0..n/2-1 on node 0, the rest on node 1 on a two-socket host, which is how the eight GPUs of an MI355X node hang off the sockets)
-and caps the intra-op pool at that share.  Must run before the first HIP call of the process (bench.py, train.py call it right after
-parsing their arguments).  FD_NO_AFFINITY=1 leaves the process alone; a single-rank run is never pinned."""
+migrates the enqueue threads across sockets.  ``pin_rank`` gives rank r a share of the CPUs of the NUMA node ITS GPU hangs off and caps the
+intra-op pool at that share:
+
+  * the node comes from sysfs -- KFD topology node k-th with SIMDs = HIP device k (``drm_render_minor`` ->
+    ``/sys/class/drm/renderD<minor>/device/numa_node``; ``HIP_VISIBLE_DEVICES`` / ``ROCR_VISIBLE_DEVICES`` index lists are honoured) -- and only
+    when that cannot be read from the even deal of round 4 (ranks 0..n/2-1 on node 0, the rest on node 1 on a two-socket host);
+  * the ranks of one node are dealt whole PHYSICAL cores (``topology/thread_siblings_list``): a cpulist like ``0-63,128-191`` sliced contiguously would
+    have put two ranks on the two hyperthreads of the same cores (ADVICE r4);
+  * the mask is applied to every thread the process already has (``/proc/self/task``): ``sched_setaffinity(0, ...)`` alone pins the calling thread.
+Must run before the first HIP call of the process (bench.py, train.py call it right after parsing their arguments).  FD_NO_AFFINITY=1 leaves the
+process alone; a single-rank run is never pinned."""
 import glob
 import os
 
@@ -20,35 +27,95 @@ def _parse_cpulist(text):
     return out
 
 
-def numa_nodes():
+def _read(path):
+    try:
+        with open(path) as f:
+            return f.read()
+    except OSError:
+        return None
+
+
+def numa_nodes(root="/"):
     """[[cpus of node 0], [cpus of node 1], ...] restricted to the CPUs this process may use; one pseudo-node when sysfs has none."""
-    allowed = set(os.sched_getaffinity(0))
+    allowed = set(os.sched_getaffinity(0)) if root == "/" else None
     nodes = []
-    for d in sorted(glob.glob("/sys/devices/system/node/node[0-9]*"), key=lambda p: int(p.rsplit("node", 1)[1])):
-        try:
-            cpus = [c for c in _parse_cpulist(open(os.path.join(d, "cpulist")).read()) if c in allowed]
-        except OSError:
+    for d in sorted(glob.glob(os.path.join(root, "sys/devices/system/node/node[0-9]*")), key=lambda p: int(p.rsplit("node", 1)[1])):
+        text = _read(os.path.join(d, "cpulist"))
+        if text is None:
             continue
-        if cpus:
-            nodes.append(cpus)
-    return nodes or [sorted(allowed)]
+        cpus = [c for c in _parse_cpulist(text) if allowed is None or c in allowed]
+        nodes.append(cpus)          # keep empty nodes: the index is the NUMA node id the GPU's numa_node file refers to
+    if not any(nodes):
+        return [sorted(allowed if allowed is not None else [])]
+    return nodes
 
 
-def rank_cpus(local_rank, local_world, nodes=None):
-    """The CPUs rank ``local_rank`` of ``local_world`` is pinned to (pure function of the node layout: testable without touching the process)."""
-    nodes = numa_nodes() if nodes is None else nodes
+def cores_of(cpus, root="/"):
+    """The logical CPUs of ``cpus`` grouped by physical core, [[cpu, sibling, ...], ...] in ascending order of each core's first CPU."""
+    left, cores = set(cpus), []
+    for c in sorted(cpus):
+        if c not in left:
+            continue
+        text = _read(os.path.join(root, f"sys/devices/system/cpu/cpu{c}/topology/thread_siblings_list"))
+        sib = [s for s in (_parse_cpulist(text) if text else [c]) if s in left] or [c]
+        if c not in sib:
+            sib = [c]
+        left -= set(sib)
+        cores.append(sorted(sib))
+    return cores
+
+
+def gpu_numa_node(device_index, root="/", env=None):
+    """NUMA node of HIP device ``device_index`` from sysfs, or None when it cannot be determined (no KFD topology, numa_node = -1, a visible-devices
+    variable that is not a plain index list)."""
+    env = os.environ if env is None else env
+    idx = device_index
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = env.get(var)
+        if v:
+            try:
+                idx = [int(x) for x in v.split(",")][idx]
+            except (ValueError, IndexError):
+                return None
+    gpus = []
+    for d in sorted(glob.glob(os.path.join(root, "sys/class/kfd/kfd/topology/nodes/[0-9]*")), key=lambda p: int(os.path.basename(p))):
+        props = _read(os.path.join(d, "properties"))
+        if props is None:
+            continue
+        kv = dict(line.split(None, 1) for line in props.splitlines() if len(line.split(None, 1)) == 2)
+        if int(kv.get("simd_count", "0")) > 0 and int(kv.get("drm_render_minor", "-1")) >= 0:
+            gpus.append(int(kv["drm_render_minor"]))
+    if idx >= len(gpus):
+        return None
+    text = _read(os.path.join(root, f"sys/class/drm/renderD{gpus[idx]}/device/numa_node"))
+    try:
+        node = int(text)
+    except (TypeError, ValueError):
+        return None
+    return node if node >= 0 else None
+
+
+def rank_cpus(local_rank, local_world, nodes=None, gpu_nodes=None, root="/"):
+    """The CPUs rank ``local_rank`` of ``local_world`` is pinned to (pure function of the node layout: testable without touching the process).
+    ``gpu_nodes``: NUMA node of every local rank's device (None entries = unknown); default: read from sysfs."""
+    nodes = numa_nodes(root) if nodes is None else nodes
     nn = len(nodes)
-    node = min(local_rank * nn // local_world, nn - 1)
-    peers = [r for r in range(local_world) if min(r * nn // local_world, nn - 1) == node]
-    cpus = nodes[node]
+    if gpu_nodes is None:
+        gpu_nodes = [gpu_numa_node(r, root) for r in range(local_world)]
+    if any(g is None or g >= nn or not nodes[g] for g in gpu_nodes):
+        gpu_nodes = [min(r * nn // local_world, nn - 1) for r in range(local_world)]        # round 4's even deal
+    node = gpu_nodes[local_rank]
+    peers = [r for r in range(local_world) if gpu_nodes[r] == node]
+    cores = cores_of(nodes[node], root)
     k, n = peers.index(local_rank), len(peers)
-    per = max(len(cpus) // n, 1)
-    share = cpus[k * per:(k + 1) * per] if k < n - 1 else cpus[k * per:]
-    return share or cpus
+    per = max(len(cores) // n, 1)
+    mine = cores[k * per:(k + 1) * per] if k < n - 1 else cores[k * per:]
+    share = sorted(c for core in mine for c in core)
+    return share or sorted(nodes[node])
 
 
 def pin_rank(local_rank, local_world, max_threads=8):
-    """Pins the process and sizes torch's intra-op pool; returns (cpus, threads) or None when nothing was done."""
+    """Pins the process (all of its threads) and sizes torch's intra-op pool; returns (cpus, threads) or None when nothing was done."""
     if local_world <= 1 or os.environ.get("FD_NO_AFFINITY") is not None or not hasattr(os, "sched_setaffinity"):
         return None
     cpus = rank_cpus(local_rank, local_world)
@@ -56,6 +123,11 @@ def pin_rank(local_rank, local_world, max_threads=8):
         os.sched_setaffinity(0, cpus)
     except OSError:
         return None
+    for t in os.listdir("/proc/self/task") if os.path.isdir("/proc/self/task") else []:     # threads that exist already (BLAS / OpenMP pools started at import)
+        try:
+            os.sched_setaffinity(int(t), cpus)
+        except (OSError, ValueError):
+            pass
     threads = max(1, min(len(cpus), max_threads))
     os.environ.setdefault("OMP_NUM_THREADS", str(threads))
     import torch

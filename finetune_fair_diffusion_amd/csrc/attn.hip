@@ -188,9 +188,9 @@ constexpr int dkdv_waves(int D, bool QTR = false) { return D <= 64 ? 2 : 1; }
 #endif
 
 // ---- "-D through the matrix pipe" (round 4).  dS = P o (dP - D), D = rowsum(dO o O): where the contraction over d is padded (d = 40 -> 48: eight spare
-// k-slots behind column 39) the subtraction rides in the dP = dO . V^T MFMAs: three slots of the dO operand carry -D / 256 split into three 16-bit
-// pieces (hi + mid + lo: 33 / 24 significant bits in fp16 / bf16; the 1 / 256 keeps |D| up to 1.6e7 inside the fp16 range under loss scaling), the
-// same three slots of the V operand carry 256.0 -- products and accumulation are exact in the fp32 accumulator, so dP' = dP - D comes out of the
+// k-slots behind column 39) the subtraction rides in the dP = dO . V^T MFMAs: three slots of the dO operand carry -D split into three 16-bit
+// pieces at the scales 256, 1, 1 / 256 (split3_scaled: |D| up to 1.6e7 stays inside the fp16 range, no piece is ever subnormal), the
+// same three slots of the V operand carry those scales -- products and accumulation are exact in the fp32 accumulator, so dP' = dP - D comes out of the
 // accumulation itself and the VALU-bound score loop loses one of its ~7.5 issue slots per element (and the dK/dV kernel its per-element LDS read of D).
 // ---- "pre-scaled q" (round 4; negative ``scale`` argument of the three entry points).  The projection that writes q multiplies it by softmax_scale *
 // log2(e) in its fp32 epilogue (fd_gemm_desc.colscale: one rounding, as before), so the QK^T accumulator IS the exponent's argument up to the
@@ -212,6 +212,25 @@ __device__ __forceinline__ void split3(float x, f16& h0, f16& h1, f16& h2) {
     const float r1 = x - (float)h0;
     h1 = (f16)r1;
     h2 = (f16)(r1 - (float)h1);
+}
+// -D for the dO . V^T product: three pieces at three SCALES -- x = 256 h0 + h1 + h2 / 256 against V slots (256, 1, 1/256) -- so that every piece
+// is either a NORMAL 16-bit number or exactly zero, whatever |D| is.  The round-4 form carried x / 256 in all three slots: under loss scaling
+// (dO ~ 1e-3 .. 1e-4 at the 64^2 level) |D| drops below 256 * 6.1e-5 = 0.016, the leading piece became an fp16 subnormal (8e-6 absolute error floor on D, and
+// all of D lost if the matrix pipe flushes subnormal inputs).  Here a piece that would be subnormal is replaced by zero and its value moves to the next,
+// finer slot: absolute error floor 6.1e-5 / 256 * 2^-11 ~ 1e-10 down to |D| ~ 2.4e-7, below which D is dropped (nothing in a scaled backward is that small
+// and still matters).  bf16 has the fp32 exponent range: the flush branches never fire and the pieces carry 3 x 8 bits as before.
+#ifdef FD_BF16
+#define FD_WD_MIN_NORMAL 1.1754944e-38f
+#else
+#define FD_WD_MIN_NORMAL 6.103515625e-5f
+#endif
+__device__ __forceinline__ void split3_scaled(float x, f16& h0, f16& h1, f16& h2) {
+    const float x0 = x * (1.f / 256.f);
+    h0 = fabsf(x0) >= FD_WD_MIN_NORMAL ? (f16)x0 : (f16)0.f;
+    const float r1 = x - 256.f * (float)h0;                          // exact: the product has 11 significant bits
+    h1 = fabsf(r1) >= FD_WD_MIN_NORMAL ? (f16)r1 : (f16)0.f;
+    const float r2 = (r1 - (float)h1) * 256.f;
+    h2 = fabsf(r2) >= FD_WD_MIN_NORMAL ? (f16)r2 : (f16)0.f;
 }
 
 // ================================================================================== forward
@@ -371,7 +390,9 @@ __global__ __launch_bounds__(256, QB == 1 ? fwd_waves(D) : (D <= 64 ? 2 : 1)) vo
 #pragma unroll
                 for (int qb = 0; qb < QB; ++qb) {
                     const float delta = mv[qb] ? mxv[qb] : 0.f;
-                    const float alpha = __builtin_amdgcn_exp2f(-delta);
+                    // the first tile always moves the reference point, possibly DOWN (all of its scores below -128: delta < -128, exp2(-delta) = inf and
+                    // inf * 0 = NaN in the still-zero O / l): nothing has been accumulated before it, so the factor there is 1
+                    const float alpha = k0 == 0 ? 1.f : __builtin_amdgcn_exp2f(-delta);
 #pragma unroll
                     for (int i = 0; i < NDV; ++i)
 #pragma unroll
@@ -559,7 +580,7 @@ __global__ __launch_bounds__(256, dq_waves(D)) void attn_bwd_dq_kernel(const f16
     constexpr bool DFOLD = dfold<D>();
     if (DFOLD && g == 1) {                           // this lane's columns D .. D + 2 of its query's dO row
         f16 h0, h1, h2;
-        split3(-dd * (1.f / 256.f), h0, h1, h2);
+        split3_scaled(-dd, h0, h1, h2);
         gf[NKS - 1][0] = h0; gf[NKS - 1][1] = h1; gf[NKS - 1][2] = h2;
     }
     f32x16 acc[NDV];
@@ -578,7 +599,7 @@ __global__ __launch_bounds__(256, dq_waves(D)) void attn_bwd_dq_kernel(const f16
     if (DFOLD || PRE) {
         __syncthreads();                               // behind zero_row_pad's writes of the same columns
         for (int c = threadIdx.x; c < 64 * 3; c += 256) {    // never overwritten: store_rows writes columns < D
-            if (DFOLD) Vs[(c / 3) * DKP + D + c % 3] = (f16)256.f;
+            if (DFOLD) Vs[(c / 3) * DKP + D + c % 3] = c % 3 == 0 ? (f16)256.f : c % 3 == 1 ? (f16)1.f : (f16)(1.f / 256.f);      // the scales of split3_scaled
             if (PRE) Ks[(c / 3) * DKP + D + c % 3] = (f16)1.f;
         }
     }
@@ -697,7 +718,9 @@ __global__ __launch_bounds__(256, dkdv_waves(D, QTR)) void attn_bwd_dkdv_kernel(
     }
     constexpr bool DFOLD = dfold<D>();
     static_assert(!PRE || (pre_ok<D>() && QTR), "pre-scaled q: head dims with three spare contraction slots, transpose-read form");
-    if (DFOLD && g == 1) vf[NKS - 1][0] = vf[NKS - 1][1] = vf[NKS - 1][2] = (f16)256.f;       // columns D .. D + 2 of this lane's V row (see split3)
+    if (DFOLD && g == 1) {                                                                     // columns D .. D + 2 of this lane's V row: the scales of split3_scaled
+        vf[NKS - 1][0] = (f16)256.f; vf[NKS - 1][1] = (f16)1.f; vf[NKS - 1][2] = (f16)(1.f / 256.f);
+    }
     if (PRE && g == 1) kf[NKS - 1][0] = kf[NKS - 1][1] = kf[NKS - 1][2] = (f16)1.f;           // ... and of its K row: they meet -lse in q's
     f32x16 dk[NDV], dv[NDV];
 #pragma unroll
@@ -755,7 +778,7 @@ __global__ __launch_bounds__(256, dkdv_waves(D, QTR)) void attn_bwd_dkdv_kernel(
             const float ddv = tq < Tq ? Db[tq] : 0.f;
             if (DFOLD) {                                // -D of query row tq into columns D .. D + 2 of its dO row (store_rows writes columns < D only)
                 f16 h0, h1, h2;
-                split3(-ddv * (1.f / 256.f), h0, h1, h2);
+                split3_scaled(-ddv, h0, h1, h2);
                 f16* gp = Gs + threadIdx.x * DKP + D;
                 gp[0] = h0; gp[1] = h1; gp[2] = h2;
             } else dd_s[threadIdx.x] = ddv;

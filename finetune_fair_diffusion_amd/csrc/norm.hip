@@ -626,6 +626,15 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const f16* x, const f16*
         }
     }
     f16x8 xv[R][MAXV], dv[BWD ? R : 1][MAXV];
+#ifdef FD_LN_ZERO_INIT      // measurement build (scratch/r05_passes.sh h): rules "a lane reads an uninitialised register" in or out of the packed-fp32 hazard
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            xv[r][i] = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
+            if (BWD) dv[r][i] = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
+        }
+#endif
 #pragma unroll
     for (int r = 0; r < R; ++r)
 #pragma unroll

@@ -186,6 +186,7 @@ class FairnessTrainer:
         # collectives run whenever there is more than one rank -- or, with FD_FORCE_COLLECTIVES=1 and an initialised process group, on a
         # single rank too (the only way to drive the RCCL code path on a one-GPU box: RCCL refuses two ranks on one device)
         self.collectives = world_size > 1 or (os.environ.get("FD_FORCE_COLLECTIVES") is not None and dist.is_available() and dist.is_initialized())
+        self._hbm_reserve = int(os.environ.get("FD_HBM_RESERVE_MB", "2048" if self.collectives else "0")) << 20
         self.device = device or unet.device
         self.banks = []
         if getattr(args, "train_unet", False):
@@ -312,7 +313,7 @@ class FairnessTrainer:
         (288 GB holds the whole 20-step chain at batch 8); the remaining steps are recomputed in the backward."""
         sch = self.sch if sch is None else sch       # a prefetched R2 rollout of the NEXT step brings its own scheduler object (S may differ)
         graphed = None
-        if (self.r2_graph and unet is self.eval_unet and unet is not self.unet and unet.lora_bank is None and _CFG_PAIR
+        if (self.r2_graph and unet_mod.GraphedForward.usable() and unet is self.eval_unet and unet is not self.unet and unet.lora_bank is None and _CFG_PAIR
                 and not keep_inputs and not keep_activations and not record_prompt and torch.cuda.current_stream() != torch.cuda.default_stream()):
             graphed = getattr(unet, "graphed", None) or unet_mod.GraphedForward(unet)
         sch.set_timesteps(S)
@@ -373,7 +374,10 @@ class FairnessTrainer:
             except Exception:
                 other = cached // 2
             self._other_stream_cache = other
-        return free + max(cached - self._other_stream_cache, 0)
+        # a multi-rank run shares the device with RCCL: its communicator is resident before the first step (factory.build_trainer broadcasts the LoRA init),
+        # so ``free`` already excludes it; what arrives later -- channel buffers of collectives first used inside the step, the probability gather's
+        # staging -- is covered by a fixed reserve (FD_HBM_RESERVE_MB; measured resident set of the single-rank RCCL soak: profiles/r05_soak_s50_collectives.txt)
+        return max(free - self._hbm_reserve, 0) + max(cached - self._other_stream_cache, 0)
 
     def rollout(self, unet, enc, noises, S, keep_inputs=False, record_prompt=False, keep_activations=False):
         """noises [N,4,h,w] fp32 on device.  Returns (x_final, [x_i], {i: ctx})."""

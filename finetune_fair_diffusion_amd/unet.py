@@ -117,6 +117,8 @@ class TransformerBlock:
             old = self.cross if (self.cross is not None and self.cross.get("static") and self.cross["K"].shape == (Bk * L, self.C)) else None
             K = ops.gemm(enc, self.k2.w, out=old["K"] if old else None)
             V = ops.gemm(enc, self.v2.w, out=old["V"] if old else None)
+            if old is None:   # new buffers (first rollout, or another prompt shape): graphs captured against the old addresses must not be replayed
+                self.static_generation = getattr(self, "static_generation", 0) + 1
         else:
             K, V = ops.gemm(enc, self.k2.w), ops.gemm(enc, self.v2.w)
         self.cross = dict(static=bool(static and lo is None), K=K, V=V, Vt=None if ops.ATTN_TR else ops.transpose_btc(V, Bk, L, self.C), Kt=None, Bk=Bk, L=L, enc=enc, te=te)
@@ -588,10 +590,24 @@ class GraphedForward:
             g.capture_end()
         self.graphs[key] = (g, x, trow, eps)
 
+    @staticmethod
+    def usable():
+        """The capture bakes in the addresses of the cross-attention K / V.  With the transposed-copy attention forms (FD_ATTN_NO_TR) prepare_cross
+        builds a NEW V^T for every rollout, which a replay would not see: no graph there."""
+        return ops.ATTN_TR
+
     def __call__(self, lat, step_index, pair):
         """lat [N,4,H,W] fp32 on the current (side) stream -> eps [2N or N,4,H*W] fp32 (a static buffer: consume it before the next call)."""
-        key = (lat.shape[0], lat.shape[2], lat.shape[3], bool(pair))
+        assert self.usable(), "GraphedForward with transposed-copy attention: the captured V^T would be stale"
+        # the key holds everything a capture depends on: the latent shape, the CFG-pair form, the prompt shape, and the generation of the static
+        # K / V buffers (prepare_cross(static=True) allocates new ones when Bk * L changes; a graph captured against freed buffers is dropped)
+        c0 = self.unet.transformers[0].cross
+        gen = tuple(getattr(t, "static_generation", 0) for t in self.unet.transformers)
+        key = (lat.shape[0], lat.shape[2], lat.shape[3], bool(pair), c0["Bk"], c0["L"], gen)
+        assert all(t.cross is not None and t.cross.get("static") for t in self.unet.transformers), "GraphedForward: prepare_prompt() must run with static K / V first"
         if key not in self.graphs:
+            for k in [k for k in self.graphs if k[:6] == key[:6] or k[6] != gen]:      # captured against buffers that have been replaced
+                del self.graphs[k]
             self._capture(key, lat, step_index)
         g, x, trow, eps = self.graphs[key]
         x.copy_(lat)

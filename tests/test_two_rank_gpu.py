@@ -35,15 +35,8 @@ def _launch(experiment, out_dir, world=2, b_per_rank=None):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(HERE, "run_two_rank_step.py"), experiment, str(out_dir)]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
-    if r.returncode != 0 and world > 2:      # one retry on a fresh rendezvous port (eight cold processes sharing a device: seen to fail once in five runs)
-        print("first attempt failed:\n" + r.stderr[-1500:])
-        for k in range(world):
-            ep = os.path.join(out_dir, f"rank{k}.err")
-            if os.path.exists(ep):
-                print(f"---- rank {k} traceback (first attempt)\n" + open(ep).read()[-1500:])
-                os.remove(ep)
-        cmd[cmd.index("--master-port") + 1] = str(_free_port())
-        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    # no retry (round 4 retried the eight-rank launch once, "seen to fail once in five runs": a retry hides exactly the start-up race an eight-GPU node would
+    # hit without one).  Ten consecutive launches of this test, first attempts only: profiles/r05_eight_rank_launch_10x.txt.
     print(r.stdout[-3000:])
     print(r.stderr[-3000:])
     for k in range(world):
