@@ -90,5 +90,16 @@ h)  # the packed-fp32 hazard under other queue / stream count
     run shipped_q8_s3 FD_DUMMY=1
     run slp_q8_s3_again FAIRDIFF_LIB=$P/libfairdiff_hip_slp.so
     ;;
+j)  # what bounds the GEMM / conv kernels on COLD operands: L2 hit rates and request volumes, fabric requests, L1 -> L2 read latency, TA / TD stalls
+    O=gpurun_out/r05j; mkdir -p $O
+    cd /tmp && export TMPDIR=/tmp
+    i=0
+    for C in "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_READ_sum" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_DRAM_sum TCC_TAG_STALL_sum TCC_BUSY_avr" "TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_PENDING_STALL_CYCLES_sum" "TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum TD_TC_STALL_sum GRBM_GUI_ACTIVE" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_VMEM SQ_WAIT_INST_LDS SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES"; do
+      i=$((i+1))
+      timeout 600 rocprofv3 --kernel-trace --pmc $C --kernel-include-regex "gemm" --output-format csv -d /tmp/pmc_r05j_$i -o p -- python3 $R/scratch/mb_pmc_r05.py > $R/$O/pass_$i.log 2>&1
+      python3 $R/scratch/r05_pmc_summary.py /tmp/pmc_r05j_$i $R/$O/pmc_pass_$i.csv 0 > /dev/null 2>&1
+    done
+    cd $R; cp gpurun_out/pmc_r05_manifest.json $O/ 2>/dev/null; ls -la $O
+    ;;
 *) echo "unknown pass $1";;
 esac
