@@ -116,7 +116,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(fd_gemm_desc p, int ntm, i
     // NL global_load_lds per call: NAW A groups + (NL - NAW) B groups, for local k-step j (global step kbeg + j) into ring slot j & 3
     auto issue = [&](int j, auto nl_c) {
         constexpr int NL = decltype(nl_c)::value;
-        if (j >= nk) {                   // past the last k-step: keep the per-step load count uniform
+        if (j >= nk || (FD_DBG_IS(p, 1) && j >= 3)) {     // past the last k-step (or FD_GEMM_DBG = 1): keep the per-step load count uniform
 #pragma unroll
             for (int i = 0; i < NL; ++i) glds16(zp, dump);
             return;
@@ -175,34 +175,54 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(fd_gemm_desc p, int ntm, i
     const uint32_t b_frag = lds0 + (uint32_t)((NGA + wn * (WTN / 16)) * PP_GROUP) * 2 + frag;
     constexpr uint32_t STAGE_B = STAGE * 2, GROUP_B = PP_GROUP * 2;
 
-    if (lead) {
-        constexpr int NL = NAW + 3;
-        std::integral_constant<int, NL> nl;
-        issue(0, nl); issue(1, nl); issue(2, nl);
-        wait_vm<2 * NL>();               // L_0 landed
-        raw_barrier();                   // B_-1
-        for (int i = 0; i < nk; ++i) {
-            const uint32_t so = (uint32_t)(i & 3) * STAGE_B;
-            mma_k32_mid<TM, TN, 2, GROUP_B, PRIO>(acc, a_frag + so, b_frag + so, [&] {
-                wait_vm<NL>();           // this wave's L_i+1 landed (L_i+2 stays in flight)
-                raw_barrier();           // B_i, crossed in mid-step
-            });
-            issue(i + 3, nl);            // into the slot of step i-1: every wave is past B_i, i.e. done with it
+    // Main loop.  ABL / NOSYNC exist in measurement builds only (FD_GEMM_DBG, scratch/mb_pp_ablate.py): 2 = no MFMAs, 6 = no fragment reads, 7 = no vmcnt waits /
+    // barriers (timing only: the results are garbage); FD_GEMM_DBG = 1 sends every DMA behind the prologue to the zero page / dump group (same operation
+    // counts, no memory traffic).
+    auto main_loop = [&](auto abl_c, auto nosync_c) {
+        constexpr int ABL = decltype(abl_c)::value;
+        constexpr bool NOSYNC = decltype(nosync_c)::value;
+        if (lead) {
+            constexpr int NL = NAW + 3;
+            std::integral_constant<int, NL> nl;
+            issue(0, nl); issue(1, nl); issue(2, nl);
+            wait_vm<2 * NL>();               // L_0 landed
+            raw_barrier();                   // B_-1
+            for (int i = 0; i < nk; ++i) {
+                const uint32_t so = (uint32_t)(i & 3) * STAGE_B;
+                auto mid = [&] {
+                    if (!NOSYNC) {
+                        wait_vm<NL>();       // this wave's L_i+1 landed (L_i+2 stays in flight)
+                        raw_barrier();       // B_i, crossed in mid-step
+                    }
+                };
+                mma_k32_mid<TM, TN, 2, GROUP_B, PRIO, decltype(mid)&, ABL>(acc, a_frag + so, b_frag + so, mid);
+                issue(i + 3, nl);            // into the slot of step i-1: every wave is past B_i, i.e. done with it
+            }
+        } else {
+            constexpr int NL = NAW + 2;
+            std::integral_constant<int, NL> nl;
+            issue(0, nl); issue(1, nl); issue(2, nl);
+            wait_vm<2 * NL>();
+            raw_barrier();                   // B_-1
+            for (int i = 0; i < nk; ++i) {
+                if (!NOSYNC) {
+                    wait_vm<NL>();
+                    raw_barrier();           // B_i, crossed at the step boundary
+                }
+                issue(i + 3, nl);
+                const uint32_t so = (uint32_t)(i & 3) * STAGE_B;
+                auto mid = [] {};
+                mma_k32_mid<TM, TN, 2, GROUP_B, PRIO, decltype(mid)&, ABL>(acc, a_frag + so, b_frag + so, mid);
+            }
         }
-    } else {
-        constexpr int NL = NAW + 2;
-        std::integral_constant<int, NL> nl;
-        issue(0, nl); issue(1, nl); issue(2, nl);
-        wait_vm<2 * NL>();
-        raw_barrier();                   // B_-1
-        for (int i = 0; i < nk; ++i) {
-            wait_vm<NL>();
-            raw_barrier();               // B_i, crossed at the step boundary
-            issue(i + 3, nl);
-            const uint32_t so = (uint32_t)(i & 3) * STAGE_B;
-            mma_k32_mid<TM, TN, 2, GROUP_B, PRIO>(acc, a_frag + so, b_frag + so, [] {});
-        }
-    }
+    };
+#ifdef FD_BENCH_HOOKS
+    if (FD_DBG_IS(p, 2)) main_loop(std::integral_constant<int, 2>{}, std::false_type{});
+    else if (FD_DBG_IS(p, 6)) main_loop(std::integral_constant<int, 6>{}, std::false_type{});
+    else if (FD_DBG_IS(p, 7)) main_loop(std::integral_constant<int, 0>{}, std::true_type{});
+    else
+#endif
+    main_loop(std::integral_constant<int, 0>{}, std::false_type{});
     if (nsplit > 1) {                    // raw fp32 partials; splitk_reduce_kernel (gemm.hip) sums the slabs in a fixed order and applies the epilogue
         float* ws = (float*)p.workspace + (int64_t)blockIdx.y * p.M * p.N;
 #pragma unroll
@@ -219,6 +239,10 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(fd_gemm_desc p, int ntm, i
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // drain the pad loads before the ring is reused by the epilogue
     __syncthreads();
+    if (FD_DBG_IS(p, 3)) {               // measurement only (FD_GEMM_DBG = 3): no epilogue
+        if (acc[0][0][0] == 12345.678f) ((f16*)p.C)[0] = (f16)1.f;
+        return;
+    }
 
     const bool lds_epi = p.out_dtype == FD_OUT_F16 && (p.N & 7) == 0 && (p.ldc & 7) == 0 && (!p.residual || (p.ldr & 7) == 0) &&
                          (!p.rowbias || (p.ld_rowbias & 3) == 0);

@@ -13,24 +13,32 @@ static __device__ __forceinline__ void raw_barrier() { asm volatile("s_barrier" 
 // a hook that runs between the two halves of the step -- the point where the leading group crosses the workgroup barrier.
 // PRIO: s_setprio(1) from the first to the last MFMA of the step -- with the two waves of a SIMD in different roles the arbiter has something
 // to decide (the wave in its MFMA stream outranks the one doing boundary work); in a lockstep loop it is a no-op
-template <int TM, int TN, int PD, int GS, bool PRIO, class MID>
+// ABL (measurement builds only, FD_GEMM_DBG): 0 = the kernel, 2 = no MFMAs (fragment reads, waits, barriers and DMA issue only), 6 = no fragment reads (MFMAs on
+// whatever the registers hold)
+template <int TM, int TN, int PD, int GS, bool PRIO, class MID, int ABL = 0>
 static __device__ __forceinline__ void mma_k32_mid(f32x4 (&acc)[TM][TN], uint32_t a_addr, uint32_t b_addr, MID&& mid) {
     constexpr bool BRES = TN <= TM;   // the operand with fewer fragments stays resident for the step
     constexpr int NR = BRES ? TN : TM, NS = BRES ? TM : TN, R = PD + 1;
     const uint32_t r_addr = BRES ? b_addr : a_addr, s_addr = BRES ? a_addr : b_addr;
     f16x8 res[NR], ring[R];
+    if constexpr (ABL == 6) {
+#pragma unroll
+        for (int i = 0; i < NR; ++i) asm volatile("" : "=v"(res[i]));
+#pragma unroll
+        for (int i = 0; i < R; ++i) asm volatile("" : "=v"(ring[i]));
+    }
     static_for<0, NR>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
-        ds_read16<i * GS>(res[i], r_addr);
+        if constexpr (ABL != 6) ds_read16<i * GS>(res[i], r_addr);
     });
     static_for<0, PD>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
-        ds_read16<i * GS>(ring[i % R], s_addr);
+        if constexpr (ABL != 6) ds_read16<i * GS>(ring[i % R], s_addr);
     });
     if (PRIO) __builtin_amdgcn_s_setprio(1);
     static_for<0, NS>([&](auto ic) {
         constexpr int s = decltype(ic)::value;
-        if constexpr (s + PD < NS) ds_read16<(s + PD) * GS>(ring[(s + PD) % R], s_addr);
+        if constexpr (s + PD < NS && ABL != 6) ds_read16<(s + PD) * GS>(ring[(s + PD) % R], s_addr);
         constexpr int after = (NS - 1 - s) < PD ? (NS - 1 - s) : PD;
         wait_lgkm<after>();
         if constexpr (s == 0) {
@@ -40,7 +48,8 @@ static __device__ __forceinline__ void mma_k32_mid(f32x4 (&acc)[TM][TN], uint32_
         tie(ring[s % R]);
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
-            if constexpr (BRES) acc[s][r] = FD_MFMA_16x16x32(res[r], ring[s % R], acc[s][r]);
+            if constexpr (ABL == 2) asm volatile("" ::"v"(res[r]), "v"(ring[s % R]));       // keep the reads alive
+            else if constexpr (BRES) acc[s][r] = FD_MFMA_16x16x32(res[r], ring[s % R], acc[s][r]);
             else acc[r][s] = FD_MFMA_16x16x32(ring[s % R], res[r], acc[r][s]);
         }
         __builtin_amdgcn_sched_barrier(0);

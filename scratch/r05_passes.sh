@@ -101,5 +101,6 @@ j)  # what bounds the GEMM / conv kernels on COLD operands: L2 hit rates and req
     done
     cd $R; cp gpurun_out/pmc_r05_manifest.json $O/ 2>/dev/null; ls -la $O
     ;;
+k)  timeout 1200 python scratch/mb_pp_ablate.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r05k_pp_ablation.txt ;;
 *) echo "unknown pass $1";;
 esac
