@@ -30,13 +30,29 @@ def f_img(S):
 
 
 def pmc_traffic(kernel, algorithmic_bytes_per_launch):
-    """HBM-side bytes per launch of the dominant kernel from the committed PMC passes (FETCH_SIZE / WRITE_SIZE cannot be read from
-    inside a process; they are collected with rocprofv3 --pmc in separate runs on the kernel's own shapes, profiles/r03_pmc_traffic.json,
-    with the gfx950 corrections of MI355X_MICROARCH.md applied).  This run's per-launch figure = its mean ALGORITHMIC bytes per launch
-    (exact, from every launch's M, N, K) x the measured traffic / algorithmic ratio of that kernel variant."""
+    """HBM-side bytes per launch of the dominant kernel from the committed PMC passes (FETCH_SIZE / WRITE_SIZE cannot be read from inside a process; they are
+    collected with rocprofv3 --pmc in separate runs, with the gfx950 corrections of MI355X_MICROARCH.md applied: FETCH_SIZE doubled).
+    Round 5: the passes ran over THIS benchmark's own step (scratch/r05_passes.sh a: real data flow, the kernels in launch order; counter collection serialises
+    the dispatches) -- profiles/r05_pmc_{fetch,write}_size_in_situ_step.csv hold the per-(kernel, grid) means; the figure returned is the dispatch-weighted mean
+    over the kernel's grids, i.e. measured bytes per launch of the same launch mix the roofline step times.  Older trees fall back to the per-shape
+    traffic / algorithmic ratios of rounds 1-3 applied to this run's algorithmic bytes."""
+    import csv
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+    fp, wp = os.path.join(root, "r05_pmc_fetch_size_in_situ_step.csv"), os.path.join(root, "r05_pmc_write_size_in_situ_step.csv")
+    if os.path.exists(fp) and os.path.exists(wp):
+        def rows(path, col):
+            return {(r["kernel"], r["workgroups"]): (float(r[col]), int(r["dispatches"])) for r in csv.DictReader(open(path)) if r["kernel"] == kernel}
+        F, W = rows(fp, "FETCH_SIZE"), rows(wp, "WRITE_SIZE")
+        keys = [k for k in F if k in W]
+        n = sum(F[k][1] for k in keys)
+        if n:
+            traffic = sum((2.0 * F[k][0] + W[k][0]) * 1024.0 * F[k][1] for k in keys) / n
+            return traffic, ("measured in situ: dispatch-weighted mean over %d launches of this kernel in a profiled bench step (rocprofv3 --pmc FETCH_SIZE x2 gfx950 "
+                             "correction + WRITE_SIZE, separate passes, profiles/r05_pmc_*_in_situ_step.csv); this run's mean algorithmic bytes/launch: %.1f MB; "
+                             "Infinity-Cache hits are included" % (n, algorithmic_bytes_per_launch / 1e6))
     d = None
     for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
-        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", name)
+        path = os.path.join(root, name)
         if os.path.exists(path):
             d = json.load(open(path))["kernels"].get(kernel)
             if d is not None:
