@@ -102,7 +102,7 @@ j)  # what bounds the GEMM / conv kernels on COLD operands: L2 hit rates and req
     cd $R; cp gpurun_out/pmc_r05_manifest.json $O/ 2>/dev/null; ls -la $O
     ;;
 k)  timeout 1200 python scratch/mb_pp_ablate.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r05k_pp_ablation.txt ;;
-m)  # follow-up of pass l: only the PREFETCH of the next step's frozen rollout is CU-confined (its own stream "r2p"), everything else unmasked
+m)  # (needs scratch/r05_cu_mask_streams.patch) follow-up of pass l: only the PREFETCH of the next step's frozen rollout is CU-confined (its own stream "r2p"), everything else unmasked
     O=gpurun_out/r05m; mkdir -p $O
     for i in 1 2; do
       for v in "FD_NOTHING=1" "FD_CU_MASK=r2p=128-255" "FD_CU_MASK=r2p=192-255" "FD_CU_MASK=r2p=224-255" "FD_CU_MASK=r2p=128-255 FD_R2_PREFETCH_STEPS=12" "FD_CU_MASK=r2p=192-255 FD_R2_PREFETCH_STEPS=12" "FD_CU_MASK=r2p=0-255"; do
@@ -112,7 +112,7 @@ m)  # follow-up of pass l: only the PREFETCH of the next step's frozen rollout i
     done
     bench_table "$O/*.json" | tee $O/summary.txt
     ;;
-l)  # CU-masked streams (hipExtStreamCreateWithCUMask) for R1 || R2 and the backward streams, whole-step A/B, alternating arms
+l)  # (needs scratch/r05_cu_mask_streams.patch applied to step.py) VERDICT r4 item 1d: CU-masked streams (hipExtStreamCreateWithCUMask) for R1 || R2 and the backward streams, whole-step A/B, alternating arms
     O=gpurun_out/r05l; mkdir -p $O
     for i in 1 2; do
       for v in "FD_NOTHING=1" "FD_CU_MASK=r2=128-255;main=0-127" ${R05L_ALL:+"FD_CU_MASK=r2=128-255" "FD_CU_MASK=r2=128-255;1=0-127;2=128-255" "FD_CU_MASK=r2=192-255"}; do
