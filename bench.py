@@ -79,7 +79,6 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU plumbing checks)")
     ap.add_argument("--share_gpu0", action="store_true", help="plumbing check: every rank uses cuda:0")
     ap.add_argument("--dtype", default="fp16", choices=["fp16", "bf16"], help="working dtype; bf16 = BASELINE configs[4] (NOT the headline line)")
-    ap.add_argument("--fp8_attn", action="store_true", help="e4m3 QK^T / PV in the U-Net's self-attention forward (configs[4]; NOT the headline line)")
     ap.add_argument("--force_collectives", action="store_true", help="initialise the process group and run the step's collectives even at world size 1 (RCCL smoke on a one-GPU box)")
     ap.add_argument("--experiment", default="exp-1", choices=["exp-1", "exp-3", "exp-4", "exp-5"], help="exp-3/4/5: multi-attribute head + OT targets (not the headline config)")
     ap.add_argument("--no_regularisers", action="store_true", help="drop the CLIP/DINOv2 image-semantics and SFNet face-realism terms (loss_fair only)")
@@ -91,8 +90,6 @@ def main():
     a = ap.parse_args()
 
     os.environ["FD_DTYPE"] = a.dtype          # fixed before the package is imported (selects libfairdiff_hip[_bf16].so)
-    if a.fp8_attn:
-        os.environ["FD_FP8_ATTN"] = "1"
     import finetune_fair_diffusion_amd  # noqa: F401  (first: its __init__ puts GPU_MAX_HW_QUEUES=8 in the environment, which HIP reads when the device is initialised)
     import torch
     import torch.distributed as dist
@@ -172,12 +169,12 @@ def main():
     line = {
         "metric": "training-images/sec (SD-v1.5 512^2, 20-step DPM-Solver++ unroll, fairness-finetune step)",
         "value": value, "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16" if a.dtype == "fp16" else ("bf16+fp8attn" if a.fp8_attn else "bf16"),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16" if a.dtype == "fp16" else "bf16",
         "data": "synthetic",
         "config": {"workload": ("exp-1-debias-gender, batch %d/GPU, %d denoising steps, LoRA rank %d on U-Net, fp16, SD-v1.5 512x512 (BASELINE configs[1])"
-                                % (a.batch, a.S, a.rank) if a.dtype == "fp16" and not a.fp8_attn else
-                                "NOT THE HEADLINE: configs[4]-style precision (%s%s) on the configs[1] workload, batch %d/GPU, %d steps, rank %d"
-                                % (a.dtype, " + e4m3 self-attention forward" if a.fp8_attn else "", a.batch, a.S, a.rank))
+                                % (a.batch, a.S, a.rank) if a.dtype == "fp16" else
+                                "NOT THE HEADLINE: configs[4]'s working precision (%s) on the configs[1] workload, batch %d/GPU, %d steps, rank %d"
+                                % (a.dtype, a.batch, a.S, a.rank))
                                if not a.tiny else "TINY plumbing config (not a bench line)",
                    "global_batch": world * a.batch, "steps_per_s": a.steps / dt, "parallelism": f"dp{world}",
                    "algorithmic_flop_per_image": f_img(a.S),

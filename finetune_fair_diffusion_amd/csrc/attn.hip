@@ -8,7 +8,7 @@
 //   O^T[dv][q] += V^T[dv][key] . P^T[key][q]
 // with the k index of that MFMA permuted consistently on both operands (element j of a lane's
 // 8-wide operand <-> key 4*(lane>>5) + (j&3) + 8*(j>>2) of the 16-key step), which the A side
-// realises as two 8-byte LDS reads from a key-contiguous (transposed) tile.  Head dims that are
+// realises as transpose reads (ds_read_b64_tr_b16) of the row-major tile the projections wrote.  Head dims that are
 // not MFMA multiples (40, 80) are zero-padded in LDS: D -> DK (x16) for contractions over d and
 // D -> DV (x32) where d is an output dimension.
 #include "common.h"
@@ -49,26 +49,12 @@ __device__ __forceinline__ void attn_block_coords(int nblk, int H, int B, int& b
 // row index inside a 32x32 C/D tile for accumulator register r of lane-half g
 __device__ __forceinline__ int crow(int r, int g) { return (r & 3) + 8 * (r >> 2) + 4 * g; }
 
-// Row stride (halfs) of the key-contiguous LDS tiles.  ds_read_b64 is serviced in two 32-lane groups over 64 banks: the 32 lanes of a
-// group read rows ql = 0..31 at one key offset, so the stride must put them on 32 distinct bank pairs.  68 halfs = 34 banks does
-// (even rows on banks 4m, odd rows on 4m + 34); the 72 of round 1 (36 banks) made rows r and r + 16 collide, 2 cycles -> 4 per read.
-#ifndef FD_ATTN_TS
-#define FD_ATTN_TS 68
-#endif
-constexpr int TS = FD_ATTN_TS;
 // Row padding (halfs) of the backward kernels' row-major Q / dO / K / V tiles, read both as 16-byte fragments and through read_tr.
 // Measurement knob (make BENCH_HOOKS=1 EXTRA_DEFS=-DFD_ATTN_BWD_PAD=n): 8 is the shipped value.
 #ifndef FD_ATTN_BWD_PAD
 #define FD_ATTN_BWD_PAD 8
 #endif
-// the permuted-k A operand from a key-contiguous LDS tile [.][TS]: keys base + 4g + {0..3} and base + 8 + 4g + {0..3}
-__device__ __forceinline__ f16x8 read_perm(const f16* tile, int row, int base, int g) {
-    const f16x4 lo = *(const f16x4*)(tile + row * TS + base + 4 * g);
-    const f16x4 hi = *(const f16x4*)(tile + row * TS + base + 8 + 4 * g);
-    return (f16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-}
-
-// The same permuted-k A operand, but of a product whose A matrix is the TRANSPOSE of a row-major LDS tile [k][m] (row stride ``stride``
+// The permuted-k A operand of a product whose A matrix is the TRANSPOSE of a row-major LDS tile [k][m] (row stride ``stride``
 // halfs, 8-byte aligned rows): gfx950's ds_read_b64_tr_b16.  A 16-lane group fetches one [4 k][16 m] block -- lane L of the group supplies
 // the address of row L / 4, columns 4 (L % 4) .. + 3 -- and lane c receives column c, i.e. A[m0 + c][k .. k + 3].  With it V (forward),
 // K (dQ) and Q / dO (dK, dV) are consumed in the layout the projections write them in: no transposed copies in HBM, no transposed tiles.
@@ -116,16 +102,6 @@ __device__ __forceinline__ void plan_rows(TilePlan<D>& pl, int64_t ld) {
     }
 }
 template <int D>
-__device__ __forceinline__ void plan_cols(TilePlan<D>& pl, int64_t ldt) {
-    constexpr int N = D * 8, NCH = (64 * (D / 8) + 255) / 256;
-#pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-        const int c = min((int)threadIdx.x + i * 256, N - 1);
-        const int r = c >> 3, cc = (c & 7) * 8;
-        pl.off[i] = (unsigned)((r * ldt + cc) * 2);
-    }
-}
-template <int D>
 __device__ __forceinline__ void load_planned(TileRegs<D>& t, const f16* tile_base /* wave-uniform */, const TilePlan<D>& pl) {
     constexpr int NCH = (64 * (D / 8) + 255) / 256;
 #pragma unroll
@@ -141,50 +117,21 @@ __device__ __forceinline__ void store_rows(const TileRegs<D>& t, f16* dst) {
         if (c < N) *(f16x8*)(dst + r * DKP + cc) = t.r[i];
     }
 }
-template <int D>
-__device__ __forceinline__ void load_cols(TileRegs<D>& t, const f16* src, int64_t ldt, int col0, int ncols_valid) {
-    constexpr int N = D * 8, NCH = (64 * (D / 8) + 255) / 256;   // D rows x 8 chunks == 64 * D/8
-#pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-        const int c = threadIdx.x + i * 256;
-        const int r = c >> 3, cc = (c & 7) * 8;
-        t.r[i] = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
-        if (c < N && col0 + cc < ncols_valid) t.r[i] = *(const f16x8*)(src + (int64_t)r * ldt + col0 + cc);
-    }
-}
-template <int D>
-__device__ __forceinline__ void store_cols(const TileRegs<D>& t, f16* dst) {
-    constexpr int N = D * 8, NCH = (64 * (D / 8) + 255) / 256;
-#pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-        const int c = threadIdx.x + i * 256;
-        const int r = c >> 3, cc = (c & 7) * 8;
-        if (c < N) {   // rows are 8-byte aligned only (TS = 68): two 8-byte stores
-            *(f16x4*)(dst + r * TS + cc) = (f16x4){t.r[i][0], t.r[i][1], t.r[i][2], t.r[i][3]};
-            *(f16x4*)(dst + r * TS + cc + 4) = (f16x4){t.r[i][4], t.r[i][5], t.r[i][6], t.r[i][7]};
-        }
-    }
-}
-// zero the padding that staging never touches: columns [D, DKP) of a row tile / rows [D, DV) of a column tile
+// zero the padding that staging never touches: columns [D, DKP) of a row tile
 template <int D, int DKP>
 __device__ __forceinline__ void zero_row_pad(f16* dst) {
     for (int c = threadIdx.x; c < 64 * (DKP - D); c += 256) dst[(c / (DKP - D)) * DKP + D + c % (DKP - D)] = (f16)0;
 }
-template <int D, int DV>
-__device__ __forceinline__ void zero_col_pad(f16* dst) {
-    for (int c = threadIdx.x; c < (DV - D) * TS; c += 256) dst[D * TS + c] = (f16)0;
-}
-
 // Occupancy targets (waves per SIMD, the second __launch_bounds__ argument).  Without one the register allocator spreads out to whatever
 // the 4-wave workgroup allows (512 per lane): round 1 shipped 184 (forward), 202 (dQ) and 310 (dK/dV) VGPR+AGPR at d = 40, i.e. 2 / 2 / 1
 // waves per SIMD, while reading only the arch-VGPR half of that number as "fits three".  The values below are the highest occupancy
 // each head-dim class reaches WITHOUT scratch (checked on the gfx950 ISA: .amdhsa_next_free_vgpr / private_segment_fixed_size).
 constexpr int fwd_waves(int D) { return D <= 64 ? 3 : D <= 128 ? 2 : 1; }
 constexpr int dq_waves(int D) { return D <= 40 ? 3 : D <= 128 ? 2 : 1; }
-#ifdef FD_DKDV_TR_W3      // measurement: the read_tr form of dK/dV at d = 40 squeezed to three waves per SIMD (168 registers + 124 B of scratch)
-constexpr int dkdv_waves(int D, bool QTR = false) { return (QTR && D == 40) ? 3 : D <= 64 ? 2 : 1; }
+#ifdef FD_DKDV_TR_W3      // measurement: dK/dV at d = 40 squeezed to three waves per SIMD (168 registers + 124 B of scratch)
+constexpr int dkdv_waves(int D) { return D == 40 ? 3 : D <= 64 ? 2 : 1; }
 #else
-constexpr int dkdv_waves(int D, bool QTR = false) { return D <= 64 ? 2 : 1; }
+constexpr int dkdv_waves(int D) { return D <= 64 ? 2 : 1; }
 #endif
 
 // ---- "-D through the matrix pipe" (round 4).  dS = P o (dP - D), D = rowsum(dO o O): where the contraction over d is padded (d = 40 -> 48: eight spare
@@ -196,7 +143,7 @@ constexpr int dkdv_waves(int D, bool QTR = false) { return D <= 64 ? 2 : 1; }
 // log2(e) in its fp32 epilogue (fd_gemm_desc.colscale: one rounding, as before), so the QK^T accumulator IS the exponent's argument up to the
 // reference point -- and the reference point (the running maximum in the forward, the saved log-sum-exp in the backward) rides in the same three
 // spare contraction slots as -D does: q's slots carry -m or -lse split into three 16-bit pieces, K's slots carry 1.0.  p = exp2(accumulator): the
-// fused multiply-add per score element is gone from all three kernels.  Head dims with the slots only (d = 40), transpose-read forms only.
+// fused multiply-add per score element is gone from all three kernels.  Head dims with the slots only (d = 40).
 template <int D> constexpr bool pre_ok() { return D % 16 == 8; }
 #define FD_PRE_MASKED 30000.f        // "lse" of an invalid query row in the pre-scaled backward: exp2(s - 30000) == 0, and it splits into finite pieces
 
@@ -234,14 +181,15 @@ __device__ __forceinline__ void split3_scaled(float x, f16& h0, f16& h1, f16& h2
 }
 
 // ================================================================================== forward
-// VTR: ``Vt`` points at V itself ([Bk, Tkr, .] rows of stride ldk, like K) and the PV operand comes from a row-major tile through read_tr
+// V is read as the projection wrote it ([Bk, Tkr, .] rows of stride ldk, like K): the PV operand comes from its row-major tile through read_tr.
+// (Rounds 1-2 read a transposed copy V^T made by fd_transpose_btc; that form left the product in round 5 -- git history, profiles/r03_attention_transpose_read_ab.txt.)
 // QB: 32-query column blocks per wave.  QB = 1: 4 waves x 32 queries per workgroup (rounds 1-3).  QB = 2 (round 4): a wave owns 64 consecutive
 // queries, so every K / V fragment it reads from LDS feeds two MFMAs and the staged K / V tile serves 256 queries instead of 128 -- both the
 // fragment traffic and the staging per query halve (the forward was co-limited by exactly those: MFMAs + fragment reads alone 410 of 646 us,
 // staging + barriers ~190, profiles/r02_attn_fwd_d40_ablation.txt), at two waves per SIMD instead of three.
-template <int D, bool VTR, int QB, bool PRE = false>
-__global__ __launch_bounds__(256, QB == 1 ? fwd_waves(D) : (D <= 64 ? 2 : 1)) void attn_fwd_kernel(const f16* __restrict__ Q, const f16* __restrict__ K, const f16* __restrict__ Vt,
-                                                       f16* __restrict__ O, float* __restrict__ LSE, int H, int Tq, int Tk, int Tkp,
+template <int D, int QB, bool PRE = false>
+__global__ __launch_bounds__(256, QB == 1 ? fwd_waves(D) : (D <= 64 ? 2 : 1)) void attn_fwd_kernel(const f16* __restrict__ Q, const f16* __restrict__ K, const f16* __restrict__ V,
+                                                       f16* __restrict__ O, float* __restrict__ LSE, int H, int Tq, int Tk,
                                                        int Tkr, int kv_div, float scale, int ldq, int ldk) {
     constexpr int DK = (D + 15) / 16 * 16, DV = (D + 31) / 32 * 32, DKP = DK + 8;
     constexpr int NKS = DK / 16, NDV = DV / 32;
@@ -249,7 +197,7 @@ __global__ __launch_bounds__(256, QB == 1 ? fwd_waves(D) : (D <= 64 ? 2 : 1)) vo
     extern __shared__ __attribute__((aligned(16))) f16 smem[];
     constexpr int VP = tr_stride(DV);
     f16* Ks = smem;               // [64][DKP]
-    f16* Vts = smem + 64 * DKP;   // [DV][TS]   (VTR: [64][VP], keys x d)
+    f16* Vts = smem + 64 * DKP;   // [64][VP], keys x d
 
     int b, h, qblk;
     attn_block_coords((Tq + RB - 1) / RB, H, gridDim.x / (((Tq + RB - 1) / RB) * H), b, h, qblk);
@@ -284,19 +232,17 @@ __global__ __launch_bounds__(256, QB == 1 ? fwd_waves(D) : (D <= 64 ? 2 : 1)) vo
         m_run[qb] = PRE ? 0.f : -INFINITY;      // PRE: a finite reference point in the log2 domain (q's slots hold -m_run: zero to start with)
         l_run[qb] = 0.f;
     }
-    static_assert(!PRE || (pre_ok<D>() && VTR), "pre-scaled q: head dims with three spare contraction slots, transpose-read form");
+    static_assert(!PRE || pre_ok<D>(), "pre-scaled q: head dims with three spare contraction slots");
     const float sl2 = scale * LOG2E;
 
     const f16* Kb = K + (int64_t)bk * Tkr * ldk + h * D;
-    const f16* Vtb = VTR ? Vt + (int64_t)bk * Tkr * ldk + h * D : Vt + ((int64_t)bk * C + h * D) * Tkp;
+    const f16* Vtb = V + (int64_t)bk * Tkr * ldk + h * D;
 
     TileRegs<D> kreg, vreg;
     TilePlan<D> kplan, vplan;
     plan_rows<D>(kplan, ldk);
-    if (VTR) plan_rows<D>(vplan, ldk);
-    else plan_cols<D>(vplan, Tkp);
+    plan_rows<D>(vplan, ldk);
     zero_row_pad<D, DKP>(Ks);
-    if (!VTR) zero_col_pad<D, DV>(Vts);
     // Head dims with a spare padded output row (40, 80, 16): "V column D" is a column of ones, so row D of O^T accumulates sum_k p -- the softmax
     // denominator comes out of the P.V MFMAs (with the same rescaling as O) instead of 32 VALU adds and a shuffle per tile; it is the sum of
     // the fp16-rounded probabilities the numerator is built from.
@@ -310,22 +256,15 @@ __global__ __launch_bounds__(256, QB == 1 ? fwd_waves(D) : (D <= 64 ? 2 : 1)) vo
         for (int c = threadIdx.x; c < 64 * 3; c += 256) Ks[(c / 3) * DKP + D + c % 3] = (f16)1.f;   // never overwritten: store_rows writes columns < D
     }
     if (ONES) {
-        if (VTR) {
-            for (int r = threadIdx.x; r < 64; r += 256) Vts[r * VP + D] = (f16)1.f;
-        } else {
-            __syncthreads();                           // behind zero_col_pad's writes of the same row
-            for (int c = threadIdx.x; c < TS; c += 256) Vts[D * TS + c] = (f16)1.f;
-        }
+        for (int r = threadIdx.x; r < 64; r += 256) Vts[r * VP + D] = (f16)1.f;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // Q fragments landed: no VM event may pend on them inside the loop
     load_rows<D>(kreg, Kb, ldk, 0, Tk);
-    if (VTR) load_rows<D>(vreg, Vtb, ldk, 0, Tk);
-    else load_cols<D>(vreg, Vtb, Tkp, 0, Tkp);
+    load_rows<D>(vreg, Vtb, ldk, 0, Tk);
     for (int k0 = 0; k0 < Tk; k0 += 64) {
         __syncthreads();
         store_rows<D, DKP>(kreg, Ks);
-        if (VTR) store_rows<D, VP>(vreg, Vts);
-        else store_cols<D>(vreg, Vts);
+        store_rows<D, VP>(vreg, Vts);
         __syncthreads();
         f32x16 s[QB][2];
         auto scores = [&]() {
@@ -355,11 +294,10 @@ __global__ __launch_bounds__(256, QB == 1 ? fwd_waves(D) : (D <= 64 ? 2 : 1)) vo
         // compiler parks an s_waitcnt vmcnt(0) before the first MFMA and the whole load latency is exposed every tile)
         if (k0 + 128 <= Tk) {                 // next tile is an interior one: planned, unchecked loads
             load_planned<D>(kreg, Kb + (int64_t)(k0 + 64) * ldk, kplan);
-            load_planned<D>(vreg, VTR ? Vtb + (int64_t)(k0 + 64) * ldk : Vtb + (k0 + 64), vplan);
+            load_planned<D>(vreg, Vtb + (int64_t)(k0 + 64) * ldk, vplan);
         } else if (k0 + 64 < Tk) {
             load_rows<D>(kreg, Kb, ldk, k0 + 64, Tk);
-            if (VTR) load_rows<D>(vreg, Vtb, ldk, k0 + 64, Tk);
-            else load_cols<D>(vreg, Vtb, Tkp, k0 + 64, Tkp);
+            load_rows<D>(vreg, Vtb, ldk, k0 + 64, Tk);
         }
         // online softmax on the raw scores: p = exp2(s*sl2 - m*sl2) is one FMA + one v_exp per element; the
         // key mask only exists in the last (partial) tile, a wave-uniform branch
@@ -465,7 +403,7 @@ __global__ __launch_bounds__(256, QB == 1 ? fwd_waves(D) : (D <= 64 ? 2 : 1)) vo
         for (int st = 0; st < 4; ++st)
 #pragma unroll
             for (int i = 0; i < NDV; ++i) {
-                const f16x8 vf = VTR ? read_tr(Vts, VP, st * 16, i * 32, ql, g) : read_perm(Vts, i * 32 + ql, st * 16, g);
+                const f16x8 vf = read_tr(Vts, VP, st * 16, i * 32, ql, g);
 #pragma unroll
                 for (int qb = 0; qb < QB; ++qb) oacc[qb][i] = mfma32(vf, pf[qb][st], oacc[qb][i]);
             }
@@ -517,19 +455,18 @@ __global__ void attn_bwd_prep_kernel(const f16* O, const f16* dO, float* Dd, int
 }
 
 // ================================================================================== dQ
-// KTR: no transposed K in HBM (Kt == nullptr); the dQ operand K^T comes from the row-major K tile through read_tr
-template <int D, bool KTR, bool PRE = false>
+// no transposed K in HBM: the dQ operand K^T comes from the row-major K tile through read_tr
+template <int D, bool PRE = false>
 __global__ __launch_bounds__(256, dq_waves(D)) void attn_bwd_dq_kernel(const f16* __restrict__ Q, const f16* __restrict__ K, const f16* __restrict__ V,
-                                                          const f16* __restrict__ Kt, const f16* __restrict__ dO,
+                                                          const f16* __restrict__ dO,
                                                           const float* __restrict__ LSE, float* __restrict__ Dd, f16* __restrict__ dQ,
-                                                          const f16* __restrict__ O, int H, int Tq, int Tk, int Tkp, int Tkr, int kv_div,
+                                                          const f16* __restrict__ O, int H, int Tq, int Tk, int Tkr, int kv_div,
                                                           float scale, int ldq, int ldkv, int lddq) {
     constexpr int DK = (D + 15) / 16 * 16, DV = (D + 31) / 32 * 32, DKP = DK + FD_ATTN_BWD_PAD;
     constexpr int NKS = DK / 16, NDV = DV / 32;
     extern __shared__ __attribute__((aligned(16))) f16 smem[];
     f16* Ks = smem;                // [64][DKP]
     f16* Vs = Ks + 64 * DKP;       // [64][DKP]
-    f16* Kts = Vs + 64 * DKP;      // [DV][TS]
 
     int b, h, qblk;
     attn_block_coords((Tq + 127) / 128, H, gridDim.x / (((Tq + 127) / 128) * H), b, h, qblk);
@@ -552,7 +489,7 @@ __global__ __launch_bounds__(256, dq_waves(D)) void attn_bwd_dq_kernel(const f16
             gf[ks] = *(const f16x8*)(dO + ((int64_t)b * Tq + t) * C + h * D + col);
         }
     }
-    static_assert(!PRE || (pre_ok<D>() && KTR), "pre-scaled q: head dims with three spare contraction slots, transpose-read form");
+    static_assert(!PRE || pre_ok<D>(), "pre-scaled q: head dims with three spare contraction slots");
     const float lse2 = tvalid ? LSE[((int64_t)b * H + h) * Tq + t] * LOG2E : (PRE ? FD_PRE_MASKED : INFINITY);
     if (PRE && g == 1) {                             // -lse of this lane's query into columns D .. D + 2 of its (pre-scaled) q row
         f16 h0, h1, h2;
@@ -589,13 +526,11 @@ __global__ __launch_bounds__(256, dq_waves(D)) void attn_bwd_dq_kernel(const f16
 
     const f16* Kb = K + (int64_t)bk * Tkr * ldkv + h * D;
     const f16* Vb = V + (int64_t)bk * Tkr * ldkv + h * D;
-    const f16* Ktb = KTR ? nullptr : Kt + ((int64_t)bk * C + h * D) * Tkp;
 
     constexpr bool PF = D <= 80;      // register prefetch where the register file has room
-    TileRegs<D> kreg, vreg, ktreg;
+    TileRegs<D> kreg, vreg;
     zero_row_pad<D, DKP>(Ks);
     zero_row_pad<D, DKP>(Vs);
-    if (!KTR) zero_col_pad<D, DV>(Kts);
     if (DFOLD || PRE) {
         __syncthreads();                               // behind zero_row_pad's writes of the same columns
         for (int c = threadIdx.x; c < 64 * 3; c += 256) {    // never overwritten: store_rows writes columns < D
@@ -606,18 +541,15 @@ __global__ __launch_bounds__(256, dq_waves(D)) void attn_bwd_dq_kernel(const f16
     if (PF) {
         load_rows<D>(kreg, Kb, ldkv, 0, Tk);
         load_rows<D>(vreg, Vb, ldkv, 0, Tk);
-        if (!KTR) load_cols<D>(ktreg, Ktb, Tkp, 0, Tkp);
     }
     for (int k0 = 0; k0 < Tk; k0 += 64) {
         __syncthreads();
         if (!PF) {
             load_rows<D>(kreg, Kb, ldkv, k0, Tk);
             load_rows<D>(vreg, Vb, ldkv, k0, Tk);
-            if (!KTR) load_cols<D>(ktreg, Ktb, Tkp, k0, Tkp);
         }
         store_rows<D, DKP>(kreg, Ks);
         store_rows<D, DKP>(vreg, Vs);
-        if (!KTR) store_cols<D>(ktreg, Kts);
         __syncthreads();
         f16x8 dsf[4];
 #pragma unroll
@@ -634,7 +566,6 @@ __global__ __launch_bounds__(256, dq_waves(D)) void attn_bwd_dq_kernel(const f16
             if (kt == 0 && PF && k0 + 64 < Tk) {
                 load_rows<D>(kreg, Kb, ldkv, k0 + 64, Tk);
                 load_rows<D>(vreg, Vb, ldkv, k0 + 64, Tk);
-                if (!KTR) load_cols<D>(ktreg, Ktb, Tkp, k0 + 64, Tkp);
             }
             if (k0 + 64 > Tk) {                  // the key mask only exists in the last (partial) tile: a wave-uniform branch
                 asm volatile("" ::: "memory");   // keeps it a real branch (if-converted it is ~110 VALU -- as many as the softmax itself -- on every tile)
@@ -652,7 +583,7 @@ __global__ __launch_bounds__(256, dq_waves(D)) void attn_bwd_dq_kernel(const f16
         for (int st = 0; st < 4; ++st)
 #pragma unroll
             for (int i = 0; i < NDV; ++i) {
-                const f16x8 kf = KTR ? read_tr(Ks, DKP, st * 16, i * 32, ql, g) : read_perm(Kts, i * 32 + ql, st * 16, g);
+                const f16x8 kf = read_tr(Ks, DKP, st * 16, i * 32, ql, g);
                 acc[i] = mfma32(kf, dsf[st], acc[i]);
             }
     }
@@ -675,11 +606,11 @@ __global__ __launch_bounds__(256, dq_waves(D)) void attn_bwd_dq_kernel(const f16
 
 // ================================================================================== dK, dV
 // block = 128 keys (4 waves x 32), loops over 32-query tiles.  S[q][key] = Q.K^T with K,V rows in VGPRs.
-// QTR: no transposed Q / dO in HBM (Qt == dOt == nullptr); the dK / dV operands Q^T, dO^T come from the row-major tiles through read_tr
-template <int D, bool ATOMIC, bool QTR, bool PRE = false>
-__global__ __launch_bounds__(256, dkdv_waves(D, QTR)) void attn_bwd_dkdv_kernel(const f16* __restrict__ Q, const f16* __restrict__ Qt, const f16* __restrict__ K,
+// no transposed Q / dO in HBM: the dK / dV operands Q^T, dO^T come from the row-major tiles through read_tr
+template <int D, bool ATOMIC, bool PRE = false>
+__global__ __launch_bounds__(256, dkdv_waves(D)) void attn_bwd_dkdv_kernel(const f16* __restrict__ Q, const f16* __restrict__ K,
                                                             const f16* __restrict__ V, const f16* __restrict__ dO,
-                                                            const f16* __restrict__ dOt, const float* __restrict__ LSE,
+                                                            const float* __restrict__ LSE,
                                                             const float* __restrict__ Dd, void* __restrict__ dKo, void* __restrict__ dVo,
                                                             int H, int Tq, int Tk, int Tkr, int kv_div, float scale, int ldq, int ldkv, int lddkv,
                                                             int64_t slab) {
@@ -690,9 +621,7 @@ __global__ __launch_bounds__(256, dkdv_waves(D, QTR)) void attn_bwd_dkdv_kernel(
     extern __shared__ __attribute__((aligned(16))) f16 smem[];
     f16* Qs = smem;                 // [64][DKP]
     f16* Gs = Qs + 64 * DKP;        // [64][DKP]  (dO rows)
-    f16* Qts = Gs + 64 * DKP;       // [DV][TS]
-    f16* Gts = Qts + DV * TS;       // [DV][TS]
-    float* lse_s = (float*)(Gts + DV * TS);  // [64]
+    float* lse_s = (float*)(Gs + 64 * DKP + 64);  // [64]  (64 halfs of slack: read_tr runs past the last row)
     float* dd_s = lse_s + 64;                // [64]
 
     int b, h, kblk;
@@ -717,7 +646,7 @@ __global__ __launch_bounds__(256, dkdv_waves(D, QTR)) void attn_bwd_dkdv_kernel(
         }
     }
     constexpr bool DFOLD = dfold<D>();
-    static_assert(!PRE || (pre_ok<D>() && QTR), "pre-scaled q: head dims with three spare contraction slots, transpose-read form");
+    static_assert(!PRE || pre_ok<D>(), "pre-scaled q: head dims with three spare contraction slots");
     if (DFOLD && g == 1) {                                                                     // columns D .. D + 2 of this lane's V row: the scales of split3_scaled
         vf[NKS - 1][0] = (f16)256.f; vf[NKS - 1][1] = (f16)1.f; vf[NKS - 1][2] = (f16)(1.f / 256.f);
     }
@@ -729,43 +658,25 @@ __global__ __launch_bounds__(256, dkdv_waves(D, QTR)) void attn_bwd_dkdv_kernel(
 
     const f16* Qb = Q + (int64_t)b * Tq * ldq + h * D;
     const f16* Gb = dO + (int64_t)b * Tq * C + h * D;
-    const f16* Qtb = QTR ? nullptr : Qt + ((int64_t)b * C + h * D) * Tq;
-    const f16* Gtb = QTR ? nullptr : dOt + ((int64_t)b * C + h * D) * Tq;
     const float* Lb = LSE + ((int64_t)b * H + h) * Tq;
     const float* Db = Dd + ((int64_t)b * H + h) * Tq;
 
     constexpr bool PF = D <= 80;
-    TileRegs<D> qreg, greg, qtreg, gtreg;
+    TileRegs<D> qreg, greg;
     zero_row_pad<D, DKP>(Qs);
     zero_row_pad<D, DKP>(Gs);
-    if (!QTR) {
-        zero_col_pad<D, DV>(Qts);
-        zero_col_pad<D, DV>(Gts);
-    }
     if (PF) {
         load_rows<D>(qreg, Qb, ldq, 0, Tq);
         load_rows<D>(greg, Gb, C, 0, Tq);
-        if (!QTR) {
-            load_cols<D>(qtreg, Qtb, Tq, 0, Tq);
-            load_cols<D>(gtreg, Gtb, Tq, 0, Tq);
-        }
     }
     for (int q0 = 0; q0 < Tq; q0 += 64) {
         __syncthreads();
         if (!PF) {
             load_rows<D>(qreg, Qb, ldq, q0, Tq);
             load_rows<D>(greg, Gb, C, q0, Tq);
-            if (!QTR) {
-                load_cols<D>(qtreg, Qtb, Tq, q0, Tq);
-                load_cols<D>(gtreg, Gtb, Tq, q0, Tq);
-            }
         }
         store_rows<D, DKP>(qreg, Qs);
         store_rows<D, DKP>(greg, Gs);
-        if (!QTR) {
-            store_cols<D>(qtreg, Qts);
-            store_cols<D>(gtreg, Gts);
-        }
         if (threadIdx.x < 64) {
             const int tq = q0 + threadIdx.x;
             const float lsev = tq < Tq ? Lb[tq] * LOG2E : (PRE ? FD_PRE_MASKED : INFINITY);
@@ -794,8 +705,8 @@ __global__ __launch_bounds__(256, dkdv_waves(D, QTR)) void attn_bwd_dkdv_kernel(
             dsf[qt * 2 + (r >> 3)][r & 7] = (f16)(p * (DFOLD ? dp[r] : dp[r] - dd_s[qi]));   // scale applied to dK at the end
         };
         auto dvdk = [&](int st, int i) {
-            const f16x8 ga = QTR ? read_tr(Gs, DKP, st * 16, i * 32, kl, g) : read_perm(Gts, i * 32 + kl, st * 16, g);
-            const f16x8 qa = QTR ? read_tr(Qs, DKP, st * 16, i * 32, kl, g) : read_perm(Qts, i * 32 + kl, st * 16, g);
+            const f16x8 ga = read_tr(Gs, DKP, st * 16, i * 32, kl, g);
+            const f16x8 qa = read_tr(Qs, DKP, st * 16, i * 32, kl, g);
             dv[i] = mfma32(ga, pf[st], dv[i]);
             dk[i] = mfma32(qa, dsf[st], dk[i]);
         };
@@ -816,10 +727,6 @@ __global__ __launch_bounds__(256, dkdv_waves(D, QTR)) void attn_bwd_dkdv_kernel(
         if (PF && q0 + 64 < Tq) {
             load_rows<D>(qreg, Qb, ldq, q0 + 64, Tq);
             load_rows<D>(greg, Gb, C, q0 + 64, Tq);
-            if (!QTR) {
-                load_cols<D>(qtreg, Qtb, Tq, q0 + 64, Tq);
-                load_cols<D>(gtreg, Gtb, Tq, q0 + 64, Tq);
-            }
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) soft(s2[0], dp2[0], 0, r);
@@ -853,10 +760,6 @@ __global__ __launch_bounds__(256, dkdv_waves(D, QTR)) void attn_bwd_dkdv_kernel(
             if (qt == 0 && PF && q0 + 64 < Tq) {       // prefetch behind the first MFMA group (see forward)
                 load_rows<D>(qreg, Qb, ldq, q0 + 64, Tq);
                 load_rows<D>(greg, Gb, C, q0 + 64, Tq);
-                if (!QTR) {
-                    load_cols<D>(qtreg, Qtb, Tq, q0 + 64, Tq);
-                    load_cols<D>(gtreg, Gtb, Tq, q0 + 64, Tq);
-                }
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) soft(s, dp, qt, r);
@@ -917,17 +820,17 @@ static int fwd_qb(int d, int Tq, int Tk, int BH) {
     return qb;
 }
 
-template <int D, bool TR> static constexpr size_t fwd_lds() {
+template <int D> static constexpr size_t fwd_lds() {
     constexpr int DKP = (D + 15) / 16 * 16 + 8, DV = (D + 31) / 32 * 32;
-    return (size_t)(64 * DKP + (TR ? 64 * tr_stride(DV) : DV * TS)) * 2;
+    return (size_t)(64 * DKP + 64 * tr_stride(DV)) * 2;
 }
-template <int D, bool TR> static constexpr size_t dq_lds() {
-    constexpr int DKP = (D + 15) / 16 * 16 + FD_ATTN_BWD_PAD, DV = (D + 31) / 32 * 32;
-    return (size_t)(2 * 64 * DKP + (TR ? 64 : DV * TS)) * 2;      // TR: slack for the reads that run past the last row
+template <int D> static constexpr size_t dq_lds() {
+    constexpr int DKP = (D + 15) / 16 * 16 + FD_ATTN_BWD_PAD;
+    return (size_t)(2 * 64 * DKP + 64) * 2;      // + slack for the transpose reads that run past the last row
 }
-template <int D, bool TR> static constexpr size_t dkdv_lds() {
-    constexpr int DKP = (D + 15) / 16 * 16 + FD_ATTN_BWD_PAD, DV = (D + 31) / 32 * 32;
-    return (size_t)(2 * 64 * DKP + 2 * DV * TS) * 2 + 512;          // same carve-up for both forms (the TR form leaves the column tiles unused)
+template <int D> static constexpr size_t dkdv_lds() {
+    constexpr int DKP = (D + 15) / 16 * 16 + FD_ATTN_BWD_PAD;
+    return (size_t)(2 * 64 * DKP + 64) * 2 + 512;   // + the same slack + lse_s, dd_s
 }
 
 #define FD_DISPATCH_D(d, CALL)                                                       \
@@ -952,39 +855,36 @@ template <int D, bool TR> static constexpr size_t dkdv_lds() {
         }                                                                                                        \
     }
 
-extern "C" int fd_attn_fwd(const void* q, const void* k, const void* vt, void* o, float* lse, int B, int H, int Tq, int Tk, int Tkp, int Tkr,
+extern "C" int fd_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, int B, int H, int Tq, int Tk, int Tkr,
                            int d, int kv_div, float scale, int ldq, int ldk, void* stream) {
     if (ldq <= 0) ldq = H * d;
     if (ldk <= 0) ldk = H * d;
     FD_REQUIRE((ldq & 7) == 0 && (ldk & 7) == 0, "fd_attn_fwd: row strides must be multiples of 8");
-    const bool vtr = Tkp == 0;        // vt is V itself: rows of stride ldk, like k
-    FD_REQUIRE(B > 0 && H > 0 && Tq > 0 && Tk > 0 && (vtr || (Tkp >= Tk && (Tkp & 7) == 0)) && Tkr >= Tk && kv_div >= 1, "fd_attn_fwd: bad shape");
+    FD_REQUIRE(B > 0 && H > 0 && Tq > 0 && Tk > 0 && Tkr >= Tk && kv_div >= 1, "fd_attn_fwd: bad shape");
     // 64 queries per wave (QB = 2) for the long self-attention sequences of the small head dims: halves the LDS fragment traffic and the K / V
     // staging per query (see attn_fwd_kernel).  Short sequences keep QB = 1 (more workgroups, three waves per SIMD).
-    const int qb = vtr ? fwd_qb(d, Tq, Tk, B * H) : 1;       // the transposed-copy form (measurement only) stays at one block
+    const int qb = fwd_qb(d, Tq, Tk, B * H);
     dim3 grid(((Tq + 128 * qb - 1) / (128 * qb)) * H * B);
     // scale < 0: q arrives multiplied by |scale| * log2(e) (fd_gemm_desc.colscale in the projection) -- see "pre-scaled q" above
     const bool pre = scale < 0.f;
     scale = fabsf(scale);
-    FD_REQUIRE(!pre || (d % 16 == 8 && vtr), "fd_attn_fwd: pre-scaled q (negative scale) needs d %% 16 == 8 and the transpose-read form (Tkp == 0)");
-#define LAUNCH_F(DD, TRV, QBV, PREV)                                                                                                   \
-    {                                                                                                                                  \
-        ALLOW_LDS((attn_fwd_kernel<DD, TRV, QBV, PREV>), (fwd_lds<DD, TRV>()));                                                        \
-        hipLaunchKernelGGL((attn_fwd_kernel<DD, TRV, QBV, PREV>), grid, dim3(256), (fwd_lds<DD, TRV>()), (hipStream_t)stream,          \
-                           (const f16*)q, (const f16*)k, (const f16*)vt, (f16*)o, lse, H, Tq, Tk, Tkp, Tkr, kv_div, scale, ldq, ldk);  \
+    FD_REQUIRE(!pre || d % 16 == 8, "fd_attn_fwd: pre-scaled q (negative scale) needs d %% 16 == 8");
+#define LAUNCH_F(DD, QBV, PREV)                                                                                                \
+    {                                                                                                                          \
+        ALLOW_LDS((attn_fwd_kernel<DD, QBV, PREV>), (fwd_lds<DD>()));                                                          \
+        hipLaunchKernelGGL((attn_fwd_kernel<DD, QBV, PREV>), grid, dim3(256), (fwd_lds<DD>()), (hipStream_t)stream,            \
+                           (const f16*)q, (const f16*)k, (const f16*)v, (f16*)o, lse, H, Tq, Tk, Tkr, kv_div, scale, ldq, ldk); \
     }
-#define CALL(DD)                                                                 \
-    if (vtr) {                                                                   \
-        if constexpr (pre_ok<DD>()) {                                            \
-            if (pre) {                                                           \
-                if (qb == 2) LAUNCH_F(DD, true, (DD <= 64 ? 2 : 1), true)        \
-                else LAUNCH_F(DD, true, 1, true)                                 \
-                break;                                                           \
-            }                                                                    \
-        }                                                                        \
-        if (qb == 2 && DD <= 64) LAUNCH_F(DD, true, (DD <= 64 ? 2 : 1), false)   \
-        else LAUNCH_F(DD, true, 1, false)                                        \
-    } else LAUNCH_F(DD, false, 1, false)
+#define CALL(DD)                                                             \
+    if constexpr (pre_ok<DD>()) {                                            \
+        if (pre) {                                                           \
+            if (qb == 2) LAUNCH_F(DD, (DD <= 64 ? 2 : 1), true)              \
+            else LAUNCH_F(DD, 1, true)                                       \
+            break;                                                           \
+        }                                                                    \
+    }                                                                        \
+    if (qb == 2 && DD <= 64) LAUNCH_F(DD, (DD <= 64 ? 2 : 1), false)         \
+    else LAUNCH_F(DD, 1, false)
     FD_DISPATCH_D(d, CALL)
 #undef CALL
 #undef LAUNCH_F
@@ -1000,55 +900,47 @@ extern "C" int fd_attn_bwd_prep(const void* o, const void* d_o, float* D, int B,
     return fd_check_launch("fd_attn_bwd_prep");
 }
 
-extern "C" int fd_attn_bwd_dq(const void* q, const void* k, const void* v, const void* kt, const void* d_o, const float* lse, float* D,
-                              const void* o, void* dq, int B, int H, int Tq, int Tk, int Tkp, int Tkr, int d, int kv_div, float scale,
+extern "C" int fd_attn_bwd_dq(const void* q, const void* k, const void* v, const void* d_o, const float* lse, float* D,
+                              const void* o, void* dq, int B, int H, int Tq, int Tk, int Tkr, int d, int kv_div, float scale,
                               int ldq, int ldkv, int lddq, void* stream) {
     if (ldq <= 0) ldq = H * d;
     if (ldkv <= 0) ldkv = H * d;
     if (lddq <= 0) lddq = H * d;
     FD_REQUIRE((ldq & 7) == 0 && (ldkv & 7) == 0 && (lddq & 3) == 0, "fd_attn_bwd_dq: row strides");
-    const bool ktr = kt == nullptr;
-    FD_REQUIRE(B > 0 && H > 0 && Tq > 0 && Tk > 0 && (ktr || (Tkp >= Tk && (Tkp & 7) == 0)) && Tkr >= Tk && kv_div >= 1, "fd_attn_bwd_dq: bad shape");
+    FD_REQUIRE(B > 0 && H > 0 && Tq > 0 && Tk > 0 && Tkr >= Tk && kv_div >= 1, "fd_attn_bwd_dq: bad shape");
     dim3 grid(((Tq + 127) / 128) * H * B);
     const bool pre = scale < 0.f;                    // q arrives multiplied by |scale| * log2(e): see "pre-scaled q"
     scale = fabsf(scale);
-    FD_REQUIRE(!pre || (d % 16 == 8 && ktr), "fd_attn_bwd_dq: pre-scaled q (negative scale) needs d %% 16 == 8 and the transpose-read form (kt == NULL)");
-#define CALL(DD)                                                                                                                      \
-    if constexpr (pre_ok<DD>()) {                                                                                                     \
-        if (pre) {                                                                                                                    \
-            ALLOW_LDS((attn_bwd_dq_kernel<DD, true, true>), (dq_lds<DD, true>()));                                                    \
-            hipLaunchKernelGGL((attn_bwd_dq_kernel<DD, true, true>), grid, dim3(256), (dq_lds<DD, true>()), (hipStream_t)stream,      \
-                               (const f16*)q, (const f16*)k, (const f16*)v, (const f16*)kt, (const f16*)d_o, lse, D, (f16*)dq,        \
-                               (const f16*)o, H, Tq, Tk, Tkp, Tkr, kv_div, scale, ldq, ldkv, lddq);                                   \
-            break;                                                                                                                    \
-        }                                                                                                                             \
-    }                                                                                                                                 \
-    if (ktr) {                                                                                                                        \
-        ALLOW_LDS((attn_bwd_dq_kernel<DD, true>), (dq_lds<DD, true>()));                                                              \
-        hipLaunchKernelGGL((attn_bwd_dq_kernel<DD, true>), grid, dim3(256), (dq_lds<DD, true>()), (hipStream_t)stream, (const f16*)q, \
-                           (const f16*)k, (const f16*)v, (const f16*)kt, (const f16*)d_o, lse, D, (f16*)dq, (const f16*)o, H, Tq, Tk, \
-                           Tkp, Tkr, kv_div, scale, ldq, ldkv, lddq);                                                                 \
-    } else {                                                                                                                          \
-        ALLOW_LDS((attn_bwd_dq_kernel<DD, false>), (dq_lds<DD, false>()));                                                            \
-        hipLaunchKernelGGL((attn_bwd_dq_kernel<DD, false>), grid, dim3(256), (dq_lds<DD, false>()), (hipStream_t)stream,              \
-                           (const f16*)q, (const f16*)k, (const f16*)v, (const f16*)kt, (const f16*)d_o, lse, D, (f16*)dq,            \
-                           (const f16*)o, H, Tq, Tk, Tkp, Tkr, kv_div, scale, ldq, ldkv, lddq);                                       \
+    FD_REQUIRE(!pre || d % 16 == 8, "fd_attn_bwd_dq: pre-scaled q (negative scale) needs d %% 16 == 8");
+#define LAUNCH_Q(DD, PREV)                                                                                                             \
+    {                                                                                                                                  \
+        ALLOW_LDS((attn_bwd_dq_kernel<DD, PREV>), (dq_lds<DD>()));                                                                     \
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<DD, PREV>), grid, dim3(256), (dq_lds<DD>()), (hipStream_t)stream, (const f16*)q,        \
+                           (const f16*)k, (const f16*)v, (const f16*)d_o, lse, D, (f16*)dq, (const f16*)o, H, Tq, Tk, Tkr, kv_div,     \
+                           scale, ldq, ldkv, lddq);                                                                                    \
     }
+#define CALL(DD)                      \
+    if constexpr (pre_ok<DD>()) {     \
+        if (pre) {                    \
+            LAUNCH_Q(DD, true)        \
+            break;                    \
+        }                             \
+    }                                 \
+    LAUNCH_Q(DD, false)
     FD_DISPATCH_D(d, CALL)
 #undef CALL
+#undef LAUNCH_Q
     return fd_check_launch("fd_attn_bwd_dq");
 }
 
-extern "C" int fd_attn_bwd_dkdv(const void* q, const void* qt, const void* k, const void* v, const void* d_o, const void* d_ot,
+extern "C" int fd_attn_bwd_dkdv(const void* q, const void* k, const void* v, const void* d_o,
                                 const float* lse, const float* D, void* dk, void* dv, int B, int H, int Tq, int Tk, int Tkr, int d,
                                 int kv_div, float scale, int ldq, int ldkv, int lddkv, int accumulate, void* stream) {
     if (ldq <= 0) ldq = H * d;
     if (ldkv <= 0) ldkv = H * d;
     if (lddkv <= 0) lddkv = H * d;
     FD_REQUIRE((ldq & 7) == 0 && (ldkv & 7) == 0 && (lddkv & 3) == 0, "fd_attn_bwd_dkdv: row strides");
-    const bool qtr = qt == nullptr && d_ot == nullptr;
-    FD_REQUIRE(qtr || (qt && d_ot), "fd_attn_bwd_dkdv: qt and d_ot must both be given or both be NULL");
-    FD_REQUIRE(B > 0 && H > 0 && Tq > 0 && Tk > 0 && (qtr || (Tq & 7) == 0) && Tkr >= Tk && kv_div >= 1, "fd_attn_bwd_dkdv: bad shape (Tq %% 8)");
+    FD_REQUIRE(B > 0 && H > 0 && Tq > 0 && Tk > 0 && Tkr >= Tk && kv_div >= 1, "fd_attn_bwd_dkdv: bad shape");
     dim3 grid(((Tk + 127) / 128) * H * B);
     // accumulate == 2: fp32 per-sample slabs instead of atomics (dk, dv: [kv_div][Bk*Tkr][lddkv] fp32, every element written)
     const int64_t slab = accumulate == 2 ? (int64_t)(B / kv_div) * Tkr * lddkv : 0;
@@ -1056,26 +948,22 @@ extern "C" int fd_attn_bwd_dkdv(const void* q, const void* qt, const void* k, co
     // scale < 0: q arrives multiplied by |scale| * log2(e) ("pre-scaled q"): dK = scale * dS^T . q = dS^T . q' / log2(e)
     const bool pre = scale < 0.f;
     scale = pre ? 1.f / LOG2E : scale;
-    FD_REQUIRE(!pre || (d % 16 == 8 && qtr), "fd_attn_bwd_dkdv: pre-scaled q (negative scale) needs d %% 16 == 8 and the transpose-read form (qt == NULL)");
-#define LAUNCH(DD, AT, TRQ, PREV)                                                                                                      \
+    FD_REQUIRE(!pre || d % 16 == 8, "fd_attn_bwd_dkdv: pre-scaled q (negative scale) needs d %% 16 == 8");
+#define LAUNCH(DD, AT, PREV)                                                                                                           \
     {                                                                                                                                  \
-        ALLOW_LDS((attn_bwd_dkdv_kernel<DD, AT, TRQ, PREV>), (dkdv_lds<DD, TRQ>()));                                                   \
-        hipLaunchKernelGGL((attn_bwd_dkdv_kernel<DD, AT, TRQ, PREV>), grid, dim3(256), (dkdv_lds<DD, TRQ>()), (hipStream_t)stream,     \
-                           (const f16*)q, (const f16*)qt, (const f16*)k, (const f16*)v, (const f16*)d_o, (const f16*)d_ot, lse, D, dk, \
+        ALLOW_LDS((attn_bwd_dkdv_kernel<DD, AT, PREV>), (dkdv_lds<DD>()));                                                             \
+        hipLaunchKernelGGL((attn_bwd_dkdv_kernel<DD, AT, PREV>), grid, dim3(256), (dkdv_lds<DD>()), (hipStream_t)stream,               \
+                           (const f16*)q, (const f16*)k, (const f16*)v, (const f16*)d_o, lse, D, dk,                                   \
                            dv, H, Tq, Tk, Tkr, kv_div, scale, ldq, ldkv, lddkv, slab);                                                 \
     }
 #define CALL(DD)                                                     \
     if constexpr (pre_ok<DD>()) {                                    \
         if (pre) {                                                   \
-            if (kv_div > 1 || accumulate) LAUNCH(DD, true, true, true) else LAUNCH(DD, false, true, true) \
+            if (kv_div > 1 || accumulate) LAUNCH(DD, true, true) else LAUNCH(DD, false, true) \
             break;                                                   \
         }                                                            \
     }                                                                \
-    if (kv_div > 1 || accumulate) {                                  \
-        if (qtr) LAUNCH(DD, true, true, false) else LAUNCH(DD, true, false, false) \
-    } else {                                                         \
-        if (qtr) LAUNCH(DD, false, true, false) else LAUNCH(DD, false, false, false) \
-    }
+    if (kv_div > 1 || accumulate) LAUNCH(DD, true, false) else LAUNCH(DD, false, false)
     FD_DISPATCH_D(d, CALL)
 #undef CALL
 #undef LAUNCH

@@ -1,0 +1,359 @@
+// The cross-attention sub-block of BasicTransformerBlock as ONE kernel (north_star's named fusion):
+//
+//     n2 = LayerNorm2(h1);  q = n2 . Wq^T;  o = softmax(q K^T / sqrt(d)) V  (K, V: the <= 80 prompt tokens of the sample's CFG half);
+//     h2 = o . Wo^T + bo + h1;  n3 = LayerNorm3(h2)
+//
+// (diffusers attention.py BasicTransformerBlock.forward: norm2 -> attn2 -> residual -> norm3; attn2 is the attention processor selected at
+// exp-1 main:811-817.)  Unfused, that is five launches -- fd_layernorm_fwd, fd_gemm, fd_attn_fwd, fd_gemm, fd_layernorm_fwd -- and n2, q, o and
+// h2 each make a round trip through HBM.  Here a workgroup owns BM rows of the residual stream (BM * C = 20480: 64 rows at C = 320, 32 at 640,
+// 16 at 1280) and keeps them in ONE LDS tile [BM][C + 8] that is, in turn, n2, q, o and the staged h2:
+//
+//   P0  LayerNorm2 of the rows, one wave per row, same arithmetic as layernorm_kernel (bit-identical n2), written to the tile;
+//   P1  q = n2 . Wq^T: the four waves split the N = C columns (C / 4 each), so a B (weight) fragment is used by exactly one wave and goes
+//       global -> registers directly (16 bytes per lane, prefetched two k-steps ahead); A fragments come from the tile; 16x16x32 MFMAs with the
+//       operands swapped so that a lane holds q[m][n .. n + 3]; q is rounded once, multiplied by softmax_scale * log2(e), and overwrites the tile;
+//   P2  attention: wave w owns heads 2w, 2w + 1.  S^T[key][query] = K_h . q_h^T (A = K rows from global / L2, B = q rows from the tile): a lane
+//       holds ONE query and 4 keys per 16-key tile, so the softmax is in-lane plus two cross-lane steps, and the fp16 probabilities are directly
+//       the B operand of O^T[dv][query] = V^T[dv][key] . P^T[key][query] (A = rows of the transposed V the caller prepared once per rollout; the
+//       contraction's k-slots are key tiles (2j, 2j + 1) x 4 keys, the same order on both operands).  o overwrites the q columns of its head;
+//   P3  h2 = o . Wo^T as P1; fp16(acc + bias) is staged in the tile, then one wave per row adds the residual h1 (fp16(staged + h1): the
+//       rounding sequence of fd_gemm's LDS-staged epilogue, bit-identical h2 for identical o), stores h2, and LayerNorm3 of the row (as P0) -> n3.
+//
+// Algorithmic HBM traffic per row: read h1 twice (the second read is an L2 hit), write h2 and n3: 4 C * 2 B against 14 C * 2 B unfused.
+// No LoRA slabs and no recording yet: the frozen rollout R2 (exp-1 main:1844-1858) and every no-grad forward; R1 / R3 keep the five launches.
+#include "common.h"
+
+#define CA_LOG2E 1.4426950408889634f
+
+template <int C> struct CrossCfg {
+    static constexpr int BM = 20480 / C;          // rows per workgroup
+    static constexpr int TM = BM / 16;            // 16-row MFMA tiles per wave (every wave covers all rows)
+    static constexpr int WN = C / 4;              // output columns per wave
+    static constexpr int TN = WN / 16;            // 16-column MFMA tiles per wave
+    static constexpr int NK = C / 32;             // k-steps of the two projections
+    static constexpr int PD = TN <= 5 ? 3 : TN <= 10 ? 2 : 1;     // B-fragment prefetch distance (register sets: PD + 1)
+    static constexpr int LDT = C + 8;             // LDS row stride (halfs): 16-byte aligned rows, conflict-free 16-byte fragment reads
+    static constexpr int MAXV = (C / 8 + 63) / 64;                // 16-byte vectors per lane of a row
+    static constexpr int D = C / 8;               // head dim (8 heads)
+    static constexpr int NKS = (D + 31) / 32;     // k-steps of q . k^T
+    static constexpr int NDT = (D + 15) / 16;     // 16-row tiles of O^T
+};
+
+struct CrossArgs {
+    const f16* x; const float* g2; const float* b2; float eps2;
+    const f16* wq; const f16* k; const f16* vt; int Lp; int L;
+    const f16* wo; const float* bo;
+    const float* g3; const float* b3; float eps3;
+    f16* y; f16* yn; float* yn_stats;
+    int M, rows_per_sample, kv_div; float sl2;
+};
+
+// LayerNorm of one row held as MAXV vectors per lane (vector v = lane + 64 i): the arithmetic of layernorm_kernel<false, .>, statement for statement
+template <int C, int MAXV>
+__device__ __forceinline__ void ln_row(const f16x8 (&xv)[MAXV], const float (&gm)[MAXV][8], const float (&bt)[MAXV][8], float eps, int lane,
+                                       f16x8 (&out)[MAXV], float& mean_o, float& rstd_o) {
+    constexpr int V = C / 8;
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int v = lane + i * 64;
+        if (v < V) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s0 += (float)xv[i][j];
+        }
+    }
+    const float mean = wave_sum(s0) / C;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int v = lane + i * 64;
+        if (v < V) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float d = (float)xv[i][j] - mean;
+                s1 += d * d;
+            }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(s1) / C + eps);
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) out[i][j] = (f16)(((float)xv[i][j] - mean) * rstd * gm[i][j] + bt[i][j]);
+    mean_o = mean;
+    rstd_o = rstd;
+}
+
+// acc[i][j] (+)= tile rows [16 i, 16 i + 16) . W rows [n0 + 16 j, ...)^T over K = C; lane (l15, lg) ends up holding C[m = 16 i + l15][n = n0 + 16 j + 4 lg .. + 3]
+template <int C>
+__device__ __forceinline__ void project(f32x4 (&acc)[CrossCfg<C>::TM][CrossCfg<C>::TN], const f16* __restrict__ tile, const f16* __restrict__ W, int n0, int l15,
+                                        int lg) {
+    using Cf = CrossCfg<C>;
+    constexpr int TM = Cf::TM, TN = Cf::TN, NK = Cf::NK, PD = Cf::PD, NS = PD + 1;
+    f16x8 bf[NS][TN];
+    const f16* wp = W + (int64_t)(n0 + l15) * C + lg * 8;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < PD; ++s)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bf[s][j] = *(const f16x8*)(wp + (int64_t)j * 16 * C + s * 32);
+#pragma unroll
+    for (int ks = 0; ks < NK; ++ks) {
+        if (ks + PD < NK) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[(ks + PD) % NS][j] = *(const f16x8*)(wp + (int64_t)j * 16 * C + (ks + PD) * 32);
+        }
+        f16x8 af[TM];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[i] = *(const f16x8*)(tile + (i * 16 + l15) * Cf::LDT + ks * 32 + lg * 8);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = FD_MFMA_16x16x32(bf[ks % NS][j], af[i], acc[i][j]);
+    }
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void cross_block_kernel(CrossArgs a) {
+    using Cf = CrossCfg<C>;
+    constexpr int BM = Cf::BM, TM = Cf::TM, TN = Cf::TN, LDT = Cf::LDT, MAXV = Cf::MAXV, D = Cf::D, NKS = Cf::NKS, NDT = Cf::NDT, V = C / 8;
+    constexpr int RPW = BM / 4;                   // rows per wave in the row-wise phases
+    __shared__ __attribute__((aligned(16))) f16 tile[BM * LDT];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l15 = lane & 15, lg = lane >> 4;
+    const int row0 = blockIdx.x * BM;
+    const int bk = (row0 / a.rows_per_sample) / a.kv_div;
+
+    // ---------------------------------------------------------------- P0: n2 = LayerNorm2(h1) -> tile
+    {
+        float gm[MAXV][8], bt[MAXV][8];
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int v = lane + i * 64;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                gm[i][j] = v < V ? a.g2[v * 8 + j] : 0.f;
+                bt[i][j] = v < V ? a.b2[v * 8 + j] : 0.f;
+            }
+        }
+        f16x8 xv[RPW][MAXV];
+#pragma unroll
+        for (int r = 0; r < RPW; ++r)
+#pragma unroll
+            for (int i = 0; i < MAXV; ++i) {
+                const int v = lane + i * 64;
+                xv[r][i] = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
+                if (v < V) xv[r][i] = *(const f16x8*)(a.x + (int64_t)(row0 + wave * RPW + r) * C + v * 8);
+            }
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) {
+            f16x8 o[MAXV];
+            float mean, rstd;
+            ln_row<C, MAXV>(xv[r], gm, bt, a.eps2, lane, o, mean, rstd);
+#pragma unroll
+            for (int i = 0; i < MAXV; ++i) {
+                const int v = lane + i * 64;
+                if (v < V) *(f16x8*)(tile + (wave * RPW + r) * LDT + v * 8) = o[i];
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---------------------------------------------------------------- P1: q = n2 . Wq^T, scaled into the exponent's domain -> tile
+    f32x4 acc[TM][TN];
+    const int n0 = wave * Cf::WN;
+    project<C>(acc, tile, a.wq, n0, l15, lg);
+    __syncthreads();                               // every wave has read all of n2
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const f32x4 v = acc[i][j] * a.sl2;
+            *(f16x4*)(tile + (i * 16 + l15) * LDT + n0 + j * 16 + lg * 4) = (f16x4){(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+        }
+    // P2 reads only the columns this wave wrote (its two heads: 2 D = C / 4 columns): wave-local ordering is enough
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+
+    // ---------------------------------------------------------------- P2: attention over the <= 80 keys, heads 2 wave, 2 wave + 1; o overwrites q
+#pragma unroll 1
+    for (int hh = 0; hh < 2; ++hh) {
+        const int c0 = (wave * 2 + hh) * D;       // first column of the head
+        // K fragments [key tile][k-step]: lane (key = 16 kt + l15, k = 32 ks + 8 lg ..); k >= D and keys >= L are zero
+        f16x8 kf[5][NKS];
+#pragma unroll
+        for (int kt = 0; kt < 5; ++kt)
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                const int key = kt * 16 + l15, kk = ks * 32 + lg * 8;
+                kf[kt][ks] = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
+                if (key < a.L && kk < D) kf[kt][ks] = *(const f16x8*)(a.k + ((int64_t)bk * a.L + key) * C + c0 + kk);
+            }
+        // V^T fragments [dv tile][key-tile pair]: lane (dv = 16 dt + l15; keys 16 (2 jp) + 4 lg .. + 3 and 16 (2 jp + 1) + 4 lg .. + 3); rows dv >= D are
+        // another head's (or clamped): they only feed output rows that are never stored
+        f16x8 vf[NDT][3];
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) {
+            const int dv = min(c0 + dt * 16 + l15, C - 1);
+            const f16* vp = a.vt + ((int64_t)bk * C + dv) * a.Lp + lg * 4;
+#pragma unroll
+            for (int jp = 0; jp < 3; ++jp) {
+                const f16x4 lo = *(const f16x4*)(vp + jp * 32);
+                f16x4 hi = {0, 0, 0, 0};
+                if (jp < 2) hi = *(const f16x4*)(vp + jp * 32 + 16);
+                vf[dt][jp] = (f16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            }
+        }
+#pragma unroll
+        for (int mt = 0; mt < TM; ++mt) {
+            f16x8 qf[NKS];
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                const int kk = ks * 32 + lg * 8;
+                qf[ks] = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
+                if (kk < D) qf[ks] = *(const f16x8*)(tile + (mt * 16 + l15) * LDT + c0 + kk);
+            }
+            f32x4 s[5];
+#pragma unroll
+            for (int kt = 0; kt < 5; ++kt) {
+                s[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < NKS; ++ks) s[kt] = FD_MFMA_16x16x32(kf[kt][ks], qf[ks], s[kt]);
+            }
+            // lane: query mt * 16 + l15, keys 16 kt + 4 lg + r
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kt = 0; kt < 5; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (kt * 16 + lg * 4 + r >= a.L) s[kt][r] = -INFINITY;
+                    mx = fmaxf(mx, s[kt][r]);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            f16x4 p16[6];
+            float l = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 5; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    p16[kt][r] = (f16)__builtin_amdgcn_exp2f(s[kt][r] - mx);
+                    l += (float)p16[kt][r];
+                }
+            p16[5] = (f16x4){0, 0, 0, 0};
+            l += __shfl_xor(l, 16, 64);
+            l += __shfl_xor(l, 32, 64);
+            const float inv = 1.f / l;
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt) {
+                f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int jp = 0; jp < 3; ++jp) {
+                    const f16x8 pb = {p16[2 * jp][0], p16[2 * jp][1], p16[2 * jp][2], p16[2 * jp][3],
+                                      p16[2 * jp + 1][0], p16[2 * jp + 1][1], p16[2 * jp + 1][2], p16[2 * jp + 1][3]};
+                    o = FD_MFMA_16x16x32(vf[dt][jp], pb, o);
+                }
+                // lane: o[query l15][dv = 16 dt + 4 lg + r]
+                if (dt * 16 + lg * 4 < D)
+                    *(f16x4*)(tile + (mt * 16 + l15) * LDT + c0 + dt * 16 + lg * 4) =
+                        (f16x4){(f16)(o[0] * inv), (f16)(o[1] * inv), (f16)(o[2] * inv), (f16)(o[3] * inv)};
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---------------------------------------------------------------- P3: h2 = o . Wo^T + bo + h1 -> y;  n3 = LayerNorm3(h2) -> yn
+    project<C>(acc, tile, a.wo, n0, l15, lg);
+    __syncthreads();                               // every wave has read all of o
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const f32x4 bv = *(const f32x4*)(a.bo + n0 + j * 16 + lg * 4);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const f32x4 v = acc[i][j] + bv;
+            *(f16x4*)(tile + (i * 16 + l15) * LDT + n0 + j * 16 + lg * 4) = (f16x4){(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+        }
+    }
+    __syncthreads();
+    {
+        float gm[MAXV][8], bt[MAXV][8];
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int v = lane + i * 64;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                gm[i][j] = (a.yn && v < V) ? a.g3[v * 8 + j] : 0.f;
+                bt[i][j] = (a.yn && v < V) ? a.b3[v * 8 + j] : 0.f;
+            }
+        }
+        f16x8 rv[RPW][MAXV];
+#pragma unroll
+        for (int r = 0; r < RPW; ++r)
+#pragma unroll
+            for (int i = 0; i < MAXV; ++i) {
+                const int v = lane + i * 64;
+                rv[r][i] = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
+                if (v < V) rv[r][i] = *(const f16x8*)(a.x + (int64_t)(row0 + wave * RPW + r) * C + v * 8);
+            }
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) {
+            const int64_t row = row0 + wave * RPW + r;
+            f16x8 hv[MAXV];
+#pragma unroll
+            for (int i = 0; i < MAXV; ++i) {
+                const int v = lane + i * 64;
+                hv[i] = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
+                if (v < V) {
+                    const f16x8 st = *(const f16x8*)(tile + (wave * RPW + r) * LDT + v * 8);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) hv[i][j] = (f16)((float)st[j] + (float)rv[r][i][j]);
+                    *(f16x8*)(a.y + row * C + v * 8) = hv[i];
+                }
+            }
+            if (a.yn) {
+                f16x8 o[MAXV];
+                float mean, rstd;
+                ln_row<C, MAXV>(hv, gm, bt, a.eps3, lane, o, mean, rstd);
+#pragma unroll
+                for (int i = 0; i < MAXV; ++i) {
+                    const int v = lane + i * 64;
+                    if (v < V) *(f16x8*)(a.yn + row * C + v * 8) = o[i];
+                }
+                if (a.yn_stats && lane == 0) {
+                    a.yn_stats[row * 2] = mean;
+                    a.yn_stats[row * 2 + 1] = rstd;
+                }
+            }
+        }
+    }
+}
+
+extern "C" int fd_cross_attn_block(const fd_cross_block_desc* dp, void* stream) {
+    FD_REQUIRE_DESC(dp, fd_cross_block_desc, "fd_cross_attn_block");
+    const fd_cross_block_desc& d = *dp;
+    FD_REQUIRE(d.x && d.ln2_gamma && d.ln2_beta && d.wq && d.k && d.vt && d.wo && d.bo && d.y, "fd_cross_attn_block: null operand");
+    FD_REQUIRE(!d.yn || (d.ln3_gamma && d.ln3_beta), "fd_cross_attn_block: yn needs ln3_gamma / ln3_beta");
+    FD_REQUIRE(d.C == 320 || d.C == 640 || d.C == 1280, "fd_cross_attn_block: C=%d (320 / 640 / 1280: eight heads of 40 / 80 / 160)", d.C);
+    FD_REQUIRE(d.heads == 8, "fd_cross_attn_block: heads=%d (8)", d.heads);
+    const int bm = 20480 / d.C;
+    FD_REQUIRE(d.M > 0 && d.M % bm == 0 && d.rows_per_sample > 0 && d.rows_per_sample % bm == 0 && d.M % d.rows_per_sample == 0,
+               "fd_cross_attn_block: M=%d and rows_per_sample=%d must be multiples of the %d-row tile", d.M, d.rows_per_sample, bm);
+    FD_REQUIRE(d.L > 0 && d.L <= 80 && d.Lp >= 80 && (d.Lp & 3) == 0 && d.kv_div >= 1 && (d.M / d.rows_per_sample) % d.kv_div == 0,
+               "fd_cross_attn_block: L=%d (<= 80 keys), Lp=%d (>= 80, key-padded rows of vt), kv_div=%d", d.L, d.Lp, d.kv_div);
+    CrossArgs a;
+    a.x = (const f16*)d.x; a.g2 = d.ln2_gamma; a.b2 = d.ln2_beta; a.eps2 = d.ln2_eps;
+    a.wq = (const f16*)d.wq; a.k = (const f16*)d.k; a.vt = (const f16*)d.vt; a.Lp = d.Lp; a.L = d.L;
+    a.wo = (const f16*)d.wo; a.bo = d.bo; a.g3 = d.ln3_gamma; a.b3 = d.ln3_beta; a.eps3 = d.ln3_eps;
+    a.y = (f16*)d.y; a.yn = (f16*)d.yn; a.yn_stats = d.yn_stats;
+    a.M = d.M; a.rows_per_sample = d.rows_per_sample; a.kv_div = d.kv_div;
+    a.sl2 = d.scale * CA_LOG2E;
+    const dim3 grid(d.M / bm), block(256);
+    switch (d.C) {
+        case 320: hipLaunchKernelGGL(cross_block_kernel<320>, grid, block, 0, (hipStream_t)stream, a); break;
+        case 640: hipLaunchKernelGGL(cross_block_kernel<640>, grid, block, 0, (hipStream_t)stream, a); break;
+        default: hipLaunchKernelGGL(cross_block_kernel<1280>, grid, block, 0, (hipStream_t)stream, a); break;
+    }
+    return fd_check_launch("fd_cross_attn_block");
+}

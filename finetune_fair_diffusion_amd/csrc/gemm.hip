@@ -176,12 +176,12 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(fd_gemm_desc p, int ntm,
 // CONV: 0 = dense operands, 1 = the 3x3 gathers (stride 1 / stride 2 / nearest-up2 / transposed stride 2), 2 = the Upsample2D phase pair
 // (FD_CONV_UP2P, FD_CONV_UP2P_BWD) -- its own instantiation: compiled into variant 1 the extra gather arithmetic cost the 8-wave 256x320
 // and the 512x128 gathers 34 and 52 spilled registers
-// CV = 3 / 4 / 6: variants 0 / 1 / 2 with the GroupNorm-statistics epilogue (fd_gemm_desc.gn_stats); CV = 5: variant 0 with the LayerNorm second output
-// (fd_gemm_desc.ln_out; BN == N == 320 only).
+// CV = 3 / 4 / 6: variants 0 / 1 / 2 with the GroupNorm-statistics epilogue (fd_gemm_desc.gn_stats)
 template <int BM, int BN, int WGM, int WGN, int CV>
 __global__ __launch_bounds__(WGM * WGN * 64) void gemm_big_kernel(fd_gemm_desc p, int ntm, int ntn, int gn) {
-    constexpr int CONV = CV == 5 ? 0 : CV == 6 ? 2 : CV >= 3 ? CV - 3 : CV;      // CV = 6: the phase pair (variant 2) with the statistics epilogue (FD_CONV_UP2PI)
-    constexpr bool WSTATS = CV == 3 || CV == 4 || CV == 6, WLN = CV == 5;
+    static_assert(CV != 5, "CV = 5 was the LayerNorm second output (scratch/gemm_ln_epilogue_experiment.h)");
+    constexpr int CONV = CV == 6 ? 2 : CV >= 3 ? CV - 3 : CV;      // CV = 6: the phase pair (variant 2) with the statistics epilogue (FD_CONV_UP2PI)
+    constexpr bool WSTATS = CV == 3 || CV == 4 || CV == 6;
     constexpr int NW = WGM * WGN;                   // 8 or 16 waves
     static_assert(NW == 8 || NW == 16, "8 or 16 waves");
     constexpr int WTM = BM / WGM, WTN = BN / WGN;   // wave tile
@@ -475,12 +475,6 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_big_kernel(fd_gemm_desc p
         constexpr int TMC = (NW * WTM * (WTN + 4) <= LDS_HALFS) ? TM : TM / 2;
         static_assert(NW * TMC * 16 * (WTN + 4) <= LDS_HALFS, "epilogue staging does not fit");
         __syncthreads();
-        if constexpr (WLN) {
-            constexpr int STAGE_HALFS = NW * TMC * 16 * (WTN + 4);
-            static_assert(STAGE_HALFS * 2 + 2 * WGM * 64 * WGN * 8 <= LDS_HALFS * 2, "LayerNorm epilogue: row table does not fit behind the staging");
-            gemm_epilogue_ln<TM, TN, TMC, WGM, WGN>(p, acc, smem + wave * (TMC * 16) * (WTN + 4), (float*)(smem + STAGE_HALFS), wm, wn, m0 + wm * WTM,
-                                                    n0 + wn * WTN, lane);
-        } else
         gemm_epilogue_lds<TM, TN, TMC, WSTATS>(p, acc, smem + wave * (TMC * 16) * (WTN + 4), m0 + wm * WTM, n0 + wn * WTN, lane, 0, 0, up_phase);
     } else {
         gemm_epilogue<TM, TN>(p, acc, m0 + wm * WTM, n0 + wn * WTN, l15, lg, 0, 0, up_phase);
@@ -538,16 +532,6 @@ static int launch_big(const fd_gemm_desc& d, hipStream_t s, int nsplit = 1) {
     const int nph = (d.conv && (d.conv_mode == FD_CONV_UP2P || d.conv_mode == FD_CONV_UP2PI)) ? 4 : 1;
     long gnl = l2_budget / ((long)BN * ktot * 2);
     const int gn = (int)(gnl < 1 ? 1 : (gnl > ntn ? ntn : gnl));
-    if constexpr (BN == 320 && WGM == 4 && WGN == 4) {
-        if (d.ln_out) {                               // LayerNorm second output (fd_gemm checked eligibility: dense, N == 320, plain epilogue, no split-K)
-            static std::once_flag once_ln;
-            std::call_once(once_ln, [] {
-                (void)hipFuncSetAttribute((const void*)gemm_big_kernel<BM, BN, WGM, WGN, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            });
-            hipLaunchKernelGGL((gemm_big_kernel<BM, BN, WGM, WGN, 5>), dim3(ntm * ntn, 1), dim3(WGM * WGN * 64), lds, s, d, ntm, ntn, gn);
-            return fd_check_launch("fd_gemm(big, LayerNorm epilogue)");
-        }
-    }
     if constexpr (BN / WGN == 80) {
         if (d.gn_stats && nsplit == 1 && d.conv && d.conv_mode == FD_CONV_UP2PI) {       // the phase pair writing the interleaved result, with statistics
             static std::once_flag once_st6;
@@ -800,7 +784,7 @@ static int gemm_tile(const fd_gemm_desc& d) {
 // ONE dispatch decision shared by fd_gemm, fd_gemm_kernel_name and fd_gemm_stats_rows (the launcher and the name function had drifted
 // apart once): which kernel family takes the problem, with which tile / wave grid / split-K factor, and whether that kernel can write gn_stats.
 enum { GK_SKINNY, GK_GLDS, GK_BIG, GK_PP };
-struct GemmPlan { int kind, bm, bn, wgm, wgn, nsplit, cv; bool stats_ok, ln_ok; };
+struct GemmPlan { int kind, bm, bn, wgm, wgn, nsplit, cv; bool stats_ok; };
 static GemmPlan gemm_plan(const fd_gemm_desc& d /* K2 already normalised */) {
     GemmPlan g = {};
     const int sel = gemm_tile(d), t = sel % 1000000;
@@ -826,9 +810,6 @@ static GemmPlan gemm_plan(const fd_gemm_desc& d /* K2 already normalised */) {
                          (!d.rowbias || (d.ld_rowbias & 3) == 0);
     g.stats_ok = (g.kind == GK_PP || (g.kind == GK_BIG && g.bn / g.wgn == 80)) && g.nsplit == 1 && lds_epi && d.act != FD_ACT_GEGLU &&
                  d.batch <= 1 && (d.N % 80) == 0 && (g.cv < 2 || (d.conv_mode == FD_CONV_UP2PI && (d.M & 31) == 0));
-    // the LayerNorm second output lives in gemm_epilogue_ln: 16-wave lockstep 320-wide tiles whose one n-tile holds whole rows, bias / residual only
-    g.ln_ok = g.kind == GK_BIG && g.bn == 320 && g.wgm == 4 && g.wgn == 4 && d.N == 320 && g.nsplit == 1 && g.cv == 0 && lds_epi &&
-              d.act == FD_ACT_NONE && !d.rowbias && d.alpha == 1.f && d.batch <= 1 && !d.gn_stats && d.colscale_cols == 0;
     return g;
 }
 
@@ -843,7 +824,7 @@ extern "C" int fd_gemm_kernel_name(const fd_gemm_desc* dp, char* buf, int n) {
     const bool st = d.gn_stats && g.stats_ok;
     switch (g.kind) {
         case GK_PP: snprintf(buf, n, "gemm_pp_kernel<%d, %d, %s>", g.bm, (d.conv ? 1 : 0) + (st ? 2 : 0), (pp_mode() & 4) ? "true" : "false"); break;
-        case GK_BIG: snprintf(buf, n, "gemm_big_kernel<%d, %d, %d, %d, %d>", g.bm, g.bn, g.wgm, g.wgn, (d.ln_out && g.ln_ok) ? 5 : st ? (g.cv == 2 ? 6 : g.cv + 3) : g.cv); break;
+        case GK_BIG: snprintf(buf, n, "gemm_big_kernel<%d, %d, %d, %d, %d>", g.bm, g.bn, g.wgm, g.wgn, st ? (g.cv == 2 ? 6 : g.cv + 3) : g.cv); break;
         case GK_SKINNY: snprintf(buf, n, "gemm_skinny_kernel<%d, %d, 1>", g.bn / 16, d.K >= 1280 ? 4 : d.K >= 640 ? 2 : 1); break;
         default: snprintf(buf, n, "gemm_glds_kernel<%d, %d, %s>", g.bm, g.bn, d.conv ? "true" : "false"); break;
     }
@@ -857,13 +838,6 @@ extern "C" int fd_gemm_stats_rows(const fd_gemm_desc* dp) {
     fd_gemm_desc d = *dp;
     if (d.K2 <= 0 || !d.A2) d.K2 = 0;
     return gemm_plan(d).stats_ok ? 32 : 0;
-}
-
-extern "C" int fd_gemm_ln_ok(const fd_gemm_desc* dp) {
-    FD_REQUIRE_DESC(dp, fd_gemm_desc, "fd_gemm_ln_ok");
-    fd_gemm_desc d = *dp;
-    if (d.K2 <= 0 || !d.A2) d.K2 = 0;
-    return gemm_plan(d).ln_ok ? 1 : 0;
 }
 
 extern "C" int fd_gemm(const fd_gemm_desc* dp, void* stream) {
@@ -903,9 +877,6 @@ extern "C" int fd_gemm(const fd_gemm_desc* dp, void* stream) {
     const GemmPlan g = gemm_plan(d);
     if (d.gn_stats) FD_REQUIRE(g.stats_ok, "fd_gemm: gn_stats set but the kernel for M=%d N=%d K=%d has no statistics epilogue (ask fd_gemm_stats_rows first)",
                                d.M, d.N, d.K);
-    if (d.ln_out)
-        FD_REQUIRE(g.ln_ok && d.ln_gamma && d.ln_beta && (d.ld_ln & 7) == 0, "fd_gemm: ln_out set but the kernel for M=%d N=%d K=%d cannot write it "
-                   "(ask fd_gemm_ln_ok first; gamma, beta required, ld_ln %% 8 == 0)", d.M, d.N, d.K);
     if (d.conv && d.conv_mode >= FD_CONV_UP2P)
         FD_REQUIRE(g.kind == GK_BIG, "fd_gemm(conv up2 phases): shape not taken by the big-tile kernels (Cin %% 64, enough tiles); use FD_CONV_UP2");
     switch (g.kind) {

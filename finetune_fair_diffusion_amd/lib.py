@@ -18,7 +18,7 @@ LIB_PATH = os.environ.get("FAIRDIFF_LIB") or os.path.join(_HERE, _DEFAULT_LIB)  
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "fairdiff_hip.h")
 
 
-ABI_VERSION = 3      # FD_ABI_VERSION of include/fairdiff_hip.h; load() refuses a library whose fd_version() differs
+ABI_VERSION = 4      # FD_ABI_VERSION of include/fairdiff_hip.h; load() refuses a library whose fd_version() differs
 
 
 class _Desc(ctypes.Structure):
@@ -58,8 +58,6 @@ class GemmDesc(_Desc):
         ("W", ctypes.c_int32), ("Cin", ctypes.c_int32), ("Ho", ctypes.c_int32), ("Wo", ctypes.c_int32),
         ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_int64),
         ("gn_stats", ctypes.c_void_p),
-        ("ln_out", ctypes.c_void_p), ("ld_ln", ctypes.c_int64), ("ln_gamma", ctypes.c_void_p), ("ln_beta", ctypes.c_void_p),
-        ("ln_stats", ctypes.c_void_p), ("ln_eps", ctypes.c_float),
         ("colscale", ctypes.c_float), ("colscale_cols", ctypes.c_int32),
     ]
 
@@ -79,6 +77,16 @@ class LoraRefreshDesc(_Desc):
                 ("K", ctypes.c_int32), ("N", ctypes.c_int32), ("scale", ctypes.c_float)]
 
 
+class CrossBlockDesc(_Desc):
+    """Mirror of ``fd_cross_block_desc`` (include/fairdiff_hip.h)."""
+    _fields_ = [("struct_size", ctypes.c_int32), ("x", ctypes.c_void_p), ("ln2_gamma", ctypes.c_void_p), ("ln2_beta", ctypes.c_void_p), ("ln2_eps", ctypes.c_float),
+                ("wq", ctypes.c_void_p), ("k", ctypes.c_void_p), ("vt", ctypes.c_void_p), ("L", ctypes.c_int32), ("Lp", ctypes.c_int32),
+                ("wo", ctypes.c_void_p), ("bo", ctypes.c_void_p), ("ln3_gamma", ctypes.c_void_p), ("ln3_beta", ctypes.c_void_p), ("ln3_eps", ctypes.c_float),
+                ("y", ctypes.c_void_p), ("yn", ctypes.c_void_p), ("yn_stats", ctypes.c_void_p),
+                ("M", ctypes.c_int32), ("C", ctypes.c_int32), ("heads", ctypes.c_int32), ("rows_per_sample", ctypes.c_int32), ("kv_div", ctypes.c_int32),
+                ("scale", ctypes.c_float)]
+
+
 _CTYPE = {"int": ctypes.c_int, "int32_t": ctypes.c_int32, "int64_t": ctypes.c_int64, "float": ctypes.c_float}
 
 
@@ -95,6 +103,8 @@ def parse_header(path=HEADER_PATH):
                 a = " ".join(a.split())
                 if "fd_gemm_desc" in a:
                     argtypes.append(ctypes.POINTER(GemmDesc))
+                elif "fd_cross_block_desc" in a:
+                    argtypes.append(ctypes.POINTER(CrossBlockDesc))
                 elif "*" in a:
                     argtypes.append(ctypes.c_void_p)
                 else:

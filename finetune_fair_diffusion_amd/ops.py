@@ -86,24 +86,10 @@ TIMER = None
 
 
 GN_STATS = os.environ.get("FD_NO_GN_STATS") is None      # A/B switch: GroupNorm statistics from the producer's epilogue (fd_gemm_desc.gn_stats)
-# LayerNorm as a second output of the producing GEMM (fd_gemm_desc.ln_out): built, parity-tested, and OFF by default -- isolated it saves 8 us per pair at
-# M = 65536 (GEMM 30 + LayerNorm 28 -> 50 us), inside the multi-stream step the long exposed epilogue of a one-tile-per-CU kernel costs more than the
-# memory-bound pass it replaces, which overlaps with the other streams' kernels (same-box A/B 1361-1381 vs 1361-1372 ms; in-situ kernel time 73 us
-# against ~33 + 29; profiles/r04_layernorm_epilogue.txt).  FD_LN_EPILOGUE=1 turns it on.
-LN_EPILOGUE = os.environ.get("FD_LN_EPILOGUE") is not None
 
-
-def _gemm_call(d, conv, out=None, gn_stats=False, ln=None):
-    """``ln`` = (gamma, beta, eps): returns (normalised copy, per-row (mean, rstd)) when the kernel fd_gemm picks can write the LayerNorm of the
-    output rows itself, else None (the caller runs fd_layernorm_fwd)."""
+def _gemm_call(d, conv, out=None, gn_stats=False):
     ws = gemm_workspace()
     d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * 4
-    fused_ln = None
-    if ln is not None and LN_EPILOGUE and _lib.get().fd_gemm_ln_ok(ctypes.byref(d)):
-        y = torch.empty((d.M, d.N), dtype=F16, device=out.device)
-        st = torch.empty((d.M, 2), dtype=F32, device=out.device)
-        d.ln_out, d.ld_ln, d.ln_gamma, d.ln_beta, d.ln_stats, d.ln_eps = y.data_ptr(), d.N, _chk(ln[0], F32).data_ptr(), _chk(ln[1], F32).data_ptr(), st.data_ptr(), ln[2]
-        fused_ln = (y, st)
     if gn_stats and GN_STATS:
         # the kernel fd_gemm picks decides the chunk height (its wave-tile rows); 0 = no statistics epilogue for this problem.  The buffer rides on
         # the output tensor OBJECT: ``groupnorm`` finds it there, and anything that makes a new tensor of the output (cat, slicing) drops it
@@ -115,7 +101,7 @@ def _gemm_call(d, conv, out=None, gn_stats=False, ln=None):
             out.gn_stats = (st, rows)
     if TIMER is None:
         _call("fd_gemm", ctypes.byref(d), _stream())
-        return fused_ln
+        return
     buf = ctypes.create_string_buffer(128)
     split = _lib.get().fd_gemm_kernel_name(ctypes.byref(d), buf, 128)
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -131,7 +117,6 @@ def _gemm_call(d, conv, out=None, gn_stats=False, ln=None):
     # splitk_reduce_kernel of a split launch together with its GEMM)
     TIMER.records.append((buf.value.decode(), flops, nbytes, a, b, split > 1))
     TIMER.shapes.append((d.M, d.N, d.K, d.K2, d.conv_mode if conv else -1, int(d.act), int(bool(d.residual)), split))
-    return fused_ln
 
 
 def _chk(t, dtype=F16):
@@ -172,12 +157,11 @@ def gemm(a, b, *, a2=None, b2=None, bias=None, rowbias=None, rows_per_batch=0, r
     if ln is None:
         _gemm_call(d, False, out, gn_stats)
         return out
-    # ln = (gamma, beta, eps): also return LayerNorm(out) and its per-row statistics -- from the GEMM's own epilogue where one tile holds whole rows
-    # (N == 320), from fd_layernorm_fwd otherwise
-    fused = _gemm_call(d, False, out, False, ln)
-    if fused is None:
-        fused = layernorm(out, ln[0], ln[1], ln[2], save_stats=True)
-    return out, fused[0], fused[1]
+    # ln = (gamma, beta, eps): also return LayerNorm(out) and its per-row statistics (fd_layernorm_fwd; the form that wrote them from the GEMM's own
+    # epilogue was never a win inside the step and lives in scratch/gemm_ln_epilogue_experiment.h)
+    _gemm_call(d, False, out, False)
+    y, st = layernorm(out, ln[0], ln[1], ln[2], save_stats=True)
+    return out, y, st
 
 
 def interleave_geglu(w, bias):
@@ -270,15 +254,14 @@ def conv3x3(x, w, B, H, W, *, mode=CONV_NORMAL, bias=None, rowbias=None, residua
 CONV_UP2P, CONV_UP2P_BWD, CONV_UP2PI = 4, 5, 6
 _BIG_TILES = (256320, 128320, 128160, 256128, 256256, 512128)
 _NO_UP2P = os.environ.get("FD_NO_UP2P") is not None      # A/B switch: nearest-up2 convs as 3x3 gathers at the high resolution
-_UP2P_SHUFFLE = os.environ.get("FD_UP2P_SHUFFLE") is not None   # A/B switch: phase-major output + fd_phase_shuffle instead of the row-mapping epilogue
 
 
-def _up2p_desc(x, w, out, B, H, W, Cin, Cout, bwd, bias=None, interleaved=False):
+def _up2p_desc(x, w, out, B, H, W, Cin, Cout, bwd, bias=None):
     d = _lib.GemmDesc()
     if bwd:   # x = dOut [B*2H*2W, Cin] (high-res), out [B*H*W, Cout]
         d.K, d.conv_mode, d.H, d.W = 16 * Cin, CONV_UP2P_BWD, 2 * H, 2 * W
-    else:     # x [B*H*W, Cin], out [4, B*H*W, Cout] phase-major, or (interleaved) the channels-last result [B*2H*2W, Cout] itself
-        d.K, d.conv_mode, d.H, d.W = 4 * Cin, (CONV_UP2PI if interleaved else CONV_UP2P), H, W
+    else:     # x [B*H*W, Cin], out = the channels-last result [B*2H*2W, Cout]: the epilogue maps the rows of the four phases
+        d.K, d.conv_mode, d.H, d.W = 4 * Cin, CONV_UP2PI, H, W
     d.A, d.lda, d.B, d.ldb, d.C, d.ldc = x.data_ptr(), Cin, w.data_ptr(), d.K, out.data_ptr(), Cout
     if bias is not None:
         d.bias = _chk(bias, F32).data_ptr()
@@ -295,17 +278,10 @@ def conv_up2(x, conv, B, H, W):
     Cin, Cout = conv.cin, conv.cout
     if not _NO_UP2P and Cin % 64 == 0 and Cout % 8 == 0:
         out = torch.empty((4 * B * H * W, Cout), dtype=F16, device=x.device)
-        # the four phases go straight into the channels-last result (FD_CONV_UP2PI: the epilogue maps rows; no fd_phase_shuffle pass), and the
+        # the four phases go straight into the channels-last result (FD_CONV_UP2PI: the epilogue maps rows), and the
         # epilogue leaves the GroupNorm statistics of the result behind in phase-major chunk order (``per`` = chunks per image and phase)
-        d = _up2p_desc(_chk(x), conv.wk_up2p, out, B, H, W, Cin, Cout, False, conv.bias, interleaved=not _UP2P_SHUFFLE)
+        d = _up2p_desc(_chk(x), conv.wk_up2p, out, B, H, W, Cin, Cout, False, conv.bias)
         if _lib.get().fd_gemm_tile(ctypes.byref(d)) in _BIG_TILES:
-            if _UP2P_SHUFFLE:       # A/B: phase-major output + a shuffle pass (rounds 2-3)
-                ph = out
-                d.C = ph.data_ptr()
-                _gemm_call(d, True)
-                out = torch.empty((4 * B * H * W, Cout), dtype=F16, device=x.device)
-                _call("fd_phase_shuffle", _p(ph), _p(out), B, H, W, Cout, _stream())
-                return out, 2 * H, 2 * W
             _gemm_call(d, True, out, gn_stats=(H * W) % 32 == 0)
             if getattr(out, "gn_stats", None) is not None:
                 out.gn_stats = out.gn_stats + ((H * W) // 32,)
@@ -463,10 +439,11 @@ def _rows(t):
     return t.stride(0)
 
 
-def transpose_btc(x, B, T, C, Tp=None):
-    """x [B*T, C] (rows may be strided) -> [B, C, Tp]."""
+def transpose_btc(x, B, T, C, Tp=None, out=None):
+    """x [B*T, C] (rows may be strided) -> [B, C, Tp] (keys past T are zero)."""
     Tp = Tp or ((T + 7) // 8 * 8)
-    y = torch.empty((B, C, Tp), dtype=F16, device=x.device)
+    y = torch.empty((B, C, Tp), dtype=F16, device=x.device) if out is None else out
+    assert y.shape == (B, C, Tp) and y.dtype == F16 and y.is_contiguous()
     _call("fd_transpose_btc", _p(x), _rows(x), _p(y), B, T, C, Tp, _stream())
     return y
 
@@ -505,9 +482,7 @@ def to_f32(x, scale=1.0):
 
 # ----------------------------------------------------------------------------- attention
 # The attention kernels consume V (forward), K (dQ) and Q / dO (dK, dV) in the row-major layout the projections write them in, through LDS
-# transpose reads (ds_read_b64_tr_b16).  FD_ATTN_NO_TR=1 restores the round-1/2 form with transposed copies made by fd_transpose_btc
-# (measurement switch; both forms are in the library).
-ATTN_TR = os.environ.get("FD_ATTN_NO_TR") is None
+# transpose reads (ds_read_b64_tr_b16); the round-1/2 form with transposed copies made by fd_transpose_btc left the library in round 5.
 LOG2E = 1.4426950408889634
 # "Pre-scaled q" (round 4): for head dims with spare contraction slots (d = 40) the projection writes q * (d^-0.5 * log2 e) -- in its fp32 epilogue, one
 # rounding as before (fd_gemm_desc.colscale) -- and the three attention kernels take the QK^T accumulator as the exponent's argument, the softmax
@@ -516,31 +491,25 @@ PRESCALED_Q = os.environ.get("FD_NO_PRESCALED_Q") is None
 
 
 def q_prescale(d):
-    """Factor the q projection folds into its epilogue for head dim ``d``, or None where the attention kernels have no spare contraction slots
-    (or the transposed-copy forms are in use)."""
-    return (d ** -0.5) * LOG2E if (PRESCALED_Q and ATTN_TR and d % 16 == 8) else None
+    """Factor the q projection folds into its epilogue for head dim ``d``, or None where the attention kernels have no spare contraction slots."""
+    return (d ** -0.5) * LOG2E if (PRESCALED_Q and d % 16 == 8) else None
 
 
-def attn_fwd(q, k, vt, B, H, Tq, Tk, d, kv_div=1, scale=None, need_lse=False, kv_rows=None, v=None, prescaled=False):
-    """q [B*Tq, H*d], k [Bk*Tkr, H*d] (2-D; rows may be strided: column slices of a wider buffer), and EITHER v (same shape and row
-    stride as k; read through LDS transpose reads) OR vt [Bk, H*d, Tkp] (the transposed copy).
+def attn_fwd(q, k, v, B, H, Tq, Tk, d, kv_div=1, scale=None, need_lse=False, kv_rows=None, prescaled=False):
+    """q [B*Tq, H*d], k [Bk*Tkr, H*d] (2-D; rows may be strided: column slices of a wider buffer), v: same shape and row stride as k.
     ``kv_rows``: rows per batch item of the k buffer when it is row-padded beyond the Tk keys (ViT token buffers).
     ``prescaled``: q holds q * scale * log2(e) (``q_prescale``); the C-ABI takes that as a negative ``scale``."""
     Tkr = kv_rows or Tk
-    if v is not None:
-        assert vt is None and _rows(v) == _rows(k) and v.shape == k.shape
-        vp, Tkp = v, 0
-    else:
-        vp, Tkp = _chk(vt), vt.shape[-1]
+    assert _rows(v) == _rows(k) and v.shape == k.shape
     o = torch.empty((q.shape[0], H * d), dtype=F16, device=q.device)
     lse = torch.empty((B, H, Tq), dtype=F32, device=q.device) if need_lse else None
     scale = scale if scale is not None else d ** -0.5
-    _call("fd_attn_fwd", _p(q), _p(k), _p(vp), _p(o), _p(lse), B, H, Tq, Tk, Tkp, Tkr, d, kv_div,
+    _call("fd_attn_fwd", _p(q), _p(k), _p(v), _p(o), _p(lse), B, H, Tq, Tk, Tkr, d, kv_div,
           -scale if prescaled else scale, _rows(q), _rows(k), _stream())
     return (o, lse) if need_lse else o
 
 
-def attn_bwd(q, k, v, o, do, lse, B, H, Tq, Tk, d, kv_div=1, scale=None, kt=None, dk_acc=None, dv_acc=None, kv_rows=None, dqkv=None, tr=None,
+def attn_bwd(q, k, v, o, do, lse, B, H, Tq, Tk, d, kv_div=1, scale=None, dk_acc=None, dv_acc=None, kv_rows=None, dqkv=None,
              dk_out=None, dv_out=None, prescaled=False):
     """Returns (dq, dk, dv).  With ``dk_acc`` / ``dv_acc`` (fp32 [Bk*Tk, C]; mandatory when kv_div > 1, i.e. shared K/V) dk/dv are ADDED
     into those buffers with fp32 atomics -- safe for launches that run concurrently on different streams.
@@ -556,14 +525,6 @@ def attn_bwd(q, k, v, o, do, lse, B, H, Tq, Tk, d, kv_div=1, scale=None, kt=None
     C = H * d
     assert _rows(k) == _rows(v)
     Dd = torch.empty((B, H, Tq), dtype=F32, device=q.device)     # D = rowsum(dO*O): produced inside the dq kernel, read by dk/dv
-    Bk = B // kv_div
-    tr = ATTN_TR if tr is None else tr
-    if tr:
-        kt, Tkp = None, 0
-    else:
-        if kt is None:
-            kt = transpose_btc(k, Bk, Tkr, C)
-        Tkp = kt.shape[-1]
     if dqkv is not None:
         assert kv_div == 1 and dqkv.shape == (q.shape[0], 3 * C) and dqkv.is_contiguous() and Tkr == Tk and dqkv.dtype == F16
         dq, dk, dv = dqkv[:, :C], dqkv[:, C:2 * C], dqkv[:, 2 * C:]
@@ -583,11 +544,9 @@ def attn_bwd(q, k, v, o, do, lse, B, H, Tq, Tk, d, kv_div=1, scale=None, kt=None
             assert kv_div == 1, "shared K/V (kv_div > 1) needs the fp32 accumulators dk_acc / dv_acc"
             mk = torch.empty if Tkr == Tk else torch.zeros
             dk, dv = mk((k.shape[0], C), dtype=F16, device=q.device), mk((k.shape[0], C), dtype=F16, device=q.device)
-    _call("fd_attn_bwd_dq", _p(q), _p(k), _p(v), _p(kt), _p(_chk(do)), _p(lse), _p(Dd), _p(_chk(o)), _p(dq), B, H, Tq, Tk, Tkp, Tkr, d,
+    _call("fd_attn_bwd_dq", _p(q), _p(k), _p(v), _p(_chk(do)), _p(lse), _p(Dd), _p(_chk(o)), _p(dq), B, H, Tq, Tk, Tkr, d,
           kv_div, scale, _rows(q), _rows(k), _rows(dq), _stream())
-    qt = None if tr else transpose_btc(q, B, Tq, C, Tq)
-    dot = None if tr else transpose_btc(do, B, Tq, C, Tq)
-    _call("fd_attn_bwd_dkdv", _p(q), _p(qt), _p(k), _p(v), _p(do), _p(dot), _p(lse), _p(Dd), _p(dk), _p(dv), B, H, Tq, Tk, Tkr, d, kv_div, scale,
+    _call("fd_attn_bwd_dkdv", _p(q), _p(k), _p(v), _p(do), _p(lse), _p(Dd), _p(dk), _p(dv), B, H, Tq, Tk, Tkr, d, kv_div, scale,
           _rows(q), _rows(k), lddkv, 2 if dk_out is not None else int(dk_acc is not None), _stream())
     if dk_out is not None:
         n = dk_out.numel()
@@ -597,29 +556,31 @@ def attn_bwd(q, k, v, o, do, lse, B, H, Tq, Tk, d, kv_div=1, scale=None, kt=None
     return dq, dk, dv
 
 
-# FP8 (e4m3) self-attention forward -- BASELINE configs[4]; switched on by FD_FP8_ATTN=1 / bench.py --fp8_attn (not the headline config)
-FP8_ATTN = os.environ.get("FD_FP8_ATTN") is not None
+# The cross-attention sub-block (LayerNorm2 -> to_q -> attention over the prompt tokens -> to_out + residual -> LayerNorm3) as one launch, for forwards
+# that neither record nor carry LoRA slabs (csrc/crossattn.hip).  FD_NO_FUSED_CROSS=1: the five separate launches.
+FUSED_CROSS = os.environ.get("FD_NO_FUSED_CROSS") is None
+CROSS_LP = 80          # key padding of the transposed V the fused kernel reads
 
 
-def fp8_attn_ok(T, d):
-    return FP8_ATTN and T % 64 == 0 and d in (40, 80, 160)
+def cross_block_ok(M, C, heads, L, rows_per_sample):
+    return (FUSED_CROSS and C in (320, 640, 1280) and heads == 8 and L <= CROSS_LP and M % (20480 // C) == 0 and rows_per_sample % (20480 // C) == 0)
 
 
-def attn_fwd_fp8(q, k, v, B, H, T, d, scale=None, need_lse=False):
-    """Self-attention forward with e4m3 QK^T / PV (per-row Q scale, per-64-key-tile K and V scales); o, lse as ``attn_fwd``."""
-    DK8, DV8 = (d + 15) // 16 * 16, (d + 31) // 32 * 32
-    dev = q.device
-    k8 = torch.empty((B, H, T, DK8), dtype=torch.uint8, device=dev)
-    v8t = torch.empty((B, H, DV8, T), dtype=torch.uint8, device=dev)
-    sk = torch.empty((B, H, T // 64), dtype=F32, device=dev)
-    sv = torch.empty((B, H, T // 64), dtype=F32, device=dev)
-    assert _rows(k) == _rows(v)
-    _call("fd_attn_fp8_quant_kv", _p(k), _p(v), _p(k8), _p(v8t), _p(sk), _p(sv), B, H, T, d, _rows(k), _stream())
-    o = torch.empty((q.shape[0], H * d), dtype=F16, device=dev)
-    lse = torch.empty((B, H, T), dtype=F32, device=dev) if need_lse else None
-    _call("fd_attn_fwd_fp8", _p(q), _p(k8), _p(v8t), _p(sk), _p(sv), _p(o), _p(lse), B, H, T, d, scale if scale is not None else d ** -0.5,
-          _rows(q), _stream())
-    return (o, lse) if need_lse else o
+def cross_attn_block(x, ln2, wq, k, vt, L, wo, bo, ln3, heads, rows_per_sample, kv_div, need_stats=False):
+    """x [M, C] -> (y [M, C], LayerNorm3(y) [M, C], its (mean, rstd) [M, 2] or None).  ln2 / ln3 = (gamma, beta, eps); k [Bk*L, C]; vt [Bk, C, Lp]."""
+    M, C = x.shape
+    d = _lib.CrossBlockDesc()
+    y, yn = torch.empty_like(x), torch.empty_like(x)
+    st = torch.empty((M, 2), dtype=F32, device=x.device) if need_stats else None
+    d.x, d.ln2_gamma, d.ln2_beta, d.ln2_eps = _chk(x).data_ptr(), _chk(ln2[0], F32).data_ptr(), _chk(ln2[1], F32).data_ptr(), ln2[2]
+    d.wq, d.k, d.vt, d.L, d.Lp = _chk(wq).data_ptr(), _chk(k).data_ptr(), _chk(vt).data_ptr(), L, vt.shape[-1]
+    assert wq.shape == (C, C) and wo.shape == (C, C) and k.shape[1] == C and vt.shape[1] == C and k.shape[0] == vt.shape[0] * L
+    d.wo, d.bo = _chk(wo).data_ptr(), _chk(bo, F32).data_ptr()
+    d.ln3_gamma, d.ln3_beta, d.ln3_eps = _chk(ln3[0], F32).data_ptr(), _chk(ln3[1], F32).data_ptr(), ln3[2]
+    d.y, d.yn, d.yn_stats = y.data_ptr(), yn.data_ptr(), (st.data_ptr() if st is not None else None)
+    d.M, d.C, d.heads, d.rows_per_sample, d.kv_div, d.scale = M, C, heads, rows_per_sample, kv_div, (C // heads) ** -0.5
+    _call("fd_cross_attn_block", ctypes.byref(d), _stream())
+    return y, yn, st
 
 
 # ----------------------------------------------------------------------------- LoRA / scheduler / optimizer

@@ -313,7 +313,7 @@ class FairnessTrainer:
         (288 GB holds the whole 20-step chain at batch 8); the remaining steps are recomputed in the backward."""
         sch = self.sch if sch is None else sch       # a prefetched R2 rollout of the NEXT step brings its own scheduler object (S may differ)
         graphed = None
-        if (self.r2_graph and unet_mod.GraphedForward.usable() and unet is self.eval_unet and unet is not self.unet and unet.lora_bank is None and _CFG_PAIR
+        if (self.r2_graph and unet is self.eval_unet and unet is not self.unet and unet.lora_bank is None and _CFG_PAIR
                 and not keep_inputs and not keep_activations and not record_prompt and torch.cuda.current_stream() != torch.cuda.default_stream()):
             graphed = getattr(unet, "graphed", None) or unet_mod.GraphedForward(unet)
         sch.set_timesteps(S)

@@ -106,7 +106,7 @@ class TransformerBlock:
 
     # -- cross-attention K/V for the rollout's prompt embeddings (timestep invariant) ------------
     def prepare_cross(self, enc, Bk, L, record, static=False):
-        """enc: [Bk*L, xdim] fp16.  Caches K [Bk*L,C], V (and, with ops.ATTN_TR off, the transposed copies K^T, V^T [Bk,C,Lp])."""
+        """enc: [Bk*L, xdim] fp16.  Caches K, V [Bk*L,C]."""
         lo = self.lora2
         te = ops.gemm(enc, lo.down_kv16) if lo is not None else None
         rp = lo.k.rp if lo is not None else 0
@@ -121,10 +121,12 @@ class TransformerBlock:
                 self.static_generation = getattr(self, "static_generation", 0) + 1
         else:
             K, V = ops.gemm(enc, self.k2.w), ops.gemm(enc, self.v2.w)
-        self.cross = dict(static=bool(static and lo is None), K=K, V=V, Vt=None if ops.ATTN_TR else ops.transpose_btc(V, Bk, L, self.C), Kt=None, Bk=Bk, L=L, enc=enc, te=te)
+        self.cross = dict(static=bool(static and lo is None), K=K, V=V, Bk=Bk, L=L, enc=enc, te=te)
+        if lo is None and not record and ops.FUSED_CROSS and L <= ops.CROSS_LP and self.C in (320, 640, 1280) and self.heads == 8:
+            # the one-launch cross-attention sub-block (ops.cross_attn_block) reads V transposed, keys zero-padded to 80: made once per rollout; a captured
+            # forward holds its address like K's and V's
+            self.cross["Vt80"] = ops.transpose_btc(V, Bk, L, self.C, ops.CROSS_LP, out=old.get("Vt80") if (static and old) else None)
         if record:
-            if not ops.ATTN_TR:
-                self.cross["Kt"] = ops.transpose_btc(K, Bk, L, self.C)
             self.cross["dK"] = torch.zeros((Bk * L, self.C), dtype=F32, device=enc.device)
             self.cross["dV"] = torch.zeros((Bk * L, self.C), dtype=F32, device=enc.device)
 
@@ -155,8 +157,8 @@ class TransformerBlock:
         # are 8 B per row: always kept
         h0, n1, ln1 = ops.gemm(g, self.proj_in.w, bias=self.proj_in.bias, ln=(self.ln1.gamma, self.ln1.beta, 1e-5))
         l1 = self.lora1
-        # q leaves its projection multiplied by d^-0.5 * log2(e) where the attention kernels can take it that way (ops.q_prescale; not on the e4m3 path)
-        qs = None if ops.fp8_attn_ok(HW, d) else ops.q_prescale(d)
+        # q leaves its projection multiplied by d^-0.5 * log2(e) where the attention kernels can take it that way (ops.q_prescale)
+        qs = ops.q_prescale(d)
         csq = (qs, C) if qs is not None else None
         if l1 is not None:
             t1 = ops.gemm(n1, l1.down_qkv16)
@@ -165,23 +167,25 @@ class TransformerBlock:
             t1 = None
             qkv = ops.gemm(n1, self.wqkv, colscale=csq)
         q, k, v = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]           # column slices (row stride 3C): the attention kernels take strides
-        if ops.fp8_attn_ok(HW, d):       # BASELINE configs[4]: e4m3 QK^T / PV in self-attention (the backward stays in the working dtype)
-            o, lse = ops.attn_fwd_fp8(q, k, v, B, h, HW, d, need_lse=True)
-        else:
-            if ops.ATTN_TR:
-                o, lse = ops.attn_fwd(q, k, None, B, h, HW, HW, d, 1, need_lse=True, v=v, prescaled=qs is not None)
-            else:
-                o, lse = ops.attn_fwd(q, k, ops.transpose_btc(v, B, HW, C), B, h, HW, HW, d, 1, need_lse=True)
-        (h1, n2, ln2), to1 = lora_linear_fwd(o, self.o1, l1.out if l1 else None, residual=h0, ln=(self.ln2.gamma, self.ln2.beta, 1e-5))
+        o, lse = ops.attn_fwd(q, k, v, B, h, HW, HW, d, 1, need_lse=True, prescaled=qs is not None)
         l2 = self.lora2
         cr = self.cross
-        qs2 = ops.q_prescale(d) if cr["Vt"] is None else None          # the prepared K / V are in the transpose-read form
+        if (not rec and l2 is None and not pair and cr.get("Vt80") is not None and self.q2.bias is None
+                and ops.cross_block_ok(B * HW, C, h, cr["L"], HW)):
+            # no-grad forward of a frozen block: norm2 -> attn2 -> residual -> norm3 is ONE launch (csrc/crossattn.hip); n2, q2, o2 never reach HBM
+            h1, _ = lora_linear_fwd(o, self.o1, l1.out if l1 else None, residual=h0)
+            h2, n3, _ = ops.cross_attn_block(h1, (self.ln2.gamma, self.ln2.beta, 1e-5), self.q2.w, cr["K"], cr["Vt80"], cr["L"], self.o2.w, self.o2.bias,
+                                             (self.ln3.gamma, self.ln3.beta, 1e-5), h, HW, B // cr["Bk"])
+            gg = ops.gemm(n3, self.ff1_wi, bias=self.ff1_bi, act="geglu")
+            h3 = ops.gemm(gg, self.ff2.w, bias=self.ff2.bias, residual=h2)
+            return ops.gemm(h3, self.proj_out.w, bias=self.proj_out.bias, residual=x, gn_stats=True)
+        (h1, n2, ln2), to1 = lora_linear_fwd(o, self.o1, l1.out if l1 else None, residual=h0, ln=(self.ln2.gamma, self.ln2.beta, 1e-5))
+        qs2 = ops.q_prescale(d)
         q2, tq2 = lora_linear_fwd(n2, self.q2, l2.q if l2 else None, colscale=(qs2, C) if qs2 is not None else None)
         B2 = 2 * B if pair else B
         q2f, h1f, xf = (torch.cat([q2, q2]), torch.cat([h1, h1]), torch.cat([x, x])) if pair else (q2, h1, x)
         kv_div = B2 // cr["Bk"]
-        o2, lse2 = ops.attn_fwd(q2f, cr["K"], cr["Vt"], B2, h, HW, cr["L"], d, kv_div, need_lse=True, v=cr["V"] if cr["Vt"] is None else None,
-                                prescaled=qs2 is not None)
+        o2, lse2 = ops.attn_fwd(q2f, cr["K"], cr["V"], B2, h, HW, cr["L"], d, kv_div, need_lse=True, prescaled=qs2 is not None)
         (h2, n3, ln3), to2 = lora_linear_fwd(o2, self.o2, l2.out if l2 else None, residual=h1f, ln=(self.ln3.gamma, self.ln3.beta, 1e-5))
         # bit-identical to projection + fd_geglu_fwd (both halves are rounded to fp16 before the gate)
         proj = torch.empty((n3.shape[0], self.ff1_wi.shape[0]), dtype=F16, device=n3.device) if rec else None
@@ -220,10 +224,10 @@ class TransformerBlock:
         # backwards run on several HIP streams, step.py, and a plain read-modify-write of the shared buffer would lose updates)
         slot = BWD_SLOT[0] if cr.get("slots") is not None else None
         if slot is not None:     # this timestep's own fp32 dK / dV pair, written without atomics (bit-reproducible; ops.attn_bwd)
-            dq2, _, _ = ops.attn_bwd(c["q2"], cr["K"], cr["V"], c["o2"], do2, c["lse2"], B, h, HW, cr["L"], d, kv_div, kt=cr["Kt"],
+            dq2, _, _ = ops.attn_bwd(c["q2"], cr["K"], cr["V"], c["o2"], do2, c["lse2"], B, h, HW, cr["L"], d, kv_div,
                                      dk_out=cr["slots"][slot, 0], dv_out=cr["slots"][slot, 1], prescaled=c.get("qs2", False))
         else:
-            dq2, _, _ = ops.attn_bwd(c["q2"], cr["K"], cr["V"], c["o2"], do2, c["lse2"], B, h, HW, cr["L"], d, kv_div, kt=cr["Kt"],
+            dq2, _, _ = ops.attn_bwd(c["q2"], cr["K"], cr["V"], c["o2"], do2, c["lse2"], B, h, HW, cr["L"], d, kv_div,
                                      dk_acc=cr["dK"], dv_acc=cr["dV"], prescaled=c.get("qs2", False))
         if pair:
             # the shared prefix received the gradient of both halves
@@ -590,15 +594,8 @@ class GraphedForward:
             g.capture_end()
         self.graphs[key] = (g, x, trow, eps)
 
-    @staticmethod
-    def usable():
-        """The capture bakes in the addresses of the cross-attention K / V.  With the transposed-copy attention forms (FD_ATTN_NO_TR) prepare_cross
-        builds a NEW V^T for every rollout, which a replay would not see: no graph there."""
-        return ops.ATTN_TR
-
     def __call__(self, lat, step_index, pair):
         """lat [N,4,H,W] fp32 on the current (side) stream -> eps [2N or N,4,H*W] fp32 (a static buffer: consume it before the next call)."""
-        assert self.usable(), "GraphedForward with transposed-copy attention: the captured V^T would be stale"
         # the key holds everything a capture depends on: the latent shape, the CFG-pair form, the prompt shape, and the generation of the static
         # K / V buffers (prepare_cross(static=True) allocates new ones when Bk * L changes; a graph captured against freed buffers is dropped)
         c0 = self.unet.transformers[0].cross

@@ -114,10 +114,7 @@ class VisionTransformer:
             q = ops.gemm(n1, L["q"].w, bias=L["q"].bias)
             k = ops.gemm(n1, L["k"].w, bias=L["k"].bias)
             v = ops.gemm(n1, L["v"].w, bias=L["v"].bias)
-            if ops.ATTN_TR:
-                a, lse = ops.attn_fwd(q, k, None, N, H, Tp, T, d, need_lse=True, kv_rows=Tp, v=v)
-            else:
-                a, lse = ops.attn_fwd(q, k, ops.transpose_btc(v, N, Tp, D), N, H, Tp, T, d, need_lse=True, kv_rows=Tp)
+            a, lse = ops.attn_fwd(q, k, v, N, H, Tp, T, d, need_lse=True, kv_rows=Tp)
             h1 = ops.gemm(a, L["o"].w, bias=L["o"].bias, residual=x)
             n2, s2 = ops.layernorm(h1, L["ln2"].gamma, L["ln2"].beta, eps, save_stats=True)
             if record:

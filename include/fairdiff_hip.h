@@ -23,8 +23,11 @@ extern "C" {
 #define FD_OK 0
 #define FD_ERR_ARG (-1)
 #define FD_ERR_LAUNCH (-2)
-/* ABI revision of this header == fd_version() of a matching library.  3: every descriptor struct starts with ``struct_size`` (below). */
-#define FD_ABI_VERSION 3
+/* ABI revision of this header == fd_version() of a matching library.  3: every descriptor struct starts with ``struct_size`` (below);
+ * 4: fd_gemm_desc lost the ln_* fields and fd_gemm_ln_ok(), the e4m3 attention entry points and fd_phase_shuffle are gone (round 5: scratch/),
+ * the attention entry points take V / K / Q / dO as written by the projections only (no transposed-copy operands);
+ * new: fd_cross_attn_block. */
+#define FD_ABI_VERSION 4
 
 enum { FD_ACT_NONE = 0, FD_ACT_SILU = 1, FD_ACT_QUICK_GELU = 2, FD_ACT_GELU = 3, FD_ACT_RELU = 4,
        FD_ACT_HARDSWISH = 5, FD_ACT_HARDSIGMOID = 6,
@@ -42,7 +45,7 @@ enum { FD_CONV_NORMAL = 0, FD_CONV_STRIDE2 = 1, FD_CONV_UP2 = 2, FD_CONV_TRANS2 
         * (k = (((py*2+px)*2+dy)*2+dx)*Cin + c), B = [N][K].                                                                              */
        FD_CONV_UP2P_BWD = 5,
        /* FD_CONV_UP2P writing its four phases straight into the channels-last result: C = [Bn, 2H, 2W, N], the row of phase (py, px) and low-res pixel
-        * (b, y, x) being ((b*2H + 2y+py)*2W + 2x+px) -- no fd_phase_shuffle pass.  gn_stats is allowed here: chunk (phase, m / 32) of the low-res rows,
+        * (b, y, x) being ((b*2H + 2y+py)*2W + 2x+px): the form the product uses (the phase-major one needs a second pass to interleave).  gn_stats is allowed here: chunk (phase, m / 32) of the low-res rows,
         * i.e. slot phase * (M / 32) + m / 32 (M % 32 == 0); fd_groupnorm_fwd_stats takes that layout through ``per`` (chunks per image and phase). */
        FD_CONV_UP2PI = 6 };
 
@@ -91,13 +94,6 @@ typedef struct fd_gemm_desc {
      * procedure per chunk: they do not depend on the tile policy or the batch size; 0 = this problem's kernel cannot): size the buffer
      * ceil(M / rows) * (N / 10) * 2 floats; fd_gemm fails if gn_stats is set and the chosen kernel cannot write it. */
     float* gn_stats;
-    /* optional LayerNorm of the output row, written as a second output (NULL = none): ln_out[m, n] = (C[m, n] - mean_m) * rstd_m * ln_gamma[n] + ln_beta[n]
-     * over the N columns of the STORED row (BasicTransformerBlock.norm1 / norm2 / norm3 behind proj_in / attn1.to_out / attn2.to_out), ln_stats[m] =
-     * (mean_m, rstd_m) for fd_layernorm_bwd (may be NULL).  Only where one workgroup tile holds whole rows: ask fd_gemm_ln_ok() first. */
-    void* ln_out; int64_t ld_ln;
-    const float* ln_gamma; const float* ln_beta;
-    float* ln_stats;
-    float ln_eps;
     /* optional per-column factor (colscale_cols == 0: none): columns n < colscale_cols of alpha * (A.B^T + A2.B2^T) are multiplied by ``colscale``
      * in fp32 before bias / activation / rounding (colscale_cols must be a multiple of 4).  Attention.to_q inside the stacked q/k/v projection:
      * q is written pre-multiplied by softmax_scale * log2(e), which the attention kernels then take as is (negative ``scale`` argument). */
@@ -107,9 +103,6 @@ int fd_gemm(const fd_gemm_desc* d, void* stream);
 /* rows per statistics chunk of ``gn_stats`` for this problem (32), or 0 when the kernel fd_gemm would launch has no statistics epilogue
  * (split-K, the 64-column wave tiles, fp32 / GEGLU outputs, N not a multiple of 80) */
 int fd_gemm_stats_rows(const fd_gemm_desc* d);
-/* 1 when the kernel fd_gemm would launch for this problem can write ``ln_out`` (dense fp16 GEMM, N == 320 == the tile width of the 16-wave lockstep
- * kernels, bias / residual / LoRA-slab epilogue only, no split-K), else 0; fd_gemm fails if ln_out is set where this returns 0 */
-int fd_gemm_ln_ok(const fd_gemm_desc* d);
 /* tile variant fd_gemm would pick for this problem, as BM*1000+BN (128128 / 128064 / 64064) */
 int fd_gemm_tile(const fd_gemm_desc* d);
 /* name of the kernel fd_gemm launches for this problem as rocprofv3 --kernel-trace spells it (host buffer ``buf`` of ``n`` bytes);
@@ -162,8 +155,6 @@ int fd_act_bwd(const void* z, const void* dy, void* dx, int64_t n, int act, void
 int fd_add(const void* a, const void* b, void* y, int64_t n, float sa, float sb, void* stream);      /* y = sa*a + sb*b (fp16) */
 int fd_copy_cols(const void* src, int64_t lds, void* dst, int64_t ldd, int64_t M, int cols, void* stream); /* strided 2-D copy, fp16 */
 int fd_transpose_btc(const void* x /* [B,T,C], row stride ldx (0 = C) */, int64_t ldx, void* y /* [B,C,Tp] */, int B, int T, int C, int Tp, void* stream);
-/* phase-major [4][B,H,W,C] (FD_CONV_UP2P output) -> channels-last [B,2H,2W,C] */
-int fd_phase_shuffle(const void* src, void* dst, int B, int H, int W, int C, void* stream);
 int fd_downsum2x2(const void* x /* [B,2H,2W,C] */, void* y /* [B,H,W,C] */, int B, int H, int W, int C, void* stream);
 /* y = softmax(scale*x + mask); mask fp32 [.., mask_t, cols], mask row = (row / mask_ht) * mask_t + row % mask_t, or NULL */
 int fd_softmax_rows(const void* x, void* y, int64_t rows, int cols, float scale, const float* mask, int mask_t, int mask_ht, void* stream);
@@ -173,51 +164,62 @@ int fd_cast_f16_to_f32(const void* x, float* y, int64_t n, float scale, void* st
 
 /* ---- fused attention (diffusers Attention.get_attention_scores + bmm, LoRAAttnProcessor.__call__)
  * q:[B,Tq,H*d]  k:[Bk,Tkr,H*d] of which the first Tk rows are keys (Tkr>=Tk: row-padded token buffers of the ViTs)
- * vt: with Tkp == 0, V ITSELF -- [Bk,Tkr,H*d] rows of stride ldk, exactly like k -- consumed through LDS transpose reads
- *     (ds_read_b64_tr_b16; the shipped form); with Tkp > 0 a transposed copy [Bk,H*d,Tkp] (keys contiguous, Tkp>=Tk, Tkp%8==0).
+ * v: [Bk,Tkr,H*d] rows of stride ldk, exactly like k -- consumed as the projection wrote it, through LDS transpose reads (ds_read_b64_tr_b16); the
+ *    transposed-copy operands (vt, kt, qt, d_ot) of ABI <= 3 are gone.
  * sample b uses kv batch b / kv_div (cross-attention K/V are shared by each CFG half).
  * o:[B,Tq,H*d] fp16, lse:[B,H,Tq] fp32 (natural-log sum-exp of the scaled scores).
- * scale: the softmax scale (d^-0.5).  NEGATIVE scale, all three entry points (d % 16 == 8 -- the U-Net's d = 40 --, transpose-read forms only):
+ * scale: the softmax scale (d^-0.5).  NEGATIVE scale, all three entry points (d % 16 == 8 -- the U-Net's d = 40):
  *   "pre-scaled q" -- q holds q_true * |scale| * log2(e), written that way by its projection (fd_gemm_desc.colscale); the kernels then take the QK^T
  *   accumulator as the exponent's argument, the softmax reference point (forward) or the saved log-sum-exp (backward) riding in spare contraction
  *   slots of the padded head dim.  o, lse, dk, dv are unchanged in meaning and dq is still the gradient w.r.t. q_true.
  * ldq / ldk (and ldkv, lddq, lddkv below): row strides in elements of q, k/v and of the dq, dk/dv outputs; 0 = H*d (contiguous).
  * Non-trivial strides let q, k, v (and dq, dk, dv) be column slices of ONE [M, 3*H*d] buffer: the self-attention projections run as a
  * single GEMM with stacked weights and their input gradients as a single GEMM over K = 3*H*d.                                       */
-int fd_attn_fwd(const void* q, const void* k, const void* vt, void* o, float* lse, int B, int H, int Tq, int Tk,
-                int Tkp, int Tkr, int d, int kv_div, float scale, int ldq, int ldk, void* stream);
+int fd_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, int B, int H, int Tq, int Tk,
+                int Tkr, int d, int kv_div, float scale, int ldq, int ldk, void* stream);
 /* D[b,h,t] = sum_j dO*O */
 int fd_attn_bwd_prep(const void* o, const void* d_o, float* D, int B, int H, int T, int d, void* stream);
-/* dq from (q, k, v, kt, dO, lse, D).  kt == NULL (the shipped form): K^T for the dS.K product comes from the row-major K tile through
- * LDS transpose reads; else kt:[Bk,H*d,Tkp] is a transposed copy of k.  With o != NULL the kernel computes D = rowsum(dO*O) itself and WRITES it to D
+/* dq from (q, k, v, dO, lse, D): K^T for the dS.K product comes from the row-major K tile through LDS transpose reads.
+ * With o != NULL the kernel computes D = rowsum(dO*O) itself and WRITES it to D
  * for fd_attn_bwd_dkdv (fd_attn_bwd_prep is then not needed); with o == NULL it reads D. */
-int fd_attn_bwd_dq(const void* q, const void* k, const void* v, const void* kt, const void* d_o, const float* lse,
-                   float* D, const void* o, void* dq, int B, int H, int Tq, int Tk, int Tkp, int Tkr, int d, int kv_div, float scale,
+int fd_attn_bwd_dq(const void* q, const void* k, const void* v, const void* d_o, const float* lse,
+                   float* D, const void* o, void* dq, int B, int H, int Tq, int Tk, int Tkr, int d, int kv_div, float scale,
                    int ldq, int ldkv, int lddq, void* stream);
-/* dk,dv from (q, qt, k, v, dO, dOt, lse, D).  qt == dOt == NULL (the shipped form): Q^T and dO^T come from the row-major q / dO tiles
- * through LDS transpose reads (no Tq % 8 restriction); else qt, dOt:[B,H*d,Tq] are transposed copies.  When kv_div>1 the kv batch is shared by
+/* dk,dv from (q, k, v, dO, lse, D): Q^T and dO^T come from the row-major q / dO tiles through LDS transpose reads.
+ * When kv_div>1 the kv batch is shared by
  * kv_div consecutive samples; dk/dv are then fp32 [Bk,Tk,H*d] accumulated with atomics, else fp16 (overwritten).
  * ``accumulate`` == 1 selects the fp32-atomic form at kv_div == 1 too: several launches -- timesteps of the truncated chain whose
  * backwards run on different HIP streams -- may then add into one accumulator concurrently.
  * ``accumulate`` == 2 (round 4, what the training step uses): NO atomics -- dk / dv are fp32 [kv_div][Bk*Tkr][lddkv] and sample j of every
  * K/V group WRITES slab j; fd_sum_slabs then adds the slabs in a fixed order: shared dK / dV are bit-reproducible. */
-int fd_attn_bwd_dkdv(const void* q, const void* qt, const void* k, const void* v, const void* d_o, const void* d_ot,
+int fd_attn_bwd_dkdv(const void* q, const void* k, const void* v, const void* d_o,
                      const float* lse, const float* D, void* dk, void* dv, int B, int H, int Tq, int Tk, int Tkr, int d,
                      int kv_div, float scale, int ldq, int ldkv, int lddkv, int accumulate, void* stream);
 /* out[i] = sum_{s < nslab} in[s*n + i], s ascending (fp32): the fixed-order reduction behind accumulate == 2 */
 int fd_sum_slabs(const float* in, float* out, int nslab, int64_t n, void* stream);
 
-/* ---- FP8 (OCP e4m3fn) self-attention forward: BASELINE configs[4] "bf16 + MFMA fp8 attention" (per-tile scaled QK^T / PV,
- * self-attention only).  Same reference op as fd_attn_fwd for the attn1 layers; the reference itself only ran fp16 (:401-405).
- * fd_attn_fp8_quant_kv: k, v [B,T,H*d] (working dtype) -> k8 [B,H,T,DK8] (DK8 = d rounded up to 16), v8t [B,H,DV8,T] (DV8 = d rounded
- * up to 32) e4m3 bytes, zero padded, with one dequantisation scale per (b, h, 64-key tile): sk, sv [B,H,T/64] fp32 (= amax / 448).
- * fd_attn_fwd_fp8: q [B,T,H*d] (quantised in registers, one scale per query row), both contractions on v_mfma_f32_32x32x16_fp8_fp8,
- * fp32 softmax statistics; o [B,T,H*d] working dtype and lse [B,H,T] exactly as fd_attn_fwd (the backward kernels consume them).
- * T % 64 == 0, d in {40, 80, 160}.                                                                                               */
-int fd_attn_fp8_quant_kv(const void* k, const void* v, void* k8, void* v8t, float* sk, float* sv, int B, int H, int T, int d,
-                         int ldkv /* row stride of k and v, 0 = H*d */, void* stream);
-int fd_attn_fwd_fp8(const void* q, const void* k8, const void* v8t, const float* sk, const float* sv, void* o, float* lse, int B, int H,
-                    int T, int d, float scale, int ldq /* row stride of q, 0 = H*d */, void* stream);
+/* ---- the cross-attention sub-block of BasicTransformerBlock as ONE launch (diffusers attention.py BasicTransformerBlock.forward: norm2 -> attn2 ->
+ * residual -> norm3; attn2 runs the attention processor selected at exp-1 main:811-817), for forwards that neither record nor carry LoRA slabs
+ * (the frozen rollout R2, exp-1 main:1844-1858):
+ *     n2 = LayerNorm(x; ln2);  q = n2 . wq^T;  o = softmax(q k^T * scale) v;  y = o . wo^T + bo + x;  yn = LayerNorm(y; ln3)
+ * x, y, yn: [M, C] working dtype, contiguous; wq, wo: [C, C] (out, in); k: [Bk*L, C] (the L <= 80 prompt tokens per sample, as fd_attn_fwd takes
+ * them); vt: [Bk, C, Lp] = V transposed with zero-padded keys (fd_transpose_btc, Lp >= 80); row m belongs to sample m / rows_per_sample, which reads
+ * K / V batch (m / rows_per_sample) / kv_div.  C in {320, 640, 1280} with 8 heads; M and rows_per_sample multiples of 20480 / C.
+ * yn (and ln3_*) may be NULL; yn_stats [M, 2] = (mean, rstd) of LayerNorm3 or NULL.  Replaces fd_layernorm_fwd + fd_gemm + fd_attn_fwd + fd_gemm +
+ * fd_layernorm_fwd; y, yn are bit-identical to that sequence's wherever its attention output o is (the softmax here rounds q once, pre-scaled). */
+typedef struct fd_cross_block_desc {
+    int32_t struct_size;             /* sizeof(fd_cross_block_desc) */
+    const void* x;
+    const float* ln2_gamma; const float* ln2_beta; float ln2_eps;
+    const void* wq;
+    const void* k; const void* vt; int32_t L, Lp;
+    const void* wo; const float* bo;
+    const float* ln3_gamma; const float* ln3_beta; float ln3_eps;
+    void* y; void* yn; float* yn_stats;
+    int32_t M, C, heads, rows_per_sample, kv_div;
+    float scale;                     /* softmax scale, d^-0.5 */
+} fd_cross_block_desc;
+int fd_cross_attn_block(const fd_cross_block_desc* d, void* stream);
 
 /* ---- masked attention of the CLIP text encoder (transformers CLIPAttention; reference call sites :1011-1014, :1078-1081).
  * q,k,v,o: [B,T,H*d] fp16, T<=128, d<=128; key_valid [B,T] int32 or NULL; P [B,H,T,T] fp32 (saved probabilities) or NULL */

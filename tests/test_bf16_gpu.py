@@ -1,4 +1,4 @@
-"""BASELINE configs[4] (bf16 working dtype, e4m3 self-attention): the checks live in tests/run_bf16_checks.py and run in their own
+"""BASELINE configs[4]'s working dtype (bf16; its e4m3 attention left the product in round 5, see scratch/attn_fp8_experiment.hip): the checks live in tests/run_bf16_checks.py and run in their own
 process, because a process's working dtype -- which library it loads and what ``ops.F16`` is -- is fixed at import (FD_DTYPE)."""
 import os
 import subprocess
@@ -23,10 +23,6 @@ def test_bf16_kernels_unet_and_training_step(dev):
     _run({}, ["kernels", "tiny", "sd15"])
 
 
-def test_bf16_with_fp8_self_attention_in_the_sd15_unet(dev):
-    _run({"FD_FP8_ATTN": "1"}, ["sd15"])
-
-
-def test_exp3_step_in_bf16_with_fp8_self_attention(dev):
-    """BASELINE configs[4] precision on a multi-attribute step: exp-3 logic, bf16 library, e4m3 self-attention forward."""
-    _run({"FD_FP8_ATTN": "1"}, ["exp3"])
+def test_exp3_step_in_bf16(dev):
+    """BASELINE configs[4]'s working dtype on a multi-attribute step: exp-3 logic on the bf16 library."""
+    _run({}, ["exp3"])

@@ -82,17 +82,9 @@ def test_conv_up2_phase_decomposition(ops, dev, B, H, Cin, Cout):
     check(f"conv_up2 phases {Cin}->{Cout}@{H}", got, ref, 4e-3)
     old, _, _ = ops.conv3x3(xl, conv.wk, B, H, H, mode=ops.CONV_UP2, bias=conv.bias)
     check("conv_up2 phases vs 3x3 gather", y, old.float(), 4e-3)
-    # round 4: the phases are written straight into the channels-last result (FD_CONV_UP2PI, the epilogue maps rows): bit-identical to the phase-major
-    # launch + fd_phase_shuffle of rounds 2-3; where the kernel has the statistics epilogue (80-column wave tiles) the result carries GroupNorm chunk
-    # sums in phase-major order, which the norm consumes (``per``) -- against the two-launch norm on the same tensor
-    import pytest as _pt
-    mp = _pt.MonkeyPatch()
-    try:
-        mp.setattr(ops, "_UP2P_SHUFFLE", True)
-        y_sh, _, _ = ops.conv_up2(xl, conv, B, H, H)
-    finally:
-        mp.undo()
-    assert torch.equal(y, y_sh)
+    # the phases are written straight into the channels-last result (FD_CONV_UP2PI, the epilogue maps rows); where the kernel has the statistics epilogue
+    # (80-column wave tiles) the result carries GroupNorm chunk sums in phase-major order, which the norm consumes (``per``) -- against the two-launch
+    # norm on the same tensor
     st = getattr(y, "gn_stats", None)
     if Cout % 320 == 0:
         assert st is not None and len(st) == 3 and st[1] == 32 and st[2] == H * H // 32 and st[0].shape == (4 * B * H * H // 32, Cout // 10, 2)
@@ -355,44 +347,6 @@ def test_groupnorm_from_producer_statistics(ops, dev, B, HW, C1, C2, silu):
         assert torch.equal(yb, y[sl]) and torch.equal(stb[0], st[bi])
 
 
-@pytest.mark.parametrize("M,N,K,fused", [(32768, 320, 320, True), (65536, 320, 320, True), (12800, 320, 1280, True), (10250, 320, 320, True),
-                                           (4096, 320, 320, False), (16384, 640, 640, False)])
-def test_gemm_layernorm_epilogue(ops, dev, M, N, K, fused, monkeypatch):
-    """fd_gemm_desc.ln_out: the GEMM whose tile holds whole rows writes LayerNorm(row) as a second output.  C itself is
-    bit-identical to the launch without it; the normalised copy and the saved statistics against torch and against fd_layernorm_fwd on the same
-    C; M tails; shapes whose kernel cannot (small M, N != 320) fall back to the standalone pass inside ops.gemm."""
-    import ctypes
-    from finetune_fair_diffusion_amd import lib
-    monkeypatch.setattr(ops, "LN_EPILOGUE", True)          # off by default in the product (profiles/r04_layernorm_epilogue.txt); FD_LN_EPILOGUE=1 turns it on
-    a, b = rnd(M, K, dev=dev, seed=1), rnd(N, K, dev=dev, scale=0.1, seed=2)
-    a2, b2 = rnd(M, 8, dev=dev, seed=3), rnd(N, 8, dev=dev, seed=4)
-    bias, res = rnd(N, dev=dev, dtype=torch.float32, seed=5), rnd(M, N, dev=dev, seed=6) * 3 + 0.5
-    gamma = rnd(N, dev=dev, dtype=torch.float32, seed=7) * 0.2 + 1
-    beta = rnd(N, dev=dev, dtype=torch.float32, seed=8) * 0.2
-    d = lib.GemmDesc(); d.M, d.N, d.K, d.K2, d.batch, d.ldc, d.alpha, d.ldr = M, N, K, 8, 1, N, 1.0, N
-    d.A2 = d.residual = 1 << 20
-    ws = ops.gemm_workspace()
-    d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * 4
-    assert bool(lib.get().fd_gemm_ln_ok(ctypes.byref(d))) == fused
-    plain = ops.gemm(a, b, a2=a2, b2=b2, bias=bias, residual=res)
-    c, n, st = ops.gemm(a, b, a2=a2, b2=b2, bias=bias, residual=res, ln=(gamma, beta, 1e-5))
-    assert torch.equal(plain, c)
-    ref = F.layer_norm(c.float(), (N,), gamma, beta, 1e-5)
-    check("LayerNorm from the GEMM epilogue", n, ref, 2e-3)
-    mean = c.double().mean(1)
-    rstd = 1.0 / torch.sqrt(c.double().var(1, unbiased=False) + 1e-5)
-    check("saved mean", st[:, 0], mean, 1e-5)
-    check("saved rstd", st[:, 1], rstd, 1e-5)
-    n0, st0 = ops.layernorm(c, gamma, beta, 1e-5, save_stats=True)
-    assert float((n.float() - n0.float()).abs().max()) <= 2e-3 * float(n0.float().abs().max())
-    c2, n2, st2 = ops.gemm(a, b, a2=a2, b2=b2, bias=bias, residual=res, ln=(gamma, beta, 1e-5))
-    assert torch.equal(n, n2) and torch.equal(st, st2)
-    if fused and M >= 32768:                      # rows do not depend on the tile: the first rows alone (128-row tiles) give the same bits
-        Ms = 12800
-        cs, ns, sts = ops.gemm(a[:Ms], b, a2=a2[:Ms], b2=b2, bias=bias, residual=res[:Ms], ln=(gamma, beta, 1e-5))
-        assert torch.equal(ns, n[:Ms]) and torch.equal(sts, st[:Ms])
-
-
 @pytest.mark.parametrize("M,C", [(1000, 320), (333, 1280), (64, 768)])
 def test_layernorm(ops, dev, M, C):
     x = rnd(M, C, dev=dev, seed=1) * 3 + 1
@@ -462,59 +416,39 @@ def _attn_ref(q, k, v, H, kv_div=1):
     return o.permute(0, 2, 1, 3).reshape(B, T, C), torch.logsumexp(s, -1)
 
 
-@pytest.mark.parametrize("tr", [True, False])
 @pytest.mark.parametrize("B,H,Tq,Tk,d,kv_div", [(2, 8, 1024, 1024, 40, 1), (2, 8, 256, 256, 80, 1), (2, 4, 256, 256, 160, 1),
                                                  (1, 2, 64, 64, 160, 1), (4, 8, 1024, 13, 40, 2), (2, 2, 200, 77, 64, 1),
                                                  (2, 4, 64, 16, 32, 2), (1, 8, 4096, 4096, 40, 1), (2, 4, 100, 50, 16, 1), (1, 2, 130, 130, 128, 1)])
-def test_attention_fwd_bwd(ops, dev, B, H, Tq, Tk, d, kv_div, tr):
-    """tr = True: the shipped form -- V, K, Q, dO consumed row-major through LDS transpose reads (ds_read_b64_tr_b16); False: the form with
-    transposed copies made by fd_transpose_btc.  Same arithmetic, different operand delivery: the two must also be bit-identical."""
+def test_attention_fwd_bwd(ops, dev, B, H, Tq, Tk, d, kv_div):
+    """V, K, Q, dO are consumed row-major, as the projections write them, through LDS transpose reads (ds_read_b64_tr_b16).  (Until round 5 the
+    library also held the round-1/2 form with transposed copies made by fd_transpose_btc and this test asserted the two bit-identical.)"""
     C = H * d
     Bk = B // kv_div
     q, k, v = rnd(B, Tq, C, dev=dev, seed=1), rnd(Bk, Tk, C, dev=dev, seed=2), rnd(Bk, Tk, C, dev=dev, seed=3)
     qr, kr, vr = (t.float().requires_grad_(True) for t in (q, k, v))
     oref, lref = _attn_ref(qr, kr, vr, H, kv_div)
     q2, k2, v2 = q.reshape(B * Tq, C), k.reshape(Bk * Tk, C), v.reshape(Bk * Tk, C)
-
-    def fwd(form):
-        if form:
-            return ops.attn_fwd(q2, k2, None, B, H, Tq, Tk, d, kv_div, need_lse=True, v=v2)
-        return ops.attn_fwd(q2, k2, ops.transpose_btc(v2, Bk, Tk, C), B, H, Tq, Tk, d, kv_div, need_lse=True)
-    o, lse = fwd(tr)
+    o, lse = ops.attn_fwd(q2, k2, v2, B, H, Tq, Tk, d, kv_div, need_lse=True)
     check("attn fwd", o.reshape(B, Tq, C), oref, 3e-3)
     check("attn lse", lse, lref, 1e-3)
-    if tr:
-        o_other, lse_other = fwd(False)
-        assert torch.equal(o, o_other) and torch.equal(lse, lse_other), "transpose-read forward differs from the transposed-copy forward"
-    if Tq % 8 and not tr:
-        return
     do = rnd(B, Tq, C, dev=dev, seed=4)
     oref.backward(do.float())
-
-    def bwd(form):
-        dk_acc = torch.zeros(Bk * Tk, C, dtype=torch.float32, device=dev) if kv_div > 1 else None
-        dv_acc = torch.zeros_like(dk_acc) if kv_div > 1 else None
-        return ops.attn_bwd(q2, k2, v2, o, do.reshape(B * Tq, C), lse, B, H, Tq, Tk, d, kv_div, dk_acc=dk_acc, dv_acc=dv_acc, tr=form)
-    dq, dk, dv = bwd(tr)
+    dk_acc = torch.zeros(Bk * Tk, C, dtype=torch.float32, device=dev) if kv_div > 1 else None
+    dv_acc = torch.zeros_like(dk_acc) if kv_div > 1 else None
+    dq, dk, dv = ops.attn_bwd(q2, k2, v2, o, do.reshape(B * Tq, C), lse, B, H, Tq, Tk, d, kv_div, dk_acc=dk_acc, dv_acc=dv_acc)
     check("attn dq", dq.reshape(B, Tq, C), qr.grad, 5e-3)
     check("attn dk", dk.reshape(Bk, Tk, C), kr.grad, 5e-3)
     check("attn dv", dv.reshape(Bk, Tk, C), vr.grad, 5e-3)
-    if tr and Tq % 8 == 0:
-        dq2, dk2, dv2 = bwd(False)
-        assert torch.equal(dq, dq2), "transpose-read dQ differs"
-        if kv_div == 1:            # the shared-K/V form adds with fp32 atomics: order-dependent low bits
-            assert torch.equal(dk, dk2) and torch.equal(dv, dv2), "transpose-read dK / dV differ"
-    if Tq % 8 == 0 or tr:
-        # the deterministic form of shared dK / dV (round 4): per-sample fp32 slabs + fixed-order sum instead of atomics -- same values as the
-        # atomics form up to the order of kv_div fp32 additions, BIT-identical between two launches, also at kv_div == 1
-        outs = []
-        for _ in range(2):
-            dko, dvo = torch.full((Bk * Tk, C), 7.0, dtype=torch.float32, device=dev), torch.full((Bk * Tk, C), -3.0, dtype=torch.float32, device=dev)
-            dq3, _, _ = ops.attn_bwd(q2, k2, v2, o, do.reshape(B * Tq, C), lse, B, H, Tq, Tk, d, kv_div, dk_out=dko, dv_out=dvo, tr=tr)
-            outs.append((dq3, dko, dvo))
-        assert all(torch.equal(a, b) for a, b in zip(outs[0], outs[1])) and torch.equal(outs[0][0], dq)
-        check("attn dk (slabs)", outs[0][1].reshape(Bk, Tk, C), kr.grad, 5e-3)
-        check("attn dv (slabs)", outs[0][2].reshape(Bk, Tk, C), vr.grad, 5e-3)
+    # the deterministic form of shared dK / dV (round 4): per-sample fp32 slabs + fixed-order sum instead of atomics -- same values as the
+    # atomics form up to the order of kv_div fp32 additions, BIT-identical between two launches, also at kv_div == 1
+    outs = []
+    for _ in range(2):
+        dko, dvo = torch.full((Bk * Tk, C), 7.0, dtype=torch.float32, device=dev), torch.full((Bk * Tk, C), -3.0, dtype=torch.float32, device=dev)
+        dq3, _, _ = ops.attn_bwd(q2, k2, v2, o, do.reshape(B * Tq, C), lse, B, H, Tq, Tk, d, kv_div, dk_out=dko, dv_out=dvo)
+        outs.append((dq3, dko, dvo))
+    assert all(torch.equal(a, b) for a, b in zip(outs[0], outs[1])) and torch.equal(outs[0][0], dq)
+    check("attn dk (slabs)", outs[0][1].reshape(Bk, Tk, C), kr.grad, 5e-3)
+    check("attn dv (slabs)", outs[0][2].reshape(Bk, Tk, C), vr.grad, 5e-3)
 
 
 @pytest.mark.parametrize("B,H,Tq,Tk,kv_div", [(2, 8, 1024, 1024, 1), (1, 8, 4096, 4096, 1), (4, 8, 1024, 13, 2), (2, 4, 300, 77, 1), (16, 8, 4096, 77, 8)])
@@ -532,10 +466,10 @@ def test_attention_with_prescaled_q(ops, dev, B, H, Tq, Tk, kv_div):
     qr, kr, vr = (qp.float() / fac).requires_grad_(True), k.float().requires_grad_(True), v.float().requires_grad_(True)
     oref, lref = _attn_ref(qr, kr, vr, H, kv_div)
     q2, k2, v2 = qp.reshape(B * Tq, C), k.reshape(Bk * Tk, C), v.reshape(Bk * Tk, C)
-    o, lse = ops.attn_fwd(q2, k2, None, B, H, Tq, Tk, d, kv_div, need_lse=True, v=v2, prescaled=True)
+    o, lse = ops.attn_fwd(q2, k2, v2, B, H, Tq, Tk, d, kv_div, need_lse=True, prescaled=True)
     check("attn fwd (pre-scaled q)", o.reshape(B, Tq, C), oref, 3e-3)
     check("attn lse (pre-scaled q)", lse, lref, 1e-3)
-    o_b, lse_b = ops.attn_fwd(q2, k2, None, B, H, Tq, Tk, d, kv_div, need_lse=True, v=v2, prescaled=True)
+    o_b, lse_b = ops.attn_fwd(q2, k2, v2, B, H, Tq, Tk, d, kv_div, need_lse=True, prescaled=True)
     assert torch.equal(o, o_b) and torch.equal(lse, lse_b)
     do = rnd(B, Tq, C, dev=dev, seed=4)
     oref.backward(do.float())
@@ -567,7 +501,7 @@ def test_attention_backward_with_small_upstream_gradients(ops, dev, gscale, pres
     kr, vr = k.float().requires_grad_(True), v.float().requires_grad_(True)
     oref, _ = _attn_ref(qr, kr, vr, H, 1)
     q2, k2, v2 = qp.reshape(B * T, C), k.reshape(B * T, C), v.reshape(B * T, C)
-    o, lse = ops.attn_fwd(q2, k2, None, B, H, T, T, d, 1, need_lse=True, v=v2, prescaled=prescaled)
+    o, lse = ops.attn_fwd(q2, k2, v2, B, H, T, T, d, 1, need_lse=True, prescaled=prescaled)
     do = (rnd(B, T, C, dev=dev, seed=4).float() * gscale).half()
     oref.backward(do.float())
     dko, dvo = torch.empty(B * T, C, dtype=torch.float32, device=dev), torch.empty(B * T, C, dtype=torch.float32, device=dev)
@@ -594,7 +528,7 @@ def test_attention_prescaled_forward_with_a_very_negative_first_key_tile(ops, de
     qp = (q.float() * fac).half()
     oref, lref = _attn_ref((qp.float() / fac), k.float(), v.float(), H, 1)
     for qb_T in (T,):
-        o, lse = ops.attn_fwd(qp.reshape(B * T, C), k.reshape(B * T, C), None, B, H, T, T, d, 1, need_lse=True, v=v.reshape(B * T, C), prescaled=True)
+        o, lse = ops.attn_fwd(qp.reshape(B * T, C), k.reshape(B * T, C), v.reshape(B * T, C), B, H, T, T, d, 1, need_lse=True, prescaled=True)
         assert torch.isfinite(o).all() and torch.isfinite(lse).all()
         check("attn fwd (pre-scaled q, first tile far below the rest)", o.reshape(B, T, C), oref, 3e-3)
         check("attn lse (same)", lse, lref, 1e-3)
@@ -621,6 +555,51 @@ def test_gemm_column_scale(ops, dev, M, N, K, cols):
     check("gemm colscale + bias + residual", c2, ref2 + bias + res.float(), 2e-3)
 
 
+@pytest.mark.parametrize("C,B,HW,L,kv_div", [(320, 4, 1024, 77, 2), (320, 2, 4096, 77, 1), (640, 4, 256, 77, 2), (640, 2, 1024, 13, 1), (1280, 4, 64, 77, 2),
+                                              (1280, 2, 256, 80, 1), (320, 2, 64, 1, 1)])
+def test_cross_attn_block_one_launch(ops, dev, C, B, HW, L, kv_div):
+    """fd_cross_attn_block (csrc/crossattn.hip; north_star's named fusion): LayerNorm2 -> attn2.to_q -> attention over the L prompt tokens -> attn2.to_out +
+    residual -> LayerNorm3 in ONE launch, against (i) torch fp32 on the same fp16 inputs and (ii) the five separate launches of this library it replaces
+    (diffusers BasicTransformerBlock.forward: norm2 / attn2 / norm3; the processor selected at exp-1 main:811-817).  The two paths round q differently (here
+    once, pre-scaled; there fp16 first where d != 40), so (ii) is a tolerance, not bit-equality; the LayerNorms and the output epilogue follow the separate
+    kernels' arithmetic statement for statement."""
+    import torch.nn.functional as F
+    H, d, M, Bk = 8, C // 8, B * HW, B // kv_div
+    x = rnd(M, C, dev=dev, seed=1)
+    g2, b2 = rnd(C, dev=dev, dtype=torch.float32, seed=2) * 0.2 + 1, rnd(C, dev=dev, dtype=torch.float32, seed=3) * 0.2
+    g3, b3 = rnd(C, dev=dev, dtype=torch.float32, seed=4) * 0.2 + 1, rnd(C, dev=dev, dtype=torch.float32, seed=5) * 0.2
+    wq, wo = rnd(C, C, dev=dev, scale=C ** -0.5, seed=6), rnd(C, C, dev=dev, scale=C ** -0.5, seed=7)
+    bo = rnd(C, dev=dev, dtype=torch.float32, seed=8) * 0.1
+    k, v = rnd(Bk * L, C, dev=dev, seed=9), rnd(Bk * L, C, dev=dev, seed=10)
+    vt = ops.transpose_btc(v, Bk, L, C, ops.CROSS_LP)
+    assert ops.cross_block_ok(M, C, H, L, HW)
+    y, yn, st = ops.cross_attn_block(x, (g2, b2, 1e-5), wq, k, vt, L, wo, bo, (g3, b3, 1e-5), H, HW, kv_div, need_stats=True)
+    # (i) torch fp32
+    xf = x.float()
+    n2 = F.layer_norm(xf, (C,), g2, b2, 1e-5)
+    q = n2 @ wq.float().t()
+    o, _ = _attn_ref(q.view(B, HW, C), k.float().view(Bk, L, C), v.float().view(Bk, L, C), H, kv_div)
+    yr = o.reshape(M, C) @ wo.float().t() + bo + xf
+    ynr = F.layer_norm(yr, (C,), g3, b3, 1e-5)
+    check(f"cross block C={C}: y vs fp32", y, yr, 3e-3)
+    check(f"cross block C={C}: LayerNorm3(y) vs fp32", yn, ynr, 4e-3)
+    check("cross block: LayerNorm3 mean", st[:, 0], yr.mean(-1), 2e-3)
+    # (ii) the five launches
+    n2s = ops.layernorm(x, g2, b2, 1e-5)
+    qs = ops.q_prescale(d)
+    q2 = ops.gemm(n2s, wq, colscale=(qs, C) if qs is not None else None)
+    o2 = ops.attn_fwd(q2, k, v, B, H, HW, L, d, kv_div, prescaled=qs is not None)
+    ys = ops.gemm(o2, wo, bias=bo, residual=x)
+    yns, sts = ops.layernorm(ys, g3, b3, 1e-5, save_stats=True)
+    check("cross block: y vs the separate launches", y, ys.float(), 2e-3)
+    check("cross block: LayerNorm3(y) vs the separate launches", yn, yns.float(), 3e-3)
+    frac = float((y != ys).float().mean())
+    print(f"cross block C={C} M={M} L={L}: {100 * frac:.2f} % of y differ from the separate launches (by fp16 ulps)")
+    # determinism: no atomics, fixed reduction orders
+    y2, yn2, _ = ops.cross_attn_block(x, (g2, b2, 1e-5), wq, k, vt, L, wo, bo, (g3, b3, 1e-5), H, HW, kv_div)
+    assert torch.equal(y, y2) and torch.equal(yn, yn2)
+
+
 @pytest.mark.parametrize("B,H,T,d", [(2, 8, 1024, 40), (2, 8, 256, 80), (1, 4, 64, 160)])
 def test_attention_strided_qkv_slices(ops, dev, B, H, T, d):
     """q, k, v as column slices of ONE [M, 3C] projection buffer and dq, dk, dv written as slices of one [M, 3C] gradient buffer (the
@@ -629,43 +608,15 @@ def test_attention_strided_qkv_slices(ops, dev, B, H, T, d):
     qkv = rnd(B * T, 3 * C, dev=dev, seed=1)
     q, k, v = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
     qc, kc, vc = q.contiguous(), k.contiguous(), v.contiguous()
-    o_ref, lse_ref = ops.attn_fwd(qc, kc, ops.transpose_btc(vc, B, T, C), B, H, T, T, d, 1, need_lse=True)
-    vt = ops.transpose_btc(v, B, T, C)
-    assert torch.equal(vt, ops.transpose_btc(vc, B, T, C))
-    o, lse = ops.attn_fwd(q, k, vt, B, H, T, T, d, 1, need_lse=True)
+    o_ref, lse_ref = ops.attn_fwd(qc, kc, vc, B, H, T, T, d, 1, need_lse=True)
+    o, lse = ops.attn_fwd(q, k, v, B, H, T, T, d, 1, need_lse=True)          # v itself, row stride 3C
     assert torch.equal(o, o_ref) and torch.equal(lse, lse_ref)
-    o_tr, lse_tr = ops.attn_fwd(q, k, None, B, H, T, T, d, 1, need_lse=True, v=v)      # the shipped form: v itself, row stride 3C
-    assert torch.equal(o_tr, o_ref) and torch.equal(lse_tr, lse_ref)
     do = rnd(B * T, C, dev=dev, seed=4)
     dq_r, dk_r, dv_r = ops.attn_bwd(qc, kc, vc, o_ref, do, lse_ref, B, H, T, T, d, 1)
     dqkv = torch.full((B * T, 3 * C), float("nan"), dtype=qkv.dtype, device=dev)
     dq, dk, dv = ops.attn_bwd(q, k, v, o, do, lse, B, H, T, T, d, 1, dqkv=dqkv)
     assert dq.data_ptr() == dqkv.data_ptr() and torch.isfinite(dqkv.float()).all()
     assert torch.equal(dqkv[:, :C], dq_r) and torch.equal(dqkv[:, C:2 * C], dk_r) and torch.equal(dqkv[:, 2 * C:], dv_r)
-    o8 = ops.attn_fwd_fp8(q, k, v, B, H, T, d)
-    assert torch.equal(o8, ops.attn_fwd_fp8(qc, kc, vc, B, H, T, d))
-
-
-@pytest.mark.parametrize("B,H,T,d", [(2, 8, 1024, 40), (1, 8, 4096, 40), (2, 8, 256, 80), (2, 4, 256, 160), (1, 2, 64, 160)])
-def test_attention_fwd_fp8_band(ops, dev, B, H, T, d):
-    """BASELINE configs[4]: e4m3 QK^T / PV self-attention forward (per-row Q scale, per-64-key-tile K / V scales, fp32 softmax).
-    The reference never ran fp8, so acceptance is a stated BAND on the hardest input (white-noise q, k, v: no structure for the 3-bit
-    significand to exploit; measured 6.6e-2 .. 1.0e-1 max, 5e-2 RMS, LSE 3.6e-2): O within 1.5e-1 of max|O| and 7e-2 relative RMS of the
-    fp32 reference (the 16-bit kernel sits at 3e-3), LSE within 5e-2 absolute; the same band vs the 16-bit path of this library.
-    In the network the effect is an order of magnitude smaller: SD-v1.5 U-Net eps with e4m3 self-attention at all four levels differs
-    from the fp32 oracle by 1.3e-2 max / 9.5e-3 RMS (tests/run_bf16_checks.py::sd15_unet)."""
-    C = H * d
-    q, k, v = rnd(B, T, C, dev=dev, seed=1), rnd(B, T, C, dev=dev, seed=2), rnd(B, T, C, dev=dev, seed=3)
-    oref, lref = _attn_ref(q.float(), k.float(), v.float(), H)
-    o8, lse8 = ops.attn_fwd_fp8(q.reshape(B * T, C), k.reshape(B * T, C), v.reshape(B * T, C), B, H, T, d, need_lse=True)
-    vt = ops.transpose_btc(v.reshape(B * T, C), B, T, C)
-    o16, lse16 = ops.attn_fwd(q.reshape(B * T, C), k.reshape(B * T, C), vt, B, H, T, T, d, 1, need_lse=True)
-    rms = float((o8.reshape(B, T, C).float() - oref).pow(2).mean().sqrt() / oref.pow(2).mean().sqrt())
-    print(f"fp8 attention d={d} T={T}: rel RMS err vs fp32 {rms:.3e}; max|lse err| {float((lse8 - lref).abs().max()):.3e}")
-    check("attn fp8 fwd vs fp32", o8.reshape(B, T, C), oref, 1.5e-1)
-    check("attn fp8 fwd vs 16-bit path", o8.reshape(B, T, C), o16.reshape(B, T, C).float(), 1.5e-1)
-    assert rms < 7e-2              # RMS error relative to the RMS of O
-    assert float((lse8 - lref).abs().max()) < 5e-2
 
 
 @pytest.mark.parametrize("M,N,R", [(4096, 320, 4), (1000, 1280, 50), (777, 768, 16)])
