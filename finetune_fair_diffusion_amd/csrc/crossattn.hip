@@ -5,8 +5,7 @@
 //
 // (diffusers attention.py BasicTransformerBlock.forward: norm2 -> attn2 -> residual -> norm3; attn2 is the attention processor selected at
 // exp-1 main:811-817.)  Unfused, that is five launches -- fd_layernorm_fwd, fd_gemm, fd_attn_fwd, fd_gemm, fd_layernorm_fwd -- and n2, q, o and
-// h2 each make a round trip through HBM.  Here a workgroup owns BM rows of the residual stream (BM * C = 20480: 64 rows at C = 320, 32 at 640,
-// 16 at 1280) and keeps them in ONE LDS tile [BM][C + 8] that is, in turn, n2, q, o and the staged h2:
+// h2 each make a round trip through HBM.  Here a workgroup owns BM rows of the residual stream (64 rows and keeps them in ONE LDS tile [BM][C + 8] that is, in turn, n2, q, o and the staged h2:
 //
 //   P0  LayerNorm2 of the rows, one wave per row, same arithmetic as layernorm_kernel (bit-identical n2), written to the tile;
 //   P1  q = n2 . Wq^T: the four waves split the N = C columns (C / 4 each), so a B (weight) fragment is used by exactly one wave and goes
@@ -26,17 +25,20 @@
 #define CA_LOG2E 1.4426950408889634f
 
 template <int C> struct CrossCfg {
-    static constexpr int BM = 20480 / C;          // rows per workgroup
+    static constexpr int BM = 64;                 // rows per workgroup (C = 640: 83 KB of LDS, one workgroup per CU)
     static constexpr int TM = BM / 16;            // 16-row MFMA tiles per wave (every wave covers all rows)
     static constexpr int WN = C / 4;              // output columns per wave
     static constexpr int TN = WN / 16;            // 16-column MFMA tiles per wave
     static constexpr int NK = C / 32;             // k-steps of the two projections
-    static constexpr int PD = TN <= 5 ? 3 : TN <= 10 ? 2 : 1;     // B-fragment prefetch distance (register sets: PD + 1)
+    static constexpr int PD = TN <= 5 ? 3 : 1;     // B-fragment prefetch distance (register sets: PD + 1)
     static constexpr int LDT = C + 8;             // LDS row stride (halfs): 16-byte aligned rows, conflict-free 16-byte fragment reads
     static constexpr int MAXV = (C / 8 + 63) / 64;                // 16-byte vectors per lane of a row
     static constexpr int D = C / 8;               // head dim (8 heads)
     static constexpr int NKS = (D + 31) / 32;     // k-steps of q . k^T
     static constexpr int NDT = (D + 15) / 16;     // 16-row tiles of O^T
+    // workgroups per CU the register allocation is held to: two at C = 320 (253 registers, no scratch), so that one's row-wise phases and weight
+    // latencies hide under the other's MFMAs; the wider tiles need more than 256 registers for their B-fragment sets (348 B of scratch when capped)
+    static constexpr int OCC = C == 320 ? 2 : 1;
 };
 
 struct CrossArgs {
@@ -48,39 +50,62 @@ struct CrossArgs {
     int M, rows_per_sample, kv_div; float sl2;
 };
 
-// LayerNorm of one row held as MAXV vectors per lane (vector v = lane + 64 i): the arithmetic of layernorm_kernel<false, .>, statement for statement
-template <int C, int MAXV>
-__device__ __forceinline__ void ln_row(const f16x8 (&xv)[MAXV], const float (&gm)[MAXV][8], const float (&bt)[MAXV][8], float eps, int lane,
-                                       f16x8 (&out)[MAXV], float& mean_o, float& rstd_o) {
-    constexpr int V = C / 8;
-    float s0 = 0.f, s1 = 0.f;
+// LayerNorm of R rows, each held as MAXV vectors per lane (vector v = lane + 64 i): per row the arithmetic of layernorm_kernel<false, .>, statement for
+// statement (bit-identical outputs); the rows' shuffle trees are walked level by level so that R independent cross-lane exchanges are in flight instead of one
+template <int R>
+__device__ __forceinline__ void wave_sum_rows(float (&s)[R]) {
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
-        const int v = lane + i * 64;
-        if (v < V) {
+    for (int o = 32; o > 0; o >>= 1) {
+        float t[R];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) s0 += (float)xv[i][j];
-        }
+        for (int r = 0; r < R; ++r) t[r] = __shfl_xor(s[r], o, 64);
+#pragma unroll
+        for (int r = 0; r < R; ++r) s[r] += t[r];
     }
-    const float mean = wave_sum(s0) / C;
+}
+template <int C, int MAXV, int R>
+__device__ __forceinline__ void ln_rows(const f16x8 (&xv)[R][MAXV], float eps, int lane, float (&mean)[R], float (&rstd)[R]) {
+    constexpr int V = C / 8;
+    float s0[R], s1[R];
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
-        const int v = lane + i * 64;
-        if (v < V) {
+    for (int r = 0; r < R; ++r) {
+        s0[r] = 0.f;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float d = (float)xv[i][j] - mean;
-                s1 += d * d;
+        for (int i = 0; i < MAXV; ++i) {
+            const int v = lane + i * 64;
+            if (v < V) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) s0[r] += (float)xv[r][i][j];
             }
         }
     }
-    const float rstd = rsqrtf(wave_sum(s1) / C + eps);
+    wave_sum_rows<R>(s0);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        mean[r] = s0[r] / C;
+        s1[r] = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int v = lane + i * 64;
+            if (v < V) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float d = (float)xv[r][i][j] - mean[r];
+                    s1[r] += d * d;
+                }
+            }
+        }
+    }
+    wave_sum_rows<R>(s1);
+#pragma unroll
+    for (int r = 0; r < R; ++r) rstd[r] = rsqrtf(s1[r] / C + eps);
+}
+template <int MAXV>
+__device__ __forceinline__ void ln_apply(const f16x8 (&xv)[MAXV], float mean, float rstd, const float (&gm)[MAXV][8], const float (&bt)[MAXV][8], f16x8 (&out)[MAXV]) {
 #pragma unroll
     for (int i = 0; i < MAXV; ++i)
 #pragma unroll
         for (int j = 0; j < 8; ++j) out[i][j] = (f16)(((float)xv[i][j] - mean) * rstd * gm[i][j] + bt[i][j]);
-    mean_o = mean;
-    rstd_o = rstd;
 }
 
 // acc[i][j] (+)= tile rows [16 i, 16 i + 16) . W rows [n0 + 16 j, ...)^T over K = C; lane (l15, lg) ends up holding C[m = 16 i + l15][n = n0 + 16 j + 4 lg .. + 3]
@@ -116,11 +141,12 @@ __device__ __forceinline__ void project(f32x4 (&acc)[CrossCfg<C>::TM][CrossCfg<C
 }
 
 template <int C>
-__global__ __launch_bounds__(256) void cross_block_kernel(CrossArgs a) {
+__global__ __launch_bounds__(256, CrossCfg<C>::OCC) void cross_block_kernel(CrossArgs a) {
     using Cf = CrossCfg<C>;
     constexpr int BM = Cf::BM, TM = Cf::TM, TN = Cf::TN, LDT = Cf::LDT, MAXV = Cf::MAXV, D = Cf::D, NKS = Cf::NKS, NDT = Cf::NDT, V = C / 8;
     constexpr int RPW = BM / 4;                   // rows per wave in the row-wise phases
-    __shared__ __attribute__((aligned(16))) f16 tile[BM * LDT];
+    constexpr int RG = RPW * MAXV <= 16 ? RPW : 16 / MAXV;      // ... taken in groups of RG rows (<= 16 vectors = 64 registers of row data per lane at a time)
+    extern __shared__ __attribute__((aligned(16))) f16 tile[];       // [BM][LDT]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l15 = lane & 15, lg = lane >> 4;
     const int row0 = blockIdx.x * BM;
@@ -138,24 +164,28 @@ __global__ __launch_bounds__(256) void cross_block_kernel(CrossArgs a) {
                 bt[i][j] = v < V ? a.b2[v * 8 + j] : 0.f;
             }
         }
-        f16x8 xv[RPW][MAXV];
-#pragma unroll
-        for (int r = 0; r < RPW; ++r)
-#pragma unroll
-            for (int i = 0; i < MAXV; ++i) {
-                const int v = lane + i * 64;
-                xv[r][i] = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
-                if (v < V) xv[r][i] = *(const f16x8*)(a.x + (int64_t)(row0 + wave * RPW + r) * C + v * 8);
-            }
-#pragma unroll
-        for (int r = 0; r < RPW; ++r) {
-            f16x8 o[MAXV];
-            float mean, rstd;
-            ln_row<C, MAXV>(xv[r], gm, bt, a.eps2, lane, o, mean, rstd);
-#pragma unroll
-            for (int i = 0; i < MAXV; ++i) {
-                const int v = lane + i * 64;
-                if (v < V) *(f16x8*)(tile + (wave * RPW + r) * LDT + v * 8) = o[i];
+#pragma unroll 1
+        for (int rg = 0; rg < RPW; rg += RG) {
+            f16x8 xv[RG][MAXV];
+    #pragma unroll
+            for (int r = 0; r < RG; ++r)
+    #pragma unroll
+                for (int i = 0; i < MAXV; ++i) {
+                    const int v = lane + i * 64;
+                    xv[r][i] = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
+                    if (v < V) xv[r][i] = *(const f16x8*)(a.x + (int64_t)(row0 + wave * RPW + rg + r) * C + v * 8);
+                }
+            float mean[RG], rstd[RG];
+            ln_rows<C, MAXV, RG>(xv, a.eps2, lane, mean, rstd);
+    #pragma unroll
+            for (int r = 0; r < RG; ++r) {
+                f16x8 o[MAXV];
+                ln_apply<MAXV>(xv[r], mean[r], rstd[r], gm, bt, o);
+    #pragma unroll
+                for (int i = 0; i < MAXV; ++i) {
+                    const int v = lane + i * 64;
+                    if (v < V) *(f16x8*)(tile + (wave * RPW + rg + r) * LDT + v * 8) = o[i];
+                }
             }
         }
     }
@@ -164,7 +194,18 @@ __global__ __launch_bounds__(256) void cross_block_kernel(CrossArgs a) {
     // ---------------------------------------------------------------- P1: q = n2 . Wq^T, scaled into the exponent's domain -> tile
     f32x4 acc[TM][TN];
     const int n0 = wave * Cf::WN;
-    project<C>(acc, tile, a.wq, n0, l15, lg);
+#ifdef FD_CROSS_SKIP        // measurement builds only (scratch/r05_passes.sh o): phases left out, results meaningless
+    constexpr int SKIP = FD_CROSS_SKIP;
+#else
+    constexpr int SKIP = 0;
+#endif
+    if (!(SKIP & 2)) project<C>(acc, tile, a.wq, n0, l15, lg);
+    else {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){1.f, 1.f, 1.f, 1.f};
+    }
     __syncthreads();                               // every wave has read all of n2
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -179,7 +220,7 @@ __global__ __launch_bounds__(256) void cross_block_kernel(CrossArgs a) {
 
     // ---------------------------------------------------------------- P2: attention over the <= 80 keys, heads 2 wave, 2 wave + 1; o overwrites q
 #pragma unroll 1
-    for (int hh = 0; hh < 2; ++hh) {
+    for (int hh = 0; hh < ((SKIP & 4) ? 0 : 2); ++hh) {
         const int c0 = (wave * 2 + hh) * D;       // first column of the head
         // K fragments [key tile][k-step]: lane (key = 16 kt + l15, k = 32 ks + 8 lg ..); k >= D and keys >= L are zero
         f16x8 kf[5][NKS];
@@ -265,7 +306,7 @@ __global__ __launch_bounds__(256) void cross_block_kernel(CrossArgs a) {
     __syncthreads();
 
     // ---------------------------------------------------------------- P3: h2 = o . Wo^T + bo + h1 -> y;  n3 = LayerNorm3(h2) -> yn
-    project<C>(acc, tile, a.wo, n0, l15, lg);
+    if (!(SKIP & 8)) project<C>(acc, tile, a.wo, n0, l15, lg);
     __syncthreads();                               // every wave has read all of o
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -288,42 +329,50 @@ __global__ __launch_bounds__(256) void cross_block_kernel(CrossArgs a) {
                 bt[i][j] = (a.yn && v < V) ? a.b3[v * 8 + j] : 0.f;
             }
         }
-        f16x8 rv[RPW][MAXV];
-#pragma unroll
-        for (int r = 0; r < RPW; ++r)
-#pragma unroll
-            for (int i = 0; i < MAXV; ++i) {
-                const int v = lane + i * 64;
-                rv[r][i] = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
-                if (v < V) rv[r][i] = *(const f16x8*)(a.x + (int64_t)(row0 + wave * RPW + r) * C + v * 8);
-            }
-#pragma unroll
-        for (int r = 0; r < RPW; ++r) {
-            const int64_t row = row0 + wave * RPW + r;
-            f16x8 hv[MAXV];
-#pragma unroll
-            for (int i = 0; i < MAXV; ++i) {
-                const int v = lane + i * 64;
-                hv[i] = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
-                if (v < V) {
-                    const f16x8 st = *(const f16x8*)(tile + (wave * RPW + r) * LDT + v * 8);
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) hv[i][j] = (f16)((float)st[j] + (float)rv[r][i][j]);
-                    *(f16x8*)(a.y + row * C + v * 8) = hv[i];
+#pragma unroll 1
+        for (int rg = 0; rg < RPW; rg += RG) {
+            f16x8 rv[RG][MAXV];
+    #pragma unroll
+            for (int r = 0; r < RG; ++r)
+    #pragma unroll
+                for (int i = 0; i < MAXV; ++i) {
+                    const int v = lane + i * 64;
+                    rv[r][i] = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
+                    if (v < V) rv[r][i] = *(const f16x8*)(a.x + (int64_t)(row0 + wave * RPW + rg + r) * C + v * 8);
+                }
+            f16x8 hv[RG][MAXV];
+    #pragma unroll
+            for (int r = 0; r < RG; ++r) {
+                const int64_t row = row0 + wave * RPW + rg + r;
+    #pragma unroll
+                for (int i = 0; i < MAXV; ++i) {
+                    const int v = lane + i * 64;
+                    hv[r][i] = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
+                    if (v < V) {
+                        const f16x8 st = *(const f16x8*)(tile + (wave * RPW + rg + r) * LDT + v * 8);
+    #pragma unroll
+                        for (int j = 0; j < 8; ++j) hv[r][i][j] = (f16)((float)st[j] + (float)rv[r][i][j]);
+                        *(f16x8*)(a.y + row * C + v * 8) = hv[r][i];
+                    }
                 }
             }
             if (a.yn) {
-                f16x8 o[MAXV];
-                float mean, rstd;
-                ln_row<C, MAXV>(hv, gm, bt, a.eps3, lane, o, mean, rstd);
-#pragma unroll
-                for (int i = 0; i < MAXV; ++i) {
-                    const int v = lane + i * 64;
-                    if (v < V) *(f16x8*)(a.yn + row * C + v * 8) = o[i];
-                }
-                if (a.yn_stats && lane == 0) {
-                    a.yn_stats[row * 2] = mean;
-                    a.yn_stats[row * 2 + 1] = rstd;
+                float mean[RG], rstd[RG];
+                ln_rows<C, MAXV, RG>(hv, a.eps3, lane, mean, rstd);
+    #pragma unroll
+                for (int r = 0; r < RG; ++r) {
+                    const int64_t row = row0 + wave * RPW + rg + r;
+                    f16x8 o[MAXV];
+                    ln_apply<MAXV>(hv[r], mean[r], rstd[r], gm, bt, o);
+    #pragma unroll
+                    for (int i = 0; i < MAXV; ++i) {
+                        const int v = lane + i * 64;
+                        if (v < V) *(f16x8*)(a.yn + row * C + v * 8) = o[i];
+                    }
+                    if (a.yn_stats && lane == 0) {
+                        a.yn_stats[row * 2] = mean[r];
+                        a.yn_stats[row * 2 + 1] = rstd[r];
+                    }
                 }
             }
         }
@@ -335,9 +384,11 @@ extern "C" int fd_cross_attn_block(const fd_cross_block_desc* dp, void* stream) 
     const fd_cross_block_desc& d = *dp;
     FD_REQUIRE(d.x && d.ln2_gamma && d.ln2_beta && d.wq && d.k && d.vt && d.wo && d.bo && d.y, "fd_cross_attn_block: null operand");
     FD_REQUIRE(!d.yn || (d.ln3_gamma && d.ln3_beta), "fd_cross_attn_block: yn needs ln3_gamma / ln3_beta");
-    FD_REQUIRE(d.C == 320 || d.C == 640 || d.C == 1280, "fd_cross_attn_block: C=%d (320 / 640 / 1280: eight heads of 40 / 80 / 160)", d.C);
+    // C = 1280 (the 16^2 / 8^2 levels, M <= 4096 rows) is refused: a 64-row tile of 1280 columns does not fit the LDS, and with 16-row tiles every workgroup
+    // streams both 3.3 MB weight matrices for 16 rows -- measured 205 us against 103 us for the five launches (profiles/r05_cross_block_fused.txt)
+    FD_REQUIRE(d.C == 320 || d.C == 640, "fd_cross_attn_block: C=%d (320 / 640: eight heads of 40 / 80)", d.C);
     FD_REQUIRE(d.heads == 8, "fd_cross_attn_block: heads=%d (8)", d.heads);
-    const int bm = 20480 / d.C;
+    const int bm = 64;
     FD_REQUIRE(d.M > 0 && d.M % bm == 0 && d.rows_per_sample > 0 && d.rows_per_sample % bm == 0 && d.M % d.rows_per_sample == 0,
                "fd_cross_attn_block: M=%d and rows_per_sample=%d must be multiples of the %d-row tile", d.M, d.rows_per_sample, bm);
     FD_REQUIRE(d.L > 0 && d.L <= 80 && d.Lp >= 80 && (d.Lp & 3) == 0 && d.kv_div >= 1 && (d.M / d.rows_per_sample) % d.kv_div == 0,
@@ -350,10 +401,17 @@ extern "C" int fd_cross_attn_block(const fd_cross_block_desc* dp, void* stream) 
     a.M = d.M; a.rows_per_sample = d.rows_per_sample; a.kv_div = d.kv_div;
     a.sl2 = d.scale * CA_LOG2E;
     const dim3 grid(d.M / bm), block(256);
-    switch (d.C) {
-        case 320: hipLaunchKernelGGL(cross_block_kernel<320>, grid, block, 0, (hipStream_t)stream, a); break;
-        case 640: hipLaunchKernelGGL(cross_block_kernel<640>, grid, block, 0, (hipStream_t)stream, a); break;
-        default: hipLaunchKernelGGL(cross_block_kernel<1280>, grid, block, 0, (hipStream_t)stream, a); break;
+#define CROSS_LAUNCH(CC)                                                                                                        \
+    {                                                                                                                           \
+        constexpr size_t lds = (size_t)CrossCfg<CC>::BM * CrossCfg<CC>::LDT * 2;                                                \
+        static bool once = false;                                                                                               \
+        if (!once) {                                                                                                            \
+            (void)hipFuncSetAttribute((const void*)cross_block_kernel<CC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            once = true;                                                                                                        \
+        }                                                                                                                       \
+        hipLaunchKernelGGL(cross_block_kernel<CC>, grid, block, lds, (hipStream_t)stream, a);                                   \
     }
+    if (d.C == 320) CROSS_LAUNCH(320) else CROSS_LAUNCH(640)
+#undef CROSS_LAUNCH
     return fd_check_launch("fd_cross_attn_block");
 }

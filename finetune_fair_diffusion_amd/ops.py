@@ -562,8 +562,11 @@ FUSED_CROSS = os.environ.get("FD_NO_FUSED_CROSS") is None
 CROSS_LP = 80          # key padding of the transposed V the fused kernel reads
 
 
+CROSS_WIDTHS = tuple(int(c) for c in os.environ.get("FD_FUSED_CROSS_C", "320,640").split(",") if c)      # measurement: which levels take the fused kernel
+
+
 def cross_block_ok(M, C, heads, L, rows_per_sample):
-    return (FUSED_CROSS and C in (320, 640, 1280) and heads == 8 and L <= CROSS_LP and M % (20480 // C) == 0 and rows_per_sample % (20480 // C) == 0)
+    return (FUSED_CROSS and C in CROSS_WIDTHS and heads == 8 and C in (320, 640) and L <= CROSS_LP and M % 64 == 0 and rows_per_sample % 64 == 0)
 
 
 def cross_attn_block(x, ln2, wq, k, vt, L, wo, bo, ln3, heads, rows_per_sample, kv_div, need_stats=False):

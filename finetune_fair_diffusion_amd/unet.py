@@ -122,7 +122,7 @@ class TransformerBlock:
         else:
             K, V = ops.gemm(enc, self.k2.w), ops.gemm(enc, self.v2.w)
         self.cross = dict(static=bool(static and lo is None), K=K, V=V, Bk=Bk, L=L, enc=enc, te=te)
-        if lo is None and not record and ops.FUSED_CROSS and L <= ops.CROSS_LP and self.C in (320, 640, 1280) and self.heads == 8:
+        if lo is None and not record and ops.FUSED_CROSS and L <= ops.CROSS_LP and self.C in ops.CROSS_WIDTHS and self.heads == 8:
             # the one-launch cross-attention sub-block (ops.cross_attn_block) reads V transposed, keys zero-padded to 80: made once per rollout; a captured
             # forward holds its address like K's and V's
             self.cross["Vt80"] = ops.transpose_btc(V, Bk, L, self.C, ops.CROSS_LP, out=old.get("Vt80") if (static and old) else None)

@@ -204,7 +204,7 @@ int fd_sum_slabs(const float* in, float* out, int nslab, int64_t n, void* stream
  *     n2 = LayerNorm(x; ln2);  q = n2 . wq^T;  o = softmax(q k^T * scale) v;  y = o . wo^T + bo + x;  yn = LayerNorm(y; ln3)
  * x, y, yn: [M, C] working dtype, contiguous; wq, wo: [C, C] (out, in); k: [Bk*L, C] (the L <= 80 prompt tokens per sample, as fd_attn_fwd takes
  * them); vt: [Bk, C, Lp] = V transposed with zero-padded keys (fd_transpose_btc, Lp >= 80); row m belongs to sample m / rows_per_sample, which reads
- * K / V batch (m / rows_per_sample) / kv_div.  C in {320, 640, 1280} with 8 heads; M and rows_per_sample multiples of 20480 / C.
+ * K / V batch (m / rows_per_sample) / kv_div.  C in {320, 640} with 8 heads (the 64^2 / 32^2 levels; wider levels keep the separate launches); M and rows_per_sample multiples of 64.
  * yn (and ln3_*) may be NULL; yn_stats [M, 2] = (mean, rstd) of LayerNorm3 or NULL.  Replaces fd_layernorm_fwd + fd_gemm + fd_attn_fwd + fd_gemm +
  * fd_layernorm_fwd; y, yn are bit-identical to that sequence's wherever its attention output o is (the softmax here rounds q once, pre-scaled). */
 typedef struct fd_cross_block_desc {

@@ -16,7 +16,7 @@ def timeit(fn, n=20, rep=5):
     return sorted(ts)[len(ts) // 2]
 B, L, H = 16, 77, 8
 print("C HW M fused_us separate_us (ln2 q attn out ln3)")
-for C, HW in ((320, 4096), (640, 1024), (1280, 256), (1280, 64)):
+for C, HW in ((320, 4096), (640, 1024)):
     M, d, Bk = B * HW, C // 8, 2
     x = rnd(M, C); g2, b2, g3, b3 = (rnd(C, dt=torch.float32) for _ in range(4)); wq, wo = rnd(C, C, scale=C ** -0.5), rnd(C, C, scale=C ** -0.5)
     bo = rnd(C, dt=torch.float32); k, v = rnd(Bk * L, C), rnd(Bk * L, C); vt = ops.transpose_btc(v, Bk, L, C, 80)
@@ -32,4 +32,4 @@ for C, HW in ((320, 4096), (640, 1024), (1280, 256), (1280, 64)):
         y = ops.gemm(o, wo, bias=bo, residual=x); return ops.layernorm(y, g3, b3)
     s = timeit(sep)
     gf = (4.0 * M * C * C + 4.0 * M * L * C) / 1e9
-    print(f"{C} {HW} {M} fused {f:.1f} us ({gf / f * 1e-3:.0f} TF)  separate {s:.1f} us  parts " + " ".join(f"{p:.1f}" for p in parts), flush=True)
+    print(f"{C} {HW} {M} fused {f:.1f} us ({gf / f * 1e3:.0f} TF)  separate {s:.1f} us  parts " + " ".join(f"{p:.1f}" for p in parts), flush=True)

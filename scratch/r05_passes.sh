@@ -102,6 +102,37 @@ j)  # what bounds the GEMM / conv kernels on COLD operands: L2 hit rates and req
     cd $R; cp gpurun_out/pmc_r05_manifest.json $O/ 2>/dev/null; ls -la $O
     ;;
 k)  timeout 1200 python scratch/mb_pp_ablate.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r05k_pp_ablation.txt ;;
+z)  # final validation of the tree: full GPU suite, smoke, the driver's default bench line, a 20-step line, the fused cross-attention A/B, a kernel trace
+    O=gpurun_out/r05z; mkdir -p $O
+    python -m pytest tests -m gpu -x -q -s > $O/pytest_gpu.log 2>&1; echo rc=$? >> $O/pytest_gpu.log; tail -4 $O/pytest_gpu.log
+    python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -1 $O/smoke.log
+    python bench.py > $O/bench_default.json 2> $O/bench_default.err; cut -c1-250 $O/bench_default.json
+    for i in 1 2; do
+      for v in "FD_NO_FUSED_CROSS=1" "FD_NOTHING=1"; do
+        n=$(echo "$v" | tr '=;, ' '____')
+        env $v $B --steps 6 --warmup 2 > $O/ab_${n}_$i.json 2> $O/ab_${n}_$i.err || tail -3 $O/ab_${n}_$i.err
+      done
+    done
+    bench_table "$O/ab_*.json" | tee $O/ab_summary.txt
+    python bench.py --steps 20 --warmup 5 --cpu_baseline_bounded > $O/bench_steps20.json 2> $O/bench_steps20.err; cut -c1-250 $O/bench_steps20.json
+    cd /tmp && export TMPDIR=/tmp
+    timeout 900 rocprofv3 --kernel-trace -d /tmp/prof_r05z -o r05z -- python3 $R/bench.py --steps 4 --warmup 2 --no_cpu_baseline --no_roofline > $R/$O/bench_trace.json 2> $R/$O/bench_trace.err
+    cd $R
+    DB=$(find /tmp/prof_r05z -name "*.db" | head -1)
+    python scratch/profsum.py $DB $O/kernel_stats.csv 30 > $O/kernel_stats_top.txt; head -12 $O/kernel_stats_top.txt | cut -c1-200
+    ;;
+n)  # fused cross-attention sub-block: parity, isolated timing, whole-step A/B (alternating arms)
+    O=gpurun_out/r05n; mkdir -p $O
+    python -m pytest tests/test_kernels_gpu.py -m gpu -x -q -s -k "cross_attn_block" > $O/test_cross.log 2>&1; tail -3 $O/test_cross.log
+    python scratch/mb_cross.py 2>&1 | tee $O/mb_cross.txt
+    for i in 1 2; do
+      for v in "FD_NO_FUSED_CROSS=1" "FD_FUSED_CROSS_C=320" "FD_FUSED_CROSS_C=320,640" "FD_FUSED_CROSS_C=320,640,1280"; do
+        n=$(echo "$v" | tr '=;, ' '____')
+        env $v $B --steps 6 --warmup 2 > $O/${n}_$i.json 2> $O/${n}_$i.err || tail -3 $O/${n}_$i.err
+      done
+    done
+    bench_table "$O/*.json" | tee $O/summary.txt
+    ;;
 m)  # (needs scratch/r05_cu_mask_streams.patch) follow-up of pass l: only the PREFETCH of the next step's frozen rollout is CU-confined (its own stream "r2p"), everything else unmasked
     O=gpurun_out/r05m; mkdir -p $O
     for i in 1 2; do

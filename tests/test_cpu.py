@@ -264,7 +264,7 @@ def test_gemm_dispatch_name_statistics_rows_and_launcher_agree():
     for f in ("x", "ln2_gamma", "ln2_beta", "wq", "k", "vt", "wo", "bo", "y"):
         setattr(c, f, 1 << 20)
     c.M, c.C, c.heads, c.rows_per_sample, c.kv_div, c.L, c.Lp, c.scale = 4096, 320, 8, 1024, 1, 77, 80, 40 ** -0.5
-    for field, bad, msg in (("C", 512, b"C=512"), ("L", 81, b"<= 80 keys"), ("M", 4100, b"multiples of the 64-row tile"), ("heads", 5, b"heads=5"), ("Lp", 72, b"Lp=72")):
+    for field, bad, msg in (("C", 1280, b"C=1280"), ("L", 81, b"<= 80 keys"), ("M", 4100, b"multiples of the 64-row tile"), ("heads", 5, b"heads=5"), ("Lp", 72, b"Lp=72")):
         good = getattr(c, field)
         setattr(c, field, bad)
         assert L.fd_cross_attn_block(ctypes.byref(c), None) == -1 and msg in L.fd_last_error(), (field, L.fd_last_error())

@@ -555,8 +555,8 @@ def test_gemm_column_scale(ops, dev, M, N, K, cols):
     check("gemm colscale + bias + residual", c2, ref2 + bias + res.float(), 2e-3)
 
 
-@pytest.mark.parametrize("C,B,HW,L,kv_div", [(320, 4, 1024, 77, 2), (320, 2, 4096, 77, 1), (640, 4, 256, 77, 2), (640, 2, 1024, 13, 1), (1280, 4, 64, 77, 2),
-                                              (1280, 2, 256, 80, 1), (320, 2, 64, 1, 1)])
+@pytest.mark.parametrize("C,B,HW,L,kv_div", [(320, 4, 1024, 77, 2), (320, 2, 4096, 77, 1), (640, 4, 256, 77, 2), (640, 2, 1024, 13, 1), (640, 2, 64, 80, 1),
+                                              (320, 2, 64, 1, 1)])
 def test_cross_attn_block_one_launch(ops, dev, C, B, HW, L, kv_div):
     """fd_cross_attn_block (csrc/crossattn.hip; north_star's named fusion): LayerNorm2 -> attn2.to_q -> attention over the L prompt tokens -> attn2.to_out +
     residual -> LayerNorm3 in ONE launch, against (i) torch fp32 on the same fp16 inputs and (ii) the five separate launches of this library it replaces
