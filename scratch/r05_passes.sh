@@ -121,6 +121,38 @@ z)  # final validation of the tree: full GPU suite, smoke, the driver's default 
     DB=$(find /tmp/prof_r05z -name "*.db" | head -1)
     python scratch/profsum.py $DB $O/kernel_stats.csv 30 > $O/kernel_stats_top.txt; head -12 $O/kernel_stats_top.txt | cut -c1-200
     ;;
+q)  # would hipBLASLt's full-chip persistent tiles pay inside the step?  plain GEMMs of the medium-M levels routed through torch (measurement switch FD_BLASLT)
+    O=gpurun_out/r05q; mkdir -p $O
+    for i in 1 2; do
+      for v in "FD_NOTHING=1" "FD_BLASLT=1" "FD_BLASLT=1 FD_BLASLT_MAXM=65536 FD_BLASLT_MINN=320" "FD_BLASLT=1 FD_BLASLT_MAXM=4096"; do
+        n=$(echo "$v" | tr '=;, ' '____')
+        env $v $B --steps 6 --warmup 2 > $O/${n}_$i.json 2> $O/${n}_$i.err || tail -3 $O/${n}_$i.err
+      done
+    done
+    bench_table "$O/*.json" | tee $O/summary.txt
+    ;;
+p)  # calibration against hipBLASLt (torch): which kernels it picks on the step's dense shapes, and the tile-policy thresholds re-measured inside the step
+    O=gpurun_out/r05p; mkdir -p $O
+    cd /tmp && export TMPDIR=/tmp
+    timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_r05p -o p -- python3 $R/scratch/mb_blaslt_names.py > $R/$O/names.log 2>&1
+    cd $R
+    find /tmp/prof_r05p -name "*kernel_stats*" | head -2
+    python - <<'PY' > $O/blaslt_kernels.txt
+import glob, csv
+for f in glob.glob('/tmp/prof_r05p/**/*kernel_stats.csv', recursive=True):
+    for r in csv.DictReader(open(f)):
+        print(r.get('Name', '')[:260], r.get('Calls'), r.get('AverageNs'))
+PY
+    cat $O/blaslt_kernels.txt | cut -c1-300
+    L=$P/libfairdiff_hip_bench.so
+    for i in 1 2; do
+      for v in "FD_NOTHING=1" "FD_GEMM_T256=200 FD_GEMM_T128=160" "FD_GEMM_T256=160 FD_GEMM_T128=128" "FD_GEMM_T256=257 FD_GEMM_T128=200"; do
+        n=$(echo "$v" | tr '=;, ' '____')
+        env FAIRDIFF_LIB=$L $v $B --steps 6 --warmup 2 > $O/tile_${n}_$i.json 2> $O/tile_${n}_$i.err || tail -3 $O/tile_${n}_$i.err
+      done
+    done
+    bench_table "$O/tile_*.json" | tee $O/tile_summary.txt
+    ;;
 n)  # fused cross-attention sub-block: parity, isolated timing, whole-step A/B (alternating arms)
     O=gpurun_out/r05n; mkdir -p $O
     python -m pytest tests/test_kernels_gpu.py -m gpu -x -q -s -k "cross_attn_block" > $O/test_cross.log 2>&1; tail -3 $O/test_cross.log
