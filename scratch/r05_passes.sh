@@ -121,6 +121,21 @@ z)  # final validation of the tree: full GPU suite, smoke, the driver's default 
     DB=$(find /tmp/prof_r05z -name "*.db" | head -1)
     python scratch/profsum.py $DB $O/kernel_stats.csv 30 > $O/kernel_stats_top.txt; head -12 $O/kernel_stats_top.txt | cut -c1-200
     ;;
+r)  # is the step bound by the host's enqueue rate?  a busy-wait in front of every C-ABI call (FD_HOST_SPIN_US), whole step
+    O=gpurun_out/r05r; mkdir -p $O
+    for i in 1 2; do
+      for v in "FD_HOST_SPIN_US=0" "FD_HOST_SPIN_US=1" "FD_HOST_SPIN_US=2" "FD_HOST_SPIN_US=4"; do
+        n=$(echo "$v" | tr '=;, ' '____')
+        env $v $B --steps 6 --warmup 2 > $O/${n}_$i.json 2> $O/${n}_$i.err || tail -3 $O/${n}_$i.err
+      done
+    done
+    bench_table "$O/*.json" | tee $O/summary.txt
+    python - <<'PY'
+import json, glob
+for f in sorted(glob.glob('gpurun_out/r05r/*.json')):
+    d = json.loads(open(f).read().strip().splitlines()[-1]); print(f, d['config'].get('host_ms_between_phase_marks'))
+PY
+    ;;
 q)  # would hipBLASLt's full-chip persistent tiles pay inside the step?  plain GEMMs of the medium-M levels routed through torch (measurement switch FD_BLASLT)
     O=gpurun_out/r05q; mkdir -p $O
     for i in 1 2; do
