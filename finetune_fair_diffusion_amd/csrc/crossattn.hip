@@ -7,7 +7,7 @@
 // exp-1 main:811-817.)  Unfused, that is five launches -- fd_layernorm_fwd, fd_gemm, fd_attn_fwd, fd_gemm, fd_layernorm_fwd -- and n2, q, o and
 // h2 each make a round trip through HBM.  Here a workgroup owns BM rows of the residual stream (64 rows and keeps them in ONE LDS tile [BM][C + 8] that is, in turn, n2, q, o and the staged h2:
 //
-//   P0  LayerNorm2 of the rows, one wave per row, same arithmetic as layernorm_kernel (bit-identical n2), written to the tile;
+//   P0  LayerNorm2 of the rows, one wave per row, same arithmetic as layernorm_kernel (identical statistics; outputs within one ulp), written to the tile;
 //   P1  q = n2 . Wq^T: the four waves split the N = C columns (C / 4 each), so a B (weight) fragment is used by exactly one wave and goes
 //       global -> registers directly (16 bytes per lane, prefetched two k-steps ahead); A fragments come from the tile; 16x16x32 MFMAs with the
 //       operands swapped so that a lane holds q[m][n .. n + 3]; q is rounded once, multiplied by softmax_scale * log2(e), and overwrites the tile;
@@ -19,7 +19,12 @@
 //       rounding sequence of fd_gemm's LDS-staged epilogue, bit-identical h2 for identical o), stores h2, and LayerNorm3 of the row (as P0) -> n3.
 //
 // Algorithmic HBM traffic per row: read h1 twice (the second read is an L2 hit), write h2 and n3: 4 C * 2 B against 14 C * 2 B unfused.
-// No LoRA slabs and no recording yet: the frozen rollout R2 (exp-1 main:1844-1858) and every no-grad forward; R1 / R3 keep the five launches.
+// Template arguments: LORA -- the LoRA slabs of attn2.to_q / to_out ride in the kernel: t = tile . down^T (N = the padded rank, one 16-row MFMA tile per wave, rounded to
+// the working dtype like fd_gemm's skinny kernel does) is parked in a second small LDS tile and enters the projection as one more k-step against up (the
+// second K-slab of fd_gemm, same order); REC -- everything the backward consumes is written on the way: n2, the LayerNorm2 statistics, q as fd_attn_bwd_* take it, t_q,
+// o, the log-sum-exp, t_o, the LayerNorm3 statistics (7 C * 2 B per row more; the recording forward of the finetuned model R1 = R3's forward, exp-1 main:1786-1795).
+// The plain instantiation serves the frozen rollout R2 (exp-1 main:1844-1858).  The first transformer block of the U-Net keeps the separate launches (its query is
+// computed once for the CFG pair), and so do the C = 1280 levels.
 #include "common.h"
 
 #define CA_LOG2E 1.4426950408889634f
@@ -48,7 +53,13 @@ struct CrossArgs {
     const float* g3; const float* b3; float eps3;
     f16* y; f16* yn; float* yn_stats;
     int M, rows_per_sample, kv_div; float sl2;
+    // LoRA slabs of attn2.to_q / to_out (LORA): down [rp, C] (row stride ld_*d), up [C, rp] (row stride ld_*u), rp <= 16
+    const f16* qd; const f16* qu; const f16* od; const f16* ou; int ld_qd, ld_qu, ld_od, ld_ou, rp;
+    // what the backward needs (REC): n2, LayerNorm2 statistics, q as the attention backward takes it (times q_store), t_q = n2 . down_q^T, o, the log-sum-exp, t_o
+    f16* n2_out; float* ln2_stats; f16* q_out; f16* tq_out; f16* o_out; float* lse_out; f16* to_out; float q_store;
 };
+
+constexpr int CROSS_LDB = 40;        // row stride (halfs) of the LoRA t tile [64][32 + 8]: 16-byte aligned rows
 
 // LayerNorm of R rows, each held as MAXV vectors per lane (vector v = lane + 64 i): per row the arithmetic of layernorm_kernel<false, .>, statement for
 // statement (bit-identical outputs); the rows' shuffle trees are walked level by level so that R independent cross-lane exchanges are in flight instead of one
@@ -109,9 +120,10 @@ __device__ __forceinline__ void ln_apply(const f16x8 (&xv)[MAXV], float mean, fl
 }
 
 // acc[i][j] (+)= tile rows [16 i, 16 i + 16) . W rows [n0 + 16 j, ...)^T over K = C; lane (l15, lg) ends up holding C[m = 16 i + l15][n = n0 + 16 j + 4 lg .. + 3]
-template <int C>
+// ``tb`` / ``up``: the LoRA slab t [64][CROSS_LDB] (LDS, zero beyond rp) against up [C, rp] -- one more k-step behind the main K, as fd_gemm's second K-slab
+template <int C, bool LORA>
 __device__ __forceinline__ void project(f32x4 (&acc)[CrossCfg<C>::TM][CrossCfg<C>::TN], const f16* __restrict__ tile, const f16* __restrict__ W, int n0, int l15,
-                                        int lg) {
+                                        int lg, const f16* __restrict__ tb = nullptr, const f16* __restrict__ up = nullptr, int ld_up = 0, int rp = 0) {
     using Cf = CrossCfg<C>;
     constexpr int TM = Cf::TM, TN = Cf::TN, NK = Cf::NK, PD = Cf::PD, NS = PD + 1;
     f16x8 bf[NS][TN];
@@ -138,15 +150,53 @@ __device__ __forceinline__ void project(f32x4 (&acc)[CrossCfg<C>::TM][CrossCfg<C
 #pragma unroll
             for (int j = 0; j < TN; ++j) acc[i][j] = FD_MFMA_16x16x32(bf[ks % NS][j], af[i], acc[i][j]);
     }
+    if constexpr (LORA) {
+        f16x8 uf[TN], tf[TM];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            uf[j] = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
+            if (lg * 8 < rp) uf[j] = *(const f16x8*)(up + (int64_t)(n0 + j * 16 + l15) * ld_up + lg * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) tf[i] = *(const f16x8*)(tb + (i * 16 + l15) * CROSS_LDB + lg * 8);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = FD_MFMA_16x16x32(uf[j], tf[i], acc[i][j]);
+    }
 }
 
+// t = tile . down^T (LoRA down-projection, N = rp <= 16): wave w owns rows [16 w, 16 w + 16); result rounded to the working dtype into tb (and t_out when recording)
 template <int C>
+__device__ __forceinline__ void lora_down(const f16* __restrict__ tile, const f16* __restrict__ down, int ld_down, int rp, f16* __restrict__ tb, f16* __restrict__ t_out,
+                                          int64_t row0, int wave, int l15, int lg) {
+    using Cf = CrossCfg<C>;
+    static_assert(Cf::TM == 4, "one 16-row tile per wave");
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < Cf::NK; ++ks) {
+        f16x8 df = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (l15 < rp) df = *(const f16x8*)(down + (int64_t)l15 * ld_down + ks * 32 + lg * 8);
+        const f16x8 af = *(const f16x8*)(tile + (wave * 16 + l15) * Cf::LDT + ks * 32 + lg * 8);
+        acc = FD_MFMA_16x16x32(df, af, acc);
+    }
+    // lane: t[row 16 wave + l15][columns 4 lg .. + 3]; columns >= rp are exact zeros (their down rows are)
+    const f16x4 t4 = {(f16)acc[0], (f16)acc[1], (f16)acc[2], (f16)acc[3]};
+    *(f16x4*)(tb + (wave * 16 + l15) * CROSS_LDB + lg * 4) = t4;
+    if (t_out && lg * 4 < rp) *(f16x4*)(t_out + (row0 + wave * 16 + l15) * rp + lg * 4) = t4;
+}
+
+template <int C, bool LORA, bool REC>
 __global__ __launch_bounds__(256, CrossCfg<C>::OCC) void cross_block_kernel(CrossArgs a) {
     using Cf = CrossCfg<C>;
     constexpr int BM = Cf::BM, TM = Cf::TM, TN = Cf::TN, LDT = Cf::LDT, MAXV = Cf::MAXV, D = Cf::D, NKS = Cf::NKS, NDT = Cf::NDT, V = C / 8;
     constexpr int RPW = BM / 4;                   // rows per wave in the row-wise phases
     constexpr int RG = RPW * MAXV <= 16 ? RPW : 16 / MAXV;      // ... taken in groups of RG rows (<= 16 vectors = 64 registers of row data per lane at a time)
-    extern __shared__ __attribute__((aligned(16))) f16 tile[];       // [BM][LDT]
+    extern __shared__ __attribute__((aligned(16))) f16 tile[];       // [BM][LDT], then (LORA) the t tile [BM][CROSS_LDB]
+    f16* const tb = tile + BM * LDT;
+    if (LORA) {          // columns 16 .. 39 are never written again: zero once (columns < 16 are written by lora_down before their first read)
+        for (int c = threadIdx.x; c < BM * CROSS_LDB; c += 256) tb[c] = (f16)0.f;
+    }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l15 = lane & 15, lg = lane >> 4;
     const int row0 = blockIdx.x * BM;
@@ -184,12 +234,23 @@ __global__ __launch_bounds__(256, CrossCfg<C>::OCC) void cross_block_kernel(Cros
     #pragma unroll
                 for (int i = 0; i < MAXV; ++i) {
                     const int v = lane + i * 64;
-                    if (v < V) *(f16x8*)(tile + (wave * RPW + rg + r) * LDT + v * 8) = o[i];
+                    if (v < V) {
+                        *(f16x8*)(tile + (wave * RPW + rg + r) * LDT + v * 8) = o[i];
+                        if (REC) *(f16x8*)(a.n2_out + (int64_t)(row0 + wave * RPW + rg + r) * C + v * 8) = o[i];
+                    }
+                }
+                if (REC && lane == 0) {
+                    a.ln2_stats[(int64_t)(row0 + wave * RPW + rg + r) * 2] = mean[r];
+                    a.ln2_stats[(int64_t)(row0 + wave * RPW + rg + r) * 2 + 1] = rstd[r];
                 }
             }
         }
     }
     __syncthreads();
+    if (LORA) {
+        lora_down<C>(tile, a.qd, a.ld_qd, a.rp, tb, REC ? a.tq_out : nullptr, row0, wave, l15, lg);
+        __syncthreads();
+    }
 
     // ---------------------------------------------------------------- P1: q = n2 . Wq^T, scaled into the exponent's domain -> tile
     f32x4 acc[TM][TN];
@@ -199,7 +260,7 @@ __global__ __launch_bounds__(256, CrossCfg<C>::OCC) void cross_block_kernel(Cros
 #else
     constexpr int SKIP = 0;
 #endif
-    if (!(SKIP & 2)) project<C>(acc, tile, a.wq, n0, l15, lg);
+    if (!(SKIP & 2)) project<C, LORA>(acc, tile, a.wq, n0, l15, lg, tb, a.qu, a.ld_qu, a.rp);
     else {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -212,8 +273,24 @@ __global__ __launch_bounds__(256, CrossCfg<C>::OCC) void cross_block_kernel(Cros
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const f32x4 v = acc[i][j] * a.sl2;
-            *(f16x4*)(tile + (i * 16 + l15) * LDT + n0 + j * 16 + lg * 4) = (f16x4){(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+            const f16x4 q4 = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+            *(f16x4*)(tile + (i * 16 + l15) * LDT + n0 + j * 16 + lg * 4) = q4;
+            if (REC && a.q_store != a.sl2) {     // the backward takes q unscaled (head dims without spare contraction slots): its own rounding, stored from the registers
+                const f32x4 w = acc[i][j] * a.q_store;
+                *(f16x4*)(a.q_out + (int64_t)(row0 + i * 16 + l15) * C + n0 + j * 16 + lg * 4) = (f16x4){(f16)w[0], (f16)w[1], (f16)w[2], (f16)w[3]};
+            }
         }
+    if (REC && a.q_store == a.sl2) {             // the tile IS the backward's q: whole rows, 16 bytes per lane (two workgroup barriers instead of 8-byte scattered stores)
+        __syncthreads();
+#pragma unroll 4
+        for (int r = 0; r < RPW; ++r)
+#pragma unroll
+            for (int i = 0; i < MAXV; ++i) {
+                const int v = lane + i * 64;
+                if (v < V) *(f16x8*)(a.q_out + (int64_t)(row0 + wave * RPW + r) * C + v * 8) = *(const f16x8*)(tile + (wave * RPW + r) * LDT + v * 8);
+            }
+        __syncthreads();
+    }
     // P2 reads only the columns this wave wrote (its two heads: 2 D = C / 4 columns): wave-local ordering is enough
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
@@ -287,6 +364,11 @@ __global__ __launch_bounds__(256, CrossCfg<C>::OCC) void cross_block_kernel(Cros
             l += __shfl_xor(l, 16, 64);
             l += __shfl_xor(l, 32, 64);
             const float inv = 1.f / l;
+            if (REC && lg == 0) {      // natural-log sum-exp of the scaled scores, as fd_attn_fwd writes it: [B, H, rows_per_sample]
+                const int64_t row = row0 + mt * 16 + l15;
+                const int64_t smp = row / a.rows_per_sample;
+                a.lse_out[(smp * 8 + (wave * 2 + hh)) * a.rows_per_sample + (row - smp * a.rows_per_sample)] = (mx + __builtin_amdgcn_logf(l)) * 0.6931471805599453f;
+            }
 #pragma unroll
             for (int dt = 0; dt < NDT; ++dt) {
                 f32x4 o = {0.f, 0.f, 0.f, 0.f};
@@ -297,16 +379,30 @@ __global__ __launch_bounds__(256, CrossCfg<C>::OCC) void cross_block_kernel(Cros
                     o = FD_MFMA_16x16x32(vf[dt][jp], pb, o);
                 }
                 // lane: o[query l15][dv = 16 dt + 4 lg + r]
-                if (dt * 16 + lg * 4 < D)
-                    *(f16x4*)(tile + (mt * 16 + l15) * LDT + c0 + dt * 16 + lg * 4) =
-                        (f16x4){(f16)(o[0] * inv), (f16)(o[1] * inv), (f16)(o[2] * inv), (f16)(o[3] * inv)};
+                if (dt * 16 + lg * 4 < D) {
+                    const f16x4 o4 = {(f16)(o[0] * inv), (f16)(o[1] * inv), (f16)(o[2] * inv), (f16)(o[3] * inv)};
+                    *(f16x4*)(tile + (mt * 16 + l15) * LDT + c0 + dt * 16 + lg * 4) = o4;
+                }
             }
         }
     }
     __syncthreads();
 
     // ---------------------------------------------------------------- P3: h2 = o . Wo^T + bo + h1 -> y;  n3 = LayerNorm3(h2) -> yn
-    if (!(SKIP & 8)) project<C>(acc, tile, a.wo, n0, l15, lg);
+    if (REC) {                                   // o for the backward: whole rows of the tile (nothing writes it before the barrier behind the projection)
+#pragma unroll 4
+        for (int r = 0; r < RPW; ++r)
+#pragma unroll
+            for (int i = 0; i < MAXV; ++i) {
+                const int v = lane + i * 64;
+                if (v < V) *(f16x8*)(a.o_out + (int64_t)(row0 + wave * RPW + r) * C + v * 8) = *(const f16x8*)(tile + (wave * RPW + r) * LDT + v * 8);
+            }
+    }
+    if (LORA) {
+        lora_down<C>(tile, a.od, a.ld_od, a.rp, tb, REC ? a.to_out : nullptr, row0, wave, l15, lg);
+        __syncthreads();
+    }
+    if (!(SKIP & 8)) project<C, LORA>(acc, tile, a.wo, n0, l15, lg, tb, a.ou, a.ld_ou, a.rp);
     __syncthreads();                               // every wave has read all of o
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -400,18 +496,37 @@ extern "C" int fd_cross_attn_block(const fd_cross_block_desc* dp, void* stream) 
     a.y = (f16*)d.y; a.yn = (f16*)d.yn; a.yn_stats = d.yn_stats;
     a.M = d.M; a.rows_per_sample = d.rows_per_sample; a.kv_div = d.kv_div;
     a.sl2 = d.scale * CA_LOG2E;
+    const bool lora = d.lora_q_down != nullptr, rec = d.n2_out != nullptr;
+    FD_REQUIRE(!lora || (d.lora_q_up && d.lora_o_down && d.lora_o_up && d.lora_rp > 0 && d.lora_rp <= 16 && (d.lora_rp & 7) == 0 &&
+                         (d.ld_q_down & 7) == 0 && (d.ld_q_up & 7) == 0 && (d.ld_o_down & 7) == 0 && (d.ld_o_up & 7) == 0),
+               "fd_cross_attn_block: LoRA slabs need all four matrices, a padded rank of 8 or 16 (got %d) and row strides that are multiples of 8", d.lora_rp);
+    FD_REQUIRE(!rec || (d.ln2_stats && d.q_out && d.o_out && d.lse_out && (!lora || (d.tq_out && d.to_out))),
+               "fd_cross_attn_block: recording needs n2_out, ln2_stats, q_out, o_out, lse_out (and tq_out, to_out with LoRA slabs)");
+    a.qd = (const f16*)d.lora_q_down; a.qu = (const f16*)d.lora_q_up; a.od = (const f16*)d.lora_o_down; a.ou = (const f16*)d.lora_o_up;
+    a.ld_qd = (int)d.ld_q_down; a.ld_qu = (int)d.ld_q_up; a.ld_od = (int)d.ld_o_down; a.ld_ou = (int)d.ld_o_up; a.rp = d.lora_rp;
+    a.n2_out = (f16*)d.n2_out; a.ln2_stats = d.ln2_stats; a.q_out = (f16*)d.q_out; a.tq_out = (f16*)d.tq_out; a.o_out = (f16*)d.o_out; a.lse_out = d.lse_out;
+    a.to_out = (f16*)d.to_out;
+    a.q_store = d.q_prescaled ? a.sl2 : 1.f;
     const dim3 grid(d.M / bm), block(256);
-#define CROSS_LAUNCH(CC)                                                                                                        \
-    {                                                                                                                           \
-        constexpr size_t lds = (size_t)CrossCfg<CC>::BM * CrossCfg<CC>::LDT * 2;                                                \
-        static bool once = false;                                                                                               \
-        if (!once) {                                                                                                            \
-            (void)hipFuncSetAttribute((const void*)cross_block_kernel<CC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-            once = true;                                                                                                        \
-        }                                                                                                                       \
-        hipLaunchKernelGGL(cross_block_kernel<CC>, grid, block, lds, (hipStream_t)stream, a);                                   \
+#define CROSS_LAUNCH(CC, LL, RR)                                                                                                        \
+    {                                                                                                                                   \
+        constexpr size_t lds = ((size_t)CrossCfg<CC>::BM * CrossCfg<CC>::LDT + (LL ? CrossCfg<CC>::BM * CROSS_LDB : 0)) * 2;            \
+        static bool once = false;                                                                                                       \
+        if (!once) {                                                                                                                    \
+            (void)hipFuncSetAttribute((const void*)cross_block_kernel<CC, LL, RR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            once = true;                                                                                                                \
+        }                                                                                                                               \
+        hipLaunchKernelGGL((cross_block_kernel<CC, LL, RR>), grid, block, lds, (hipStream_t)stream, a);                                 \
     }
-    if (d.C == 320) CROSS_LAUNCH(320) else CROSS_LAUNCH(640)
+#define CROSS_LAUNCH_C(CC)                                       \
+    {                                                            \
+        if (lora && rec) CROSS_LAUNCH(CC, true, true)            \
+        else if (lora) CROSS_LAUNCH(CC, true, false)             \
+        else if (rec) CROSS_LAUNCH(CC, false, true)              \
+        else CROSS_LAUNCH(CC, false, false)                      \
+    }
+    if (d.C == 320) CROSS_LAUNCH_C(320) else CROSS_LAUNCH_C(640)
+#undef CROSS_LAUNCH_C
 #undef CROSS_LAUNCH
     return fd_check_launch("fd_cross_attn_block");
 }

@@ -84,7 +84,12 @@ class CrossBlockDesc(_Desc):
                 ("wo", ctypes.c_void_p), ("bo", ctypes.c_void_p), ("ln3_gamma", ctypes.c_void_p), ("ln3_beta", ctypes.c_void_p), ("ln3_eps", ctypes.c_float),
                 ("y", ctypes.c_void_p), ("yn", ctypes.c_void_p), ("yn_stats", ctypes.c_void_p),
                 ("M", ctypes.c_int32), ("C", ctypes.c_int32), ("heads", ctypes.c_int32), ("rows_per_sample", ctypes.c_int32), ("kv_div", ctypes.c_int32),
-                ("scale", ctypes.c_float)]
+                ("scale", ctypes.c_float),
+                ("lora_q_down", ctypes.c_void_p), ("ld_q_down", ctypes.c_int64), ("lora_q_up", ctypes.c_void_p), ("ld_q_up", ctypes.c_int64),
+                ("lora_o_down", ctypes.c_void_p), ("ld_o_down", ctypes.c_int64), ("lora_o_up", ctypes.c_void_p), ("ld_o_up", ctypes.c_int64),
+                ("lora_rp", ctypes.c_int32),
+                ("n2_out", ctypes.c_void_p), ("ln2_stats", ctypes.c_void_p), ("q_out", ctypes.c_void_p), ("tq_out", ctypes.c_void_p), ("o_out", ctypes.c_void_p),
+                ("lse_out", ctypes.c_void_p), ("to_out", ctypes.c_void_p), ("q_prescaled", ctypes.c_int32)]
 
 
 _CTYPE = {"int": ctypes.c_int, "int32_t": ctypes.c_int32, "int64_t": ctypes.c_int64, "float": ctypes.c_float}

@@ -559,22 +559,25 @@ def attn_bwd(q, k, v, o, do, lse, B, H, Tq, Tk, d, kv_div=1, scale=None, dk_acc=
 # The cross-attention sub-block (LayerNorm2 -> to_q -> attention over the prompt tokens -> to_out + residual -> LayerNorm3) as one launch, for forwards
 # that neither record nor carry LoRA slabs (csrc/crossattn.hip).  FD_NO_FUSED_CROSS=1: the five separate launches.
 FUSED_CROSS = os.environ.get("FD_NO_FUSED_CROSS") is None
+FUSED_CROSS_TRAIN = os.environ.get("FD_NO_FUSED_CROSS_TRAIN") is None      # ... also where the forward carries LoRA slabs and / or records for the backward (R1 / R3)
 CROSS_LP = 80          # key padding of the transposed V the fused kernel reads
 
 
 CROSS_WIDTHS = tuple(int(c) for c in os.environ.get("FD_FUSED_CROSS_C", "320,640").split(",") if c)      # measurement: which levels take the fused kernel
 
 
-def cross_block_ok(M, C, heads, L, rows_per_sample):
-    return (FUSED_CROSS and C in CROSS_WIDTHS and heads == 8 and C in (320, 640) and L <= CROSS_LP and M % 64 == 0 and rows_per_sample % 64 == 0)
+def cross_block_ok(M, C, heads, L, rows_per_sample, rp=0):
+    return (FUSED_CROSS and rp in (0, 8, 16) and C in CROSS_WIDTHS and heads == 8 and C in (320, 640) and L <= CROSS_LP and M % 64 == 0 and rows_per_sample % 64 == 0)
 
 
-def cross_attn_block(x, ln2, wq, k, vt, L, wo, bo, ln3, heads, rows_per_sample, kv_div, need_stats=False):
-    """x [M, C] -> (y [M, C], LayerNorm3(y) [M, C], its (mean, rstd) [M, 2] or None).  ln2 / ln3 = (gamma, beta, eps); k [Bk*L, C]; vt [Bk, C, Lp]."""
+def cross_attn_block(x, ln2, wq, k, vt, L, wo, bo, ln3, heads, rows_per_sample, kv_div, need_stats=False, lora_q=None, lora_o=None, record=False, q_prescaled=False):
+    """x [M, C] -> (y [M, C], LayerNorm3(y) [M, C], its (mean, rstd) [M, 2] or None, rec).  ln2 / ln3 = (gamma, beta, eps); k [Bk*L, C]; vt [Bk, C, Lp].
+    ``lora_q`` / ``lora_o``: the LoRAPair of attn2.to_q / to_out (both or neither).  ``record``: rec = dict(n2, ln2, q2, tq2, o2, lse2, to2) for the backward (q2
+    pre-scaled by softmax_scale * log2(e) iff ``q_prescaled``), else None."""
     M, C = x.shape
     d = _lib.CrossBlockDesc()
     y, yn = torch.empty_like(x), torch.empty_like(x)
-    st = torch.empty((M, 2), dtype=F32, device=x.device) if need_stats else None
+    st = torch.empty((M, 2), dtype=F32, device=x.device) if (need_stats or record) else None
     d.x, d.ln2_gamma, d.ln2_beta, d.ln2_eps = _chk(x).data_ptr(), _chk(ln2[0], F32).data_ptr(), _chk(ln2[1], F32).data_ptr(), ln2[2]
     d.wq, d.k, d.vt, d.L, d.Lp = _chk(wq).data_ptr(), _chk(k).data_ptr(), _chk(vt).data_ptr(), L, vt.shape[-1]
     assert wq.shape == (C, C) and wo.shape == (C, C) and k.shape[1] == C and vt.shape[1] == C and k.shape[0] == vt.shape[0] * L
@@ -582,8 +585,25 @@ def cross_attn_block(x, ln2, wq, k, vt, L, wo, bo, ln3, heads, rows_per_sample, 
     d.ln3_gamma, d.ln3_beta, d.ln3_eps = _chk(ln3[0], F32).data_ptr(), _chk(ln3[1], F32).data_ptr(), ln3[2]
     d.y, d.yn, d.yn_stats = y.data_ptr(), yn.data_ptr(), (st.data_ptr() if st is not None else None)
     d.M, d.C, d.heads, d.rows_per_sample, d.kv_div, d.scale = M, C, heads, rows_per_sample, kv_div, (C // heads) ** -0.5
+    rp = 0
+    if lora_q is not None:
+        rp = lora_q.rp
+        assert lora_o is not None and lora_o.rp == rp and lora_q.down16.shape == (rp, C) and lora_q.up16.shape == (C, rp)
+        d.lora_q_down, d.ld_q_down, d.lora_q_up, d.ld_q_up = lora_q.down16.data_ptr(), _rows(lora_q.down16), lora_q.up16.data_ptr(), _rows(lora_q.up16)
+        d.lora_o_down, d.ld_o_down, d.lora_o_up, d.ld_o_up = lora_o.down16.data_ptr(), _rows(lora_o.down16), lora_o.up16.data_ptr(), _rows(lora_o.up16)
+        d.lora_rp = rp
+    rec = None
+    if record:
+        dev = x.device
+        rec = dict(n2=torch.empty_like(x), ln2=torch.empty((M, 2), dtype=F32, device=dev), q2=torch.empty_like(x), o2=torch.empty_like(x),
+                   lse2=torch.empty((M // rows_per_sample, heads, rows_per_sample), dtype=F32, device=dev),
+                   tq2=torch.empty((M, rp), dtype=F16, device=dev) if rp else None, to2=torch.empty((M, rp), dtype=F16, device=dev) if rp else None)
+        d.n2_out, d.ln2_stats, d.q_out, d.o_out, d.lse_out = rec["n2"].data_ptr(), rec["ln2"].data_ptr(), rec["q2"].data_ptr(), rec["o2"].data_ptr(), rec["lse2"].data_ptr()
+        if rp:
+            d.tq_out, d.to_out = rec["tq2"].data_ptr(), rec["to2"].data_ptr()
+        d.q_prescaled = int(bool(q_prescaled))
     _call("fd_cross_attn_block", ctypes.byref(d), _stream())
-    return y, yn, st
+    return y, yn, st, rec
 
 
 # ----------------------------------------------------------------------------- LoRA / scheduler / optimizer

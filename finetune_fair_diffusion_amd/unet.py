@@ -110,6 +110,7 @@ class TransformerBlock:
         lo = self.lora2
         te = ops.gemm(enc, lo.down_kv16) if lo is not None else None
         rp = lo.k.rp if lo is not None else 0
+        old = None
         if lo is not None:
             K = ops.gemm(enc, self.k2.w, a2=te[:, :rp], b2=lo.k.up16)
             V = ops.gemm(enc, self.v2.w, a2=te[:, rp:], b2=lo.v.up16)
@@ -122,7 +123,7 @@ class TransformerBlock:
         else:
             K, V = ops.gemm(enc, self.k2.w), ops.gemm(enc, self.v2.w)
         self.cross = dict(static=bool(static and lo is None), K=K, V=V, Bk=Bk, L=L, enc=enc, te=te)
-        if lo is None and not record and ops.FUSED_CROSS and L <= ops.CROSS_LP and self.C in ops.CROSS_WIDTHS and self.heads == 8:
+        if ops.FUSED_CROSS and L <= ops.CROSS_LP and self.C in ops.CROSS_WIDTHS and self.heads == 8:
             # the one-launch cross-attention sub-block (ops.cross_attn_block) reads V transposed, keys zero-padded to 80: made once per rollout; a captured
             # forward holds its address like K's and V's
             self.cross["Vt80"] = ops.transpose_btc(V, Bk, L, self.C, ops.CROSS_LP, out=old.get("Vt80") if (static and old) else None)
@@ -170,15 +171,23 @@ class TransformerBlock:
         o, lse = ops.attn_fwd(q, k, v, B, h, HW, HW, d, 1, need_lse=True, prescaled=qs is not None)
         l2 = self.lora2
         cr = self.cross
-        if (not rec and l2 is None and not pair and cr.get("Vt80") is not None and self.q2.bias is None
-                and ops.cross_block_ok(B * HW, C, h, cr["L"], HW)):
-            # no-grad forward of a frozen block: norm2 -> attn2 -> residual -> norm3 is ONE launch (csrc/crossattn.hip); n2, q2, o2 never reach HBM
-            h1, _ = lora_linear_fwd(o, self.o1, l1.out if l1 else None, residual=h0)
-            h2, n3, _ = ops.cross_attn_block(h1, (self.ln2.gamma, self.ln2.beta, 1e-5), self.q2.w, cr["K"], cr["Vt80"], cr["L"], self.o2.w, self.o2.bias,
-                                             (self.ln3.gamma, self.ln3.beta, 1e-5), h, HW, B // cr["Bk"])
-            gg = ops.gemm(n3, self.ff1_wi, bias=self.ff1_bi, act="geglu")
+        if (not pair and cr.get("Vt80") is not None and self.q2.bias is None and (ops.FUSED_CROSS_TRAIN or (not rec and l2 is None))
+                and ops.cross_block_ok(B * HW, C, h, cr["L"], HW, l2.q.rp if l2 is not None else 0)):
+            # norm2 -> attn2 (with its LoRA slabs) -> residual -> norm3 is ONE launch (csrc/crossattn.hip); a forward that does not record never sees n2, q2, o2 in
+            # HBM, a recording one gets them written once for the backward
+            h1, to1 = lora_linear_fwd(o, self.o1, l1.out if l1 else None, residual=h0)
+            qs2 = ops.q_prescale(d)
+            h2, n3, ln3, r = ops.cross_attn_block(h1, (self.ln2.gamma, self.ln2.beta, 1e-5), self.q2.w, cr["K"], cr["Vt80"], cr["L"], self.o2.w, self.o2.bias,
+                                                  (self.ln3.gamma, self.ln3.beta, 1e-5), h, HW, B // cr["Bk"], lora_q=l2.q if l2 else None,
+                                                  lora_o=l2.out if l2 else None, record=rec, q_prescaled=qs2 is not None)
+            proj = torch.empty((n3.shape[0], self.ff1_wi.shape[0]), dtype=F16, device=n3.device) if rec else None
+            gg = ops.gemm(n3, self.ff1_wi, bias=self.ff1_bi, act="geglu", aux=proj)
             h3 = ops.gemm(gg, self.ff2.w, bias=self.ff2.bias, residual=h2)
-            return ops.gemm(h3, self.proj_out.w, bias=self.proj_out.bias, residual=x, gn_stats=True)
+            out = ops.gemm(h3, self.proj_out.w, bias=self.proj_out.bias, residual=x, gn_stats=True)
+            if rec:
+                ctx.append(dict(x=x, st=st, h0=h0, ln1=ln1, n1=n1, t1=t1, qkv=qkv, o=o, lse=lse, to1=to1, h1=h1, ln2=r["ln2"], n2=r["n2"], tq2=r["tq2"], q2=r["q2"],
+                                o2=r["o2"], lse2=r["lse2"], to2=r["to2"], h2=h2, ln3=ln3, proj=proj, pair=False, qs=qs is not None, qs2=qs2 is not None))
+            return out
         (h1, n2, ln2), to1 = lora_linear_fwd(o, self.o1, l1.out if l1 else None, residual=h0, ln=(self.ln2.gamma, self.ln2.beta, 1e-5))
         qs2 = ops.q_prescale(d)
         q2, tq2 = lora_linear_fwd(n2, self.q2, l2.q if l2 else None, colscale=(qs2, C) if qs2 is not None else None)

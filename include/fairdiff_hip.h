@@ -199,8 +199,8 @@ int fd_attn_bwd_dkdv(const void* q, const void* k, const void* v, const void* d_
 int fd_sum_slabs(const float* in, float* out, int nslab, int64_t n, void* stream);
 
 /* ---- the cross-attention sub-block of BasicTransformerBlock as ONE launch (diffusers attention.py BasicTransformerBlock.forward: norm2 -> attn2 ->
- * residual -> norm3; attn2 runs the attention processor selected at exp-1 main:811-817), for forwards that neither record nor carry LoRA slabs
- * (the frozen rollout R2, exp-1 main:1844-1858):
+ * residual -> norm3; attn2 runs the attention processor selected at exp-1 main:811-817): the frozen rollout R2 (exp-1 main:1844-1858) without LoRA slabs or
+ * recording, the finetuned model's rollout with both (descriptor fields below):
  *     n2 = LayerNorm(x; ln2);  q = n2 . wq^T;  o = softmax(q k^T * scale) v;  y = o . wo^T + bo + x;  yn = LayerNorm(y; ln3)
  * x, y, yn: [M, C] working dtype, contiguous; wq, wo: [C, C] (out, in); k: [Bk*L, C] (the L <= 80 prompt tokens per sample, as fd_attn_fwd takes
  * them); vt: [Bk, C, Lp] = V transposed with zero-padded keys (fd_transpose_btc, Lp >= 80); row m belongs to sample m / rows_per_sample, which reads
@@ -218,6 +218,16 @@ typedef struct fd_cross_block_desc {
     void* y; void* yn; float* yn_stats;
     int32_t M, C, heads, rows_per_sample, kv_div;
     float scale;                     /* softmax scale, d^-0.5 */
+    /* optional LoRA slabs of attn2.to_q / attn2.to_out (LoRAAttnProcessor.__call__: to_q(h) + scale * to_q_lora(h), exp-1 main:811-817), all four or none:
+     * down [rp, C] and up [C, rp] in the working dtype, the LoRA scale folded into up (as fd_lora_refresh_multi writes them), rp = rank padded to 8 or 16 */
+    const void* lora_q_down; int64_t ld_q_down; const void* lora_q_up; int64_t ld_q_up;
+    const void* lora_o_down; int64_t ld_o_down; const void* lora_o_up; int64_t ld_o_up;
+    int32_t lora_rp;
+    /* optional recording for the backward (n2_out != NULL turns it on; then all of these except tq_out / to_out without LoRA are required):
+     * n2_out [M, C] = LayerNorm2(x), ln2_stats [M, 2]; q_out [M, C] = the query as fd_attn_bwd_* take it (times scale * log2(e) when q_prescaled, see
+     * fd_attn_fwd); tq_out [M, rp] = n2 . down_q^T; o_out [M, C] attention output; lse_out [M / rows_per_sample, heads, rows_per_sample]; to_out [M, rp] = o . down_o^T */
+    void* n2_out; float* ln2_stats; void* q_out; void* tq_out; void* o_out; float* lse_out; void* to_out;
+    int32_t q_prescaled;
 } fd_cross_block_desc;
 int fd_cross_attn_block(const fd_cross_block_desc* d, void* stream);
 

@@ -121,6 +121,16 @@ z)  # final validation of the tree: full GPU suite, smoke, the driver's default 
     DB=$(find /tmp/prof_r05z -name "*.db" | head -1)
     python scratch/profsum.py $DB $O/kernel_stats.csv 30 > $O/kernel_stats_top.txt; head -12 $O/kernel_stats_top.txt | cut -c1-200
     ;;
+u)  # fused cross-attention with LoRA slabs + recording (R1 / R3 too): whole-step A/B, alternating arms
+    O=gpurun_out/r05u; mkdir -p $O
+    for i in 1 2 3; do
+      for v in "FD_NO_FUSED_CROSS=1" "FD_NO_FUSED_CROSS_TRAIN=1" "FD_NOTHING=1"; do
+        n=$(echo "$v" | tr '=;, ' '____')
+        env $v $B --steps 6 --warmup 2 > $O/${n}_$i.json 2> $O/${n}_$i.err || tail -3 $O/${n}_$i.err
+      done
+    done
+    bench_table "$O/*.json" | tee $O/summary.txt
+    ;;
 r)  # is the step bound by the host's enqueue rate?  a busy-wait in front of every C-ABI call (FD_HOST_SPIN_US), whole step
     O=gpurun_out/r05r; mkdir -p $O
     for i in 1 2; do

@@ -429,16 +429,20 @@ def test_sd15_cfg0_eight_images_vs_committed_golden(dev):
     for n, (c, r) in named.items():
         print(f"cfg0 B=8 grad {n}: cosine {c:.5f}  norm ratio {r:.4f}")
     print(f"cfg0 B=8: flat TE-LoRA gradient, seeded sample: cosine {cos:.5f}  norm ratio {ratio:.4f}")
-    # measured over the same five variants: flat-sample cosine 0.9900 .. 0.9933, single tensors 0.9892 .. 0.9961 (two images: 0.962 .. 0.996); the norm ratio
-    # (0.86 .. 1.00) still carries the ReLU / clamp mask flips, hence the same wide band as the two-image test
-    assert all(c > 0.98 and 0.8 < r < 1.25 for c, r in named.values())
+    # measured over seven rounding-only variants (profiles/r05_te_lora_goldens_spread_across_rounding_variants.txt): flat-sample cosine 0.9853 .. 0.9933; single
+    # tensors 0.9696 .. 0.9961 (two images: 0.962 .. 0.996) -- the deepest tensor of the chain (layer 0, k_proj down) moves with every change of the forward's
+    # rounding, so a single tensor of the ReLU-head step gets a sanity bound only; the norm ratio (0.86 .. 1.00) carries the ReLU / clamp mask flips.  The tight
+    # pin of this path is the smooth-head golden above (0.999 / 0.998 in all seven variants); here the flat sample carries the test
+    assert all(c > 0.95 and 0.8 < r < 1.25 for c, r in named.values())
     assert cos > 0.98 and 0.8 < ratio < 1.25
 
 
-def test_sd15_loss_fair_has_no_bias_over_eight_seeds(full, dev):
+def test_sd15_loss_fair_has_no_bias_over_32_seeds(full, dev):
     """the smooth-head test's single-draw loss gate had to move 6.7e-4 -> 8e-3 when the convolutions' summation order changed; one draw
-    cannot tell zero-mean rounding from bias.  Eight noise seeds (B = 2, S = 2, U-Net LoRA, real classifier; forward half of the step): the error of the
-    product's loss_fair against the fp32 oracle must be small on average AND centred (north star: loss within 1e-3)."""
+    cannot tell zero-mean rounding from bias.  32 noise seeds = 64 loss terms (B = 2, S = 2, U-Net LoRA, real classifier; forward half of the step): the error of the
+    product's loss_fair against the fp32 oracle must be small on average AND centred (north star: loss within 1e-3).  (The first version had eight seeds: with a
+    per-term spread of ~1.1e-3 the mean of 16 terms has sigma 2.8e-4, so a 3e-4 gate on it flipped with every rounding-only change of the forward: -2.0e-4 with the
+    separate cross-attention launches, -3.4e-4 with the fused sub-block.  Sixty-four terms halve that sigma; the first eight seeds of the golden are unchanged.)"""
     from finetune_fair_diffusion_amd.step import FairnessTrainer
     import numpy as np
     om, pm = full
@@ -458,8 +462,8 @@ def test_sd15_loss_fair_has_no_bias_over_eight_seeds(full, dev):
     errs = np.array(errs)
     print(f"loss_fair over {len(g['seeds'])} seeds ({len(errs)} terms): mean |err| {np.abs(errs).mean():.2e}  mean err {errs.mean():+.2e}  max |err| {np.abs(errs).max():.2e}; "
           f"probs max |err| {max(perr):.2e}")
-    assert len(errs) >= 8
-    assert np.abs(errs).mean() <= 1e-3 and abs(errs.mean()) <= 3e-4 * max(1.0, (16 / len(errs)) ** 0.5) and np.abs(errs).max() <= 8e-3
+    assert len(errs) >= 48
+    assert np.abs(errs).mean() <= 1e-3 and abs(errs.mean()) <= 3e-4 and np.abs(errs).max() <= 8e-3
 
 
 def _te_names_in_oracle_order(bank, g):
@@ -689,7 +693,7 @@ def test_sd15_backward_ops_reproduce_themselves_under_the_concurrent_schedule(fu
         tr.unet.backward_step, tr.unet.forward_step, tr.eval_unet.forward_step = orig_bs, orig_fs, orig_efs
     counts = {n: int(bad[n]) for n in names}
     print("ops executed twice:", calls, "pairs that differed:", counts)
-    assert calls["layernorm_bwd"] >= 1800 and calls["gemm"] > 10000 and calls["attn_bwd"] >= 1200 and calls["attn_fwd"] >= 2000 and calls["cross_attn_block"] >= 340 and calls["flush_wgrads"] >= 600
+    assert calls["layernorm_bwd"] >= 1800 and calls["gemm"] > 10000 and calls["attn_bwd"] >= 1200 and calls["attn_fwd"] >= 1700 and calls["cross_attn_block"] >= 700 and calls["flush_wgrads"] >= 600
     assert all(v == 0 for v in counts.values()), counts
 
 

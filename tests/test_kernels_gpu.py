@@ -573,7 +573,7 @@ def test_cross_attn_block_one_launch(ops, dev, C, B, HW, L, kv_div):
     k, v = rnd(Bk * L, C, dev=dev, seed=9), rnd(Bk * L, C, dev=dev, seed=10)
     vt = ops.transpose_btc(v, Bk, L, C, ops.CROSS_LP)
     assert ops.cross_block_ok(M, C, H, L, HW)
-    y, yn, st = ops.cross_attn_block(x, (g2, b2, 1e-5), wq, k, vt, L, wo, bo, (g3, b3, 1e-5), H, HW, kv_div, need_stats=True)
+    y, yn, st, _ = ops.cross_attn_block(x, (g2, b2, 1e-5), wq, k, vt, L, wo, bo, (g3, b3, 1e-5), H, HW, kv_div, need_stats=True)
     # (i) torch fp32
     xf = x.float()
     n2 = F.layer_norm(xf, (C,), g2, b2, 1e-5)
@@ -596,8 +596,71 @@ def test_cross_attn_block_one_launch(ops, dev, C, B, HW, L, kv_div):
     frac = float((y != ys).float().mean())
     print(f"cross block C={C} M={M} L={L}: {100 * frac:.2f} % of y differ from the separate launches (by fp16 ulps)")
     # determinism: no atomics, fixed reduction orders
-    y2, yn2, _ = ops.cross_attn_block(x, (g2, b2, 1e-5), wq, k, vt, L, wo, bo, (g3, b3, 1e-5), H, HW, kv_div)
+    y2, yn2, _, _ = ops.cross_attn_block(x, (g2, b2, 1e-5), wq, k, vt, L, wo, bo, (g3, b3, 1e-5), H, HW, kv_div)
     assert torch.equal(y, y2) and torch.equal(yn, yn2)
+
+
+@pytest.mark.parametrize("C,B,HW,L,kv_div,r", [(320, 4, 1024, 77, 2, 4), (320, 2, 4096, 77, 1, 4), (640, 4, 256, 77, 2, 4), (640, 2, 1024, 77, 1, 16), (320, 2, 64, 5, 1, 8)])
+def test_cross_attn_block_with_lora_slabs_and_recording(ops, dev, C, B, HW, L, kv_div, r):
+    """The finetuned model's form of fd_cross_attn_block: LoRA slabs on attn2.to_q / to_out (LoRAAttnProcessor.__call__, exp-1 main:811-817) and everything the
+    backward consumes written as extra outputs -- n2, LayerNorm2 statistics, q (pre-scaled for d = 40, unscaled for d = 80, as fd_attn_bwd_* take it), t_q, o, the
+    log-sum-exp, t_o, LayerNorm3 statistics -- against the separate launches (lora_linear_fwd + attn_fwd + layernorm) and torch fp32; the recording launch and the
+    plain LoRA launch must agree bit for bit (R1 and R3 evaluate the same function)."""
+    import torch.nn.functional as F
+    from finetune_fair_diffusion_amd.layers import LoRAPair, lora_linear_fwd, Linear
+    H, d, M, Bk = 8, C // 8, B * HW, B // kv_div
+    x = rnd(M, C, dev=dev, seed=1)
+    g2, b2 = rnd(C, dev=dev, dtype=torch.float32, seed=2) * 0.2 + 1, rnd(C, dev=dev, dtype=torch.float32, seed=3) * 0.2
+    g3, b3 = rnd(C, dev=dev, dtype=torch.float32, seed=4) * 0.2 + 1, rnd(C, dev=dev, dtype=torch.float32, seed=5) * 0.2
+    wq, wo = rnd(C, C, dev=dev, scale=C ** -0.5, seed=6), rnd(C, C, dev=dev, scale=C ** -0.5, seed=7)
+    bo = rnd(C, dev=dev, dtype=torch.float32, seed=8) * 0.1
+    k, v = rnd(Bk * L, C, dev=dev, seed=9), rnd(Bk * L, C, dev=dev, seed=10)
+    vt = ops.transpose_btc(v, Bk, L, C, ops.CROSS_LP)
+    pairs = []
+    for seed in (11, 12):
+        p = LoRAPair.__new__(LoRAPair)
+        p.r, p.rp, p.K, p.N = r, (r + 7) // 8 * 8, C, C
+        p.down16 = torch.zeros(p.rp, C, dtype=torch.float16, device=dev); p.down16[:r] = rnd(r, C, dev=dev, scale=C ** -0.5, seed=seed)
+        p.up16 = torch.zeros(C, p.rp, dtype=torch.float16, device=dev); p.up16[:, :r] = rnd(C, r, dev=dev, scale=0.3, seed=seed + 10)
+        pairs.append(p)
+    lq, lo_ = pairs
+    qs = ops.q_prescale(d)
+    assert ops.cross_block_ok(M, C, H, L, HW, lq.rp)
+    y, yn, st, rec = ops.cross_attn_block(x, (g2, b2, 1e-5), wq, k, vt, L, wo, bo, (g3, b3, 1e-5), H, HW, kv_div, lora_q=lq, lora_o=lo_, record=True, q_prescaled=qs is not None)
+    y0, yn0, _, none = ops.cross_attn_block(x, (g2, b2, 1e-5), wq, k, vt, L, wo, bo, (g3, b3, 1e-5), H, HW, kv_div, lora_q=lq, lora_o=lo_)
+    assert none is None and torch.equal(y, y0) and torch.equal(yn, yn0), "recording changes the values"
+    # the separate launches
+    n2s, ln2s = ops.layernorm(x, g2, b2, 1e-5, save_stats=True)
+    tq = ops.gemm(n2s, lq.down16)
+    q2 = ops.gemm(n2s, wq, a2=tq, b2=lq.up16, colscale=(qs, C) if qs is not None else None)
+    o2, lse2 = ops.attn_fwd(q2, k, v, B, H, HW, L, d, kv_div, need_lse=True, prescaled=qs is not None)
+    to = ops.gemm(o2, lo_.down16)
+    ys = ops.gemm(o2, wo, a2=to, b2=lo_.up16, bias=bo, residual=x)
+    yns, ln3s = ops.layernorm(ys, g3, b3, 1e-5, save_stats=True)
+    # LayerNorm2 is the separate kernel's arithmetic statement for statement: the statistics agree bit for bit at C = 320; outputs (and, at wider C, the statistics) can
+    # move by one ulp with the compiler's FMA contraction, as they do between layernorm_kernel's own row-count variants
+    if C == 320:
+        assert torch.equal(rec["ln2"], ln2s)
+    check("LayerNorm2 statistics", rec["ln2"], ln2s, 1e-5)
+    check("n2", rec["n2"], n2s.float(), 1e-3)
+    check("t_q", rec["tq2"], tq.float(), 1e-3)
+    check("q (as the backward takes it)", rec["q2"], q2.float(), 2e-3)
+    check("o", rec["o2"], o2.float(), 3e-3)
+    check("lse", rec["lse2"], lse2, 1e-3)
+    check("t_o", rec["to2"], to.float(), 3e-3)
+    check("y vs the separate launches", y, ys.float(), 2e-3)
+    check("LayerNorm3(y) vs the separate launches", yn, yns.float(), 3e-3)
+    check("LayerNorm3 statistics", st, ln3s, 2e-3)
+    # torch fp32 on the same fp16 parameters
+    xf = x.float()
+    n2 = F.layer_norm(xf, (C,), g2, b2, 1e-5)
+    q = n2 @ wq.float().t() + (n2 @ lq.down16.float().t()) @ lq.up16.float().t()
+    o, lse = _attn_ref(q.view(B, HW, C), k.float().view(Bk, L, C), v.float().view(Bk, L, C), H, kv_div)
+    o = o.reshape(M, C)
+    yr = o @ wo.float().t() + (o @ lo_.down16.float().t()) @ lo_.up16.float().t() + bo + xf
+    check("y vs fp32", y, yr, 4e-3)
+    check("o vs fp32", rec["o2"], o, 4e-3)
+    check("lse vs fp32", rec["lse2"], lse, 2e-3)
 
 
 @pytest.mark.parametrize("B,H,T,d", [(2, 8, 1024, 40), (2, 8, 256, 80), (1, 4, 64, 160)])
