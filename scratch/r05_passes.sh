@@ -121,6 +121,19 @@ z)  # final validation of the tree: full GPU suite, smoke, the driver's default 
     DB=$(find /tmp/prof_r05z -name "*.db" | head -1)
     python scratch/profsum.py $DB $O/kernel_stats.csv 30 > $O/kernel_stats_top.txt; head -12 $O/kernel_stats_top.txt | cut -c1-200
     ;;
+v)  # dense short-K GEMMs as two co-resident 128x320 workgroups per CU (gemm_l2_kernel, bench-hooks library): isolated, then the whole step
+    O=gpurun_out/r05v2; mkdir -p $O
+    L=$P/libfairdiff_hip_bench.so
+    FAIRDIFF_LIB=$L python scratch/mb_l2.py 2>&1 | grep -v amdgpu | tee $O/mb_default.txt
+    FAIRDIFF_LIB=$L FD_GEMM_L2=1 python scratch/mb_l2.py 2>&1 | grep -v amdgpu | tee $O/mb_l2.txt
+    for i in 1 2; do
+      for v in "FD_NOTHING=1" "FD_GEMM_L2=1" "FD_GEMM_L2=1 FD_GEMM_L2_MAXK=640"; do
+        n=$(echo "$v" | tr '=;, ' '____')
+        env FAIRDIFF_LIB=$L $v $B --steps 6 --warmup 2 > $O/${n}_$i.json 2> $O/${n}_$i.err || tail -3 $O/${n}_$i.err
+      done
+    done
+    bench_table "$O/*.json" | tee $O/summary.txt
+    ;;
 u)  # fused cross-attention with LoRA slabs + recording (R1 / R3 too): whole-step A/B, alternating arms
     O=gpurun_out/r05u; mkdir -p $O
     for i in 1 2 3; do
