@@ -121,6 +121,17 @@ z)  # final validation of the tree: full GPU suite, smoke, the driver's default 
     DB=$(find /tmp/prof_r05z -name "*.db" | head -1)
     python scratch/profsum.py $DB $O/kernel_stats.csv 30 > $O/kernel_stats_top.txt; head -12 $O/kernel_stats_top.txt | cut -c1-200
     ;;
+w)  # GEGLU backward fused into the FF2 data-gradient GEMM's epilogue: parity, then the whole step
+    O=gpurun_out/r05w2; mkdir -p $O
+    python -m pytest tests/test_kernels_gpu.py -m gpu -x -q -s -k "geglu" 2>&1 | tail -3
+    for i in 1 2 3; do
+      for v in "FD_NO_FUSED_GEGLU_BWD=1" "FD_NOTHING=1"; do
+        n=$(echo "$v" | tr '=;, ' '____')
+        env $v $B --steps 6 --warmup 2 > $O/${n}_$i.json 2> $O/${n}_$i.err || tail -3 $O/${n}_$i.err
+      done
+    done
+    bench_table "$O/*.json" | tee $O/summary.txt
+    ;;
 v)  # dense short-K GEMMs as two co-resident 128x320 workgroups per CU (gemm_l2_kernel, bench-hooks library): isolated, then the whole step
     O=gpurun_out/r05v2; mkdir -p $O
     L=$P/libfairdiff_hip_bench.so
