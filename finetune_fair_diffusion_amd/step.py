@@ -235,7 +235,10 @@ class FairnessTrainer:
         # over the next step's inputs (``train_step(..., next_step=...)``) its first denoising steps are enqueued on the R2 stream as soon as
         # this step's R2 has finished, i.e. underneath the VAE decode / classifier / loss / VAE backward tail, whose launches leave most of the
         # chip idle (host syncs, small kernels).  Same kernels on the same inputs: results are bit-identical with and without it.
-        self.r2_prefetch_steps = int(os.environ.get("FD_R2_PREFETCH_STEPS", "8"))     # same-box A/B: 0 -> 1442-1448 ms, 6 -> 1431-1436, 8 -> 1429, 10 -> 1440
+        # same-box A/Bs.  Round 3: 0 -> 1442-1448 ms, 6 -> 1431-1436, 8 -> 1429, 10 -> 1440.  End of round 5 (medians of 6-step runs,
+        # profiles/r05_step_ab_schedule_knobs_final_tree.txt): 0 -> 1317-1326, 2 -> 1309-1310, 4 -> 1307-1310, 5 -> 1309-1315, 6 -> 1309-1313, 7 -> 1315-1320, 8 -> 1316-1320,
+        # 10 -> 1323-1325, 12 -> 1334-1338: the flat region moved down as the tail got shorter; 5 sits in its middle
+        self.r2_prefetch_steps = int(os.environ.get("FD_R2_PREFETCH_STEPS", "5"))
         # ... and ``r2_prefetch_late`` more of them are enqueued behind the U-Net backward's last timestep: they run while the backward streams
         # drain unevenly, through the optimiser step and under the first (host-paced) forward of the next step
         self.r2_prefetch_late = int(os.environ.get("FD_R2_PREFETCH_LATE", "0"))

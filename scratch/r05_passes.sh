@@ -121,6 +121,16 @@ z)  # final validation of the tree: full GPU suite, smoke, the driver's default 
     DB=$(find /tmp/prof_r05z -name "*.db" | head -1)
     python scratch/profsum.py $DB $O/kernel_stats.csv 30 > $O/kernel_stats_top.txt; head -12 $O/kernel_stats_top.txt | cut -c1-200
     ;;
+x)  # schedule knobs re-measured on the final tree: backward streams, R2 prefetch depth
+    O=gpurun_out/r05x2; mkdir -p $O
+    for i in 1 2; do
+      for v in "FD_NOTHING=1" "FD_BWD_STREAMS=2" "FD_BWD_STREAMS=4" "FD_R2_PREFETCH_STEPS=6" "FD_R2_PREFETCH_STEPS=10" "FD_R2_PREFETCH_STEPS=12"; do
+        n=$(echo "$v" | tr '=;, ' '____')
+        env $v $B --steps 6 --warmup 2 > $O/${n}_$i.json 2> $O/${n}_$i.err || tail -3 $O/${n}_$i.err
+      done
+    done
+    bench_table "$O/*.json" | tee $O/summary.txt
+    ;;
 w)  # GEGLU backward fused into the FF2 data-gradient GEMM's epilogue: parity, then the whole step
     O=gpurun_out/r05w2; mkdir -p $O
     python -m pytest tests/test_kernels_gpu.py -m gpu -x -q -s -k "geglu" 2>&1 | tail -3
