@@ -12,7 +12,7 @@ intra-op pool at that share:
     have put two ranks on the two hyperthreads of the same cores (ADVICE r4);
   * the mask is applied to every thread the process already has (``/proc/self/task``): ``sched_setaffinity(0, ...)`` alone pins the calling thread.
 Must run before the first HIP call of the process (bench.py, train.py call it right after parsing their arguments).  FD_NO_AFFINITY=1 leaves the
-process alone; a single-rank run is never pinned."""
+process alone.  A single-rank run is pinned to the whole NUMA node of its GPU when sysfs names it, with the same cap on the intra-op pool."""
 import glob
 import os
 
@@ -114,11 +114,29 @@ def rank_cpus(local_rank, local_world, nodes=None, gpu_nodes=None, root="/"):
     return share or sorted(nodes[node])
 
 
+def single_rank_cpus(device_index, root="/", env=None):
+    """The CPUs a single-rank run is pinned to: the NUMA node of its GPU, or None when sysfs does not name one (or the host has one node)."""
+    nodes = numa_nodes(root)
+    g = gpu_numa_node(device_index, root, env)
+    if g is None or g >= len(nodes) or not nodes[g] or len(nodes) < 2:
+        return None
+    return sorted(nodes[g])
+
+
 def pin_rank(local_rank, local_world, max_threads=8):
     """Pins the process (all of its threads) and sizes torch's intra-op pool; returns (cpus, threads) or None when nothing was done."""
-    if local_world <= 1 or os.environ.get("FD_NO_AFFINITY") is not None or not hasattr(os, "sched_setaffinity"):
+    if os.environ.get("FD_NO_AFFINITY") is not None or not hasattr(os, "sched_setaffinity"):
         return None
-    cpus = rank_cpus(local_rank, local_world)
+    single = local_world <= 1
+    if single:
+        # one rank: the whole NUMA node its GPU hangs off -- and only when sysfs names that node (a guess could pin the enqueue thread to the far socket).  Same box,
+        # alternating runs of 12 steps (profiles/r05_single_rank_numa_pinning.txt): 1309.4 / 1309.5 / 1309.7 ms pinned against 1313.4 / 1318.0 / 1317.7 left alone, whose
+        # extra is two of the +70 ms steps
+        cpus = single_rank_cpus(local_rank)
+        if cpus is None:
+            return None
+    else:
+        cpus = rank_cpus(local_rank, local_world)
     try:
         os.sched_setaffinity(0, cpus)
     except OSError:
@@ -128,8 +146,10 @@ def pin_rank(local_rank, local_world, max_threads=8):
             os.sched_setaffinity(int(t), cpus)
         except (OSError, ValueError):
             pass
+    import torch
+    # the intra-op pool is capped for a single rank too: left at its default (128 threads on the pool's hosts, whose jobs get far fewer cores than CPUs) the pinned
+    # run was 1405 ms per step against 1309 with 8 threads -- the pool's spinning workers take the enqueue thread's cycles (bench.py's CPU baseline sizes its own pool)
     threads = max(1, min(len(cpus), max_threads))
     os.environ.setdefault("OMP_NUM_THREADS", str(threads))
-    import torch
     torch.set_num_threads(threads)
     return cpus, threads

@@ -259,4 +259,14 @@ def test_rank_cpu_shares_partition_the_numa_nodes(tmp_path):
     assert A.gpu_numa_node(3, root, env={}) is None
     shares = [A.rank_cpus(r, 8, root=root) for r in range(8)]
     assert sorted(c for s in shares[:4] for c in s) == sorted(nodes[0])
-    assert A.pin_rank(0, 1) is None                    # a single-rank run is never pinned
+    # (5) a single rank gets the whole NUMA node of ITS GPU -- and nothing when sysfs does not name the node (no guessing: the far socket would be worse than no pin)
+    root = str(tmp_path / "swapped")
+    assert A.single_rank_cpus(0, root, env={}) == sorted(nodes[1]) and A.single_rank_cpus(5, root, env={}) == sorted(nodes[0])
+    assert A.single_rank_cpus(0, root, env={"HIP_VISIBLE_DEVICES": "6"}) == sorted(nodes[0])
+    assert A.single_rank_cpus(0, str(tmp_path / "unknown"), env={}) is None and A.single_rank_cpus(0, str(tmp_path / "none"), env={}) is None
+    import os as _os
+    _os.environ["FD_NO_AFFINITY"] = "1"
+    try:
+        assert A.pin_rank(0, 1) is None and A.pin_rank(0, 8) is None
+    finally:
+        del _os.environ["FD_NO_AFFINITY"]
