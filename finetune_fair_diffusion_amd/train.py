@@ -112,8 +112,9 @@ def main(argv=None, experiment=None, cfgs=None, log=None):
         raise RuntimeError(f"--mixed_precision {args.mixed_precision} but this process was started with the {WORKING_DTYPE} library: the working "
                            "dtype is fixed at import: set FD_DTYPE=%s in the environment (python -m finetune_fair_diffusion_amd.train reads --mixed_precision "
                            "and the --config YAML by itself; the YAML value wins, as in the reference)" % args.mixed_precision)
-    from .affinity import pin_rank
-    pin_rank(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)))      # this rank's CPUs / intra-op threads, before the first HIP call
+    if argv is None or world > 1:      # the command line (or a torchrun rank): an embedding caller that passes its own argv keeps its process's affinity and thread pool
+        from .affinity import pin_rank
+        pin_rank(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)))      # this rank's CPUs / intra-op threads, before the first HIP call
     if not torch.cuda.is_available():
         raise RuntimeError("finetune_fair_diffusion_amd.train needs an MI355X (HIP device); there is no CPU path")
     torch.cuda.set_device(local_rank)
