@@ -93,6 +93,7 @@ def set_seed(seed, device_specific, rank):
 
 
 def main(argv=None, experiment=None, cfgs=None, log=None):
+    from_command_line = argv is None
     argv = list(argv if argv is not None else sys.argv[1:])
     if experiment is None:       # build addition: one driver for the reference's per-experiment scripts
         import argparse
@@ -112,7 +113,7 @@ def main(argv=None, experiment=None, cfgs=None, log=None):
         raise RuntimeError(f"--mixed_precision {args.mixed_precision} but this process was started with the {WORKING_DTYPE} library: the working "
                            "dtype is fixed at import: set FD_DTYPE=%s in the environment (python -m finetune_fair_diffusion_amd.train reads --mixed_precision "
                            "and the --config YAML by itself; the YAML value wins, as in the reference)" % args.mixed_precision)
-    if argv is None or world > 1:      # the command line (or a torchrun rank): an embedding caller that passes its own argv keeps its process's affinity and thread pool
+    if from_command_line or world > 1:      # the command line (or a torchrun rank): an embedding caller that passes its own argv keeps its process's affinity and thread pool
         from .affinity import pin_rank
         pin_rank(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)))      # this rank's CPUs / intra-op threads, before the first HIP call
     if not torch.cuda.is_available():
