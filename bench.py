@@ -29,17 +29,21 @@ def f_img(S):
     return 8 * S * F_UNET + 4 * F_VAE
 
 
-def pmc_traffic(kernel, algorithmic_bytes_per_launch):
+def pmc_traffic(kernel, algorithmic_bytes_per_launch, headline):
     """HBM-side bytes per launch of the dominant kernel from the committed PMC passes (FETCH_SIZE / WRITE_SIZE cannot be read from inside a process; they are
     collected with rocprofv3 --pmc in separate runs, with the gfx950 corrections of MI355X_MICROARCH.md applied: FETCH_SIZE doubled).
-    Round 5: the passes ran over THIS benchmark's own step (scratch/r05_passes.sh a: real data flow, the kernels in launch order; counter collection serialises
-    the dispatches) -- profiles/r05_pmc_{fetch,write}_size_in_situ_step.csv hold the per-(kernel, grid) means; the figure returned is the dispatch-weighted mean
-    over the kernel's grids, i.e. measured bytes per launch of the same launch mix the roofline step times.  Older trees fall back to the per-shape
-    traffic / algorithmic ratios of rounds 1-3 applied to this run's algorithmic bytes."""
+    The in-situ passes (scratch/r0N_passes.sh: real data flow, the kernels in launch order; counter collection serialises the dispatches) profiled ONE
+    configuration -- the headline one: fp16, batch 8, S = 20, exp-1, rank 4, full model, all loss terms -- and
+    profiles/r0N_pmc_{fetch,write}_size_in_situ_step.csv hold its per-(kernel, grid) means: their dispatch-weighted mean is returned only when THIS run is
+    that configuration (``headline``), i.e. for the same launch mix the roofline step times.  Any other run (other batch / S / dtype / experiment /
+    --tiny) falls back to the per-shape traffic / algorithmic ratios of rounds 1-3 applied to this run's algorithmic bytes, and says so."""
     import csv
     root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-    fp, wp = os.path.join(root, "r05_pmc_fetch_size_in_situ_step.csv"), os.path.join(root, "r05_pmc_write_size_in_situ_step.csv")
-    if os.path.exists(fp) and os.path.exists(wp):
+    for rnd in ("r06", "r05"):
+        fp, wp = os.path.join(root, rnd + "_pmc_fetch_size_in_situ_step.csv"), os.path.join(root, rnd + "_pmc_write_size_in_situ_step.csv")
+        if not (headline and os.path.exists(fp) and os.path.exists(wp)):
+            continue
+
         def rows(path, col):
             return {(r["kernel"], r["workgroups"]): (float(r[col]), int(r["dispatches"])) for r in csv.DictReader(open(path)) if r["kernel"] == kernel}
         F, W = rows(fp, "FETCH_SIZE"), rows(wp, "WRITE_SIZE")
@@ -47,9 +51,9 @@ def pmc_traffic(kernel, algorithmic_bytes_per_launch):
         n = sum(F[k][1] for k in keys)
         if n:
             traffic = sum((2.0 * F[k][0] + W[k][0]) * 1024.0 * F[k][1] for k in keys) / n
-            return traffic, ("measured in situ: dispatch-weighted mean over %d launches of this kernel in a profiled bench step (rocprofv3 --pmc FETCH_SIZE x2 gfx950 "
-                             "correction + WRITE_SIZE, separate passes, profiles/r05_pmc_*_in_situ_step.csv); this run's mean algorithmic bytes/launch: %.1f MB; "
-                             "Infinity-Cache hits are included" % (n, algorithmic_bytes_per_launch / 1e6))
+            return traffic, ("measured in situ: dispatch-weighted mean over %d launches of this kernel in a profiled bench step of the headline configuration (rocprofv3 "
+                             "--pmc FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate passes, profiles/%s_pmc_*_in_situ_step.csv); this run's mean algorithmic "
+                             "bytes/launch: %.1f MB; Infinity-Cache hits are included" % (n, rnd, algorithmic_bytes_per_launch / 1e6))
     d = None
     for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         path = os.path.join(root, name)
@@ -58,11 +62,11 @@ def pmc_traffic(kernel, algorithmic_bytes_per_launch):
             if d is not None:
                 break
     if d is None:
-        return None, "no PMC summary committed for " + kernel
+        return None, "no PMC summary committed for " + kernel + ("" if headline else " (not the headline configuration: the in-situ passes do not apply)")
     ratio = sum(x["hbm_bytes"] for x in d["shapes"]) / sum(x["algorithmic_bytes"] for x in d["shapes"])
     return algorithmic_bytes_per_launch * ratio, "bytes/launch = mean algorithmic bytes/launch of this run (%.1f MB) x %.2f, the rocprofv3 PMC ratio " \
-        "(FETCH_SIZE x2 gfx950 correction + WRITE_SIZE) / algorithmic bytes on this kernel's shapes; Infinity-Cache hits are included" % (
-            algorithmic_bytes_per_launch / 1e6, ratio)
+        "(FETCH_SIZE x2 gfx950 correction + WRITE_SIZE) / algorithmic bytes on this kernel's shapes (isolated passes of rounds 1-3%s); Infinity-Cache hits are included" % (
+            algorithmic_bytes_per_launch / 1e6, ratio, "" if headline else "; not the headline configuration, so the in-situ passes do not apply")
 
 
 def main():
@@ -233,7 +237,8 @@ def main():
         top = max(summ.items(), key=lambda kv: kv[1]["ms"])
         name, s = top
         achieved = s["flops"] / (s["ms"] * 1e-3) / 1e12
-        traffic, traffic_note = pmc_traffic(name, s["bytes"] / s["launches"])
+        headline = (a.dtype == "fp16" and a.batch == 8 and a.S == 20 and a.rank == 4 and a.experiment == "exp-1" and not a.tiny and not a.no_regularisers)
+        traffic, traffic_note = pmc_traffic(name, s["bytes"] / s["launches"], headline)
         line["roofline"] = {"bound": "mfma", "kernel": name, "achieved": achieved, "peak": MFMA_PEAK_F16 / 1e12, "unit": "TFLOP/s",
                             "frac": achieved / (MFMA_PEAK_F16 / 1e12), "traffic": traffic, "traffic_note": traffic_note,
                             "launches": s["launches"], "splitk_launches": s["splitk_launches"],

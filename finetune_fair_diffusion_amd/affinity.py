@@ -70,8 +70,10 @@ def gpu_numa_node(device_index, root="/", env=None):
     variable that is not a plain index list)."""
     env = os.environ if env is None else env
     idx = device_index
-    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
-        v = env.get(var)
+    # HIP device i -> HIP_VISIBLE_DEVICES[i] (CUDA_VISIBLE_DEVICES is its alias on ROCm and is IGNORED when HIP_VISIBLE_DEVICES is set), an index into the
+    # list the ROCr runtime exposes -> ROCR_VISIBLE_DEVICES[that] = the physical GPU (ADVICE r5: the three were chained in the wrong order, and HIP + CUDA
+    # both set were applied twice)
+    for v in (env.get("HIP_VISIBLE_DEVICES") or env.get("CUDA_VISIBLE_DEVICES"), env.get("ROCR_VISIBLE_DEVICES")):
         if v:
             try:
                 idx = [int(x) for x in v.split(",")][idx]
@@ -103,7 +105,10 @@ def rank_cpus(local_rank, local_world, nodes=None, gpu_nodes=None, root="/"):
     if gpu_nodes is None:
         gpu_nodes = [gpu_numa_node(r, root) for r in range(local_world)]
     if any(g is None or g >= nn or not nodes[g] for g in gpu_nodes):
-        gpu_nodes = [min(r * nn // local_world, nn - 1) for r in range(local_world)]        # round 4's even deal
+        # round 4's even deal -- over the nodes that HAVE CPUs (list indices are NUMA ids, so a cpuset confined to one socket leaves empty entries; dealing
+        # ranks onto those left them unpinned with the machine-sized intra-op pool)
+        ne = [i for i, n in enumerate(nodes) if n] or [0]
+        gpu_nodes = [ne[min(r * len(ne) // local_world, len(ne) - 1)] for r in range(local_world)]
     node = gpu_nodes[local_rank]
     peers = [r for r in range(local_world) if gpu_nodes[r] == node]
     cores = cores_of(nodes[node], root)

@@ -681,6 +681,7 @@ static int launch(const fd_gemm_desc& d, hipStream_t s) {
 // gemm_pp.hip: the 8-wave 256x320 ping-pong kernel (BK = 32, four-stage ring, two wave groups half a k-step apart)
 bool fd_gemm_pp_eligible(const fd_gemm_desc& d);
 int fd_gemm_launch_pp(const fd_gemm_desc& d, hipStream_t s, bool prio, int bm, int nsplit);
+bool fd_conv_halo_takes(const fd_gemm_desc& d, int bm, int nsplit);     // gemm_halo.hip: stride-1 3x3 convolutions with the halo-staged A operand
 // (round 5: the persistent streaming form of the 128x320 ping-pong kernel -- policy bit 128, measured and never selected -- and the register-B experiments
 // live in scratch/ with their measurements: gemm_pps_experiment.hip, gemm_rb_experiment.hip, gemm_rbk_experiment.hip)
 // Which problems the ping-pong kernels take (bits): 1 = stride-1 3x3 convolutions on the 256x320 tile, 2 = every dense GEMM on it,
@@ -823,7 +824,10 @@ extern "C" int fd_gemm_kernel_name(const fd_gemm_desc* dp, char* buf, int n) {
     const GemmPlan g = gemm_plan(d);
     const bool st = d.gn_stats && g.stats_ok;
     switch (g.kind) {
-        case GK_PP: snprintf(buf, n, "gemm_pp_kernel<%d, %d, %s>", g.bm, (d.conv ? 1 : 0) + (st ? 2 : 0), (pp_mode() & 4) ? "true" : "false"); break;
+        case GK_PP:
+            if (fd_conv_halo_takes(d, g.bm, g.nsplit)) snprintf(buf, n, "conv_halo_kernel<%d, %d, %d, %s>", g.bm, d.W, st ? 3 : 1, (pp_mode() & 4) ? "true" : "false");
+            else snprintf(buf, n, "gemm_pp_kernel<%d, %d, %s>", g.bm, (d.conv ? 1 : 0) + (st ? 2 : 0), (pp_mode() & 4) ? "true" : "false");
+            break;
         case GK_BIG: snprintf(buf, n, "gemm_big_kernel<%d, %d, %d, %d, %d>", g.bm, g.bn, g.wgm, g.wgn, st ? (g.cv == 2 ? 6 : g.cv + 3) : g.cv); break;
         case GK_SKINNY: snprintf(buf, n, "gemm_skinny_kernel<%d, %d, 1>", g.bn / 16, d.K >= 1280 ? 4 : d.K >= 640 ? 2 : 1); break;
         default: snprintf(buf, n, "gemm_glds_kernel<%d, %d, %s>", g.bm, g.bn, d.conv ? "true" : "false"); break;

@@ -288,8 +288,20 @@ bool fd_gemm_pp_eligible(const fd_gemm_desc& d) {
     return (d.K & 7) == 0;
 }
 
+// gemm_halo.hip: the same loop with the A operand of a stride-1 3x3 convolution staged once per channel chunk (round 6)
+bool fd_conv_halo_eligible(const fd_gemm_desc& d, int bm);
+int fd_conv_halo_launch(const fd_gemm_desc& d, hipStream_t s, bool prio, int bm);
+bool fd_conv_halo_takes(const fd_gemm_desc& d, int bm, int nsplit) {
+#ifdef FD_BENCH_HOOKS
+    const char* e = getenv("FD_CONV_HALO");          // measurement build: FD_CONV_HALO=0 keeps the per-tap gather (re-read on every call for in-process A/Bs)
+    if (e && atoi(e) == 0) return false;
+#endif
+    return nsplit == 1 && fd_conv_halo_eligible(d, bm);
+}
+
 // bm: 256 or 128 rows per tile; nsplit > 1: split-K partials into d.workspace (the caller launches the reduction)
 int fd_gemm_launch_pp(const fd_gemm_desc& d, hipStream_t s, bool prio, int bm, int nsplit) {
+    if (fd_conv_halo_takes(d, bm, nsplit)) return fd_conv_halo_launch(d, s, prio, bm);
     if (bm == 256) launch_pp_bm<256>(d, s, prio, nsplit);
     else launch_pp_bm<128>(d, s, prio, nsplit);
     return fd_check_launch("fd_gemm(pp)");

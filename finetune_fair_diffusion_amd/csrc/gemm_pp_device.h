@@ -15,10 +15,17 @@ static __device__ __forceinline__ void raw_barrier() { asm volatile("s_barrier" 
 // to decide (the wave in its MFMA stream outranks the one doing boundary work); in a lockstep loop it is a no-op
 // ABL (measurement builds only, FD_GEMM_DBG): 0 = the kernel, 2 = no MFMAs (fragment reads, waits, barriers and DMA issue only), 6 = no fragment reads (MFMAs on
 // whatever the registers hold)
-template <int TM, int TN, int PD, int GS, bool PRIO, class MID, int ABL = 0>
+// byte offset of 16-row fragment group i behind the lane's base address: i * GS for the 16-row-group staging image; AW > 0 (gemm_halo.hip): the A operand
+// is a halo image of W = AW pixels per image row, 64 bytes per pixel, AW + 8 pixel slots per LDS row -- fragment i starts 16 i pixels further on, plus
+// 8 slots for every image row crossed
+template <int AW, int GS>
+__host__ __device__ constexpr int pp_frag_off(int i) { return AW ? (16 * i + 8 * ((16 * i) / (AW ? AW : 1))) * 64 : i * GS; }
+
+template <int TM, int TN, int PD, int GS, bool PRIO, class MID, int ABL = 0, int AW = 0>
 static __device__ __forceinline__ void mma_k32_mid(f32x4 (&acc)[TM][TN], uint32_t a_addr, uint32_t b_addr, MID&& mid) {
     constexpr bool BRES = TN <= TM;   // the operand with fewer fragments stays resident for the step
     constexpr int NR = BRES ? TN : TM, NS = BRES ? TM : TN, R = PD + 1;
+    constexpr int RW = BRES ? 0 : AW, SW = BRES ? AW : 0;     // which of the two is A
     const uint32_t r_addr = BRES ? b_addr : a_addr, s_addr = BRES ? a_addr : b_addr;
     f16x8 res[NR], ring[R];
     if constexpr (ABL == 6) {
@@ -29,16 +36,16 @@ static __device__ __forceinline__ void mma_k32_mid(f32x4 (&acc)[TM][TN], uint32_
     }
     static_for<0, NR>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
-        if constexpr (ABL != 6) ds_read16<i * GS>(res[i], r_addr);
+        if constexpr (ABL != 6) ds_read16<pp_frag_off<RW, GS>(i)>(res[i], r_addr);
     });
     static_for<0, PD>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
-        if constexpr (ABL != 6) ds_read16<i * GS>(ring[i % R], s_addr);
+        if constexpr (ABL != 6) ds_read16<pp_frag_off<SW, GS>(i)>(ring[i % R], s_addr);
     });
     if (PRIO) __builtin_amdgcn_s_setprio(1);
     static_for<0, NS>([&](auto ic) {
         constexpr int s = decltype(ic)::value;
-        if constexpr (s + PD < NS && ABL != 6) ds_read16<(s + PD) * GS>(ring[(s + PD) % R], s_addr);
+        if constexpr (s + PD < NS && ABL != 6) ds_read16<pp_frag_off<SW, GS>(s + PD)>(ring[(s + PD) % R], s_addr);
         constexpr int after = (NS - 1 - s) < PD ? (NS - 1 - s) : PD;
         wait_lgkm<after>();
         if constexpr (s == 0) {

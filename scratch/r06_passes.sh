@@ -1,0 +1,39 @@
+#!/bin/bash
+# every gpurun pass of round 6 is one case branch:  bash scratch/r06_passes.sh <letter>
+mkdir -p gpurun_out
+P=$PWD/finetune_fair_diffusion_amd
+R=$PWD
+B="python bench.py --no_cpu_baseline --no_roofline"
+bench_table() {   # bench_table <glob>: value, ms/step, median, phases of every bench line that matches
+python - "$1" <<'PY'
+import json, glob, statistics, sys
+for f in sorted(glob.glob(sys.argv[1])):
+    try:
+        d = json.loads(open(f).read().strip().splitlines()[-1]); h = d['config']['host_ms_per_step']
+        print(f, round(d['value'], 3), round(d['ms_per_step'], 1), 'median', round(statistics.median(h), 1), d['config']['phase_ms'])
+    except Exception as e:
+        print(f, 'ERR', e)
+PY
+}
+case "$1" in
+a)  # what bounds the main loops -- LDS-array and matrix-pipe busy shares per kernel, isolated (the step's shapes, cold operands) and in situ
+    O=gpurun_out/r06a; mkdir -p $O
+    $B --steps 6 --warmup 2 > $O/bench_start_of_round.json 2> $O/bench_start_of_round.err; cut -c1-200 $O/bench_start_of_round.json
+    cd /tmp && export TMPDIR=/tmp
+    i=0
+    for C in "SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_INST_CYCLES_VMEM SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE"; do
+      i=$((i+1))
+      timeout 600 rocprofv3 --kernel-trace --pmc $C --kernel-include-regex "gemm" --output-format csv -d /tmp/pmc_r06a_iso_$i -o p -- python3 $R/scratch/mb_pmc_r05.py > $R/$O/iso_pass_$i.log 2>&1
+      timeout 1200 rocprofv3 --kernel-trace --pmc $C --kernel-include-regex "gemm" --output-format csv -d /tmp/pmc_r06a_situ_$i -o p -- python3 $R/bench.py --steps 1 --warmup 1 --no_cpu_baseline --no_roofline > $R/$O/situ_pass_$i.log 2>&1
+    done
+    cd $R
+    python scratch/r06_pmc_lds_summary.py $O/pmc_lds_mainloop_isolated.txt /tmp/pmc_r06a_iso_1 /tmp/pmc_r06a_iso_2 | cut -c1-330
+    python scratch/r06_pmc_lds_summary.py $O/pmc_lds_mainloop_in_situ.txt /tmp/pmc_r06a_situ_1 /tmp/pmc_r06a_situ_2 | head -30 | cut -c1-330
+    cp gpurun_out/pmc_r05_manifest.json $O/ 2>/dev/null
+    ;;
+b)  # the halo-staged convolution: parity (every tile geometry, borders, epilogues), bit-equality with the per-tap kernel and the isolated A/B on the step's shapes
+    O=gpurun_out/r06b; mkdir -p $O
+    timeout 900 python -m pytest tests/test_kernels_gpu.py -q -x -s -k "conv3x3 or statistics_epilogue" > $O/conv_tests.log 2>&1; tail -5 $O/conv_tests.log; grep "conv halo" $O/conv_tests.log | head -30
+    timeout 900 python scratch/mb_halo.py 2>&1 | grep -v amdgpu.ids | tee $O/mb_halo.txt
+    ;;
+esac

@@ -259,6 +259,18 @@ def test_rank_cpu_shares_partition_the_numa_nodes(tmp_path):
     assert A.gpu_numa_node(3, root, env={}) is None
     shares = [A.rank_cpus(r, 8, root=root) for r in range(8)]
     assert sorted(c for s in shares[:4] for c in s) == sorted(nodes[0])
+    # (4b) ADVICE r5: a cpuset confined to one socket leaves an EMPTY node entry (indices are NUMA ids): the even deal goes over the nodes that have CPUs, so
+    # every rank is pinned to something; and the visible-devices variables compose as HIP (or its alias CUDA, ignored when HIP is set) -> ROCR -> physical
+    one = [list(range(16)), []]
+    shares = [A.rank_cpus(r, 4, one, gpu_nodes=[None] * 4, root=str(tmp_path / "none")) for r in range(4)]
+    assert all(shares) and sorted(c for s in shares for c in s) == list(range(16))
+    shares = [A.rank_cpus(r, 4, [[], list(range(8))], gpu_nodes=[0, 0, 1, 1], root=str(tmp_path / "none")) for r in range(4)]      # GPUs named on the empty node
+    assert all(shares) and sorted(c for s in shares for c in s) == list(range(8))
+    sw = str(tmp_path / "swapped")
+    assert A.gpu_numa_node(0, sw, env={"CUDA_VISIBLE_DEVICES": "5"}) == 0                                              # the alias alone
+    assert A.gpu_numa_node(0, sw, env={"HIP_VISIBLE_DEVICES": "2", "CUDA_VISIBLE_DEVICES": "5"}) == 1                  # HIP set: CUDA ignored (not applied twice)
+    assert A.gpu_numa_node(1, sw, env={"CUDA_VISIBLE_DEVICES": "0,1", "ROCR_VISIBLE_DEVICES": "7,6,5,4"}) == 0         # HIP index 1 -> ROCr list [1] = GPU 6
+    assert A.gpu_numa_node(0, sw, env={"HIP_VISIBLE_DEVICES": "3", "ROCR_VISIBLE_DEVICES": "0,1,2"}) is None           # out of range: no guess
     # (5) a single rank gets the whole NUMA node of ITS GPU -- and nothing when sysfs does not name the node (no guessing: the far socket would be worse than no pin)
     root = str(tmp_path / "swapped")
     assert A.single_rank_cpus(0, root, env={}) == sorted(nodes[1]) and A.single_rank_cpus(5, root, env={}) == sorted(nodes[0])

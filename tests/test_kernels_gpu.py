@@ -137,6 +137,43 @@ def test_conv3x3_big_tiles(ops, dev, B, H, Cin, Cout):
     check("conv big stride2 dgrad", _nchw(dx, B, Ho, Wo), ref, 2e-3)
 
 
+@pytest.mark.parametrize("B,H,Cin,Cout,kernel", [(16, 64, 64, 320, "conv_halo_kernel<256, 64"), (16, 32, 192, 640, "conv_halo_kernel<256, 32"), (32, 16, 64, 1280, "conv_halo_kernel<256, 16"),
+                                                 (2, 64, 64, 640, "conv_halo_kernel<128, 64"), (8, 32, 64, 640, "conv_halo_kernel<128, 32"), (16, 16, 192, 1280, "conv_halo_kernel<128, 16"),
+                                                 (3, 64, 320, 640, "conv_halo_kernel<128, 64")])
+def test_conv3x3_halo_staged(ops, dev, B, H, Cin, Cout, kernel):
+    """Round 6: stride-1 3x3 convolutions of the 64^2 / 32^2 / 16^2 levels with the A operand staged once per 32-channel chunk (image rows + one-pixel halo,
+    nine taps = shifted fragment windows, operands by buffer_load ... lds with the hardware's range check supplying the zero padding).  Every tile geometry,
+    image borders inside and at the edge of tiles, bias / residual / row-bias epilogues and the GroupNorm-statistics instantiation --
+    against fp32 torch, and the dispatch is asserted so that the test cannot pass on the per-tap kernel."""
+    import ctypes
+    from finetune_fair_diffusion_amd import lib
+    x = rnd(B, Cin, H, H, dev=dev, seed=1)
+    w = rnd(Cout, Cin, 3, 3, dev=dev, scale=0.05, seed=2)
+    bias = rnd(Cout, dev=dev, dtype=torch.float32, seed=3)
+    res = rnd(B * H * H, Cout, dev=dev, seed=4)
+    rb = rnd(B, Cout, dev=dev, seed=5)
+    wk = w.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin).contiguous()
+    d = lib.GemmDesc(); d.M, d.N, d.K, d.batch, d.conv, d.conv_mode, d.Bn, d.H, d.W, d.Cin, d.Ho, d.Wo = B * H * H, Cout, 9 * Cin, 1, 1, 0, B, H, H, Cin, H, H
+    ws = ops.gemm_workspace(); d.workspace, d.workspace_bytes, d.ldc, d.lda, d.ldb = ws.data_ptr(), ws.numel() * 4, Cout, Cin, 9 * Cin
+    buf = ctypes.create_string_buffer(128)
+    lib.get().fd_gemm_kernel_name(ctypes.byref(d), buf, 128)
+    assert buf.value.decode().startswith(kernel), buf.value
+    ref = F.conv2d(x.float(), w.float(), bias, padding=1)
+    y, _, _ = ops.conv3x3(_nhwc(x), wk, B, H, H, bias=bias)
+    check(f"conv halo {kernel}>", _nchw(y, B, H, H), ref, 2e-3)
+    y2, _, _ = ops.conv3x3(_nhwc(x), wk, B, H, H, bias=bias, residual=res, rowbias=rb, gn_stats=True)
+    ref2 = ref + rb.float()[:, :, None, None] + _nchw(res.float(), B, H, H)
+    check(f"conv halo {kernel}> epilogue", _nchw(y2, B, H, H), ref2, 2e-3)
+    st = y2.gn_stats[0]
+    sref = _unit_sums(y2)
+    assert float(((st.double() - sref).abs() / (sref.abs() + 1.0)).max()) < 2e-5
+    # an image whose only non-zero pixels sit on the border: every halo row / column of every tile must come back as exact zeros
+    xb = torch.zeros_like(x)
+    xb[:, :, 0, :], xb[:, :, -1, :], xb[:, :, :, 0], xb[:, :, :, -1] = x[:, :, 0, :], x[:, :, -1, :], x[:, :, :, 0], x[:, :, :, -1]
+    yb, _, _ = ops.conv3x3(_nhwc(xb), wk, B, H, H)
+    check(f"conv halo {kernel}> border", _nchw(yb, B, H, H), F.conv2d(xb.float(), w.float(), None, padding=1), 2e-3)
+
+
 def test_gemm_epilogue_and_lora_slab(ops, dev):
     M, N, K, R = 777, 640, 320, 8
     a, b = rnd(M, K, dev=dev, seed=1), rnd(N, K, dev=dev, scale=0.1, seed=2)
