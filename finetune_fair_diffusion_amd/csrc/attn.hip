@@ -191,6 +191,7 @@ template <int D, int QB, bool PRE = false>
 __global__ __launch_bounds__(256, QB == 1 ? fwd_waves(D) : (D <= 64 ? 2 : 1)) void attn_fwd_kernel(const f16* __restrict__ Q, const f16* __restrict__ K, const f16* __restrict__ V,
                                                        f16* __restrict__ O, float* __restrict__ LSE, int H, int Tq, int Tk,
                                                        int Tkr, int kv_div, float scale, int ldq, int ldk) {
+    FD_WG_TRACE(7);
     constexpr int DK = (D + 15) / 16 * 16, DV = (D + 31) / 32 * 32, DKP = DK + 8;
     constexpr int NKS = DK / 16, NDV = DV / 32;
     constexpr int RB = 128 * QB;                // query rows per workgroup
@@ -462,6 +463,7 @@ __global__ __launch_bounds__(256, dq_waves(D)) void attn_bwd_dq_kernel(const f16
                                                           const float* __restrict__ LSE, float* __restrict__ Dd, f16* __restrict__ dQ,
                                                           const f16* __restrict__ O, int H, int Tq, int Tk, int Tkr, int kv_div,
                                                           float scale, int ldq, int ldkv, int lddq) {
+    FD_WG_TRACE(8);
     constexpr int DK = (D + 15) / 16 * 16, DV = (D + 31) / 32 * 32, DKP = DK + FD_ATTN_BWD_PAD;
     constexpr int NKS = DK / 16, NDV = DV / 32;
     extern __shared__ __attribute__((aligned(16))) f16 smem[];
@@ -614,6 +616,7 @@ __global__ __launch_bounds__(256, dkdv_waves(D)) void attn_bwd_dkdv_kernel(const
                                                             const float* __restrict__ Dd, void* __restrict__ dKo, void* __restrict__ dVo,
                                                             int H, int Tq, int Tk, int Tkr, int kv_div, float scale, int ldq, int ldkv, int lddkv,
                                                             int64_t slab) {
+    FD_WG_TRACE(9);
     // ATOMIC + slab > 0: no atomics -- sample j of a K/V group stores its fp32 partial into slab j (slab = elements per [Bk*Tkr, lddkv] buffer);
     // the caller sums the kv_div slabs in a fixed order (fd_sum_slabs): bit-reproducible shared dK / dV
     constexpr int DK = (D + 15) / 16 * 16, DV = (D + 31) / 32 * 32, DKP = DK + FD_ATTN_BWD_PAD;
@@ -969,3 +972,5 @@ extern "C" int fd_attn_bwd_dkdv(const void* q, const void* k, const void* v, con
 #undef LAUNCH
     return fd_check_launch("fd_attn_bwd_dkdv");
 }
+
+FD_WGT_SETTER(attn)

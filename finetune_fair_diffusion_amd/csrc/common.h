@@ -126,6 +126,45 @@ __device__ __forceinline__ float act_grad(float z, int act) {
     }
 }
 
+// ---- workgroup trace (measurement builds only, -DFD_BENCH_HOOKS): with a log buffer installed (fd_bench_wg_trace, runtime.hip) every workgroup of an
+// instrumented kernel appends (kernel id | waves << 8 | blockIdx.x << 16, XCC id << 32 | HW_ID, start, end) -- times on the 100 MHz s_memrealtime clock, which is
+// common to the whole chip -- so that scratch/wg_fill.py can say how many CUs held work at any moment of the SHIPPED multi-stream schedule (rocprofv3's kernel
+// trace serialises most dispatches: profiles/r05_kernel_trace_concurrency_start_of_round.txt).  One returning atomic + one 32-byte store per workgroup.
+#ifdef FD_BENCH_HOOKS
+static __device__ unsigned long long* fd_wgt_buf;      // [0] = record counter, records of 4 x u64 from [4] on; one copy per translation unit (FD_WGT_SETTER)
+static __device__ unsigned int fd_wgt_cap;
+struct FdWgTrace {
+    unsigned long long t0;
+    int id;
+    __device__ __forceinline__ FdWgTrace(int id_) : t0(0), id(id_) {
+        if (threadIdx.x == 0 && fd_wgt_buf) t0 = __builtin_amdgcn_s_memrealtime();
+    }
+    __device__ __forceinline__ ~FdWgTrace() {
+        if (threadIdx.x == 0 && fd_wgt_buf) {
+            const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
+            const unsigned long long i = atomicAdd(fd_wgt_buf, 1ULL);
+            if (i < fd_wgt_cap) {
+                const unsigned int hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+                unsigned long long* r = fd_wgt_buf + 4 + 4 * i;
+                r[0] = (unsigned long long)id | ((unsigned long long)((blockDim.x * blockDim.y + 63) >> 6) << 8) | ((unsigned long long)blockIdx.x << 16);
+                r[1] = ((unsigned long long)xcc << 32) | hw;
+                r[2] = t0;
+                r[3] = t1;
+            }
+        }
+    }
+};
+#define FD_WG_TRACE(id) FdWgTrace fd_wg_trace_(id)
+#define FD_WGT_SETTER(tu)                                                                  \
+    extern "C" void fd_wgt_set_##tu(unsigned long long* buf, unsigned int cap) {            \
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(fd_wgt_buf), &buf, sizeof(buf));                 \
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(fd_wgt_cap), &cap, sizeof(cap));                 \
+    }
+#else
+#define FD_WG_TRACE(id)
+#define FD_WGT_SETTER(tu)
+#endif
+
 // XCD-aware bijective remap of a linear workgroup id: consecutive remapped ids share an XCD's L2
 // (dispatcher places block b on XCD b % 8 -- speed only, never correctness).
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {

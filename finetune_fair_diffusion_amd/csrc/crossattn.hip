@@ -188,6 +188,7 @@ __device__ __forceinline__ void lora_down(const f16* __restrict__ tile, const f1
 
 template <int C, bool LORA, bool REC>
 __global__ __launch_bounds__(256, CrossCfg<C>::OCC) void cross_block_kernel(CrossArgs a) {
+    FD_WG_TRACE(10);
     using Cf = CrossCfg<C>;
     constexpr int BM = Cf::BM, TM = Cf::TM, TN = Cf::TN, LDT = Cf::LDT, MAXV = Cf::MAXV, D = Cf::D, NKS = Cf::NKS, NDT = Cf::NDT, V = C / 8;
     constexpr int RPW = BM / 4;                   // rows per wave in the row-wise phases
@@ -530,3 +531,5 @@ extern "C" int fd_cross_attn_block(const fd_cross_block_desc* dp, void* stream) 
 #undef CROSS_LAUNCH
     return fd_check_launch("fd_cross_attn_block");
 }
+
+FD_WGT_SETTER(crossattn)

@@ -44,6 +44,7 @@ __global__ void geglu_bwd_kernel(const f16* proj, const f16* dy, f16* dproj, int
     }
 }
 __global__ void geglu_bwd_il_kernel(const f16* proj, const f16* dy, f16* dproj, int64_t n4) {
+    FD_WG_TRACE(17);
     // 4 (value, gate) pairs per thread: 16 B of proj, 8 B of dy in, 16 B of dproj out
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
         const f16x8 pr = *(const f16x8*)(proj + i * 8);
@@ -107,6 +108,7 @@ __global__ void act_bwd_kernel(const f16* z, const f16* dy, f16* dx, int64_t n, 
     }
 }
 __global__ void add_kernel(const f16* a, const f16* b, f16* y, int64_t n, float sa, float sb) {
+    FD_WG_TRACE(20);
     const int64_t nv = n >> 3;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nv; i += (int64_t)gridDim.x * blockDim.x) {
         const f16x8 u = *(const f16x8*)(a + i * 8);
@@ -490,3 +492,5 @@ extern "C" int fd_sum_slabs(const float* in, float* out, int nslab, int64_t n, v
     hipLaunchKernelGGL(sum_slabs_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, in, out, nslab, n4);
     return fd_check_launch("fd_sum_slabs");
 }
+
+FD_WGT_SETTER(elementwise)

@@ -10,6 +10,7 @@
 
 template <int BM, int BN, bool CONV>
 __global__ __launch_bounds__(256) void gemm_glds_kernel(fd_gemm_desc p, int ntm, int ntn) {
+    FD_WG_TRACE(1);
     constexpr int TM = BM / 32, TN = BN / 32;
     constexpr int AI = BM / 64, BI = BN / 64;     // 16-row groups per wave per k-tile
     constexpr int EPI_HALFS = 4 * (BM / 2) * (BN / 2 + 4);           // 4 waves x (wave tile + row pad)
@@ -179,6 +180,7 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(fd_gemm_desc p, int ntm,
 // CV = 3 / 4 / 6: variants 0 / 1 / 2 with the GroupNorm-statistics epilogue (fd_gemm_desc.gn_stats)
 template <int BM, int BN, int WGM, int WGN, int CV>
 __global__ __launch_bounds__(WGM * WGN * 64) void gemm_big_kernel(fd_gemm_desc p, int ntm, int ntn, int gn) {
+    FD_WG_TRACE(2);
     static_assert(CV != 5, "CV = 5 was the LayerNorm second output (scratch/gemm_ln_epilogue_experiment.h)");
     constexpr int CONV = CV == 6 ? 2 : CV >= 3 ? CV - 3 : CV;      // CV = 6: the phase pair (variant 2) with the statistics epilogue (FD_CONV_UP2PI)
     constexpr bool WSTATS = CV == 3 || CV == 4 || CV == 6;
@@ -483,6 +485,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_big_kernel(fd_gemm_desc p
 
 // sum the split-K slabs in a fixed order and apply the epilogue
 __global__ void splitk_reduce_kernel(fd_gemm_desc p, int nsplit) {
+    FD_WG_TRACE(3);
     const int64_t n4 = (int64_t)p.M * p.N / 4;
     const float* ws = (const float*)p.workspace;
     const f16* R = (const f16*)p.residual;
@@ -569,6 +572,7 @@ static int launch_big(const fd_gemm_desc& d, hipStream_t s, int nsplit = 1) {
 // no barrier in the main loop.  KS waves of a workgroup split K in slabs of 320 and are summed through LDS in a fixed order.
 template <int NT, int KS, int RT>
 __global__ __launch_bounds__(KS * 64) void gemm_skinny_kernel(fd_gemm_desc p) {
+    FD_WG_TRACE(4);
     __shared__ float red[KS > 1 ? (KS - 1) * RT * NT * 256 : 1];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l15 = lane & 15, lg = lane >> 4;
@@ -911,3 +915,5 @@ extern "C" int fd_gemm(const fd_gemm_desc* dp, void* stream) {
             return launch<64, 64>(d, s);
     }
 }
+
+FD_WGT_SETTER(gemm)

@@ -43,6 +43,7 @@ __device__ __forceinline__ int halo_swz(int P) { return ((P >> 2) & 1) << 1; }
 // CV = 1 / 3: plain / with the GroupNorm-statistics epilogue (the numbering of gemm_pp_kernel's convolution variants)
 template <int BM, int W, int CV, bool PRIO>
 __global__ __launch_bounds__(512) void conv_halo_kernel(fd_gemm_desc p, int ntm, int ntn, int gn) {
+    FD_WG_TRACE(6);
 #if __HIP_DEVICE_COMPILE__     // the host pass does not know __amdgpu_buffer_rsrc_t and silently drops the kernel's host stub with it
     using G = halo_geo<BM, W>;
     constexpr bool WSTATS = CV >= 2;
@@ -242,3 +243,5 @@ int fd_conv_halo_launch(const fd_gemm_desc& d, hipStream_t s, bool prio, int bm)
     return fd_check_launch("fd_gemm(conv halo)");
 #endif
 }
+
+FD_WGT_SETTER(gemm_halo)

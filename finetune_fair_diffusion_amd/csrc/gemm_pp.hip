@@ -34,8 +34,10 @@
 #include "gemm_pp_device.h"
 
 // CV = 2 / 3: variants 0 / 1 (dense / stride-1 3x3 gather) with the GroupNorm-statistics epilogue (fd_gemm_desc.gn_stats)
+constexpr uint32_t PP_OOR = 0xFFFFFFF0u;          // a byte offset beyond every buffer: the range check of buffer_load returns zeros for the lane
 template <int BM, int CV, bool PRIO>
 __global__ __launch_bounds__(512) void gemm_pp_kernel(fd_gemm_desc p, int ntm, int ntn, int gn) {
+    FD_WG_TRACE(5);
     constexpr int CONV = CV & 1;
     constexpr bool WSTATS = CV >= 2;
     constexpr int WTM = BM / 2, WTN = 80, TM = WTM / 16, TN = 5;
@@ -68,8 +70,6 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(fd_gemm_desc p, int ntm, i
 
     const f16* A = (const f16*)p.A;
     const f16* B = (const f16*)p.B;
-    const f16* A2 = (const f16*)p.A2;
-    const f16* B2 = (const f16*)p.B2;
     const int nk1 = (p.K + 31) >> 5, nk2 = (p.K2 + 31) >> 5, nkt = nk1 + nk2;
     // split-K: blockIdx.y owns the k-steps [kbeg, kend) and writes raw fp32 partials to the workspace
     const int nsplit = gridDim.y;
@@ -112,6 +112,31 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(fd_gemm_desc p, int ntm, i
         b_row[i] = (n < p.N && (wave + 8 * i) < PP_NGB) ? n : -1;
     }
     f16* const dump = smem + PP_NST * STAGE + wave * PP_GROUP;
+#if __HIP_DEVICE_COMPILE__
+    // Dense operands travel by buffer_load ... lds (round 6, as in gemm_halo.hip): a 32-bit per-lane byte offset fixed for the whole launch + a scalar k offset per
+    // step, range-checked by the hardware -- rows beyond M / N carry an out-of-range offset and read zeros; no 64-bit address arithmetic and no pointer select per
+    // piece (~8 VALU each before).  K tails (K % 32 != 0: the LoRA slab) switch the tail lanes to the out-of-range offset for that step.
+    __amdgpu_buffer_rsrc_t rA, rB, rA2, rB2;
+    uint32_t a_vo[NAW], a_vo2[NAW], b_vo[3], b_vo2[3];
+    if (!CONV) {
+        auto rsrc = [](const void* base, int64_t rows, int64_t ld, int k) {
+            const int64_t bytes = base ? ((rows - 1) * ld + k) * 2 : 0;
+            return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)(uint32_t)bytes, 0x00020000);
+        };
+        rA = rsrc(p.A, p.M, p.lda, p.K); rB = rsrc(p.B, p.N, p.ldb, p.K);
+        rA2 = rsrc(p.K2 ? p.A2 : nullptr, p.M, p.lda2, p.K2); rB2 = rsrc(p.K2 ? p.B2 : nullptr, p.N, p.ldb2, p.K2);
+#pragma unroll
+        for (int i = 0; i < NAW; ++i) {
+            a_vo[i] = a_off[i] >= 0 ? (uint32_t)(a_off[i] * (int)p.lda + kchunk) * 2 : PP_OOR;
+            a_vo2[i] = a_off[i] >= 0 ? (uint32_t)(a_off[i] * (int)p.lda2 + kchunk) * 2 : PP_OOR;
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            b_vo[i] = b_row[i] >= 0 ? (uint32_t)(b_row[i] * (int)p.ldb + kchunk) * 2 : PP_OOR;
+            b_vo2[i] = b_row[i] >= 0 ? (uint32_t)(b_row[i] * (int)p.ldb2 + kchunk) * 2 : PP_OOR;
+        }
+    }
+#endif
 
     // NL global_load_lds per call: NAW A groups + (NL - NAW) B groups, for local k-step j (global step kbeg + j) into ring slot j & 3
     auto issue = [&](int j, auto nl_c) {
@@ -142,23 +167,28 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(fd_gemm_desc p, int ntm, i
                 glds16(src, st + (NGA + wave + 8 * i) * PP_GROUP);
             }
         } else {
+#if __HIP_DEVICE_COMPILE__
             const bool seg2 = kt >= nk1;
-            const f16* Ap = seg2 ? A2 : A;
-            const f16* Bp = seg2 ? B2 : B;
-            const int64_t la = seg2 ? p.lda2 : p.lda, lb = seg2 ? p.ldb2 : p.ldb;
-            const int Kseg = seg2 ? p.K2 : p.K;
-            const int kk = (seg2 ? kt - nk1 : kt) * 32 + kchunk;
-            const bool kok = kk < Kseg;
+            const int k0 = (seg2 ? kt - nk1 : kt) * 32;
+            const int rem = (seg2 ? p.K2 : p.K) - k0;                       // >= 32 except in a slab's tail step
+            const bool kok = kchunk < rem;
+            const uint32_t so = (uint32_t)k0 * 2;
+            if (!seg2) {
 #pragma unroll
-            for (int i = 0; i < NAW; ++i) {
-                const f16* src = (kok && a_off[i] >= 0) ? Ap + (int64_t)a_off[i] * la + kk : zp;
-                glds16(src, st + (wave + 8 * i) * PP_GROUP);
-            }
+                for (int i = 0; i < NAW; ++i)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (__attribute__((address_space(3))) void*)(st + (wave + 8 * i) * PP_GROUP), 16, kok ? a_vo[i] : PP_OOR, so, 0, 0);
 #pragma unroll
-            for (int i = 0; i < NL - NAW; ++i) {
-                const f16* src = (kok && b_row[i] >= 0) ? Bp + (int64_t)b_row[i] * lb + kk : zp;
-                glds16(src, st + (NGA + wave + 8 * i) * PP_GROUP);
+                for (int i = 0; i < NL - NAW; ++i)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (__attribute__((address_space(3))) void*)(st + (NGA + wave + 8 * i) * PP_GROUP), 16, kok ? b_vo[i] : PP_OOR, so, 0, 0);
+            } else {
+#pragma unroll
+                for (int i = 0; i < NAW; ++i)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rA2, (__attribute__((address_space(3))) void*)(st + (wave + 8 * i) * PP_GROUP), 16, kok ? a_vo2[i] : PP_OOR, so, 0, 0);
+#pragma unroll
+                for (int i = 0; i < NL - NAW; ++i)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rB2, (__attribute__((address_space(3))) void*)(st + (NGA + wave + 8 * i) * PP_GROUP), 16, kok ? b_vo2[i] : PP_OOR, so, 0, 0);
             }
+#endif
         }
     };
 
@@ -285,7 +315,9 @@ static void launch_pp_bm(const fd_gemm_desc& d, hipStream_t s, bool prio, int ns
 bool fd_gemm_pp_eligible(const fd_gemm_desc& d) {
     if (d.batch > 1 || (d.N % 320) != 0) return false;
     if (d.conv) return d.conv_mode == FD_CONV_NORMAL && (d.Cin & 31) == 0 && d.K2 == 0;
-    return (d.K & 7) == 0;
+    // dense operands go through buffer descriptors with 32-bit byte offsets
+    const int64_t lim = 1LL << 31;
+    return (d.K & 7) == 0 && (int64_t)d.M * d.lda < lim && (int64_t)d.N * d.ldb < lim && (d.K2 == 0 || ((int64_t)d.M * d.lda2 < lim && (int64_t)d.N * d.ldb2 < lim));
 }
 
 // gemm_halo.hip: the same loop with the A operand of a stride-1 3x3 convolution staged once per channel chunk (round 6)
@@ -306,3 +338,5 @@ int fd_gemm_launch_pp(const fd_gemm_desc& d, hipStream_t s, bool prio, int bm, i
     else launch_pp_bm<128>(d, s, prio, nsplit);
     return fd_check_launch("fd_gemm(pp)");
 }
+
+FD_WGT_SETTER(gemm_pp)

@@ -140,6 +140,7 @@ struct WgradBatch {
 
 template <int RP, int CV, int CGB>
 __global__ __launch_bounds__(256) void lora_wgrad_partial_multi(WgradBatch b, float* __restrict__ scratch) {
+    FD_WG_TRACE(18);
     __shared__ float red[(256 / CGB - 1) * CGB * (CV * RP + 1)];
     int p = 0;
 #pragma unroll 1
@@ -150,6 +151,7 @@ __global__ __launch_bounds__(256) void lora_wgrad_partial_multi(WgradBatch b, fl
 }
 
 __global__ __launch_bounds__(256) void lora_wgrad_final_multi(WgradBatch b, const float* __restrict__ scratch, int RP) {
+    FD_WG_TRACE(19);
     const int o = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (o >= b.ostart[b.n]) return;
     int p = 0;
@@ -304,3 +306,5 @@ extern "C" int fd_lora_refresh_multi(const fd_lora_refresh_desc* descs, int n, v
     }
     return fd_check_launch("fd_lora_refresh_multi");
 }
+
+FD_WGT_SETTER(lora)

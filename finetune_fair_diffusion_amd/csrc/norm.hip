@@ -29,6 +29,7 @@ __device__ __forceinline__ f16x8 gn_load(const GNArgs& a, int64_t pix, int c) {
 // MODE 0: per-group (sum x, sum x^2). MODE 1: per-group (sum dz*gamma, sum dz*gamma*xhat)
 template <int MODE>
 __global__ void gn_reduce_kernel(GNArgs a, float* partial /* [B,nchunks,G,2] */) {
+    FD_WG_TRACE(11);
     extern __shared__ float part[];  // [blockDim.x][16]: per-thread per-channel partial sums (fixed-order reduction below)
     const int C = a.C1 + a.C2, V = C >> 3, cg = C / a.G;
     const int b = blockIdx.y, chunk = blockIdx.x;
@@ -190,6 +191,7 @@ __device__ __forceinline__ void gn_block_stats_units(const GNArgs& a, const GNUn
 
 template <bool UNITS>
 __global__ void gn_apply_kernel(GNArgs a, f16* y, const float* partial, float n, float* stats_out, GNUnits un) {
+    FD_WG_TRACE(12);
     __shared__ float st[128];
     __shared__ float ps[UNITS ? 1024 : 1];
     const int C = a.C1 + a.C2, V = C >> 3, cg = C / a.G;
@@ -234,6 +236,7 @@ __global__ void gn_apply_kernel(GNArgs a, f16* y, const float* partial, float n,
 }
 
 __global__ void gn_bwd_apply_kernel(GNArgs a, const float* partial, float n, const f16* add1, const f16* add2, f16* dx1, f16* dx2) {
+    FD_WG_TRACE(13);
     __shared__ float s12[128];
     const int C = a.C1 + a.C2, V = C >> 3, cg = C / a.G;
     const int b = blockIdx.y, chunk = blockIdx.x;
@@ -347,6 +350,7 @@ __device__ __forceinline__ void gn_group_total(const float* red, int w, int lane
 
 template <int MAXV>
 __global__ __launch_bounds__(256) void gn_fused_fwd_kernel(GNArgs a, f16* y, float* stats_out, GNFused f) {
+    FD_WG_TRACE(14);
     __shared__ float red[256 * 4];
     __shared__ float st[8];
     const int C = a.C1 + a.C2, cg = C / a.G;
@@ -426,6 +430,7 @@ __global__ __launch_bounds__(256) void gn_fused_fwd_kernel(GNArgs a, f16* y, flo
 }
 
 __global__ __launch_bounds__(256) void gn_fused_bwd_kernel(GNArgs a, const f16* add1, const f16* add2, f16* dx1, f16* dx2, GNFused f) {
+    FD_WG_TRACE(15);
     __shared__ float red[256 * 4];
     __shared__ float st[8];
     const int C = a.C1 + a.C2, cg = C / a.G;
@@ -611,6 +616,7 @@ extern "C" int fd_groupnorm_bwd(const void* x1, int C1, const void* x2, int C2, 
 template <bool BWD, int MAXV, int R>
 __global__ __launch_bounds__(256) void layernorm_kernel(const f16* x, const f16* dy, const float* gamma, const float* beta,
                                                         const f16* add, f16* out, float* mean_rstd, int M, int C, float eps) {
+    FD_WG_TRACE(16);
     const int lane = threadIdx.x & 63;
     const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
     if (row0 >= M) return;
@@ -751,3 +757,5 @@ extern "C" int fd_layernorm_bwd(const void* x, const void* dy, const float* gamm
     launch_layernorm<true>((hipStream_t)stream, (const f16*)x, (const f16*)dy, gamma, (const float*)nullptr, (const f16*)add, (f16*)dx, (float*)mean_rstd, M, C, 0.f);
     return fd_check_launch("fd_layernorm_bwd");
 }
+
+FD_WGT_SETTER(norm)

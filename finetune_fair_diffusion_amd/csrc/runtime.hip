@@ -31,3 +31,16 @@ extern "C" const char* fd_build_info(void) { return "packed_fp32=off"; }
 #else
 extern "C" const char* fd_build_info(void) { return "packed_fp32=on"; }
 #endif
+
+#ifdef FD_BENCH_HOOKS
+// measurement builds: install (or remove: buf = nullptr) the workgroup-trace log in every translation unit that has instrumented kernels (common.h)
+extern "C" {
+void fd_wgt_set_gemm(unsigned long long*, unsigned int); void fd_wgt_set_gemm_pp(unsigned long long*, unsigned int); void fd_wgt_set_gemm_halo(unsigned long long*, unsigned int);
+void fd_wgt_set_attn(unsigned long long*, unsigned int); void fd_wgt_set_crossattn(unsigned long long*, unsigned int); void fd_wgt_set_norm(unsigned long long*, unsigned int);
+void fd_wgt_set_elementwise(unsigned long long*, unsigned int); void fd_wgt_set_lora(unsigned long long*, unsigned int);
+void fd_bench_wg_trace(unsigned long long* buf, unsigned int cap) {
+    fd_wgt_set_gemm(buf, cap); fd_wgt_set_gemm_pp(buf, cap); fd_wgt_set_gemm_halo(buf, cap); fd_wgt_set_attn(buf, cap); fd_wgt_set_crossattn(buf, cap);
+    fd_wgt_set_norm(buf, cap); fd_wgt_set_elementwise(buf, cap); fd_wgt_set_lora(buf, cap);
+}
+}
+#endif

@@ -36,4 +36,24 @@ b)  # the halo-staged convolution: parity (every tile geometry, borders, epilogu
     timeout 900 python -m pytest tests/test_kernels_gpu.py -q -x -s -k "conv3x3 or statistics_epilogue" > $O/conv_tests.log 2>&1; tail -5 $O/conv_tests.log; grep "conv halo" $O/conv_tests.log | head -30
     timeout 900 python scratch/mb_halo.py 2>&1 | grep -v amdgpu.ids | tee $O/mb_halo.txt
     ;;
+c)  # whole step with the halo-staged convolutions (same box: the bench-hooks library with FD_CONV_HALO=0 / 1 alternating, then the product library)
+    O=gpurun_out/r06c; mkdir -p $O
+    for i in 1 2; do
+      for v in "FD_CONV_HALO=0" "FD_CONV_HALO=1"; do
+        n=$(echo "$v" | tr '=;, ' '____')
+        env FAIRDIFF_LIB=$P/libfairdiff_hip_bench.so $v $B --steps 6 --warmup 2 > $O/${n}_$i.json 2> $O/${n}_$i.err || tail -3 $O/${n}_$i.err
+      done
+    done
+    $B --steps 8 --warmup 2 > $O/product.json 2> $O/product.err || tail -3 $O/product.err
+    bench_table "$O/*.json" | tee $O/summary.txt
+    ;;
+d)  # dense GEMMs on the ping-pong kernel now that its operands go through buffer descriptors: parity tests, then the isolated A/B against the shipped policy
+    O=gpurun_out/r06d; mkdir -p $O
+    timeout 900 python -m pytest tests/test_kernels_gpu.py -q -x -k "gemm" > $O/gemm_tests.log 2>&1; tail -3 $O/gemm_tests.log
+    timeout 900 python scratch/mb_pp_dense.py 2>&1 | grep -v amdgpu.ids | tee $O/mb_pp_dense.txt
+    ;;
+e)  # chip fill under the shipped schedule, from per-workgroup (CU, start, end) records of the instrumented bench-hooks kernels
+    O=gpurun_out/r06e; mkdir -p $O
+    timeout 1200 python scratch/wg_fill.py $O/wg_fill_shipped_schedule.txt 3 2>&1 | grep -v amdgpu.ids | tail -60 | cut -c1-400
+    ;;
 esac
