@@ -746,8 +746,9 @@ static int gemm_tile(const fd_gemm_desc& d) {
         static const long t256 = bench_env("FD_GEMM_T256") ? atol(bench_env("FD_GEMM_T256")) : 100;
         static const long t128 = bench_env("FD_GEMM_T128") ? atol(bench_env("FD_GEMM_T128")) : 80;
         static const long maxsplit = bench_env("FD_GEMM_MAXSPLIT") ? atol(bench_env("FD_GEMM_MAXSPLIT")) : 8;
+        static const long tc256 = bench_env("FD_CONV_T256") ? atol(bench_env("FD_CONV_T256")) : 0;      // measurement only: its own threshold for the stride-1 3x3 convolutions
         if (d.N % 320 == 0) {
-            if (m256 * (d.N / 320) >= t256) return 256320;
+            if (m256 * (d.N / 320) >= ((tc256 && d.conv && d.conv_mode == FD_CONV_NORMAL) ? tc256 : t256)) return 256320;
             if (m128 * (d.N / 320) >= t128) return 128320;
         }
         const bool can_split = d.workspace && (d.N & 3) == 0 && (d.ldc & 3) == 0 && d.act != FD_ACT_GEGLU && phs == 1;

@@ -38,6 +38,9 @@ struct halo_geo {
 constexpr int HALO_BST = PP_NGB * PP_GROUP;                              // halfs per B stage (20 KB)
 template <int BM, int W> constexpr size_t halo_lds() { return (size_t)(2 * halo_geo<BM, W>::ABUF + PP_NST * HALO_BST + PP_NW * PP_GROUP) * sizeof(f16); }
 
+#ifndef HALO_A_AUX
+#define HALO_A_AUX 0          // cache policy of the A pieces (measurement: -DHALO_A_AUX=2 = nt, streamed-once hint)
+#endif
 __device__ __forceinline__ int halo_swz(int P) { return ((P >> 2) & 1) << 1; }
 
 // CV = 1 / 3: plain / with the GroupNorm-statistics epilogue (the numbering of gemm_pp_kernel's convolution variants)
@@ -119,7 +122,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(fd_gemm_desc p, int ntm,
         const bool live = cc < nch && j < G::NPIECE;
         uint32_t c32 = live ? (uint32_t)(cc << 6) : 0u;
         asm volatile("" : "+s"(c32));
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (__attribute__((address_space(3))) void*)(live ? abuf + (cc & 1) * G::ABUF + j * PP_GROUP : dump), 16, a_src[i], c32, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (__attribute__((address_space(3))) void*)(live ? abuf + (cc & 1) * G::ABUF + j * PP_GROUP : dump), 16, a_src[i], c32, 0, HALO_A_AUX);
     };
 
     f32x4 acc[TM][TN];

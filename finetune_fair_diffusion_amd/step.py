@@ -207,6 +207,9 @@ class FairnessTrainer:
         self.keep_activations = True
         self.activation_mem_fraction = 0.85
         self.last_ctx_bytes = self.last_ctx_budget = 0
+        self._full_ctx_bytes = 0      # bytes of one timestep's FULL context (measured by the first recording rollout)
+        # None: automatic (lean recording when S full contexts do not fit, from the second step on); True / False force it (FD_LEAN_ACTIVATIONS=1 / 0)
+        self.lean_activations = {"1": True, "0": False}.get(os.environ.get("FD_LEAN_ACTIVATIONS", ""), None)
         # R1 and the forward half of R3 evaluate the same function on the same inputs (same prompt, noise, S and LoRA
         # weights; only the grad bookkeeping differs in the reference).  With deterministic, batch-invariant kernels the
         # two are bit-identical (asserted in tests), so R3 can consume R1's recorded rollout/decode/classifier forward.
@@ -322,6 +325,13 @@ class FairnessTrainer:
         sch.set_timesteps(S)
         unet.prepare_timesteps(sch.timesteps)
         unet.prepare_prompt(enc, record=record_prompt)
+        if keep_activations and self.lean_activations is not False:
+            # Lean recording (round 6; the reference's own memory lever is recompute, :748): when S timesteps of full contexts do not fit -- known from the previous
+            # step's measured context size -- the transformer blocks keep half as much per token (unet.lean_record) and the backward recomputes three LayerNorms
+            # and the FF1 projection per block instead of recomputing WHOLE timesteps: at S = 50, B = 8 that keeps ~45 of 50 timesteps instead of 28.
+            full = self._full_ctx_bytes
+            need_lean = self.lean_activations is True or (full > 0 and S * full > self.activation_mem_fraction * self._usable_free_bytes())
+            unet.lean_record = need_lean
         lat = noises.clone()
         state, inputs, ctxs = {}, [], {}
         res.update(lat=lat, inputs=inputs, ctxs=ctxs)
@@ -345,6 +355,8 @@ class FairnessTrainer:
                     per = _ctx_bytes(ctxs[0])
                     budget = int(self.activation_mem_fraction * self._usable_free_bytes() / max(per, 1))
                     self.last_ctx_bytes, self.last_ctx_budget = per, budget
+                    if not unet.lean_record:
+                        self._full_ctx_bytes = per
                 else:
                     budget -= 1
             sch.cfg_step(i, eps, gs, lat, state)
@@ -609,7 +621,7 @@ class FairnessTrainer:
         pg = probs.to(self.device).contiguous()
         gl = [torch.empty_like(pg) for _ in range(self.world)]
         dist.all_gather(gl, pg)
-        return torch.cat([t.cpu() for t in gl])
+        return torch.cat(gl).cpu()          # concatenated on the device, ONE copy to the host (it was one copy per rank)
 
     def allreduce_grads(self):
         """(2) ONE all-reduce(SUM) per flat fp32 LoRA-gradient buffer (RCCL over xGMI on the GPU box)."""

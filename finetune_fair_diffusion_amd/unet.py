@@ -103,6 +103,7 @@ class TransformerBlock:
         self.lora1 = self.lora2 = None  # AttnLoRA for attn1 / attn2
         self.name1, self.name2 = b + "attn1.processor", b + "attn2.processor"
         self.cross = None  # per-rollout cross-attention K/V cache
+        self.lean = False  # recording forwards keep neither the pre-gate FF projection nor n1 / n2 (UNet2DConditionModel.lean_record; recomputed in the backward)
 
     # -- cross-attention K/V for the rollout's prompt embeddings (timestep invariant) ------------
     def prepare_cross(self, enc, Bk, L, record, static=False):
@@ -154,8 +155,8 @@ class TransformerBlock:
         HW, C, h, d = H * W, self.C, self.heads, self.d
         rec = ctx is not None
         g, st = ops.groupnorm(x, None, B, HW, self.groups, 1e-6, self.norm.gamma, self.norm.beta, False)
-        # the three LayerNorms ride in the epilogue of the GEMM that produces their input where its tile holds whole rows (C = 320); the statistics
-        # are 8 B per row: always kept
+        # the three LayerNorms are their own launches behind the GEMM that produces their input (ops.gemm(..., ln=...) returns y, LayerNorm(y) and the 8 B per row
+        # of statistics the backward keeps; the second-output GEMM epilogue of round 4 lost in situ and lives in scratch/ since round 5)
         h0, n1, ln1 = ops.gemm(g, self.proj_in.w, bias=self.proj_in.bias, ln=(self.ln1.gamma, self.ln1.beta, 1e-5))
         l1 = self.lora1
         # q leaves its projection multiplied by d^-0.5 * log2(e) where the attention kernels can take it that way (ops.q_prescale)
@@ -171,7 +172,7 @@ class TransformerBlock:
         o, lse = ops.attn_fwd(q, k, v, B, h, HW, HW, d, 1, need_lse=True, prescaled=qs is not None)
         l2 = self.lora2
         cr = self.cross
-        if (not pair and cr.get("Vt80") is not None and self.q2.bias is None and (ops.FUSED_CROSS_TRAIN or (not rec and l2 is None))
+        if (not pair and cr.get("Vt80") is not None and self.q2.bias is None and self.o2.bias is not None and (ops.FUSED_CROSS_TRAIN or (not rec and l2 is None))
                 and ops.cross_block_ok(B * HW, C, h, cr["L"], HW, l2.q.rp if l2 is not None else 0)):
             # norm2 -> attn2 (with its LoRA slabs) -> residual -> norm3 is ONE launch (csrc/crossattn.hip); a forward that does not record never sees n2, q2, o2 in
             # HBM, a recording one gets them written once for the backward
@@ -180,12 +181,13 @@ class TransformerBlock:
             h2, n3, ln3, r = ops.cross_attn_block(h1, (self.ln2.gamma, self.ln2.beta, 1e-5), self.q2.w, cr["K"], cr["Vt80"], cr["L"], self.o2.w, self.o2.bias,
                                                   (self.ln3.gamma, self.ln3.beta, 1e-5), h, HW, B // cr["Bk"], lora_q=l2.q if l2 else None,
                                                   lora_o=l2.out if l2 else None, record=rec, q_prescaled=qs2 is not None)
-            proj = torch.empty((n3.shape[0], self.ff1_wi.shape[0]), dtype=F16, device=n3.device) if rec else None
+            lean = rec and self.lean
+            proj = torch.empty((n3.shape[0], self.ff1_wi.shape[0]), dtype=F16, device=n3.device) if rec and not lean else None
             gg = ops.gemm(n3, self.ff1_wi, bias=self.ff1_bi, act="geglu", aux=proj)
             h3 = ops.gemm(gg, self.ff2.w, bias=self.ff2.bias, residual=h2)
             out = ops.gemm(h3, self.proj_out.w, bias=self.proj_out.bias, residual=x, gn_stats=True)
             if rec:
-                ctx.append(dict(x=x, st=st, h0=h0, ln1=ln1, n1=n1, t1=t1, qkv=qkv, o=o, lse=lse, to1=to1, h1=h1, ln2=r["ln2"], n2=r["n2"], tq2=r["tq2"], q2=r["q2"],
+                ctx.append(dict(x=x, st=st, h0=h0, ln1=ln1, n1=None if lean else n1, t1=t1, qkv=qkv, o=o, lse=lse, to1=to1, h1=h1, ln2=r["ln2"], n2=None if lean else r["n2"], tq2=r["tq2"], q2=r["q2"],
                                 o2=r["o2"], lse2=r["lse2"], to2=r["to2"], h2=h2, ln3=ln3, proj=proj, pair=False, qs=qs is not None, qs2=qs2 is not None))
             return out
         (h1, n2, ln2), to1 = lora_linear_fwd(o, self.o1, l1.out if l1 else None, residual=h0, ln=(self.ln2.gamma, self.ln2.beta, 1e-5))
@@ -197,12 +199,13 @@ class TransformerBlock:
         o2, lse2 = ops.attn_fwd(q2f, cr["K"], cr["V"], B2, h, HW, cr["L"], d, kv_div, need_lse=True, prescaled=qs2 is not None)
         (h2, n3, ln3), to2 = lora_linear_fwd(o2, self.o2, l2.out if l2 else None, residual=h1f, ln=(self.ln3.gamma, self.ln3.beta, 1e-5))
         # bit-identical to projection + fd_geglu_fwd (both halves are rounded to fp16 before the gate)
-        proj = torch.empty((n3.shape[0], self.ff1_wi.shape[0]), dtype=F16, device=n3.device) if rec else None
+        lean = rec and self.lean
+        proj = torch.empty((n3.shape[0], self.ff1_wi.shape[0]), dtype=F16, device=n3.device) if rec and not lean else None
         gg = ops.gemm(n3, self.ff1_wi, bias=self.ff1_bi, act="geglu", aux=proj)
         h3 = ops.gemm(gg, self.ff2.w, bias=self.ff2.bias, residual=h2)
         out = ops.gemm(h3, self.proj_out.w, bias=self.proj_out.bias, residual=xf, gn_stats=True)      # feeds the next ResnetBlock's norm1 / conv_norm_out
         if rec:
-            ctx.append(dict(x=x, st=st, h0=h0, ln1=ln1, n1=n1, t1=t1, qkv=qkv, o=o, lse=lse, to1=to1, h1=h1, ln2=ln2, n2=n2,
+            ctx.append(dict(x=x, st=st, h0=h0, ln1=ln1, n1=None if lean else n1, t1=t1, qkv=qkv, o=o, lse=lse, to1=to1, h1=h1, ln2=ln2, n2=None if lean else n2,
                             tq2=tq2, q2=q2f, o2=o2, lse2=lse2, to2=to2, h2=h2, ln3=ln3, proj=proj, pair=pair, qs=qs is not None, qs2=qs2 is not None))
         return out
 
@@ -220,7 +223,14 @@ class TransformerBlock:
         pair = c.get("pair", False)
         dh3 = ops.gemm(d_out, self.proj_out.wT)
         dgg = ops.gemm(dh3, self.ff2.wT)
-        dproj = ops.geglu_bwd_interleaved(c["proj"], dgg)
+        proj = c["proj"]
+        if proj is None:
+            # lean recording (round 6): the 8C-wide pre-gate projection -- 40 % of a transformer block's recorded bytes -- and the LayerNorm outputs n1 / n2
+            # (needed only by LoRA weight gradients) were not kept: recomputed here from the kept residual streams h2 / h0 / h1 by the SAME kernels the forward
+            # ran (LayerNorm, then the FF1 projection without its gate epilogue: same tile, same k order), hence bit-identical operands and gradients
+            proj = ops.gemm(ops.layernorm(c["h2"], self.ln3.gamma, self.ln3.beta, 1e-5), self.ff1_wi, bias=self.ff1_bi)
+        dproj = ops.geglu_bwd_interleaved(proj, dgg)
+        del proj
         if self._ff1_wiT is None:
             self._ff1_wiT = self.ff1_wi.t().contiguous()
         dn3 = ops.gemm(dproj, self._ff1_wiT)
@@ -246,7 +256,8 @@ class TransformerBlock:
             dh2 = ops.add(dh2[:M], dh2[M:])
             if need_dx:
                 d_out = ops.add(d_out[:M], d_out[M:])
-        dn2 = lora_linear_bwd(dq2, c["n2"], c["tq2"], self.q2, l2.q if l2 else None, gscale)
+        n2 = c["n2"] if (c["n2"] is not None or l2 is None) else ops.layernorm(c["h1"], self.ln2.gamma, self.ln2.beta, 1e-5)
+        dn2 = lora_linear_bwd(dq2, n2, c["tq2"], self.q2, l2.q if l2 else None, gscale)
         dh1 = ops.layernorm_bwd(c["h1"], dn2, self.ln2.gamma, c["ln2"], add=dh2)
         # attn1 (self)
         do1 = lora_linear_bwd(dh1, c["o"], c["to1"], self.o1, l1.out if l1 else None, gscale)
@@ -257,11 +268,12 @@ class TransformerBlock:
             self._wqkvT = self.wqkv.t().contiguous()                    # [C, 3C]
         if l1 is not None:
             t1, rp = c["t1"], l1.q.rp
+            n1 = c["n1"] if c["n1"] is not None else ops.layernorm(c["h0"], self.ln1.gamma, self.ln1.beta, 1e-5)
             u = ops.gemm(dqkv, l1.upT_qkv16)                             # [M, 3rp] = (dq up_q | dk up_k | dv up_v)
             for i, pair in enumerate((l1.q, l1.k, l1.v)):
                 gd, gu = pair.grads()
                 ops.lora_wgrad(dqkv[:, i * C:(i + 1) * C], t1[:, i * rp:(i + 1) * rp], gu, pair.r, 1, pair.r, scale=1.0 / gscale)   # d up = dy^T t
-                ops.lora_wgrad(c["n1"], u[:, i * rp:(i + 1) * rp], gd, 1, pair.K, pair.r, scale=1.0 / gscale)                       # d down = u^T n1
+                ops.lora_wgrad(n1, u[:, i * rp:(i + 1) * rp], gd, 1, pair.K, pair.r, scale=1.0 / gscale)                           # d down = u^T n1
             dn1 = ops.gemm(dqkv, self._wqkvT, a2=u, b2=l1.down_qkvT16) if need_dx else None
         else:
             dn1 = ops.gemm(dqkv, self._wqkvT) if need_dx else None
@@ -395,6 +407,17 @@ class UNet2DConditionModel:
     def refresh_lora(self):
         from .layers import refresh_pairs
         refresh_pairs([p for t in self.transformers for lo in (t.lora1, t.lora2) if lo is not None for p in lo.pairs()])
+
+    @property
+    def lean_record(self):
+        return self.transformers[0].lean
+
+    @lean_record.setter
+    def lean_record(self, flag):
+        """Recording forwards keep 10 C instead of 20 C values per token of a transformer block (no pre-gate FF projection, no n1 / n2); the backward recomputes
+        them (TransformerBlock._backward).  The training step switches it on when the rollout's activations do not all fit in HBM (step.FairnessTrainer)."""
+        for t in self.transformers:
+            t.lean = bool(flag)
 
     def prepare_backward(self):
         """Materialise every lazily built backward operand (transposed / flipped weight copies) NOW, on the current stream.  The training

@@ -225,7 +225,12 @@ typedef struct fd_cross_block_desc {
     int32_t lora_rp;
     /* optional recording for the backward (n2_out != NULL turns it on; then all of these except tq_out / to_out without LoRA are required):
      * n2_out [M, C] = LayerNorm2(x), ln2_stats [M, 2]; q_out [M, C] = the query as fd_attn_bwd_* take it (times scale * log2(e) when q_prescaled, see
-     * fd_attn_fwd); tq_out [M, rp] = n2 . down_q^T; o_out [M, C] attention output; lse_out [M / rows_per_sample, heads, rows_per_sample]; to_out [M, rp] = o . down_o^T */
+     * fd_attn_fwd); tq_out [M, rp] = n2 . down_q^T; o_out [M, C] attention output; lse_out [M / rows_per_sample, heads, rows_per_sample]; to_out [M, rp] = o . down_o^T.
+     * Rounding contract at head dim 80 (C = 640), where q cannot be stored pre-scaled: the kernel's own softmax runs on q rounded ONCE after the multiplication by
+     * scale * log2(e), while q_out is the fp16 rounding of the UNSCALED accumulator -- two roundings of one fp32 value.  fd_attn_bwd_* recompute the probabilities
+     * from q_out against lse_out, so their rows sum to 1 only to ~1e-3 relative per score (the separate launches round q once and use that in both directions).
+     * Inside the tolerances of the parity tests (test_cross_attn_block_with_lora_slabs_and_recording compares dq / dK / dV of the fused forward at C = 640 with
+     * fp32 torch); at head dim 40 (C = 320) forward and backward see the same stored q. */
     void* n2_out; float* ln2_stats; void* q_out; void* tq_out; void* o_out; float* lse_out; void* to_out;
     int32_t q_prescaled;
 } fd_cross_block_desc;

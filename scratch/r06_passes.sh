@@ -56,4 +56,59 @@ e)  # chip fill under the shipped schedule, from per-workgrou
     O=gpurun_out/r06e; mkdir -p $O
     timeout 1200 python scratch/wg_fill.py $O/wg_fill_shipped_schedule.txt 3 2>&1 | grep -v amdgpu.ids | tail -60 | cut -c1-400
     ;;
+f)  # kernel-time ranking of the current tree (rocprofv3 --kernel-trace of a bench run -> per-kernel stats) + the corrected LDS / MFMA counter summary (pass a's two counter sets)
+    O=gpurun_out/r06f; mkdir -p $O
+    cd /tmp && export TMPDIR=/tmp
+    timeout 900 rocprofv3 --kernel-trace -d /tmp/prof_r06f -o r06f -- python3 $R/bench.py --steps 4 --warmup 2 --no_cpu_baseline --no_roofline > $R/$O/bench_trace.json 2> $R/$O/bench_trace.err
+    cd $R
+    DB=$(find /tmp/prof_r06f -name "*.db" | head -1)
+    python scratch/profsum.py $DB $O/kernel_stats.csv 45 > $O/kernel_stats_top.txt; head -50 $O/kernel_stats_top.txt | cut -c1-200
+    cd /tmp
+    i=0
+    for C in "SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_INST_CYCLES_VMEM SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE"; do
+      i=$((i+1))
+      timeout 600 rocprofv3 --kernel-trace --pmc $C --kernel-include-regex "gemm|conv_halo" --output-format csv -d /tmp/pmc_r06f_iso_$i -o p -- python3 $R/scratch/mb_pmc_r05.py > $R/$O/iso_pass_$i.log 2>&1
+      timeout 1200 rocprofv3 --kernel-trace --pmc $C --kernel-include-regex "gemm|conv_halo" --output-format csv -d /tmp/pmc_r06f_situ_$i -o p -- python3 $R/bench.py --steps 1 --warmup 1 --no_cpu_baseline --no_roofline > $R/$O/situ_pass_$i.log 2>&1
+    done
+    cd $R
+    python scratch/r06_pmc_lds_summary.py $O/pmc_lds_mainloop_isolated.txt /tmp/pmc_r06f_iso_1 /tmp/pmc_r06f_iso_2 | cut -c1-300
+    python scratch/r06_pmc_lds_summary.py $O/pmc_lds_mainloop_in_situ.txt /tmp/pmc_r06f_situ_1 /tmp/pmc_r06f_situ_2 | head -24 | cut -c1-300
+    ;;
+g)  # full GPU suite + smoke on the current tree (durations kept)
+    O=gpurun_out/r06g; mkdir -p $O
+    python -m pytest tests -m gpu -x -q -s --durations=25 > $O/pytest_gpu.log 2>&1; echo rc=$? >> $O/pytest_gpu.log; tail -40 $O/pytest_gpu.log | cut -c1-200
+    python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -1 $O/smoke.log
+    ;;
+h)  # halo convolution knobs inside the step (bench-hooks library): its own tile threshold (64: the 16^2 level on 256x320 tiles = 64 workgroups; 200: the 32^2 level on
+    # 128x320 tiles = 256 workgroups), the nt cache policy on the A pieces
+    O=gpurun_out/r06h; mkdir -p $O
+    L=$P/libfairdiff_hip_bench.so
+    for i in 1 2; do
+      for v in "FD_NOTHING=1" "FD_CONV_T256=64" "FD_CONV_T256=200" "FAIRDIFF_LIB=$P/libfairdiff_hip_bench_nt.so"; do
+        n=$(echo "$v" | sed 's/=.*bench_nt.so/_nt/' | tr '=;, /' '_____')
+        env FAIRDIFF_LIB=$L $v $B --steps 6 --warmup 2 > $O/${n}_$i.json 2> $O/${n}_$i.err || tail -3 $O/${n}_$i.err
+      done
+    done
+    bench_table "$O/*.json" | tee $O/summary.txt
+    ;;
+i)  # new tests of the round (loss bias over 64 seeds with the fp16-rounding denominator, exp-4 on eight ranks, lean recording, the fused-recording attention
+    # backward) + the S = 50 exp-4 line with automatic lean recording against FD_LEAN_ACTIVATIONS=0 (round 3's schedule: whole timesteps recomputed)
+    O=gpurun_out/r06i; mkdir -p $O
+    timeout 1500 python -m pytest tests/test_fullsize_gpu.py -q -x -s -k "loss_fair_has_no_bias" > $O/loss_bias.log 2>&1; grep -i "loss_fair\|product\|fp16-rounded\|passed\|failed\|Error" $O/loss_bias.log | tail -12
+    timeout 1500 python -m pytest tests/test_two_rank_gpu.py -q -x -s -k "exp4" > $O/exp4_eight.log 2>&1; grep -i "exp-4\|passed\|failed\|Error" $O/exp4_eight.log | tail -12
+    timeout 900 python -m pytest tests/test_engine_gpu.py tests/test_kernels_gpu.py -q -x -s -k "lean_recording or cross_attn_block_with_lora" > $O/lean_cross.log 2>&1; grep -i "lean\|fused recording\|passed\|failed\|Error" $O/lean_cross.log | tail -20
+    for v in "FD_LEAN_ACTIVATIONS=0" "FD_NOTHING=1"; do
+      n=$(echo "$v" | tr '=;, ' '____')
+      env $v timeout 900 python bench.py --S 50 --experiment exp-4 --steps 3 --warmup 2 --no_cpu_baseline --no_roofline > $O/bench_exp4_s50_$n.json 2> $O/bench_exp4_s50_$n.err || tail -3 $O/bench_exp4_s50_$n.err
+    done
+    python - <<'PY'
+import json, glob
+for f in sorted(glob.glob("gpurun_out/r06i/bench_exp4_s50_*.json")):
+    try:
+        d = json.loads(open(f).read().strip().splitlines()[-1]); c = d["config"]
+        print(f, round(d["value"], 3), "img/s", round(d["ms_per_step"], 1), "ms; kept", c["r3_timesteps_kept_in_hbm"], "of 50; ctx GB", c["r3_activation_gb_per_timestep"], "peak", c["peak_hbm_gb"], c["phase_ms"])
+    except Exception as e:
+        print(f, "ERR", e)
+PY
+    ;;
 esac

@@ -5,7 +5,7 @@ CPU only.  ``latents`` (no-grad rollout, ~9 GB of host RAM, 2.5 min on 8 cores) 
 the oracle's autograd graph of the U-Net at SD-v1.5 size (more than the build container's 62 GB) and were generated on the host CPU of
 a GPU box with this same script (scratch/r03_passes.sh a copies the files back):
 
-    python tests/golden/make_oracle_step_golden.py [cfg0] [latents] [smooth] [smooth_te] [cfg0_b8] [loss_seeds]
+    python tests/golden/make_oracle_step_golden.py [cfg0] [latents] [smooth] [smooth_te] [cfg0_b8] [loss_seeds] [loss_seeds_more] [loss_seeds_fp16]
 
 (round 5: ``smooth_te``, ``cfg0_b8`` and ``loss_seeds`` were generated the same way, scratch/r05_passes.sh d.)
 
@@ -30,6 +30,11 @@ stored here without re-running the oracle.  Test infrastructure only (like every
                                        3, 3, 2 as in the reference): more terms average the mask flips that make the two-image gradient cosine chaotic
   oracle_sd15_loss_seeds_b2_s2.npz     round 5 (item 2c): loss_fair / probabilities / targets of the forward half of the step (no gradient) for eight
                                        noise seeds, U-Net LoRA r=4, batch 2, 2 steps: mean |error| and BIAS of the product's loss over seeds
+                                       (round 6, ``loss_seeds_more``: 32 further seeds APPENDED -- 64 seeds = 128 loss terms, the first 32 rows untouched)
+  oracle_sd15_loss_seeds_fp16_b2_s2.npz   round 6: the same forward for the first eight seeds with the oracle's arithmetic ROUNDED TO FP16
+                                       the way the reference's fp16 models round (weights cast once, :761-763; every module's output rounded to fp16; latents and
+                                       prompt embeddings in fp16; fp32 accumulation inside an op, as the fp16 GPU kernels of torch do) -- the denominator of
+                                       the product-vs-fp32 loss error: how far an fp16 run of the REFERENCE's own arithmetic sits from the fp32 oracle
 """
 import os
 import sys
@@ -248,6 +253,96 @@ def make_loss_seeds(om):
                         targets=np.stack([r["targets"].numpy() for r in rows]), uncertainty=np.stack([r["uncertainty"].numpy() for r in rows]))
 
 
+LOSS_SEEDS_MORE = tuple(4243 + 97 * i for i in range(32))      # round 6: 32 more (128 terms put a 3e-4 gate on the mean at >= 2 sigma)
+
+
+def _loss_forward(models, tokens, noises, S, faces, dtype=torch.float32):
+    """The forward half of fairness_step (:1746-1916) without the autograd graph -- the statement make_loss_seeds stores."""
+    te, unet, vae, clf, sch = (models[k] for k in ("text_encoder", "unet", "vae", "classifier", "scheduler"))
+    B = noises.shape[0]
+    with torch.no_grad():
+        images = fs.generate_image_no_gradient(tokens, noises, S, te, unet, vae, sch, 7.5, dtype=dtype)
+        ind, boxes, chips = faces(images)
+        preds, probs, logits = fs.get_face_gender(clf, chips, selector=ind)
+        targets, unc = fs.generate_dynamic_targets(probs, w_uncertainty=True)
+        targets[unc > 0.7] = -1
+        lf = torch.ones(B) * (-1)
+        w = ((ind == True) * (targets != -1)).nonzero().view([-1])  # noqa: E712
+        lf[w] = torch.nn.functional.cross_entropy(logits[w], targets[w], reduction="none")
+    return dict(loss_fair=lf, probs=probs, targets=targets, uncertainty=unc)
+
+
+def make_loss_seeds_more(om):
+    """Appends LOSS_SEEDS_MORE to oracle_sd15_loss_seeds_b2_s2.npz (rows 0..31 are copied as they are)."""
+    path = os.path.join(HERE, "oracle_sd15_loss_seeds_b2_s2.npz")
+    g = dict(np.load(path))
+    assert g["seeds"].tolist() == list(LOSS_SEEDS), "the file already holds other seeds"
+    tokens = factory.synthetic_tokens(L, 49408)
+    models = dict(text_encoder=om["text_encoder"], unet=om["unet"], vae=om["vae"], classifier=om["classifier"], scheduler=om["scheduler"])
+    faces = fs.SyntheticFaceProvider(224)
+    rows, t0 = [], time.time()
+    for seed in LOSS_SEEDS_MORE:
+        rows.append(_loss_forward(models, tokens, torch.randn(2, 4, 64, 64, generator=torch.Generator().manual_seed(seed)), 2, faces))
+        print(f"loss seeds (more): seed {seed}: targets {rows[-1]['targets'].tolist()} loss {rows[-1]['loss_fair'].tolist()}  ({time.time() - t0:.0f} s)", flush=True)
+    np.savez_compressed(path, seeds=np.array(LOSS_SEEDS + LOSS_SEEDS_MORE),
+                        **{k: np.concatenate([g[k], np.stack([r[k].numpy() for r in rows])]) for k in ("loss_fair", "probs", "targets", "uncertainty")})
+
+
+class Fp16Rounding:
+    """The oracle's modules with fp16 ROUNDING and fp32 arithmetic: parameters rounded once (the reference casts the frozen models wholesale, :761-763; the fp32
+    LoRA parameters are left alone, :815), the output of every leaf module rounded to fp16 (what an fp16 kernel with fp32 accumulation returns), restored on exit."""
+
+    def __init__(self, *modules):
+        self.modules = modules
+
+    def __enter__(self):
+        self.saved, self.hooks = [], []
+
+        def rnd(_m, _i, out):
+            if isinstance(out, torch.Tensor) and out.dtype == torch.float32:
+                return out.half().float()
+            return out
+        for mod in self.modules:
+            for n, p in mod.named_parameters():
+                if "lora" in n:
+                    continue
+                self.saved.append((p, p.data.clone()))
+                p.data = p.data.half().float()
+            for m in mod.modules():
+                if not list(m.children()):
+                    self.hooks.append(m.register_forward_hook(rnd))
+        return self
+
+    def __exit__(self, *a):
+        for h in self.hooks:
+            h.remove()
+        for p, d in self.saved:
+            p.data = d
+
+
+def make_loss_seeds_fp16(om, n=8):
+    tokens = factory.synthetic_tokens(L, 49408)
+    models = dict(text_encoder=om["text_encoder"], unet=om["unet"], vae=om["vae"], classifier=om["classifier"], scheduler=om["scheduler"])
+    faces = fs.SyntheticFaceProvider(224)
+    rows, t0 = [], time.time()
+
+    class HalfIO:       # latents / prompt embeddings enter the U-Net in fp16 (dtype=float16 in the reference's rollout) and eps leaves it in fp16
+        def __init__(self, u):
+            self.u = u
+
+        def __call__(self, x, t, encoder_hidden_states=None):
+            r = self.u(x.half().float(), t, encoder_hidden_states=encoder_hidden_states.half().float())
+            r.sample = r.sample.half().float()
+            return r
+    with Fp16Rounding(om["text_encoder"], om["unet"], om["vae"], om["classifier"]):
+        m16 = dict(models, unet=HalfIO(om["unet"]))
+        for seed in LOSS_SEEDS[:n]:
+            rows.append(_loss_forward(m16, tokens, torch.randn(2, 4, 64, 64, generator=torch.Generator().manual_seed(seed)), 2, faces))
+            print(f"loss seeds (fp16 rounding): seed {seed}: targets {rows[-1]['targets'].tolist()} loss {rows[-1]['loss_fair'].tolist()}  ({time.time() - t0:.0f} s)", flush=True)
+    np.savez_compressed(os.path.join(HERE, "oracle_sd15_loss_seeds_fp16_b2_s2.npz"), seeds=np.array(LOSS_SEEDS[:n]),
+                        **{k: np.stack([r[k].numpy() for r in rows]) for k in ("loss_fair", "probs", "targets", "uncertainty")})
+
+
 if __name__ == "__main__":
     what = sys.argv[1:] or ["cfg0", "latents", "smooth"]
     torch.set_num_threads(min(os.cpu_count() or 1, 64))
@@ -257,7 +352,7 @@ if __name__ == "__main__":
         make_smooth_te()
     if "cfg0_b8" in what:
         make_cfg0_b8()
-    if "latents" in what or "smooth" in what or "loss_seeds" in what:
+    if {"latents", "smooth", "loss_seeds", "loss_seeds_more", "loss_seeds_fp16"} & set(what):
         om = unet_models()
         if "latents" in what:
             make_latents(om)
@@ -265,3 +360,7 @@ if __name__ == "__main__":
             make_smooth(om)
         if "loss_seeds" in what:
             make_loss_seeds(om)
+        if "loss_seeds_fp16" in what:
+            make_loss_seeds_fp16(om)
+        if "loss_seeds_more" in what:
+            make_loss_seeds_more(om)

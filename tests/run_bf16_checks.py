@@ -7,7 +7,7 @@ Bands (bf16 has 8 significand bits against fp16's 11, i.e. 8x the rounding step;
   SD-v1.5-size U-Net eps          4e-2 (relative RMS 2e-2)
   full tiny training step         images 1e-1, exact targets, loss_fair 5e-2, end-to-end gradient cosine > 0.8 (measured 0.87; ReLU / clamp mask flips)
   exp-3 step on the d=40 model    (gender x race: 6-logit head, both sides on the oracle's OT targets)  images 1.5e-1 / RMS 4e-2, per-attribute
-                                  loss_fair 8e-2, end-to-end gradient cosine > 0.75
+                                  loss_fair 8e-2, end-to-end gradient cosine > 0.80 (measured 0.87 in rounds 3-5; the gate leaves 0.07 for rounding-only changes of the forward)
 """
 import math
 import os
@@ -197,7 +197,7 @@ def exp3_step_d40():
     got = torch.cat([tr.banks[0].view(n, grads[0]).flatten() for n in names])
     cos = float(F.cosine_similarity(got.cpu().double(), refg.double(), dim=0))
     print("cosine(exp-3 d40 unet grads) =", cos, " norm ratio =", float(got.norm().cpu() / refg.norm()))
-    assert cos > 0.75 and 0.6 < float(got.norm().cpu() / refg.norm()) < 1.6
+    assert cos > 0.80 and 0.6 < float(got.norm().cpu() / refg.norm()) < 1.6
 
 
 def sd15_unet():

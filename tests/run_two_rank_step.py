@@ -21,7 +21,7 @@ def build(experiment, dev, rank, world):
     from finetune_fair_diffusion_amd.fairness import EXPERIMENT_ATTRS
     from finetune_fair_diffusion_amd.step import FairnessTrainer
     ncls = EXPERIMENT_ATTRS[experiment][0]
-    tt = experiment == "exp-1"           # exp-1: both banks (U-Net + text encoder); exp-3: U-Net bank, OT targets
+    tt = experiment == "exp-1"           # exp-1: both banks (U-Net + text encoder); exp-3 / exp-4: U-Net bank, OT targets (exp-4: 8-logit head, three attributes)
     sds = U.synthetic_sds(train_unet=True, train_te=tt, lora_up_std=0.05, num_classes=ncls)
     pm = U.product_models(sds, dev, train_unet=True, train_te=tt, num_classes=ncls)
     args = U.make_args(train_unet=True, train_text_encoder=tt, uncertainty_threshold=0.7, train_GPU_batch_size=B_PER_RANK)

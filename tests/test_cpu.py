@@ -248,8 +248,11 @@ def test_gemm_dispatch_name_statistics_rows_and_launcher_agree():
     assert plan(65536, 320, 320, stats=True) == ("gemm_big_kernel<256, 320, 4, 4, 3>", 0, 32)
     assert plan(4096, 1280, 1280, stats=True) == ("gemm_big_kernel<128, 320, 4, 4, 3>", 0, 32)
     assert plan(65536, 2560, 320, act=7) == ("gemm_pp_kernel<256, 0, true>", 0, 0)                           # FF1 / GEGLU: ping-pong, no statistics
-    assert plan(65536, 320, 2880, conv=(16, 64, 320, 0), stats=True) == ("gemm_pp_kernel<256, 3, true>", 0, 32)
-    assert plan(4096, 1280, 11520, conv=(16, 16, 1280, 0)) == ("gemm_pp_kernel<128, 1, true>", 0, 32)
+    # stride-1 3x3 convolutions of the 64^2 / 32^2 / 16^2 levels: the halo-staged kernel (round 6); other geometries keep the per-tap ping-pong kernel
+    assert plan(65536, 320, 2880, conv=(16, 64, 320, 0), stats=True) == ("conv_halo_kernel<256, 64, 3, true>", 0, 32)
+    assert plan(16384, 640, 5760, conv=(16, 32, 640, 0)) == ("conv_halo_kernel<256, 32, 1, true>", 0, 32)
+    assert plan(4096, 1280, 11520, conv=(16, 16, 1280, 0)) == ("conv_halo_kernel<128, 16, 1, true>", 0, 32)
+    assert plan(2 * 24 * 24 * 40, 320, 2880, conv=(80, 24, 320, 0), stats=True) == ("gemm_pp_kernel<256, 3, true>", 0, 32)      # 24 x 24 maps: no halo geometry
     assert plan(16384, 320, 2880, conv=(16, 64, 320, 1), stats=True) == ("gemm_big_kernel<128, 320, 4, 4, 4>", 0, 32)     # stride 2: lockstep gather
     name, split, rows = plan(1024, 1280, 11520, conv=(16, 8, 1280, 0))                                        # 8^2 level: split-K, epilogue in the reduce kernel
     assert name == "gemm_big_kernel<128, 320, 4, 4, 1>" and split == 8 and rows == 0

@@ -339,6 +339,39 @@ def test_r1_r3_forward_bit_identical_and_shared_mode(dev):
     assert same(grads[0], grads[2])
 
 
+def test_lean_recording_gives_the_bit_identical_gradient(dev):
+    """Round 6: a recording forward in LEAN mode keeps neither the 8C-wide pre-gate FF projection nor the LayerNorm outputs n1 / n2 of a
+    transformer block (half of its recorded bytes); the backward recomputes them with the kernels the forward ran.  Same images, same loss, and the whole flat
+    LoRA gradient BIT-identical to the full-recording step -- with U-Net and text-encoder LoRA (the n2 operand feeds attn2.to_q's weight gradient), also under
+    the mixed keep / recompute schedule; and a timestep's context is measurably smaller."""
+    from finetune_fair_diffusion_amd.step import FairnessTrainer
+    om = U.oracle_models(train_unet=True, train_te=True, lora_up_std=0.05)
+    pm = U.product_models(om["sds"], dev, train_unet=True, train_te=True)
+    args = U.make_args(train_unet=True, train_text_encoder=True)
+    tokens = U.tiny_tokens()
+    noises = torch.randn(4, 4, 32, 32, generator=torch.Generator().manual_seed(12))
+    tr = FairnessTrainer(args, pm["text_encoder"], pm["unet"], pm["vae"], pm["classifier"], pm["scheduler"], eval_text_encoder=pm["eval_text_encoder"],
+                         eval_unet=pm["eval_unet"], device=dev)
+    grads = []
+    tr.sync_and_update = lambda nb, apply=True: (grads.append([b.grad.clone() for b in tr.banks]), True)[1]
+    tr.lean_activations = False
+    a = tr.train_step(tokens, noises, 4)
+    full_bytes = tr.last_ctx_bytes
+    assert not tr.unet.lean_record
+    tr.lean_activations = True
+    b = tr.train_step(tokens, noises, 4)
+    lean_bytes = tr.last_ctx_bytes
+    assert tr.unet.lean_record and lean_bytes < 0.8 * full_bytes, (lean_bytes, full_bytes)
+    assert torch.equal(a["images"], b["images"]) and torch.equal(a["loss_fair"], b["loss_fair"])
+    for ga, gb in zip(grads[0], grads[1]):
+        assert float(ga.abs().max()) > 0 and torch.equal(ga, gb)
+    # automatic mode: full contexts fit on this box -> stays full
+    tr.lean_activations = None
+    tr.train_step(tokens, noises, 4)
+    assert not tr.unet.lean_record
+    print(f"lean recording: context per timestep {full_bytes} bytes full, {lean_bytes} lean ({lean_bytes / full_bytes:.2f}x)")
+
+
 # ------------------------------------------------------------------------------------------ training driver, checkpoints, consumer
 def _train_argv(out_dir, steps, extra=()):
     return ["--synthetic", "--train_unet", "--rank", "4", "--max_train_steps", str(steps), "--checkpointing_steps", "2",

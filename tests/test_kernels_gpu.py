@@ -174,6 +174,33 @@ def test_conv3x3_halo_staged(ops, dev, B, H, Cin, Cout, kernel):
     check(f"conv halo {kernel}> border", _nchw(yb, B, H, H), F.conv2d(xb.float(), w.float(), None, padding=1), 2e-3)
 
 
+@pytest.mark.parametrize("M,N,K,K2", [(4136, 2560, 320, 8), (2048, 5120, 352, 24), (3300, 2560, 328, 0)])
+def test_gemm_pingpong_dense_buffer_operands(ops, dev, M, N, K, K2):
+    """Round 6: the dense ping-pong kernel (FF1 at the 64^2 level) fetches its operands by buffer_load ... lds -- rows beyond M must read zeros through the range
+    check (an out-of-range lane offset), and so must the K tail of a k-step (K % 32 != 0) and of the LoRA slab (K2 = 8 / 24 of a 32-wide step), whatever the scalar k
+    offset added to them.  M tails, K tails, slab tails, against fp32 torch; the dispatch is asserted."""
+    import ctypes
+    from finetune_fair_diffusion_amd import lib
+    a, b = rnd(M, K, dev=dev, seed=1), rnd(N, K, dev=dev, scale=0.1, seed=2)
+    a2, b2 = (rnd(M, K2, dev=dev, seed=3), rnd(N, K2, dev=dev, seed=4)) if K2 else (None, None)
+    bias, res = rnd(N, dev=dev, dtype=torch.float32, seed=5), rnd(M, N, dev=dev, seed=6)
+    d = lib.GemmDesc(); d.M, d.N, d.K, d.K2, d.batch, d.ldc, d.lda, d.ldb = M, N, K, K2, 1, N, K, K
+    ws = ops.gemm_workspace(); d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * 4
+    if K2:
+        d.A2, d.B2, d.lda2, d.ldb2 = a2.data_ptr(), b2.data_ptr(), K2, K2
+    buf = ctypes.create_string_buffer(128)
+    lib.get().fd_gemm_kernel_name(ctypes.byref(d), buf, 128)
+    assert buf.value.decode().startswith("gemm_pp_kernel<256, 0"), buf.value
+    # poisoned neighbours: the operands sit inside larger buffers whose other bytes are huge, so a lane that read past its row / slab would show
+    wide = torch.full((M + 8, K + 64), 6e4, dtype=torch.float16, device=dev)
+    wide[:M, :K] = a
+    c = ops.gemm(wide[:M, :K], b, a2=a2, b2=b2, bias=bias, residual=res)
+    ref = a.float() @ b.float().t() + bias + res.float()
+    if K2:
+        ref = ref + a2.float() @ b2.float().t()
+    check(f"gemm pp dense {M}x{N}x{K}+{K2}", c, ref, 2e-3)
+
+
 def test_gemm_epilogue_and_lora_slab(ops, dev):
     M, N, K, R = 777, 640, 320, 8
     a, b = rnd(M, K, dev=dev, seed=1), rnd(N, K, dev=dev, scale=0.1, seed=2)
@@ -698,6 +725,17 @@ def test_cross_attn_block_with_lora_slabs_and_recording(ops, dev, C, B, HW, L, k
     check("y vs fp32", y, yr, 4e-3)
     check("o vs fp32", rec["o2"], o, 4e-3)
     check("lse vs fp32", rec["lse2"], lse, 2e-3)
+    # the attention backward fed with what the FUSED forward recorded (at head dim 80 the stored q is the unscaled accumulator's rounding while the
+    # kernel's own softmax -- and hence lse -- ran on the pre-scaled rounding: include/fairdiff_hip.h, fd_cross_block_desc) against autograd of the fp32 statement
+    qf, kf, vf = q.detach().view(B, HW, C).requires_grad_(True), k.float().view(Bk, L, C).requires_grad_(True), v.float().view(Bk, L, C).requires_grad_(True)
+    oa, _ = _attn_ref(qf, kf, vf, H, kv_div)
+    do = rnd(M, C, dev=dev, seed=21)
+    oa.backward(do.float().view(B, HW, C))
+    dko, dvo = torch.empty(Bk * L, C, dtype=torch.float32, device=dev), torch.empty(Bk * L, C, dtype=torch.float32, device=dev)
+    dq, _, _ = ops.attn_bwd(rec["q2"], k, v, rec["o2"], do, rec["lse2"], B, H, HW, L, d, kv_div, dk_out=dko, dv_out=dvo, prescaled=qs is not None)
+    check("dq from the fused recording vs fp32 autograd", dq, qf.grad.reshape(M, C), 5e-3)
+    check("dK from the fused recording vs fp32 autograd", dko, kf.grad.reshape(Bk * L, C), 5e-3)
+    check("dV from the fused recording vs fp32 autograd", dvo, vf.grad.reshape(Bk * L, C), 5e-3)
 
 
 @pytest.mark.parametrize("B,H,T,d", [(2, 8, 1024, 40), (2, 8, 256, 80), (1, 4, 64, 160)])

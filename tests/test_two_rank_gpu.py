@@ -113,3 +113,46 @@ def test_eight_ranks_one_global_batch_exp1(dev, tmp_path, monkeypatch):
     finally:
         monkeypatch.delenv("FD_TEST_B_PER_RANK")
         importlib.reload(R)
+
+
+def test_eight_ranks_multi_attribute_exp4(dev, tmp_path, monkeypatch):
+    """BASELINE configs[3] is exp-4 on EIGHT ranks: the 8-logit head (gender x race x age), the device OT solver, the all-gather of all three
+    attributes' probabilities, the [n, 16] summed-plan all-reduce and the gradient all-reduce at world size 8 through the product's ``train_step`` -- eight
+    processes with 2 images each (gloo, all on cuda:0).  Every rank must hold the same bits after the step and derive its slice of ONE global plan.  Against one
+    process with all 16 images the Monte-Carlo plans differ by construction (every rank draws its own 100 capacity samples -- the reference's per-rank solve, exp-3
+    :1488-1536 -- and the product sums the eight plans; one rank draws 100), so targets are compared as an agreement rate and the gradient by its cosine."""
+    monkeypatch.setenv("FD_TEST_B_PER_RANK", "2")
+    import importlib
+    importlib.reload(R)
+    try:
+        ranks = _launch("exp-4", tmp_path, world=8, b_per_rank=2)
+        assert all(r["finite"] for r in ranks)
+        assert set(ranks[0]["targets"]) == {"gender", "race", "age"}
+        for r in ranks[1:]:
+            for a, b in zip(ranks[0]["grads"] + ranks[0]["params"], r["grads"] + r["params"]):
+                assert torch.equal(a, b)
+        assert float(ranks[0]["grads"][0].abs().max()) > 0
+        tr = R.build("exp-4", dev, 0, 1)
+        out = tr.train_step(U.tiny_tokens(), R.global_noises(8), R.S)
+        one = R.snapshot(tr, out)
+        # the probabilities every rank contributed are those of the single process (same images, same classifier): the exchange carried the right rows in rank order
+        probs8 = torch.cat([r["probs"] for r in ranks])
+        assert probs8.shape == one["probs"].shape and float((probs8 - one["probs"]).abs().max()) < 2e-2
+        agree = total = nset = 0
+        for a in ("gender", "race", "age"):
+            t8 = torch.cat([r["targets"][a] for r in ranks])
+            assert t8.shape == (16,) and t8.shape == one["targets"][a].shape
+            both = (t8 != -1) & (one["targets"][a] != -1)
+            agree += int((t8[both] == one["targets"][a][both]).sum())
+            total += int(both.sum())
+            nset += int((t8 != -1).sum())
+            print(f"exp-4 eight ranks, {a}: targets {t8.tolist()} | one rank {one['targets'][a].tolist()}")
+        g8, g1 = ranks[0]["grads"][0], one["grads"][0]
+        cos = float(F.cosine_similarity(g8.double(), g1.double(), dim=0))
+        print(f"exp-4 eight ranks vs one rank with 8x batch: {nset} targets set, agreement where both are set {agree} / {total}; gradient cosine {cos:.4f}  norm ratio {float(g8.norm() / g1.norm()):.3f}")
+        assert nset >= 8 and total >= 6 and agree >= 0.6 * total
+        assert cos > 0.5
+    finally:
+        monkeypatch.delenv("FD_TEST_B_PER_RANK")
+        importlib.reload(R)
+
