@@ -165,6 +165,32 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(fd_gemm_desc p, int ntm,
                 auto issue = [&] {
                     issueB(c3, t3, nl);      // into the slot of step i - 1: every wave is past B_i, i.e. done with it
                     if constexpr (t < NAP) issueA(c + 1, tc);
+#ifdef HALO_GN_PROBE
+                    // MEASUREMENT ONLY (scratch/r06 probe; results are not meaningful): what would GroupNorm + SiLU applied to the staged A operand cost inside this
+                    // loop?  Chunk c + 1 has landed behind B_9c+5; during taps 6 .. 8 every thread takes its share of the buffer's 16-byte items through
+                    // LDS -> fp32 scale / shift (read from an LDS table) -> SiLU -> fp16 -> LDS, the arithmetic of gn_apply_kernel<silu>.
+                    if constexpr (t >= 6) {
+                        constexpr int NITEM = G::NPIECE * 64, PER = (NITEM + 511) / 512;
+                        constexpr int J0 = t == 6 ? 0 : (t == 7 ? (PER + 2) / 3 : 2 * ((PER + 2) / 3)), J1 = t == 6 ? (PER + 2) / 3 : (t == 7 ? 2 * ((PER + 2) / 3) : PER);
+                        f16* nb = abuf + ((c + 1) & 1) * G::ABUF;
+                        const float* tab = (const float*)(ring + PP_NST * HALO_BST);        // the dump groups stand in for the 32-channel (a, b) table
+#pragma unroll
+                        for (int j = J0; j < J1; ++j) {
+                            const int it = tid + 512 * j;
+                            if (it < NITEM) {
+                                f16x8 v = *(f16x8*)(nb + it * 8);
+                                const f32x4 a0 = *(const f32x4*)(tab + (it & 3) * 16), a1 = *(const f32x4*)(tab + (it & 3) * 16 + 4);
+                                const f32x4 b0 = *(const f32x4*)(tab + (it & 3) * 16 + 8), b1 = *(const f32x4*)(tab + (it & 3) * 16 + 12);
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) {
+                                    const float sc = e < 4 ? a0[e & 3] : a1[e & 3], sh = e < 4 ? b0[e & 3] : b1[e & 3];
+                                    v[e] = (f16)silu_f((float)v[e] * sc + sh);
+                                }
+                                *(f16x8*)(nb + it * 8) = v;
+                            }
+                        }
+                    }
+#endif
                 };
                 if constexpr (LEAD) {
                     auto mid = [&] {

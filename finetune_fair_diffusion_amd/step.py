@@ -331,6 +331,13 @@ class FairnessTrainer:
             # and the FF1 projection per block instead of recomputing WHOLE timesteps: at S = 50, B = 8 that keeps ~45 of 50 timesteps instead of 28.
             full = self._full_ctx_bytes
             need_lean = self.lean_activations is True or (full > 0 and S * full > self.activation_mem_fraction * self._usable_free_bytes())
+            if need_lean != unet.lean_record:
+                # the caching allocator's pools hold blocks in the OTHER mode's sizes (28 timesteps x 16 pre-gate projections of 335 MB ...): they would sit
+                # unused while the new mode's blocks come fresh from the driver until nothing is left for the runtime itself (HSA_STATUS_ERROR_OUT_OF_RESOURCES,
+                # seen at S = 50 on the first lean step).  Hand them back once, at the switch (a device sync + a few ms; never in steady state).
+                torch.cuda.synchronize()
+                torch.cuda.empty_cache()
+                self._snap_calls = 0
             unet.lean_record = need_lean
         lat = noises.clone()
         state, inputs, ctxs = {}, [], {}

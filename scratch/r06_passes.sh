@@ -111,4 +111,49 @@ for f in sorted(glob.glob("gpurun_out/r06i/bench_exp4_s50_*.json")):
         print(f, "ERR", e)
 PY
     ;;
+j)  # S = 50 exp-4 with automatic lean recording (after the pool hand-back at the mode switch), 4 timed steps
+    O=gpurun_out/r06j; mkdir -p $O
+    timeout 900 python bench.py --S 50 --experiment exp-4 --steps 4 --warmup 2 --no_cpu_baseline --no_roofline > $O/bench_exp4_s50_lean.json 2> $O/bench_exp4_s50_lean.err || tail -5 $O/bench_exp4_s50_lean.err
+    python - <<'PY'
+import json
+try:
+    d = json.loads(open("gpurun_out/r06j/bench_exp4_s50_lean.json").read().strip().splitlines()[-1]); c = d["config"]
+    print(round(d["value"], 3), "img/s", round(d["ms_per_step"], 1), "ms; kept", c["r3_timesteps_kept_in_hbm"], "of 50; ctx GB", c["r3_activation_gb_per_timestep"], "peak", c["peak_hbm_gb"], c["phase_ms"], c["host_ms_per_step"])
+except Exception as e:
+    print("ERR", e)
+PY
+    ;;
+k)  # the ViT GEMMs of the tail (M = 2112 tokens, N = 1280): 128x160 tiles instead of 64x64 (threshold of the 160-wide tile 160 -> 128 / 100), whole step
+    O=gpurun_out/r06k; mkdir -p $O
+    L=$P/libfairdiff_hip_bench.so
+    for i in 1 2; do
+      for v in "FD_NOTHING=1" "FD_GEMM_T160=128" "FD_GEMM_T160=100"; do
+        n=$(echo "$v" | tr '=;, /' '_____')
+        env FAIRDIFF_LIB=$L $v $B --steps 6 --warmup 2 > $O/${n}_$i.json 2> $O/${n}_$i.err || tail -3 $O/${n}_$i.err
+      done
+    done
+    bench_table "$O/*.json" | tee $O/summary.txt
+    ;;
+z)  # final validation of the tree: full GPU suite, smoke, the driver's default bench line, a 20-step line, rocprofv3 kernel stats of the bench command,
+    # the in-situ FETCH / WRITE passes that bench.py's roofline.traffic reads, the cfg0 B = 8 cosine without the fused cross block in the recording forward
+    O=gpurun_out/r06z; mkdir -p $O
+    python -m pytest tests -m gpu -x -q -s --durations=15 > $O/pytest_gpu.log 2>&1; echo rc=$? >> $O/pytest_gpu.log; tail -22 $O/pytest_gpu.log | cut -c1-200
+    python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -1 $O/smoke.log
+    python bench.py > $O/bench_default.json 2> $O/bench_default.err; cut -c1-250 $O/bench_default.json
+    python bench.py --steps 20 --warmup 5 --cpu_baseline_bounded > $O/bench_steps20.json 2> $O/bench_steps20.err; cut -c1-250 $O/bench_steps20.json
+    env FD_NO_FUSED_CROSS_TRAIN=1 timeout 900 python -m pytest tests/test_fullsize_gpu.py -q -s -k "cfg0_eight" > $O/cfg0_b8_no_fused_cross_train.log 2>&1; grep -i "cfg0 B=8\|passed\|failed" $O/cfg0_b8_no_fused_cross_train.log
+    cd /tmp && export TMPDIR=/tmp
+    timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/prof_r06z -o r06z -- python3 $R/bench.py --steps 4 --warmup 2 --no_cpu_baseline --no_roofline > $R/$O/bench_trace.json 2> $R/$O/bench_trace.err
+    cd $R
+    DB=$(find /tmp/prof_r06z -name "*.db" | head -1)
+    python scratch/profsum.py $DB $O/kernel_stats.csv 30 > $O/kernel_stats_top.txt; head -14 $O/kernel_stats_top.txt | cut -c1-200
+    find /tmp/prof_r06z -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/rocprofv3_kernel_stats.csv 2>/dev/null
+    KR='gemm|conv_halo|attn|gn_|layernorm|geglu|splitk'
+    cd /tmp
+    timeout 1200 rocprofv3 --kernel-trace --pmc FETCH_SIZE --kernel-include-regex "$KR" --output-format csv -d /tmp/pmc_r06z_fetch -o f -- python3 $R/bench.py --steps 1 --warmup 1 --no_cpu_baseline --no_roofline > $R/$O/pmc_fetch.log 2>&1
+    timeout 1200 rocprofv3 --kernel-trace --pmc WRITE_SIZE --kernel-include-regex "$KR" --output-format csv -d /tmp/pmc_r06z_write -o w -- python3 $R/bench.py --steps 1 --warmup 1 --no_cpu_baseline --no_roofline > $R/$O/pmc_write.log 2>&1
+    cd $R
+    python scratch/r05_pmc_summary.py /tmp/pmc_r06z_fetch $O/pmc_fetch_in_situ.csv 12 > $O/pmc_fetch_top.txt 2>&1; head -8 $O/pmc_fetch_top.txt | cut -c1-200
+    python scratch/r05_pmc_summary.py /tmp/pmc_r06z_write $O/pmc_write_in_situ.csv 12 > $O/pmc_write_top.txt 2>&1; head -8 $O/pmc_write_top.txt | cut -c1-200
+    ;;
 esac
