@@ -239,7 +239,20 @@ def main():
         achieved = s["flops"] / (s["ms"] * 1e-3) / 1e12
         headline = (a.dtype == "fp16" and a.batch == 8 and a.S == 20 and a.rank == 4 and a.experiment == "exp-1" and not a.tiny and not a.no_regularisers)
         traffic, traffic_note = pmc_traffic(name, s["bytes"] / s["launches"], headline)
-        line["roofline"] = {"bound": "mfma", "kernel": name, "achieved": achieved, "peak": MFMA_PEAK_F16 / 1e12, "unit": "TFLOP/s",
+        # the same kernel under the SHIPPED multi-stream schedule: its mean duration in the committed rocprofv3 kernel trace of this command (HIP events per launch
+        # would perturb the concurrent schedule; the roofline step above times the kernels one stream at a time).  Headline configuration only.
+        in_situ = None
+        if headline:
+            import csv
+            for rnd in ("r06",):
+                path = os.path.join(ROOT, "profiles", rnd + "_bench_step_kernel_stats_final.csv")
+                if os.path.exists(path):
+                    for r in csv.DictReader(open(path)):
+                        if r["name"] == name:
+                            us = float(r["avg_us"])
+                            in_situ = {"avg_launch_us": us, "frac": s["flops"] / s["launches"] / (us * 1e-6) / MFMA_PEAK_F16, "calls": int(r["calls"]),
+                                       "source": "profiles/%s_bench_step_kernel_stats_final.csv (rocprofv3 --kernel-trace of bench.py --steps 4 --warmup 2, shipped schedule, all streams on)" % rnd}
+        line["roofline"] = {"bound": "mfma", "kernel": name, "achieved": achieved, "in_situ": in_situ, "peak": MFMA_PEAK_F16 / 1e12, "unit": "TFLOP/s",
                             "frac": achieved / (MFMA_PEAK_F16 / 1e12), "traffic": traffic, "traffic_note": traffic_note,
                             "launches": s["launches"], "splitk_launches": s["splitk_launches"],
                             "avg_launch_us": 1e3 * s["ms"] / s["launches"], "algorithmic_flop_per_launch": s["flops"] / s["launches"],

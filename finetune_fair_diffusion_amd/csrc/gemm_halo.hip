@@ -176,15 +176,15 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(fd_gemm_desc p, int ntm,
                         const float* tab = (const float*)(ring + PP_NST * HALO_BST);        // the dump groups stand in for the 32-channel (a, b) table
 #pragma unroll
                         for (int j = J0; j < J1; ++j) {
-                            const int it = tid + 512 * j;
-                            if (it < NITEM) {
+                            const int it = min(tid + 512 * j, NITEM - 1);      // branch-free (a divergent branch in the unrolled taps makes the allocator spill): the tail lanes redo the last item
+                            {
                                 f16x8 v = *(f16x8*)(nb + it * 8);
-                                const f32x4 a0 = *(const f32x4*)(tab + (it & 3) * 16), a1 = *(const f32x4*)(tab + (it & 3) * 16 + 4);
-                                const f32x4 b0 = *(const f32x4*)(tab + (it & 3) * 16 + 8), b1 = *(const f32x4*)(tab + (it & 3) * 16 + 12);
 #pragma unroll
-                                for (int e = 0; e < 8; ++e) {
-                                    const float sc = e < 4 ? a0[e & 3] : a1[e & 3], sh = e < 4 ? b0[e & 3] : b1[e & 3];
-                                    v[e] = (f16)silu_f((float)v[e] * sc + sh);
+                                for (int h = 0; h < 2; ++h) {
+                                    const f32x4 sc = *(const f32x4*)(tab + (it & 3) * 16 + h * 4), sh = *(const f32x4*)(tab + (it & 3) * 16 + 8 + h * 4);
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) v[h * 4 + e] = (f16)silu_f((float)v[h * 4 + e] * sc[e] + sh[e]);
+                                    asm volatile("" : "+v"(v));
                                 }
                                 *(f16x8*)(nb + it * 8) = v;
                             }

@@ -156,4 +156,12 @@ z)  # final validation of the tree: full GPU suite, smoke, the driver's default 
     python scratch/r05_pmc_summary.py /tmp/pmc_r06z_fetch $O/pmc_fetch_in_situ.csv 12 > $O/pmc_fetch_top.txt 2>&1; head -8 $O/pmc_fetch_top.txt | cut -c1-200
     python scratch/r05_pmc_summary.py /tmp/pmc_r06z_write $O/pmc_write_in_situ.csv 12 > $O/pmc_write_top.txt 2>&1; head -8 $O/pmc_write_top.txt | cut -c1-200
     ;;
+l)  # what would GroupNorm + SiLU applied to the staged A operand cost INSIDE the halo convolution?  The bench-hooks library against the same library with the
+    # in-LDS transform pass compiled in (-DHALO_GN_PROBE, measurement only: the 128-row instantiations; the 256-row ones spill with it), isolated launches
+    O=gpurun_out/r06l; mkdir -p $O
+    FD_CONV_HALO=1 FAIRDIFF_LIB=$P/libfairdiff_hip_bench.so timeout 600 python scratch/mb_halo.py 2>&1 | grep -v amdgpu.ids > $O/halo_plain.txt
+    FD_CONV_HALO=1 FAIRDIFF_LIB=$P/libfairdiff_hip_bench_gnp.so timeout 600 python scratch/mb_halo.py 2>&1 | grep -v amdgpu.ids > $O/halo_gn_probe.txt
+    paste -d'\n' $O/halo_plain.txt $O/halo_gn_probe.txt | cut -c1-250
+    timeout 600 python scratch/mb_gn.py 2>&1 | grep -v amdgpu.ids | tail -30 > $O/mb_gn.txt; cat $O/mb_gn.txt | cut -c1-200
+    ;;
 esac
