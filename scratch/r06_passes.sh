@@ -163,5 +163,11 @@ l)  # what would GroupNorm + SiLU applied to the staged A operand cost INSIDE th
     FD_CONV_HALO=1 FAIRDIFF_LIB=$P/libfairdiff_hip_bench_gnp.so timeout 600 python scratch/mb_halo.py 2>&1 | grep -v amdgpu.ids > $O/halo_gn_probe.txt
     paste -d'\n' $O/halo_plain.txt $O/halo_gn_probe.txt | cut -c1-250
     timeout 600 python scratch/mb_gn.py 2>&1 | grep -v amdgpu.ids | tail -30 > $O/mb_gn.txt; cat $O/mb_gn.txt | cut -c1-200
+    # the kernel trace of the SINGLE-STREAM schedule the roofline step of bench.py times (both stream overlaps off): its mean durations are the ones roofline.avg_launch_us must agree with
+    cd /tmp && export TMPDIR=/tmp
+    FD_NO_CONCURRENT_R2=1 FD_NO_CONCURRENT_BWD=1 timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/prof_r06l -o r06l -- python3 $R/bench.py --steps 2 --warmup 1 --no_cpu_baseline --no_roofline > $R/$O/bench_trace_single_stream.json 2> $R/$O/bench_trace_single_stream.err
+    cd $R
+    DB=$(find /tmp/prof_r06l -name "*.db" | head -1)
+    python scratch/profsum.py $DB $O/kernel_stats_single_stream.csv 12 > $O/kernel_stats_single_stream_top.txt; head -8 $O/kernel_stats_single_stream_top.txt | cut -c1-200
     ;;
 esac
