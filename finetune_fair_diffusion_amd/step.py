@@ -47,6 +47,16 @@ _CFG_PAIR = os.environ.get("FD_NO_CFG_PAIR") is None
 _ROCTX = os.environ.get("FD_ROCTX") is not None
 
 
+def _ctx_droppable_bytes(ctx):
+    """Bytes of one timestep's context that lean recording does not keep (unet.TransformerBlock: the pre-gate FF projection, n1, n2)."""
+    if isinstance(ctx, dict):
+        n = sum(t.numel() * t.element_size() for k in ("proj", "n1", "n2") for t in (ctx.get(k),) if isinstance(t, torch.Tensor))
+        return n + sum(_ctx_droppable_bytes(v) for v in ctx.values() if isinstance(v, (list, tuple)))
+    if isinstance(ctx, (list, tuple)):
+        return sum(_ctx_droppable_bytes(c) for c in ctx)
+    return 0
+
+
 def _ctx_bytes(obj, seen=None):
     """Bytes held by the tensors reachable from a recorded-forward context (unique storages)."""
     seen = set() if seen is None else seen
@@ -186,7 +196,7 @@ class FairnessTrainer:
         # collectives run whenever there is more than one rank -- or, with FD_FORCE_COLLECTIVES=1 and an initialised process group, on a
         # single rank too (the only way to drive the RCCL code path on a one-GPU box: RCCL refuses two ranks on one device)
         self.collectives = world_size > 1 or (os.environ.get("FD_FORCE_COLLECTIVES") is not None and dist.is_available() and dist.is_initialized())
-        self._hbm_reserve = int(os.environ.get("FD_HBM_RESERVE_MB", "2048" if self.collectives else "0")) << 20
+        self._hbm_reserve = int(os.environ.get("FD_HBM_RESERVE_MB", "2048")) << 20      # since round 6 also without collectives: the runtime itself needs room (HSA_STATUS_ERROR_OUT_OF_RESOURCES at 0 free)
         self.device = device or unet.device
         self.banks = []
         if getattr(args, "train_unet", False):
@@ -360,10 +370,17 @@ class FairnessTrainer:
                 unet._ctx = None
                 if i == 0:
                     per = _ctx_bytes(ctxs[0])
-                    budget = int(self.activation_mem_fraction * self._usable_free_bytes() / max(per, 1))
-                    self.last_ctx_bytes, self.last_ctx_budget = per, budget
+                    usable = self.activation_mem_fraction * self._usable_free_bytes()
                     if not unet.lean_record:
                         self._full_ctx_bytes = per
+                        if self.lean_activations is None and S * per > usable:
+                            # the very first recording rollout of a run (context size unknown until now) and S full contexts do not fit: timestep 0 stays as
+                            # recorded, the remaining ones are recorded lean (the backward takes either form per timestep) -- no full-mode step that fills the HBM
+                            # to the last GiB before the switch (S = 50 soak of round 6: 0.66 GiB of driver-free memory at step 0)
+                            unet.lean_record = True
+                            per -= _ctx_droppable_bytes(ctxs[0])
+                    budget = int(usable / max(per, 1))
+                    self.last_ctx_bytes, self.last_ctx_budget = per, budget
                 else:
                     budget -= 1
             sch.cfg_step(i, eps, gs, lat, state)

@@ -170,4 +170,35 @@ l)  # what would GroupNorm + SiLU applied to the staged A operand cost INSIDE th
     DB=$(find /tmp/prof_r06l -name "*.db" | head -1)
     python scratch/profsum.py $DB $O/kernel_stats_single_stream.csv 12 > $O/kernel_stats_single_stream_top.txt; head -8 $O/kernel_stats_single_stream_top.txt | cut -c1-200
     ;;
+m)  # S = 50 soak with the automatic lean recording (and with a resident RCCL communicator): memory flat, no allocator retries, all 50 timesteps kept
+    O=gpurun_out/r06m; mkdir -p $O
+    timeout 900 python scratch/soak_s50.py 14 2>&1 | grep -v amdgpu.ids > $O/soak_s50_lean.txt; tail -4 $O/soak_s50_lean.txt | cut -c1-400
+    timeout 900 python scratch/soak_s50.py 14 collectives 2>&1 | grep -v amdgpu.ids > $O/soak_s50_lean_collectives.txt; tail -3 $O/soak_s50_lean_collectives.txt | cut -c1-400
+    ;;
+n)  # dense GEMMs on the 8-wave ping-pong kernel (buffer-descriptor operands, level in isolation) INSIDE the step: does leaving a third of the register file and
+    # 15 KB of LDS to the other streams' small kernels change the in-situ picture?  FD_GEMM_PP bits: 2 = dense 256x320, 16 = dense 128x320
+    O=gpurun_out/r06n; mkdir -p $O
+    L=$P/libfairdiff_hip_bench.so
+    for i in 1 2; do
+      for v in "FD_GEMM_PP=45" "FD_GEMM_PP=47" "FD_GEMM_PP=63"; do
+        n=$(echo "$v" | tr '=;, /' '_____')
+        env FAIRDIFF_LIB=$L $v $B --steps 6 --warmup 2 > $O/${n}_$i.json 2> $O/${n}_$i.err || tail -3 $O/${n}_$i.err
+      done
+    done
+    bench_table "$O/*.json" | tee $O/summary.txt
+    ;;
+o)  # the in-rollout switch to lean recording (first step of a run) + the 2 GiB reserve: the S = 50 test, the lean test, a short soak
+    O=gpurun_out/r06o; mkdir -p $O
+    timeout 1500 python -m pytest tests/test_fullsize_gpu.py tests/test_engine_gpu.py -q -x -s -k "s50_mixed or lean_recording" > $O/tests.log 2>&1; grep -i "S=50\|lean\|passed\|failed\|Error\|grad" $O/tests.log | tail -12 | cut -c1-250
+    timeout 900 python scratch/soak_s50.py 8 2>&1 | grep -v amdgpu.ids > $O/soak_s50_lean.txt; grep "step\\\": 0,\|step\\\": 1,\|summary" $O/soak_s50_lean.txt | cut -c1-400
+    ;;
+p)  # where the single-stream tail goes: fine marks inside R3_loss_and_image_grad (CLIP / DINO forward, their backwards, the face branch, the classifier backward)
+    O=gpurun_out/r06p; mkdir -p $O
+    FD_FINE_MARKS=1 $B --steps 4 --warmup 2 > $O/fine_marks.json 2> $O/fine_marks.err || tail -3 $O/fine_marks.err
+    python - <<'PY'
+import json
+d = json.loads(open("gpurun_out/r06p/fine_marks.json").read().strip().splitlines()[-1])
+print(round(d["ms_per_step"], 1), d["config"]["phase_ms"])
+PY
+    ;;
 esac
