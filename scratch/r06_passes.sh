@@ -201,4 +201,15 @@ d = json.loads(open("gpurun_out/r06p/fine_marks.json").read().strip().splitlines
 print(round(d["ms_per_step"], 1), d["config"]["phase_ms"])
 PY
     ;;
+q)  # REJECTED (scratch/r06_concurrent_tail_rejected.patch, profiles/r06_step_ab_concurrent_tail_rejected.txt): concurrent loss tail (DINOv2 / face branch / classifier backward beside CLIP): tests, then the same-box A/B
+    O=gpurun_out/r06q; mkdir -p $O
+    timeout 1800 python -m pytest tests/test_engine_gpu.py tests/test_fullsize_gpu.py -q -x -k "regularis or face_realism or bit_reproducible or shipped_schedule or all_regularisers or detector_provider" > $O/tests.log 2>&1; tail -4 $O/tests.log | cut -c1-200
+    for i in 1 2 3; do
+      for v in "FD_NO_CONCURRENT_TAIL=1" "FD_NOTHING=1"; do
+        n=$(echo "$v" | tr '=;, /' '_____')
+        env $v $B --steps 6 --warmup 2 > $O/${n}_$i.json 2> $O/${n}_$i.err || tail -3 $O/${n}_$i.err
+      done
+    done
+    bench_table "$O/*.json" | tee $O/summary.txt
+    ;;
 esac
