@@ -74,8 +74,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     # one step in ~10 runs 100-250 ms long on this pool (host-side, with or without the Python GC: profiles/r02_step_time_jitter.txt);
     # four timed steps keep one such outlier from moving the line by more than ~3 %
-    ap.add_argument("--steps", type=int, default=4)
-    ap.add_argument("--warmup", type=int, default=2)      # the second step still grows the caching allocator's pools (40-step soak: step 2 is ~10 % long)
+    ap.add_argument("--steps", type=int, default=12)      # 16 s of timed region: one +40 ms step (seen once in 4 on one box) moves the mean by 3 ms instead of 10
+    ap.add_argument("--warmup", type=int, default=3)      # the second step still grows the caching allocator's pools (40-step soak: step 2 is ~10 % long)
     ap.add_argument("--batch", type=int, default=8, help="train_images_per_prompt_GPU")
     ap.add_argument("--S", type=int, default=20, help="denoising steps")
     ap.add_argument("--rank", type=int, default=4, help="LoRA rank")
