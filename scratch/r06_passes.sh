@@ -212,4 +212,18 @@ q)  # REJECTED (scratch/r06_concurrent_tail_rejected.patch, profiles/r06_step_ab
     done
     bench_table "$O/*.json" | tee $O/summary.txt
     ;;
+r)  # evidence passes on the final tree: SQ wave-cycle breakdown + LDS bank conflicts per kernel in situ (is the halo image's slot permutation conflict-free at every
+    # tap shift?), and the exp-4 eight-rank test five times (first attempts only)
+    O=gpurun_out/r06r; mkdir -p $O
+    cd /tmp && export TMPDIR=/tmp
+    KR='gemm|conv_halo|attn|gn_|layernorm|geglu|splitk'
+    C="SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_VMEM SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_VALU_MFMA_BUSY_CYCLES"
+    timeout 1200 rocprofv3 --kernel-trace --pmc $C --kernel-include-regex "$KR" --output-format csv -d /tmp/pmc_r06r_sq -o s -- python3 $R/bench.py --steps 1 --warmup 1 --no_cpu_baseline --no_roofline > $R/$O/pmc_sq.log 2>&1
+    cd $R
+    python scratch/r05_pmc_summary.py /tmp/pmc_r06r_sq $O/pmc_sq_in_situ.csv 30 > $O/pmc_sq_top.txt 2>&1; cut -c1-230 $O/pmc_sq_top.txt | head -34
+    for i in 1 2 3 4 5; do
+      timeout 900 python -m pytest tests/test_two_rank_gpu.py -q -s -k "exp4" > $O/exp4_$i.log 2>&1; rc=$?
+      echo "run $i: rc=$rc $(grep 'eight ranks vs one rank' $O/exp4_$i.log | cut -c1-200) $(tail -1 $O/exp4_$i.log)" | tee -a $O/exp4_summary.txt
+    done
+    ;;
 esac

@@ -1,4 +1,4 @@
-"""Stand-alone reproducer of the round-3 hazard (DESIGN "Round 4 at a glance"): the four-rows-per-wave LayerNorm backward, built WITH hipcc's SLP
+"""Stand-alone reproducer of the round-3 hazard (HISTORY.md "Rounds 2-4 at a glance"; DESIGN.md section 4 "build flags"): the four-rows-per-wave LayerNorm backward, built WITH hipcc's SLP
 vectorisation (packed-fp32 VALU code), is run N times on fixed inputs on one stream while a second stream keeps the chip busy with the step's
 GEMM / convolution / attention kernels; every output is compared bitwise with the result on an idle device.
     FAIRDIFF_LIB=<library built with -DFD_LN_BWD_MULTI_ROW and round-3 flags> python scratch/repro_packed_fp32_hazard.py [iterations]
