@@ -217,7 +217,8 @@ class FairnessTrainer:
         self.keep_activations = True
         self.activation_mem_fraction = 0.85
         self.last_ctx_bytes = self.last_ctx_budget = 0
-        self._full_ctx_bytes = 0      # bytes of one timestep's FULL context (measured by the first recording rollout)
+        self._full_ctx_bytes = 0              # bytes of one timestep's FULL context (measured by the first recording rollout)
+        self._auto_lean = False              # the automatic mode chose lean recording once: it stays (see rollout_steps)
         # None: automatic (lean recording when S full contexts do not fit, from the second step on); True / False force it (FD_LEAN_ACTIVATIONS=1 / 0)
         self.lean_activations = {"1": True, "0": False}.get(os.environ.get("FD_LEAN_ACTIVATIONS", ""), None)
         # R1 and the forward half of R3 evaluate the same function on the same inputs (same prompt, noise, S and LoRA
@@ -341,6 +342,9 @@ class FairnessTrainer:
             # and the FF1 projection per block instead of recomputing WHOLE timesteps: at S = 50, B = 8 that keeps ~45 of 50 timesteps instead of 28.
             full = self._full_ctx_bytes
             need_lean = self.lean_activations is True or (full > 0 and S * full > self.activation_mem_fraction * self._usable_free_bytes())
+            if self.lean_activations is None and (need_lean or self._auto_lean):
+                need_lean = self._auto_lean = True   # sticky in the automatic mode: a run whose S varies around the limit must not rebuild the allocator's pools every step
+                                             # (a switch costs a device sync + ~10 s of pool refill; lean recording at a smaller S costs ~2 ms per timestep)
             if need_lean != unet.lean_record:
                 # the caching allocator's pools hold blocks in the OTHER mode's sizes (28 timesteps x 16 pre-gate projections of 335 MB ...): they would sit
                 # unused while the new mode's blocks come fresh from the driver until nothing is left for the runtime itself (HSA_STATUS_ERROR_OUT_OF_RESOURCES,
@@ -377,7 +381,7 @@ class FairnessTrainer:
                             # the very first recording rollout of a run (context size unknown until now) and S full contexts do not fit: timestep 0 stays as
                             # recorded, the remaining ones are recorded lean (the backward takes either form per timestep) -- no full-mode step that fills the HBM
                             # to the last GiB before the switch (S = 50 soak of round 6: 0.66 GiB of driver-free memory at step 0)
-                            unet.lean_record = True
+                            unet.lean_record = self._auto_lean = True
                             per -= _ctx_droppable_bytes(ctxs[0])
                     budget = int(usable / max(per, 1))
                     self.last_ctx_bytes, self.last_ctx_budget = per, budget

@@ -369,6 +369,16 @@ def test_lean_recording_gives_the_bit_identical_gradient(dev):
     tr.lean_activations = None
     tr.train_step(tokens, noises, 4)
     assert not tr.unet.lean_record
+    # ... and once the automatic mode has chosen lean (here: a budget so small that four full contexts do not fit), it stays lean when the pressure goes away:
+    # a run whose S varies around the limit must not hand the allocator's pools back every step.  Same gradient either way.
+    frac, tr.activation_mem_fraction = tr.activation_mem_fraction, 1e-9
+    tr.train_step(tokens, noises, 4)
+    assert tr.unet.lean_record and tr.last_ctx_budget == 0
+    tr.activation_mem_fraction = frac
+    tr.train_step(tokens, noises, 4)
+    assert tr.unet.lean_record and tr.last_ctx_budget >= 4
+    for ga, gb, gc in zip(grads[0], grads[-2], grads[-1]):
+        assert torch.equal(ga, gb) and torch.equal(ga, gc)
     print(f"lean recording: context per timestep {full_bytes} bytes full, {lean_bytes} lean ({lean_bytes / full_bytes:.2f}x)")
 
 
